@@ -1,0 +1,9 @@
+"""city2ba_amd -- MI355X-native hot path of city2ba behind the reference's BAProblem surface.
+
+The compute lives in csrc/ (hand-written HIP for gfx950) behind the C ABI of include/city2ba_hip.h;
+this package is the thin host-side mirror.  No CPU fallback exists."""
+from ._lib import City2baError, device_count, lib  # noqa: F401
+from .baproblem import BAProblem  # noqa: F401
+from . import noise  # noqa: F401
+
+__all__ = ["BAProblem", "City2baError", "device_count", "lib", "noise"]

@@ -1,0 +1,106 @@
+"""ctypes binding of include/city2ba_hip.h (the C-ABI shared library built from csrc/).
+
+There is NO CPU fallback: if the HIP library is missing this module raises at import of the
+first symbol, and every compute entry point fails with C2B_ERR_NO_DEVICE when no GPU is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcity2ba_hip.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_INDEX_OUT_OF_RANGE = -2
+ERR_HIP = -3
+ERR_OOM = -4
+ERR_NO_DEVICE = -5
+CAMBLK_DOUBLES = 28
+STATS_DOUBLES = 20
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_d = C.c_double
+_int = C.c_int
+
+# name -> (restype, argtypes).  Kept in one table so tests can check every symbol the header declares.
+SIGNATURES = {
+    "c2b_version": (C.c_char_p, []),
+    "c2b_last_error": (C.c_char_p, []),
+    "c2b_device_count": (_int, [C.POINTER(_int)]),
+    "c2b_workspace_bytes": (_i64, [_i64]),
+    "c2b_cameras_from_bal": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_cameras_to_bal": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_cameras_prepare_state": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_cameras_prepare_bal": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_points_pad": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_points_unpad": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_expand_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "c2b_project": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "c2b_reprojection_error_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
+    "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
+    "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
+    "c2b_add_drift_normalized": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
+    "c2b_add_noise_entities": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
+    "c2b_add_noise_observations": (_int, [_vp, _i64, _i64, _d, _u64, _vp]),
+    "c2b_add_sin_noise": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _d, _d, _vp]),
+    "c2b_partition_cameras": (_int, [_vp, _i64, _int, _vp]),
+    "c2b_problem_create": (_int, [_int, C.POINTER(_vp)]),
+    "c2b_problem_destroy": (None, [_vp]),
+    "c2b_problem_upload": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_problem_upload_bal": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_problem_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "c2b_problem_download": (_int, [_vp, _vp, _vp, _vp]),
+    "c2b_problem_download_bal": (_int, [_vp, _vp]),
+    "c2b_problem_project": (_int, [_vp, _vp]),
+    "c2b_problem_total_reprojection_error": (_int, [_vp, _d, C.POINTER(_d)]),
+    "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),
+    "c2b_problem_stats": (_int, [_vp, _vp]),
+    "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),
+    "c2b_problem_add_drift": (_int, [_vp, _d, _d, _d, _vp, _u64]),
+    "c2b_problem_add_drift_normalized": (_int, [_vp, _d, _d, _d, _u64]),
+    "c2b_problem_add_noise": (_int, [_vp, _d, _d, _d, _d, _u64]),
+    "c2b_problem_add_sin_noise": (_int, [_vp, _vp, _vp, _d, _d]),
+}
+
+
+class City2baError(RuntimeError):
+    """Mirrors the reference's failure modes: bad arguments / the asserts of
+    src/baproblem.rs:345-346, 365-369 (status -2) / device errors."""
+
+    def __init__(self, status, message):
+        super().__init__("city2ba_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "city2ba_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)          # AttributeError here = header/library mismatch
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        raise City2baError(status, lib().c2b_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = _int(0)
+    rc = lib().c2b_device_count(C.byref(n))
+    return n.value if rc == OK else 0

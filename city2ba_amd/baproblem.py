@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's BAProblem<SnavelyCamera> for the hot path, over the C ABI.
+
+Names, argument meaning and failure behaviour follow src/baproblem.rs (methods) and src/noise.rs
+(free functions taking and returning a problem).  All arithmetic runs in the HIP library; this
+file only moves numpy buffers across the boundary.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class BAProblem:
+    """cameras + points + vis_graph (CSR) resident on one MI355X.
+
+    `vis_graph` is the flattening of Vec<Vec<(usize,(f64,f64))>> (src/baproblem.rs:256-260):
+    row_ptr[n_cam+1], pt_idx[n_obs], uv[n_obs,2], camera-major, in-camera order preserved."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        L.check(L.lib().c2b_problem_create(int(device), C.byref(self._h)))
+        self._row_ptr = np.zeros(1, dtype=np.uint64)
+        self._pt_idx = np.zeros(0, dtype=np.uint64)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib().c2b_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- constructors -------------------------------------------------------------------
+    @classmethod
+    def from_visibility(cls, cams15, points, row_ptr, pt_idx, uv, device=0):
+        """BAProblem::from_visibility (src/baproblem.rs:360-376); cameras as in-memory
+        SnavelyCamera records [n,15] (R col-major, t, intrin)."""
+        self = cls(device)
+        self._upload(_f64(cams15, (-1, 15)), False, points, row_ptr, pt_idx, uv)
+        return self
+
+    @classmethod
+    def from_bal(cls, bal9, points, row_ptr, pt_idx, uv, device=0):
+        """Same with cameras as the 9-vectors a .bal/.bbal file holds (src/baproblem.rs:605-608)."""
+        self = cls(device)
+        self._upload(_f64(bal9, (-1, 9)), True, points, row_ptr, pt_idx, uv)
+        return self
+
+    @classmethod
+    def new(cls, bal9, points, obs, device=0):
+        """BAProblem::new (src/baproblem.rs:342-355): obs = iterable of (cam, point, u, v)."""
+        bal9 = _f64(bal9, (-1, 9))
+        points = _f64(points, (-1, 3))
+        obs = list(obs)
+        n_cam = len(bal9)
+        for (ci, pi, _, _) in obs:
+            if not (0 <= ci < n_cam):       # assert!(cam_i < cams.len())
+                raise L.City2baError(L.ERR_INDEX_OUT_OF_RANGE, "camera index %d out of range" % ci)
+            if not (0 <= pi < len(points)):  # assert!(p_i < points.len())
+                raise L.City2baError(L.ERR_INDEX_OUT_OF_RANGE, "point index %d out of range" % pi)
+        order = sorted(range(len(obs)), key=lambda k: obs[k][0])     # stable: keeps push order
+        counts = np.bincount([obs[k][0] for k in order], minlength=n_cam) if obs else np.zeros(n_cam, int)
+        row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        pt_idx = np.array([obs[k][1] for k in order], dtype=np.uint64)
+        uv = np.array([[obs[k][2], obs[k][3]] for k in order], dtype=np.float64).reshape(-1, 2)
+        return cls.from_bal(bal9, points, row_ptr, pt_idx, uv, device)
+
+    def _upload(self, cams, is_bal, points, row_ptr, pt_idx, uv):
+        points = _f64(points, (-1, 3))
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint64)
+        uv = _f64(uv, (-1, 2))
+        if len(row_ptr) != len(cams) + 1:          # assert!(cams.len() == obs.len())
+            raise L.City2baError(L.ERR_INVALID_ARGUMENT, "row_ptr must have n_cameras + 1 entries")
+        if len(pt_idx) != len(uv) or (len(row_ptr) and int(row_ptr[-1]) != len(pt_idx)):
+            raise L.City2baError(L.ERR_INVALID_ARGUMENT, "row_ptr[-1], pt_idx and uv disagree on n_obs")
+        fn = L.lib().c2b_problem_upload_bal if is_bal else L.lib().c2b_problem_upload
+        L.check(fn(self._h, len(cams), _ptr(cams), len(points), _ptr(points), _ptr(row_ptr), _ptr(pt_idx), _ptr(uv)))
+        self._row_ptr, self._pt_idx = row_ptr, pt_idx
+
+    # ---- counters (src/baproblem.rs:378-390) --------------------------------------------------
+    def _sizes(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().c2b_problem_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def num_cameras(self):
+        return self._sizes()[0]
+
+    def num_points(self):
+        return self._sizes()[1]
+
+    def num_observations(self):
+        return self._sizes()[2]
+
+    def __str__(self):   # Display, src/baproblem.rs:788-801
+        return "Bundle Adjustment Problem with %d cameras, %d points, and %d observations" % self._sizes()
+
+    # ---- data access -----------------------------------------------------------------------------
+    @property
+    def row_ptr(self):
+        return self._row_ptr
+
+    @property
+    def pt_idx(self):
+        return self._pt_idx
+
+    def cameras(self):
+        """in-memory SnavelyCamera records [n,15]"""
+        out = np.empty((self.num_cameras(), 15))
+        L.check(L.lib().c2b_problem_download(self._h, _ptr(out), None, None))
+        return out
+
+    def cameras_bal(self):
+        """SnavelyCamera::to_vec for every camera [n,9] (src/baproblem.rs:189-202)"""
+        out = np.empty((self.num_cameras(), 9))
+        L.check(L.lib().c2b_problem_download_bal(self._h, _ptr(out)))
+        return out
+
+    def points(self):
+        out = np.empty((self.num_points(), 3))
+        L.check(L.lib().c2b_problem_download(self._h, None, _ptr(out), None))
+        return out
+
+    def observations(self):
+        out = np.empty((self.num_observations(), 2))
+        L.check(L.lib().c2b_problem_download(self._h, None, None, _ptr(out)))
+        return out
+
+    # ---- hot path ------------------------------------------------------------------------------------
+    def project(self):
+        """camera.project(camera.project_world(point)) for every observation (src/baproblem.rs:272)."""
+        out = np.empty((self.num_observations(), 2))
+        L.check(L.lib().c2b_problem_project(self._h, _ptr(out)))
+        return out
+
+    def total_reprojection_error(self, norm):
+        """src/baproblem.rs:265-279"""
+        out = C.c_double()
+        L.check(L.lib().c2b_problem_total_reprojection_error(self._h, float(norm), C.byref(out)))
+        return out.value
+
+    def residual_jacobian(self):
+        """r [n,2], Jc [n,2,9] (w t f k1 k2 columns), Jp [n,2,3].  Build-defined: the reference has
+        no Jacobian."""
+        n = self.num_observations()
+        r, Jc, Jp = np.empty((n, 2)), np.empty((n, 2, 9)), np.empty((n, 2, 3))
+        L.check(L.lib().c2b_problem_residual_jacobian(self._h, _ptr(r), _ptr(Jc), _ptr(Jp)))
+        return r, Jc, Jp
+
+    def _stats(self):
+        s = np.empty(L.STATS_DOUBLES)
+        L.check(L.lib().c2b_problem_stats(self._h, _ptr(s)))
+        return s
+
+    def mean(self):          # src/baproblem.rs:282-289
+        return self._stats()[0:3].copy()
+
+    def std(self):           # src/baproblem.rs:292-304
+        return self._stats()[3:6].copy()
+
+    def extent(self):        # src/baproblem.rs:307-331
+        s = self._stats()
+        return s[6:9].copy(), s[9:12].copy()
+
+    def dimensions(self):    # src/baproblem.rs:334-337
+        return self._stats()[12:15].copy()
+
+    def drift_origin(self):
+        """element of centers ++ points closest to the world origin (src/noise.rs:75-87)"""
+        s = self._stats()
+        return s[15:18].copy(), int(s[18])
+
+    def visibility_pairs(self, cam_idx, pt_idx, max_dist):
+        """predicate of the generator loops (src/synthetic.rs:285-291; src/generate.rs:448-454)"""
+        cam_idx = np.ascontiguousarray(cam_idx, dtype=np.uint32)
+        pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint32)
+        n = len(cam_idx)
+        if len(pt_idx) != n:
+            raise L.City2baError(L.ERR_INVALID_ARGUMENT, "cam_idx and pt_idx differ in length")
+        uv = np.empty((n, 2))
+        keep = np.empty(n, dtype=np.uint8)
+        L.check(L.lib().c2b_problem_visibility_pairs(self._h, n, _ptr(cam_idx), _ptr(pt_idx), float(max_dist),
+                                                     _ptr(uv), _ptr(keep)))
+        return uv, keep

@@ -1,0 +1,265 @@
+// camera_math.hpp -- device-side Snavely/BAL camera algebra for gfx950.
+//
+// Compiled with -ffp-contract=off: everything the reference defines (projection, center,
+// transform, Rodrigues maps) is evaluated in the reference's operation order with separate
+// IEEE mul/add/div/sqrt so that it rounds like the Rust CPU path (Rust never contracts).
+// FMAs appear only where written explicitly (the build-defined Jacobian, Newton steps).
+//
+// Reference items restated: src/baproblem.rs:78-102 (Rodrigues maps), :141-175 (Camera
+// methods).  cgmath 0.17 semantics (column-major Matrix3, trace-method quaternion, cofactor
+// inverse, v * (1/|v|) normalisation) are the published algorithms of that crate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c2b {
+
+#define C2B_DEV __device__ __forceinline__
+
+constexpr int kCamBlk = 28;       // doubles per camblk record (C2B_CAMBLK_DOUBLES)
+constexpr int kCamHot = 24;       // leading doubles the per-observation kernels stage in LDS
+// camblk offsets
+constexpr int kR = 0, kT = 9, kIntr = 12, kJl = 15, kCenter = 24;
+
+constexpr double kEps = 2.220446049250313e-16;   // f64::EPSILON
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- small vector helpers (cgmath evaluation order) ----------------------------------
+C2B_DEV double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// col-major 3x3 (cam15 state): m[3*c + r]
+C2B_DEV void cm_mat_vec(const double *m, double x, double y, double z, double o[3]) {
+    o[0] = dot3(m[0], m[3], m[6], x, y, z);
+    o[1] = dot3(m[1], m[4], m[7], x, y, z);
+    o[2] = dot3(m[2], m[5], m[8], x, y, z);
+}
+
+// out = a * b, all col-major; out[c][r] = a.row(r) . b.col(c)
+C2B_DEV void cm_mat_mul(const double *a, const double *b, double *o) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            o[3 * c + r] = dot3(a[r], a[3 + r], a[6 + r], b[3 * c], b[3 * c + 1], b[3 * c + 2]);
+}
+
+// -(R^-1 t) with cgmath's Matrix3::invert (cross products / determinant), src/baproblem.rs:161-163
+C2B_DEV void cm_center(const double *m, double tx, double ty, double tz, double c[3]) {
+    const double m00 = m[0], m01 = m[1], m02 = m[2];   // column 0 (c, r)
+    const double m10 = m[3], m11 = m[4], m12 = m[5];   // column 1
+    const double m20 = m[6], m21 = m[7], m22 = m[8];   // column 2
+    const double det = m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02) +
+                       m20 * (m01 * m12 - m11 * m02);
+    // rows of the inverse: (c1 x c2)/det, (c2 x c0)/det, (c0 x c1)/det
+    const double a0 = (m11 * m22 - m12 * m21) / det, a1 = (m12 * m20 - m10 * m22) / det,
+                 a2 = (m10 * m21 - m11 * m20) / det;
+    const double b0 = (m21 * m02 - m22 * m01) / det, b1 = (m22 * m00 - m20 * m02) / det,
+                 b2 = (m20 * m01 - m21 * m00) / det;
+    const double c0 = (m01 * m12 - m02 * m11) / det, c1 = (m02 * m10 - m00 * m12) / det,
+                 c2 = (m00 * m11 - m01 * m10) / det;
+    c[0] = -dot3(a0, a1, a2, tx, ty, tz);
+    c[1] = -dot3(b0, b1, b2, tx, ty, tz);
+    c[2] = -dot3(c0, c1, c2, tx, ty, tz);
+}
+
+// Matrix3::from_axis_angle, col-major out
+C2B_DEV void cm_from_axis_angle(double ax, double ay, double az, double angle, double *o) {
+    double s, c;
+    sincos(angle, &s, &c);
+    const double k = 1.0 - c;
+    o[0] = k * ax * ax + c;       o[1] = k * ax * ay + s * az;  o[2] = k * ax * az - s * ay;
+    o[3] = k * ax * ay - s * az;  o[4] = k * ay * ay + c;       o[5] = k * ay * az + s * ax;
+    o[6] = k * ax * az + s * ay;  o[7] = k * ay * az - s * ax;  o[8] = k * az * az + c;
+}
+
+// From<Matrix3> for Quaternion (trace method); q = {s, x, y, z}; m col-major
+C2B_DEV void cm_quat_from_mat(const double *m, double q[4]) {
+    const double m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5],
+                 m20 = m[6], m21 = m[7], m22 = m[8];
+    const double trace = m00 + m11 + m22;
+    double w, x, y, z, s;
+    if (trace >= 0.0) {
+        s = sqrt(1.0 + trace);
+        w = 0.5 * s; s = 0.5 / s;
+        x = (m12 - m21) * s; y = (m20 - m02) * s; z = (m01 - m10) * s;
+    } else if (m00 > m11 && m00 > m22) {
+        s = sqrt((m00 - m11 - m22) + 1.0);
+        x = 0.5 * s; s = 0.5 / s;
+        y = (m10 + m01) * s; z = (m02 + m20) * s; w = (m12 - m21) * s;
+    } else if (m11 > m22) {
+        s = sqrt((m11 - m00 - m22) + 1.0);
+        y = 0.5 * s; s = 0.5 / s;
+        z = (m21 + m12) * s; x = (m10 + m01) * s; w = (m20 - m02) * s;
+    } else {
+        s = sqrt((m22 - m00 - m11) + 1.0);
+        z = 0.5 * s; s = 0.5 / s;
+        x = (m02 + m20) * s; y = (m21 + m12) * s; w = (m01 - m10) * s;
+    }
+    q[0] = w; q[1] = x; q[2] = y; q[3] = z;
+}
+
+// From<Quaternion> for Matrix3, col-major out
+C2B_DEV void cm_mat_from_quat(const double q[4], double *o) {
+    const double s = q[0], x = q[1], y = q[2], z = q[3];
+    const double x2 = x + x, y2 = y + y, z2 = z + z;
+    const double xx2 = x2 * x, xy2 = x2 * y, xz2 = x2 * z;
+    const double yy2 = y2 * y, yz2 = y2 * z, zz2 = z2 * z;
+    const double sy2 = y2 * s, sz2 = z2 * s, sx2 = x2 * s;
+    o[0] = 1.0 - yy2 - zz2; o[1] = xy2 + sz2;       o[2] = xz2 - sy2;
+    o[3] = xy2 - sz2;       o[4] = 1.0 - xx2 - zz2; o[5] = yz2 + sx2;
+    o[6] = xz2 + sy2;       o[7] = yz2 - sx2;       o[8] = 1.0 - xx2 - yy2;
+}
+
+// from_rodrigues, src/baproblem.rs:78-90
+C2B_DEV void from_rodrigues(double w0, double w1, double w2, double *Rcm) {
+    const double theta2 = dot3(w0, w1, w2, w0, w1, w2);
+    if (theta2 > kEps) {
+        const double angle = sqrt(theta2);
+        const double inv = 1.0 / angle;
+        cm_from_axis_angle(w0 * inv, w1 * inv, w2 * inv, angle, Rcm);
+    } else {
+        const double m[9] = {1.0, w2, -w1, -w2, 1.0, w0, w1, -w0, 1.0};
+        double q[4];
+        cm_quat_from_mat(m, q);
+        cm_mat_from_quat(q, Rcm);
+    }
+}
+
+// to_rodrigues, src/baproblem.rs:93-102
+C2B_DEV void to_rodrigues(const double *Rcm, double w[3]) {
+    double q[4];
+    cm_quat_from_mat(Rcm, q);
+    const double angle = 2.0 * acos(q[0]);
+    const double one_m = 1.0 - q[0] * q[0];
+    if (one_m < kEps) {
+        w[0] = w[1] = w[2] = 0.0;
+    } else {
+        const double d = sqrt(one_m);
+        const double ax = q[1] / d, ay = q[2] / d, az = q[3] / d;
+        const double inv = 1.0 / sqrt(dot3(ax, ay, az, ax, ay, az));
+        w[0] = (ax * inv) * angle; w[1] = (ay * inv) * angle; w[2] = (az * inv) * angle;
+    }
+}
+
+// Camera::transform, src/baproblem.rs:165-171 (new loc uses the OLD dir), in place on cam15
+C2B_DEV void transform_cam15(double *cam, const double *dRcm, double dx, double dy, double dz) {
+    double c[3], v[3], nr[9];
+    cm_center(cam, cam[9], cam[10], cam[11], c);
+    cm_mat_vec(cam, c[0] + dx, c[1] + dy, c[2] + dz, v);
+    cm_mat_mul(cam, dRcm, nr);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cam[i] = nr[i];
+    cam[9] = -1.0 * v[0]; cam[10] = -1.0 * v[1]; cam[11] = -1.0 * v[2];
+}
+
+// Left Jacobian of SO(3), J_l(w) = I + a [w]x + b [w]x^2 (row-major out).  Build-defined
+// (feeds the Jacobian's rotation columns); series below |w| = 0.1 to avoid cancellation.
+C2B_DEV void left_jacobian(double w0, double w1, double w2, double *J) {
+    const double t2 = (w0 * w0 + w1 * w1) + w2 * w2;
+    double a, b;
+    if (t2 < 1e-2) {
+        a = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800))));
+        b = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800))));
+    } else {
+        const double t = sqrt(t2);
+        double sh, ch, s, c;
+        sincos(0.5 * t, &sh, &ch);
+        sincos(t, &s, &c);
+        (void)ch; (void)c;
+        a = 2.0 * sh * sh / t2;
+        b = (t - s) / (t2 * t);
+    }
+    // K = [w]x ; K^2 = w w^T - t2 I
+    J[0] = 1.0 + b * (w0 * w0 - t2); J[1] = -a * w2 + b * w0 * w1;    J[2] = a * w1 + b * w0 * w2;
+    J[3] = a * w2 + b * w0 * w1;     J[4] = 1.0 + b * (w1 * w1 - t2); J[5] = -a * w0 + b * w1 * w2;
+    J[6] = -a * w1 + b * w0 * w2;    J[7] = a * w0 + b * w1 * w2;     J[8] = 1.0 + b * (w2 * w2 - t2);
+}
+
+// Fill one camblk record from the state (col-major R, t, intrin) and the Rodrigues vector the
+// Jacobian columns refer to.
+C2B_DEV void fill_camblk(const double *cam15, double w0, double w1, double w2, double *blk) {
+    // row-major R
+    blk[0] = cam15[0]; blk[1] = cam15[3]; blk[2] = cam15[6];
+    blk[3] = cam15[1]; blk[4] = cam15[4]; blk[5] = cam15[7];
+    blk[6] = cam15[2]; blk[7] = cam15[5]; blk[8] = cam15[8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) blk[9 + i] = cam15[9 + i];
+    left_jacobian(w0, w1, w2, blk + kJl);
+    double c[3];
+    cm_center(cam15, cam15[9], cam15[10], cam15[11], c);
+    blk[24] = c[0]; blk[25] = c[1]; blk[26] = c[2]; blk[27] = 0.0;
+}
+
+// ---- per-observation hot path ----------------------------------------------------------
+struct Proj {
+    double qx, qy, qz;     // camera-frame point  (project_world, src/baproblem.rs:141-143)
+    double px, py;         // -q.xy / q.z
+    double n, rad;         // |p|^2 and 1 + k1 n + k2 n^2
+    double u, v;           // pixel             (project, src/baproblem.rs:145-151)
+};
+
+// cam points at a camblk-shaped record (LDS or global).  |p|^4 is evaluated as n*n; the
+// reference writes magnitude().powf(4.0) (= pow(sqrt(n),4)), a <= 2.5 ulp different rounding
+// of the same value (libm pow is not reproducible across platforms anyway).
+C2B_DEV Proj project_obs(const double *cam, double X, double Y, double Z) {
+    Proj p;
+    p.qx = dot3(cam[0], cam[1], cam[2], X, Y, Z) + cam[9];
+    p.qy = dot3(cam[3], cam[4], cam[5], X, Y, Z) + cam[10];
+    p.qz = dot3(cam[6], cam[7], cam[8], X, Y, Z) + cam[11];
+    p.px = -p.qx / p.qz;
+    p.py = -p.qy / p.qz;
+    p.n = p.px * p.px + p.py * p.py;
+    p.rad = 1.0 + cam[13] * p.n + cam[14] * (p.n * p.n);
+    const double fr = cam[12] * p.rad;
+    p.u = fr * p.px;
+    p.v = fr * p.py;
+    return p;
+}
+
+// |x|^norm with the two norms the reference's callers use special-cased (exact for both).
+C2B_DEV double abs_pow(double x, double norm) {
+    const double a = fabs(x);
+    if (norm == 2.0) return a * a;
+    if (norm == 1.0) return a;
+    return pow(a, norm);
+}
+
+// ---- Philox4x32-10 + Box-Muller (build-defined draw scheme) -------------
+enum : uint32_t { kStreamDriftCam = 1, kStreamDriftPt = 2, kStreamNoiseCam = 3,
+                  kStreamNoisePt = 4, kStreamNoiseObs = 5 };
+
+C2B_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                           uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot,
+                         double &z0, double &z1) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), slot, stream, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), o);
+    const uint64_t a = ((uint64_t)o[1] << 32) | o[0];
+    const uint64_t b = ((uint64_t)o[3] << 32) | o[2];
+    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   // (0,1]
+    const double u2 = (double)(b >> 11) * 0x1.0p-53;         // [0,1)
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(6.283185307179586476925286766559 * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+}  // namespace c2b

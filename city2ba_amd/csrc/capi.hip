@@ -1,0 +1,700 @@
+// capi.hip -- the extern "C" boundary of include/city2ba_hip.h (gfx950 only).
+//
+// Level 0: stateless asynchronous launchers over device pointers.
+// Level 1: a BAProblem resident on one device, host buffers in / out, synchronous.
+#include "../../include/city2ba_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace c2b;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                           \
+    } while (0)
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)((n + b - 1) / b); }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// workspace layout: [0, kRedBlocks*kStatRec) stats records | then one partial per observation tile
+constexpr int64_t kWsStatsDoubles = (int64_t)kRedBlocks * kStatRec;
+
+}  // namespace
+
+extern "C" {
+
+const char *c2b_version(void) { return "city2ba_hip 0.1.0 (gfx950)"; }
+const char *c2b_last_error(void) { return g_err; }
+
+int c2b_device_count(int *count) {
+    if (!count) return fail(C2B_ERR_INVALID_ARGUMENT, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(C2B_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return C2B_OK;
+}
+
+int64_t c2b_workspace_bytes(int64_t n_obs) {
+    if (n_obs < 0) n_obs = 0;
+    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
+    return (kWsStatsDoubles + tiles + 16) * (int64_t)sizeof(double);
+}
+
+/* ------------------------------- level 0 --------------------------------------------- */
+
+int c2b_cameras_from_bal(const double *bal9, int64_t n, double *cam15, void *stream) {
+    if (n < 0 || (n && (!bal9 || !cam15))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_from_bal: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_cameras_from_bal, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), bal9, n, cam15);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_cameras_to_bal(const double *cam15, int64_t n, double *bal9, void *stream) {
+    if (n < 0 || (n && (!bal9 || !cam15))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_to_bal: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_cameras_to_bal, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n, bal9);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_cameras_prepare_state(const double *cam15, int64_t n, double *camblk, void *stream) {
+    if (n < 0 || (n && (!cam15 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_state: bad arguments");
+    if (!n) return C2B_OK;
+    if (!aligned16(camblk)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cameras_prepare<false>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n, camblk);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_cameras_prepare_bal(const double *bal9, int64_t n, double *camblk, void *stream) {
+    if (n < 0 || (n && (!bal9 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_bal: bad arguments");
+    if (!n) return C2B_OK;
+    if (!aligned16(camblk)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cameras_prepare<true>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), bal9, n, camblk);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_points_pad(const double *pts3, int64_t n, double *pts4, void *stream) {
+    if (n < 0 || (n && (!pts3 || !pts4))) return fail(C2B_ERR_INVALID_ARGUMENT, "points_pad: bad arguments");
+    if (!n) return C2B_OK;
+    if (!aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "pts4 must be 16-byte aligned");
+    hipLaunchKernelGGL(k_points_pad, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), pts3, n,
+                       reinterpret_cast<double4 *>(pts4));
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_points_unpad(const double *pts4, int64_t n, double *pts3, void *stream) {
+    if (n < 0 || (n && (!pts3 || !pts4))) return fail(C2B_ERR_INVALID_ARGUMENT, "points_unpad: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_points_unpad, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream),
+                       reinterpret_cast<const double4 *>(pts4), n, pts3);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_expand_rows(const uint64_t *row_ptr, int64_t n_cam, int64_t obs_base, int64_t n_obs,
+                    uint32_t *cam_idx, void *stream) {
+    if (n_cam < 0 || n_obs < 0 || obs_base < 0 || (n_obs && (!row_ptr || !cam_idx)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "expand_rows: bad arguments");
+    if (n_cam >= (int64_t)1 << 32) return fail(C2B_ERR_INVALID_ARGUMENT, "expand_rows: n_cam exceeds u32");
+    if (!n_obs) return C2B_OK;
+    hipLaunchKernelGGL(k_expand_rows, dim3(blocks_for(n_obs)), dim3(kBlock), 0, S(stream), row_ptr, n_cam,
+                       obs_base, n_obs, cam_idx);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+static int check_obs_args(const char *who, const void *camblk, const void *pts4, const void *cam_idx,
+                          const void *pt_idx, int64_t n) {
+    if (n < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: negative count", who);
+    if (n && (!camblk || !pts4 || !cam_idx || !pt_idx)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: NULL input", who);
+    if (n && (!aligned16(camblk) || !aligned16(pts4)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s: camblk/pts4 must be 16-byte aligned", who);
+    return C2B_OK;
+}
+
+int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                int64_t n_obs, double *uv_out, void *stream) {
+    int rc = check_obs_args("project", camblk, pts4, cam_idx, pt_idx, n_obs);
+    if (rc) return rc;
+    if (!n_obs) return C2B_OK;
+    if (!uv_out || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "project: uv_out NULL or misaligned");
+    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_observations<MODE_PROJECT>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_obs,
+                       tiles, 0.0, 0.0, reinterpret_cast<double2 *>(uv_out), (uint8_t *)nullptr, (double *)nullptr);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                               const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double norm,
+                               void *workspace, double *out_sum, void *stream) {
+    int rc = check_obs_args("reprojection_error_sum", camblk, pts4, cam_idx, pt_idx, n_obs);
+    if (rc) return rc;
+    if (!out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: out_sum is NULL");
+    if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
+    if (!uv_obs || !aligned16(uv_obs) || !workspace)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: uv_obs/workspace NULL or misaligned");
+    double *partials = reinterpret_cast<double *>(workspace) + kWsStatsDoubles;
+    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_observations<MODE_ERROR>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
+                       reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm, 0.0, (double2 *)nullptr,
+                       (uint8_t *)nullptr, partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, S(stream), partials, tiles, out_sum);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                          const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
+                          double *Jp, double norm, void *workspace, double *out_sum, void *stream) {
+    int rc = check_obs_args("residual_jacobian", camblk, pts4, cam_idx, pt_idx, n_obs);
+    if (rc) return rc;
+    if (!n_obs) {
+        if (out_sum) HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream)));
+        return C2B_OK;
+    }
+    if (!uv_obs || !r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: NULL buffer");
+    if (!aligned16(uv_obs) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: uv/r/Jc/Jp must be 16-byte aligned");
+    if (out_sum && !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: workspace is NULL");
+    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
+    double *partials = workspace ? reinterpret_cast<double *>(workspace) + kWsStatsDoubles : nullptr;
+    if (out_sum) {
+        hipLaunchKernelGGL(k_residual_jacobian<true>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
+                           reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
+                           reinterpret_cast<double2 *>(r), Jc, Jp, partials);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, S(stream), partials, tiles, out_sum);
+        LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_residual_jacobian<false>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
+                           reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
+                           reinterpret_cast<double2 *>(r), Jc, Jp, (double *)nullptr);
+        LAUNCH_CHECK();
+    }
+    return C2B_OK;
+}
+
+int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                         const uint32_t *pt_idx, int64_t n_pairs, double max_dist, double *uv_out,
+                         uint8_t *keep, void *stream) {
+    int rc = check_obs_args("visibility_pairs", camblk, pts4, cam_idx, pt_idx, n_pairs);
+    if (rc) return rc;
+    if (!n_pairs) return C2B_OK;
+    if (!uv_out || !keep || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_pairs: NULL/misaligned output");
+    const int64_t tiles = (n_pairs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_observations<MODE_VISIBILITY>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_pairs,
+                       tiles, 0.0, max_dist, reinterpret_cast<double2 *>(uv_out), keep, (double *)nullptr);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, void *workspace,
+              double *stats, void *stream) {
+    if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: bad arguments");
+    const int64_t n = n_cam + n_pts;
+    if (n == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: empty problem (the reference's fold1().unwrap() panics)");
+    if ((n_cam && !camblk) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: NULL input");
+    double *rec = reinterpret_cast<double *>(workspace);
+    int grid = (int)((n + kBlock - 1) / kBlock);
+    if (grid > kRedBlocks) grid = kRedBlocks;
+    const double4 *p4 = reinterpret_cast<const double4 *>(pts4);
+    hipLaunchKernelGGL(k_stats_pass1, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, rec);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_fold1, dim3(1), dim3(64), 0, S(stream), rec, grid, stats);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_pass2, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, stats, rec);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_fold2, dim3(1), dim3(64), 0, S(stream), rec, grid, n, stats);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_add_drift(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *origin,
+                  double strength, double angle_strength, double std, double dir_x, double dir_y, double dir_z,
+                  uint64_t seed, void *stream) {
+    if (n_cam < 0 || n_pts < 0 || !origin || (n_cam && !cam15) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift: bad arguments");
+    if (!(std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift: std must be >= 0 (rand's Normal::new panics)");
+    const int64_t n = n_cam + n_pts;
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_add_drift, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
+                       reinterpret_cast<double4 *>(pts4), n_pts, origin, strength, angle_strength, std, dir_x, dir_y,
+                       dir_z, (const double *)nullptr, seed);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_add_drift_normalized(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats,
+                             double strength, double angle_strength, double std, uint64_t seed, void *stream) {
+    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized: bad arguments");
+    if (!(std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized: std must be >= 0");
+    const int64_t n = n_cam + n_pts;
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_add_drift, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
+                       reinterpret_cast<double4 *>(pts4), n_pts, stats + 15, strength, angle_strength, std, 0.0, 0.0,
+                       0.0, stats, seed);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_add_noise_entities(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats,
+                           double translation_std, double rotation_std, double point_std, uint64_t seed,
+                           void *stream) {
+    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_entities: bad arguments");
+    if (!(translation_std >= 0.0) || !(rotation_std >= 0.0) || !(point_std >= 0.0))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise: standard deviations must be >= 0");
+    const int64_t n = n_cam + n_pts;
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_add_noise_entities, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
+                       reinterpret_cast<double4 *>(pts4), n_pts, stats, translation_std, rotation_std, point_std, seed);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_add_noise_observations(double *uv, int64_t n_obs, int64_t obs_base, double observations_std, uint64_t seed,
+                               void *stream) {
+    if (n_obs < 0 || obs_base < 0 || (n_obs && !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_observations: bad arguments");
+    if (!(observations_std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise: standard deviations must be >= 0");
+    if (!n_obs) return C2B_OK;
+    if (!aligned16(uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_observations: uv must be 16-byte aligned");
+    hipLaunchKernelGGL(k_add_noise_observations, dim3(blocks_for(n_obs)), dim3(kBlock), 0, S(stream),
+                       reinterpret_cast<double2 *>(uv), n_obs, obs_base, observations_std, seed);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_add_sin_noise(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats, double dir_x,
+                      double dir_y, double dir_z, double ndir_x, double ndir_y, double ndir_z, double strength,
+                      double frequency, void *stream) {
+    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "add_sin_noise: bad arguments");
+    const int64_t n = n_cam + n_pts;
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_add_sin_noise, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
+                       reinterpret_cast<double4 *>(pts4), n_pts, stats, dir_x, dir_y, dir_z, ndir_x, ndir_y, ndir_z,
+                       strength, frequency);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, int64_t *bounds) {
+    if (!row_ptr || !bounds || n_cam < 0 || n_parts < 1) return fail(C2B_ERR_INVALID_ARGUMENT, "partition_cameras: bad arguments");
+    const uint64_t total = row_ptr[n_cam];
+    bounds[0] = 0;
+    int64_t c = 0;
+    for (int k = 1; k < n_parts; ++k) {
+        // first camera whose prefix reaches k/n_parts of the observations
+        const uint64_t target = (uint64_t)(((__uint128_t)total * (unsigned)k) / (unsigned)n_parts);
+        int64_t lo = c, hi = n_cam;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (row_ptr[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        c = lo;
+        bounds[k] = c;
+    }
+    bounds[n_parts] = n_cam;
+    return C2B_OK;
+}
+
+/* ------------------------------- level 1 --------------------------------------------- */
+
+struct c2b_problem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n_cam = 0, n_pts = 0, n_obs = 0;
+    double *cam15 = nullptr, *bal9 = nullptr, *camblk = nullptr, *pts4 = nullptr, *uv = nullptr;
+    uint32_t *cam_idx = nullptr, *pt_idx = nullptr;
+    void *ws = nullptr;
+    double *stats = nullptr, *scalar = nullptr;
+    bool bal_valid = false;     // bal9 still describes the cameras (no mutation since upload_bal)
+    bool blk_valid = false;     // camblk matches cam15 (and bal_valid mode)
+};
+
+static void free_buffers(c2b_problem *p) {
+    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->cam15 = p->bal9 = p->camblk = p->pts4 = p->uv = nullptr;
+    p->cam_idx = p->pt_idx = nullptr;
+    p->ws = nullptr; p->stats = p->scalar = nullptr;
+    p->n_cam = p->n_pts = p->n_obs = 0;
+    p->bal_valid = p->blk_valid = false;
+}
+
+int c2b_problem_create(int device, c2b_problem **out) {
+    if (!out) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(C2B_ERR_NO_DEVICE, "problem_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_create: device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    c2b_problem *p = new (std::nothrow) c2b_problem();
+    if (!p) return fail(C2B_ERR_OOM, "problem_create: host allocation failed");
+    p->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete p; return fail(C2B_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = p;
+    return C2B_OK;
+}
+
+void c2b_problem_destroy(c2b_problem *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    free_buffers(p);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+static int ensure_camblk(c2b_problem *p) {
+    if (p->blk_valid) return C2B_OK;
+    int rc = p->bal_valid ? c2b_cameras_prepare_bal(p->bal9, p->n_cam, p->camblk, p->stream)
+                          : c2b_cameras_prepare_state(p->cam15, p->n_cam, p->camblk, p->stream);
+    if (rc) return rc;
+    p->blk_valid = true;
+    return C2B_OK;
+}
+
+static int upload_common(c2b_problem *p, int64_t n_cam, const double *cams, bool is_bal, int64_t n_pts,
+                         const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_upload: problem is NULL");
+    if (n_cam < 0 || n_pts < 0 || (n_cam && !cams) || (n_pts && !pts3) || !row_ptr)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_upload: bad arguments");
+    if (n_cam >= ((int64_t)1 << 32) || n_pts >= ((int64_t)1 << 32))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_upload: device indices are 32-bit");
+    // assert!(cams.len() == obs.len()) is structural here; row_ptr must be a monotone prefix
+    if (row_ptr[0] != 0) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_upload: row_ptr[0] != 0");
+    for (int64_t c = 0; c < n_cam; ++c)
+        if (row_ptr[c + 1] < row_ptr[c]) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_upload: row_ptr not monotone at camera %lld", (long long)c);
+    const int64_t n_obs = (int64_t)row_ptr[n_cam];
+    if (n_obs && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_upload: NULL observations");
+    std::vector<uint32_t> pi32((size_t)n_obs);
+    for (int64_t o = 0; o < n_obs; ++o) {
+        // assert!(ci < &points.len()), src/baproblem.rs:368
+        if (pt_idx[o] >= (uint64_t)n_pts)
+            return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "problem_upload: observation %lld refers to point %llu >= %lld",
+                        (long long)o, (unsigned long long)pt_idx[o], (long long)n_pts);
+        pi32[(size_t)o] = (uint32_t)pt_idx[o];
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    free_buffers(p);
+    auto dalloc = [&](void **q, size_t bytes) -> hipError_t { return hipMalloc(q, bytes ? bytes : 16); };
+    HIP_TRY(dalloc((void **)&p->cam15, sizeof(double) * 15 * n_cam));
+    HIP_TRY(dalloc((void **)&p->bal9, sizeof(double) * 9 * n_cam));
+    HIP_TRY(dalloc((void **)&p->camblk, sizeof(double) * kCamBlk * n_cam));
+    HIP_TRY(dalloc((void **)&p->pts4, sizeof(double) * 4 * n_pts));
+    HIP_TRY(dalloc((void **)&p->uv, sizeof(double) * 2 * n_obs));
+    HIP_TRY(dalloc((void **)&p->cam_idx, sizeof(uint32_t) * n_obs));
+    HIP_TRY(dalloc((void **)&p->pt_idx, sizeof(uint32_t) * n_obs));
+    HIP_TRY(dalloc(&p->ws, (size_t)c2b_workspace_bytes(n_obs)));
+    HIP_TRY(dalloc((void **)&p->stats, sizeof(double) * C2B_STATS_DOUBLES));
+    HIP_TRY(dalloc((void **)&p->scalar, sizeof(double) * 2));
+    p->n_cam = n_cam; p->n_pts = n_pts; p->n_obs = n_obs;
+
+    // staging through temporary device buffers (row_ptr, packed points)
+    uint64_t *d_row = nullptr;
+    double *d_p3 = nullptr;
+    HIP_TRY(dalloc((void **)&d_row, sizeof(uint64_t) * (n_cam + 1)));
+    hipError_t e = dalloc((void **)&d_p3, sizeof(double) * 3 * n_pts);
+    if (e != hipSuccess) { (void)hipFree(d_row); return fail(C2B_ERR_OOM, "problem_upload: %s", hipGetErrorString(e)); }
+    int rc = C2B_OK;
+    do {
+#define UP_TRY(expr) { hipError_t e2 = (expr); if (e2 != hipSuccess) { rc = fail(C2B_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e2)); break; } }
+        UP_TRY(hipMemcpyAsync(d_row, row_ptr, sizeof(uint64_t) * (n_cam + 1), hipMemcpyHostToDevice, p->stream));
+        if (n_pts) UP_TRY(hipMemcpyAsync(d_p3, pts3, sizeof(double) * 3 * n_pts, hipMemcpyHostToDevice, p->stream));
+        if (n_obs) {
+            UP_TRY(hipMemcpyAsync(p->pt_idx, pi32.data(), sizeof(uint32_t) * n_obs, hipMemcpyHostToDevice, p->stream));
+            UP_TRY(hipMemcpyAsync(p->uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, p->stream));
+        }
+        if (is_bal) {
+            if (n_cam) UP_TRY(hipMemcpyAsync(p->bal9, cams, sizeof(double) * 9 * n_cam, hipMemcpyHostToDevice, p->stream));
+            if ((rc = c2b_cameras_from_bal(p->bal9, n_cam, p->cam15, p->stream))) break;
+        } else {
+            if (n_cam) UP_TRY(hipMemcpyAsync(p->cam15, cams, sizeof(double) * 15 * n_cam, hipMemcpyHostToDevice, p->stream));
+        }
+        if ((rc = c2b_points_pad(d_p3, n_pts, p->pts4, p->stream))) break;
+        if ((rc = c2b_expand_rows(d_row, n_cam, 0, n_obs, p->cam_idx, p->stream))) break;
+        UP_TRY(hipStreamSynchronize(p->stream));
+#undef UP_TRY
+    } while (0);
+    (void)hipFree(d_row);
+    (void)hipFree(d_p3);
+    if (rc) return rc;
+    p->bal_valid = is_bal;
+    p->blk_valid = false;
+    return C2B_OK;
+}
+
+int c2b_problem_upload(c2b_problem *p, int64_t n_cam, const double *cams15, int64_t n_pts, const double *pts3,
+                       const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    return upload_common(p, n_cam, cams15, false, n_pts, pts3, row_ptr, pt_idx, uv);
+}
+
+int c2b_problem_upload_bal(c2b_problem *p, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
+                           const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    return upload_common(p, n_cam, bal9, true, n_pts, pts3, row_ptr, pt_idx, uv);
+}
+
+int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs) {
+    if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_sizes: problem is NULL");
+    if (n_cam) *n_cam = p->n_cam;
+    if (n_pts) *n_pts = p->n_pts;
+    if (n_obs) *n_obs = p->n_obs;
+    return C2B_OK;
+}
+
+#define NEED_UPLOADED(p, who)                                                              \
+    if (!(p)) return fail(C2B_ERR_INVALID_ARGUMENT, who ": problem is NULL");              \
+    if (!(p)->ws) return fail(C2B_ERR_INVALID_ARGUMENT, who ": nothing uploaded");         \
+    HIP_TRY(hipSetDevice((p)->device));
+
+int c2b_problem_download(c2b_problem *p, double *cams15, double *pts3, double *uv) {
+    NEED_UPLOADED(p, "problem_download");
+    if (cams15 && p->n_cam)
+        HIP_TRY(hipMemcpyAsync(cams15, p->cam15, sizeof(double) * 15 * p->n_cam, hipMemcpyDeviceToHost, p->stream));
+    if (uv && p->n_obs)
+        HIP_TRY(hipMemcpyAsync(uv, p->uv, sizeof(double) * 2 * p->n_obs, hipMemcpyDeviceToHost, p->stream));
+    double *d_p3 = nullptr;
+    if (pts3 && p->n_pts) {
+        HIP_TRY(hipMalloc((void **)&d_p3, sizeof(double) * 3 * p->n_pts));
+        int rc = c2b_points_unpad(p->pts4, p->n_pts, d_p3, p->stream);
+        if (rc) { (void)hipFree(d_p3); return rc; }
+        hipError_t e = hipMemcpyAsync(pts3, d_p3, sizeof(double) * 3 * p->n_pts, hipMemcpyDeviceToHost, p->stream);
+        if (e != hipSuccess) { (void)hipFree(d_p3); return fail(C2B_ERR_HIP, "download points: %s", hipGetErrorString(e)); }
+    }
+    hipError_t e = hipStreamSynchronize(p->stream);
+    if (d_p3) (void)hipFree(d_p3);
+    if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_download: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+int c2b_problem_download_bal(c2b_problem *p, double *bal9) {
+    NEED_UPLOADED(p, "problem_download_bal");
+    if (!bal9) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_download_bal: bal9 is NULL");
+    if (!p->n_cam) return C2B_OK;
+    if (!p->bal_valid) {
+        // to_vec (src/baproblem.rs:189-202) of the current state
+        int rc = c2b_cameras_to_bal(p->cam15, p->n_cam, p->bal9, p->stream);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(bal9, p->bal9, sizeof(double) * 9 * p->n_cam, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+}
+
+int c2b_problem_project(c2b_problem *p, double *uv_out) {
+    NEED_UPLOADED(p, "problem_project");
+    if (!p->n_obs) return C2B_OK;
+    if (!uv_out) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_project: uv_out is NULL");
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    double *d_uv = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_uv, sizeof(double) * 2 * p->n_obs));
+    rc = c2b_project(p->camblk, p->pts4, p->cam_idx, p->pt_idx, p->n_obs, d_uv, p->stream);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(uv_out, d_uv, sizeof(double) * 2 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
+    hipError_t e2 = hipStreamSynchronize(p->stream);
+    (void)hipFree(d_uv);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return fail(C2B_ERR_HIP, "problem_project: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return C2B_OK;
+}
+
+int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *out) {
+    NEED_UPLOADED(p, "problem_total_reprojection_error");
+    if (!out) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_error: out is NULL");
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    rc = c2b_reprojection_error_sum(p->camblk, p->pts4, p->cam_idx, p->pt_idx, p->uv, p->n_obs, norm, p->ws,
+                                    p->scalar, p->stream);
+    if (rc) return rc;
+    double sum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sum, p->scalar, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    *out = std::pow(sum, 1.0 / norm);          // .powf(1. / norm), src/baproblem.rs:278
+    return C2B_OK;
+}
+
+int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double *Jp) {
+    NEED_UPLOADED(p, "problem_residual_jacobian");
+    if (!p->n_obs) return C2B_OK;
+    if (!r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_residual_jacobian: NULL output");
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    double *d_r = nullptr, *d_Jc = nullptr, *d_Jp = nullptr;
+    hipError_t e = hipMalloc((void **)&d_r, sizeof(double) * 2 * p->n_obs);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_Jc, sizeof(double) * 18 * p->n_obs);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_Jp, sizeof(double) * 6 * p->n_obs);
+    if (e == hipSuccess) {
+        rc = c2b_residual_jacobian(p->camblk, p->pts4, p->cam_idx, p->pt_idx, p->uv, p->n_obs, d_r, d_Jc, d_Jp, 2.0,
+                                   nullptr, nullptr, p->stream);
+        if (!rc) {
+            e = hipMemcpyAsync(r, d_r, sizeof(double) * 2 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(Jc, d_Jc, sizeof(double) * 18 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(Jp, d_Jp, sizeof(double) * 6 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
+        }
+        hipError_t e2 = hipStreamSynchronize(p->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    if (d_r) (void)hipFree(d_r);
+    if (d_Jc) (void)hipFree(d_Jc);
+    if (d_Jp) (void)hipFree(d_Jp);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_residual_jacobian: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+static int compute_stats(c2b_problem *p) {
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    return c2b_stats(p->camblk, p->n_cam, p->pts4, p->n_pts, p->ws, p->stats, p->stream);
+}
+
+int c2b_problem_stats(c2b_problem *p, double *stats) {
+    NEED_UPLOADED(p, "problem_stats");
+    if (!stats) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_stats: stats is NULL");
+    int rc = compute_stats(p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stats, p->stats, sizeof(double) * C2B_STATS_DOUBLES, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+}
+
+int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                                 double max_dist, double *uv_out, uint8_t *keep) {
+    NEED_UPLOADED(p, "problem_visibility_pairs");
+    if (n_pairs < 0 || (n_pairs && (!cam_idx || !pt_idx || !uv_out || !keep)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_pairs: bad arguments");
+    if (!n_pairs) return C2B_OK;
+    for (int64_t i = 0; i < n_pairs; ++i)
+        if (cam_idx[i] >= (uint64_t)p->n_cam || pt_idx[i] >= (uint64_t)p->n_pts)
+            return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "problem_visibility_pairs: pair %lld out of range", (long long)i);
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    uint32_t *d_c = nullptr, *d_p = nullptr;
+    double *d_uv = nullptr;
+    uint8_t *d_k = nullptr;
+    hipError_t e = hipMalloc((void **)&d_c, sizeof(uint32_t) * n_pairs);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_p, sizeof(uint32_t) * n_pairs);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_uv, sizeof(double) * 2 * n_pairs);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_k, n_pairs);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, cam_idx, sizeof(uint32_t) * n_pairs, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_p, pt_idx, sizeof(uint32_t) * n_pairs, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) {
+        rc = c2b_visibility_pairs(p->camblk, p->pts4, d_c, d_p, n_pairs, max_dist, d_uv, d_k, p->stream);
+        if (!rc) {
+            e = hipMemcpyAsync(uv_out, d_uv, sizeof(double) * 2 * n_pairs, hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(keep, d_k, n_pairs, hipMemcpyDeviceToHost, p->stream);
+        }
+        hipError_t e2 = hipStreamSynchronize(p->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    if (d_c) (void)hipFree(d_c);
+    if (d_p) (void)hipFree(d_p);
+    if (d_uv) (void)hipFree(d_uv);
+    if (d_k) (void)hipFree(d_k);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_pairs: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+static void cameras_mutated(c2b_problem *p) { p->bal_valid = false; p->blk_valid = false; }
+
+int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength, double std, const double dir[3],
+                          uint64_t seed) {
+    NEED_UPLOADED(p, "problem_add_drift");
+    if (!dir) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_add_drift: dir is NULL");
+    int rc = compute_stats(p);
+    if (rc) return rc;
+    rc = c2b_add_drift(p->cam15, p->n_cam, p->pts4, p->n_pts, p->stats + 15, strength, angle_strength, std, dir[0],
+                       dir[1], dir[2], seed, p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+}
+
+int c2b_problem_add_drift_normalized(c2b_problem *p, double strength, double angle_strength, double std,
+                                     uint64_t seed) {
+    NEED_UPLOADED(p, "problem_add_drift_normalized");
+    int rc = compute_stats(p);
+    if (rc) return rc;
+    rc = c2b_add_drift_normalized(p->cam15, p->n_cam, p->pts4, p->n_pts, p->stats, strength, angle_strength, std, seed,
+                                  p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+}
+
+int c2b_problem_add_noise(c2b_problem *p, double translation_std, double rotation_std, double point_std,
+                          double observations_std, uint64_t seed) {
+    NEED_UPLOADED(p, "problem_add_noise");
+    int rc = compute_stats(p);
+    if (rc) return rc;
+    rc = c2b_add_noise_entities(p->cam15, p->n_cam, p->pts4, p->n_pts, p->stats, translation_std, rotation_std,
+                                point_std, seed, p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    rc = c2b_add_noise_observations(p->uv, p->n_obs, 0, observations_std, seed, p->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+}
+
+int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double noise_dir[3], double strength,
+                              double frequency) {
+    NEED_UPLOADED(p, "problem_add_sin_noise");
+    if (!dir || !noise_dir) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_add_sin_noise: NULL direction");
+    int rc = compute_stats(p);
+    if (rc) return rc;
+    rc = c2b_add_sin_noise(p->cam15, p->n_cam, p->pts4, p->n_pts, p->stats, dir[0], dir[1], dir[2], noise_dir[0],
+                           noise_dir[1], noise_dir[2], strength, frequency, p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,615 @@
+// kernels.hpp -- gfx950 kernels of the city2ba hot path (included by capi.hip only).
+//
+// Design (MI355X: 256 CUs / 8 XCDs, wave64, 160 KB LDS per CU, HBM-bound stores):
+//   * one observation per lane; 256-lane workgroups walk the camera-major observation list,
+//     so a workgroup touches a short contiguous run of cameras: their 192-B hot records are
+//     staged once in LDS and every lane reads its camera by ds_read broadcast;
+//   * point gather = two aligned 16-B loads from the padded [n][4] point table (L2/MALL
+//     resident: 47.5 MB at --blocks 128);
+//   * the 2x9 / 2x3 Jacobian blocks are transposed through wave-private LDS (144-B and 48-B
+//     lane strides are bank-conflict-free for ds_write_b128) and leave as 1-KiB-per-instruction
+//     contiguous global stores -- the kernel's 208 B/observation of output is what binds it
+//     to HBM;
+//   * tile -> workgroup map is XCD-aware: the 8 XCDs each stream a contiguous eighth of the
+//     observation list so that a camera's / point's neighbours hit the same 4 MiB L2;
+//   * reductions are wave shuffles -> LDS -> per-workgroup partial -> fixed-order second pass
+//     (no float atomics: run-to-run reproducible).
+#pragma once
+#include "camera_math.hpp"
+
+namespace c2b {
+
+constexpr int kBlock = 256;          // lanes per workgroup (4 waves)
+constexpr int kWaves = kBlock / 64;
+constexpr int kCamTile = 64;         // cameras staged in LDS per workgroup (12 KB)
+constexpr int kRedBlocks = 1024;     // grid of the entity reductions
+constexpr int kStatRec = 16;         // doubles per stats partial record
+
+// ---- XCD-aware tile map (bijective for any n_tiles; cdna guide T1) -----------------------
+C2B_DEV int64_t xcd_tile(int64_t bid, int64_t n_tiles) {
+    const int64_t q = n_tiles >> 3, r = n_tiles & 7;
+    const int64_t xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+C2B_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+C2B_DEV double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+C2B_DEV double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// ---- per-camera kernels ---------------------------------------------------------------------
+__global__ void k_cameras_from_bal(const double *__restrict__ bal9, int64_t n, double *__restrict__ cam15) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *b = bal9 + 9 * i;
+    double R[9];
+    from_rodrigues(b[0], b[1], b[2], R);
+    double *o = cam15 + 15 * i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[9 + k] = b[3 + k];
+}
+
+__global__ void k_cameras_to_bal(const double *__restrict__ cam15, int64_t n, double *__restrict__ bal9) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double c[15], w[3];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+    to_rodrigues(c, w);
+    double *o = bal9 + 9 * i;
+    o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[3 + k] = c[9 + k];
+}
+
+template <bool FROM_BAL>
+__global__ void k_cameras_prepare(const double *__restrict__ in, int64_t n, double *__restrict__ camblk) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double c[15], w[3], blk[kCamBlk];
+    if (FROM_BAL) {
+        const double *b = in + 9 * i;
+        w[0] = b[0]; w[1] = b[1]; w[2] = b[2];
+        from_rodrigues(w[0], w[1], w[2], c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[9 + k] = b[3 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) c[k] = in[15 * i + k];
+        to_rodrigues(c, w);
+    }
+    fill_camblk(c, w[0], w[1], w[2], blk);
+    double *o = camblk + (int64_t)kCamBlk * i;
+#pragma unroll
+    for (int k = 0; k < kCamBlk; ++k) o[k] = blk[k];
+}
+
+__global__ void k_points_pad(const double *__restrict__ p3, int64_t n, double4 *__restrict__ p4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    p4[i] = make_double4(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2], 0.0);
+}
+__global__ void k_points_unpad(const double4 *__restrict__ p4, int64_t n, double *__restrict__ p3) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double4 v = p4[i];
+    p3[3 * i] = v.x; p3[3 * i + 1] = v.y; p3[3 * i + 2] = v.z;
+}
+
+// cam_idx[o] = (first c with row_ptr[c] > o + base) - 1
+__global__ void k_expand_rows(const uint64_t *__restrict__ row_ptr, int64_t n_cam, int64_t base,
+                              int64_t n_obs, uint32_t *__restrict__ cam_idx) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_obs) return;
+    const uint64_t key = (uint64_t)(o + base);
+    int64_t lo = 0, hi = n_cam + 1;          // search in row_ptr[0..n_cam]
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (row_ptr[mid] > key) hi = mid; else lo = mid + 1;
+    }
+    cam_idx[o] = (uint32_t)(lo - 1);
+}
+
+// ---- camera staging: the run of cameras a tile touches -> LDS -----------------------------------
+// Returns the first camera of the tile; lanes whose camera falls outside the staged run read
+// global memory instead (unsorted cam_idx or > kCamTile cameras per tile: correct, just slower).
+C2B_DEV uint32_t stage_cameras(const double *__restrict__ camblk, const uint32_t *__restrict__ cam_idx,
+                               int64_t tile0, int64_t n, double *sCam, uint32_t &n_staged) {
+    const int64_t last = (tile0 + kBlock < n ? tile0 + kBlock : n) - 1;
+    const uint32_t c_first = __builtin_amdgcn_readfirstlane(cam_idx[tile0]);
+    const uint32_t c_last = __builtin_amdgcn_readfirstlane(cam_idx[last]);
+    uint32_t cnt = c_last >= c_first ? c_last - c_first + 1 : 1;
+    if (cnt > (uint32_t)kCamTile) cnt = kCamTile;
+    n_staged = cnt;
+    // kCamHot doubles = 12 x 16 B per camera
+    const int chunks = (int)cnt * (kCamHot / 2);
+    for (int ch = threadIdx.x; ch < chunks; ch += kBlock) {
+        const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
+        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+        *reinterpret_cast<double2 *>(sCam + k * kCamHot + 2 * j) = v;
+    }
+    return c_first;
+}
+
+// ---- project / error / visibility: the light per-observation kernels ----------------------------
+enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_observations(
+    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
+    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
+    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_tiles, double norm, double max_dist,
+    double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) double sCam[kCamTile * kCamHot];
+    __shared__ double sRed[kWaves];
+    const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
+    const int64_t tile0 = tile * kBlock;
+    const int64_t o = tile0 + threadIdx.x;
+    const bool valid = o < n;
+
+    uint32_t ci = 0, pi = 0;
+    if (valid) { ci = cam_idx[o]; pi = pt_idx[o]; }
+    double4 X = make_double4(0, 0, -1, 0);
+    if (valid) X = pts4[pi];
+
+    uint32_t n_staged;
+    const uint32_t c_first = stage_cameras(camblk, cam_idx, tile0, n, sCam, n_staged);
+    __syncthreads();
+
+    double e = 0.0;
+    if (valid) {
+        const uint32_t local = ci - c_first;
+        const bool in_lds = local < n_staged;
+        const double *cam = in_lds ? (sCam + local * kCamHot) : (camblk + (int64_t)ci * kCamBlk);
+        if (MODE == MODE_VISIBILITY) {
+            // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1
+            const double *g = camblk + (int64_t)ci * kCamBlk + kCenter;
+            const double dx = g[0] - X.x, dy = g[1] - X.y, dz = g[2] - X.z;
+            const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
+            const Proj p = project_obs(cam, X.x, X.y, X.z);
+            const bool front = dist < max_dist && p.qz <= 0.0;
+            const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
+            const double nan = __longlong_as_double(0x7ff8000000000000LL);
+            uv_out[o] = front ? make_double2(p.u, p.v) : make_double2(nan, nan);
+            keep[o] = k ? 1 : 0;
+        } else {
+            const Proj p = project_obs(cam, X.x, X.y, X.z);
+            if (MODE == MODE_PROJECT) {
+                uv_out[o] = make_double2(p.u, p.v);
+            } else {
+                const double2 ob = uv_obs[o];
+                e = abs_pow(p.u - ob.x, norm) + abs_pow(p.v - ob.y, norm);
+            }
+        }
+    }
+    if (MODE == MODE_ERROR) {
+        const double w = wave_sum(e);
+        if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[tile] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    }
+}
+
+// ---- residual + Jacobian (+ fused error partials) ------------------------------------------------
+// LDS per workgroup: cameras 12 KB + 4 wave-private transposition slabs of 9 KB = 48 KB
+//   -> 3 workgroups (12 waves) per CU.
+constexpr int kSlabBytes = 64 * 144;   // one wave's 64 x (2x9) doubles
+
+template <bool WITH_ERR>
+__global__ __launch_bounds__(kBlock) void k_residual_jacobian(
+    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
+    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
+    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_tiles, double norm,
+    double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
+    double *__restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) double sCam[kCamTile * kCamHot];
+    __shared__ __attribute__((aligned(16))) char sSlab[kWaves * kSlabBytes];
+    __shared__ double sRed[kWaves];
+
+    const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
+    const int64_t tile0 = tile * kBlock;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = tile0 + wave * 64;          // first observation of this wave
+    const int64_t o = wave0 + lane;
+    const bool valid = o < n;
+
+    uint32_t ci = 0, pi = 0;
+    double2 ob = make_double2(0, 0);
+    if (valid) { ci = cam_idx[o]; pi = pt_idx[o]; ob = uv_obs[o]; }
+    double4 X = make_double4(0, 0, -1, 0);
+    if (valid) X = pts4[pi];
+
+    uint32_t n_staged;
+    const uint32_t c_first = stage_cameras(camblk, cam_idx, tile0, n, sCam, n_staged);
+    __syncthreads();
+
+    const uint32_t local = ci - c_first;
+    const double *cam = (valid && local < n_staged) ? (sCam + local * kCamHot)
+                                                    : (camblk + (int64_t)ci * kCamBlk);
+    const Proj p = project_obs(cam, X.x, X.y, X.z);
+    const double r0 = p.u - ob.x, r1 = p.v - ob.y;
+
+    // ---- Jacobian (explicit FMAs; no reference arithmetic to mirror) ----
+    const double f = cam[12], k1 = cam[13], k2 = cam[14];
+    // -1/z by v_rcp_f64 + two Newton steps (~full precision, cheaper than an IEEE divide)
+    double iz = __builtin_amdgcn_rcp(p.qz);
+    iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
+    iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
+    const double s = -f * iz;                                   // f * (-1/z)
+    const double c = fma(4.0 * k2, p.n, 2.0 * k1);              // d rad / d n * 2
+    const double cpx = c * p.px;
+    const double B00 = fma(cpx, p.px, p.rad), B01 = cpx * p.py, B11 = fma(c * p.py, p.py, p.rad);
+    const double g = fma(c, p.n, p.rad);
+    const double a00 = s * B00, a01 = s * B01, a02 = s * p.px * g;
+    const double a10 = s * B01, a11 = s * B11, a12 = s * p.py * g;
+    // y = R X  (= q - t)
+    const double yx = p.qx - cam[9], yy = p.qy - cam[10], yz = p.qz - cam[11];
+    // v_i = y x a_i ;  Jw_i = v_i^T J_l
+    const double v0x = fma(yy, a02, -yz * a01), v0y = fma(yz, a00, -yx * a02), v0z = fma(yx, a01, -yy * a00);
+    const double v1x = fma(yy, a12, -yz * a11), v1y = fma(yz, a10, -yx * a12), v1z = fma(yx, a11, -yy * a10);
+    const double *Jl = cam + kJl;
+    double jc[18], jp[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        jc[j] = fma(v0z, Jl[6 + j], fma(v0y, Jl[3 + j], v0x * Jl[j]));
+        jc[9 + j] = fma(v1z, Jl[6 + j], fma(v1y, Jl[3 + j], v1x * Jl[j]));
+        jp[j] = fma(a02, cam[6 + j], fma(a01, cam[3 + j], a00 * cam[j]));
+        jp[3 + j] = fma(a12, cam[6 + j], fma(a11, cam[3 + j], a10 * cam[j]));
+    }
+    jc[3] = a00; jc[4] = a01; jc[5] = a02;
+    jc[12] = a10; jc[13] = a11; jc[14] = a12;
+    const double fn = f * p.n, fnn = fn * p.n;
+    jc[6] = p.rad * p.px;  jc[15] = p.rad * p.py;
+    jc[7] = fn * p.px;     jc[16] = fn * p.py;
+    jc[8] = fnn * p.px;    jc[17] = fnn * p.py;
+
+    // ---- residual: 16 B per lane, already coalesced ----
+    if (valid) r_out[o] = make_double2(r0, r1);
+
+    // ---- transpose through the wave-private slab, leave as contiguous 1-KiB stores ----
+    char *slab = sSlab + wave * kSlabBytes;
+    const int64_t n_wave = n - wave0 < 64 ? (n - wave0 > 0 ? n - wave0 : 0) : 64;  // valid lanes
+    {
+        double2 *w = reinterpret_cast<double2 *>(slab + lane * 144);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] = make_double2(jc[2 * k], jc[2 * k + 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        char *dst = reinterpret_cast<char *>(Jc) + wave0 * 144;
+        const int64_t bytes = n_wave * 144;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int off = (k * 64 + lane) * 16;
+            const double2 v = *reinterpret_cast<const double2 *>(slab + off);
+            if (off < bytes) *reinterpret_cast<double2 *>(dst + off) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+        double2 *w = reinterpret_cast<double2 *>(slab + lane * 48);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] = make_double2(jp[2 * k], jp[2 * k + 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        char *dst = reinterpret_cast<char *>(Jp) + wave0 * 48;
+        const int64_t bytes = n_wave * 48;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int off = (k * 64 + lane) * 16;
+            const double2 v = *reinterpret_cast<const double2 *>(slab + off);
+            if (off < bytes) *reinterpret_cast<double2 *>(dst + off) = v;
+        }
+    }
+
+    if (WITH_ERR) {
+        const double e = valid ? abs_pow(r0, norm) + abs_pow(r1, norm) : 0.0;
+        const double w = wave_sum(e);
+        if (lane == 0) sRed[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[tile] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    }
+}
+
+// fixed-order sum of n partials by one 1024-lane workgroup
+__global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ partials, int64_t n,
+                                                      double *__restrict__ out) {
+    __shared__ double sRed[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += partials[i];
+    const double w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sRed[i];
+        out[0] = t;
+    }
+}
+
+// ---- stats over camera centers ++ points ------------------------------------------------------------
+// record: [0..2] sum(x/num) | [3..5] min | [6..8] max | [9] best dist | [10] best index | [11..13] best xyz
+C2B_DEV void entity_xyz(const double *__restrict__ camblk, int64_t n_cam, const double4 *__restrict__ pts4,
+                        int64_t i, double &x, double &y, double &z) {
+    if (i < n_cam) {
+        const double *c = camblk + i * kCamBlk + kCenter;
+        x = c[0]; y = c[1]; z = c[2];
+    } else {
+        const double4 p = pts4[i - n_cam];
+        x = p.x; y = p.y; z = p.z;
+    }
+}
+
+// closest to origin with fold1's semantics (src/noise.rs:80-86): strict <, ties -> later index
+C2B_DEV void argmin_merge(double &bd, double &bi, double &bx, double &by, double &bz, double d,
+                          double i, double x, double y, double z) {
+    const bool take = (bi < 0.0) || (i >= 0.0 && (d < bd || (d == bd && i > bi)));
+    if (take) { bd = d; bi = i; bx = x; by = y; bz = z; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_stats_pass1(const double *__restrict__ camblk, int64_t n_cam,
+                                                       const double4 *__restrict__ pts4, int64_t n_pts,
+                                                       double *__restrict__ rec) {
+    __shared__ double sh[kWaves][kStatRec];
+    const int64_t n = n_cam + n_pts;
+    const double num = (double)n;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double s0 = 0, s1 = 0, s2 = 0, mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
+    double bd = 0, bi = -1.0, bx = 0, by = 0, bz = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double x, y, z;
+        entity_xyz(camblk, n_cam, pts4, i, x, y, z);
+        s0 += x / num; s1 += y / num; s2 += z / num;
+        mn0 = fmin(mn0, x); mn1 = fmin(mn1, y); mn2 = fmin(mn2, z);
+        mx0 = fmax(mx0, x); mx1 = fmax(mx1, y); mx2 = fmax(mx2, z);
+        const double d = sqrt(dot3(x, y, z, x, y, z));
+        argmin_merge(bd, bi, bx, by, bz, d, (double)i, x, y, z);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    mn0 = wave_min(mn0); mn1 = wave_min(mn1); mn2 = wave_min(mn2);
+    mx0 = wave_max(mx0); mx1 = wave_max(mx1); mx2 = wave_max(mx2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double d = __shfl_down(bd, off, 64), i = __shfl_down(bi, off, 64);
+        const double x = __shfl_down(bx, off, 64), y = __shfl_down(by, off, 64), z = __shfl_down(bz, off, 64);
+        argmin_merge(bd, bi, bx, by, bz, d, i, x, y, z);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        double *o = sh[wave];
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = mn0; o[4] = mn1; o[5] = mn2;
+        o[6] = mx0; o[7] = mx1; o[8] = mx2; o[9] = bd; o[10] = bi; o[11] = bx; o[12] = by; o[13] = bz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = rec + (int64_t)blockIdx.x * kStatRec;
+        double t[kStatRec];
+#pragma unroll
+        for (int k = 0; k < kStatRec; ++k) t[k] = sh[0][k];
+        for (int w = 1; w < kWaves; ++w) {
+            t[0] += sh[w][0]; t[1] += sh[w][1]; t[2] += sh[w][2];
+            for (int k = 3; k < 6; ++k) t[k] = fmin(t[k], sh[w][k]);
+            for (int k = 6; k < 9; ++k) t[k] = fmax(t[k], sh[w][k]);
+            argmin_merge(t[9], t[10], t[11], t[12], t[13], sh[w][9], sh[w][10], sh[w][11], sh[w][12], sh[w][13]);
+        }
+#pragma unroll
+        for (int k = 0; k < kStatRec; ++k) o[k] = t[k];
+    }
+}
+
+// single workgroup: fold the per-workgroup records -> stats[0..2]=mean, [6..8]=min, [9..11]=max,
+// [12..14]=dim, [15..17]=origin, [18]=origin index
+__global__ __launch_bounds__(64) void k_stats_fold1(const double *__restrict__ rec, int n_rec,
+                                                   double *__restrict__ stats) {
+    if (threadIdx.x != 0) return;
+    double t[kStatRec];
+    for (int k = 0; k < kStatRec; ++k) t[k] = rec[k];
+    for (int b = 1; b < n_rec; ++b) {
+        const double *r = rec + (int64_t)b * kStatRec;
+        t[0] += r[0]; t[1] += r[1]; t[2] += r[2];
+        for (int k = 3; k < 6; ++k) t[k] = fmin(t[k], r[k]);
+        for (int k = 6; k < 9; ++k) t[k] = fmax(t[k], r[k]);
+        argmin_merge(t[9], t[10], t[11], t[12], t[13], r[9], r[10], r[11], r[12], r[13]);
+    }
+    for (int k = 0; k < 3; ++k) {
+        stats[k] = t[k];
+        stats[6 + k] = t[3 + k];
+        stats[9 + k] = t[6 + k];
+        stats[12 + k] = t[6 + k] - t[3 + k];
+        stats[15 + k] = t[11 + k];
+    }
+    stats[18] = t[10];
+}
+
+__global__ __launch_bounds__(kBlock) void k_stats_pass2(const double *__restrict__ camblk, int64_t n_cam,
+                                                       const double4 *__restrict__ pts4, int64_t n_pts,
+                                                       const double *__restrict__ stats, double *__restrict__ rec) {
+    __shared__ double sh[kWaves][3];
+    const int64_t n = n_cam + n_pts;
+    const double m0 = stats[0], m1 = stats[1], m2 = stats[2];
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double x, y, z;
+        entity_xyz(camblk, n_cam, pts4, i, x, y, z);
+        s0 += (x - m0) * (x - m0); s1 += (y - m1) * (y - m1); s2 += (z - m2) * (z - m2);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[wave][0] = s0; sh[wave][1] = s1; sh[wave][2] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = rec + (int64_t)blockIdx.x * kStatRec;
+        for (int k = 0; k < 3; ++k) o[k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_stats_fold2(const double *__restrict__ rec, int n_rec, int64_t n_ent,
+                                                   double *__restrict__ stats) {
+    if (threadIdx.x != 0) return;
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int b = 0; b < n_rec; ++b) {
+        const double *r = rec + (int64_t)b * kStatRec;
+        t0 += r[0]; t1 += r[1]; t2 += r[2];
+    }
+    const double num = (double)n_ent;
+    const double a = sqrt(t0 / num), b = sqrt(t1 / num), c = sqrt(t2 / num);
+    stats[3] = a; stats[4] = b; stats[5] = c;
+    stats[19] = sqrt(dot3(a, b, c, a, b, c));            // |std()|  (InnerSpace::magnitude)
+}
+
+// ---- noise kernels -------------------------------------------------------------------------------------
+// add_drift, src/noise.rs:68-116.  One lane per entity (cameras first, then points).
+__global__ __launch_bounds__(kBlock) void k_add_drift(double *__restrict__ cam15, int64_t n_cam,
+                                                     double4 *__restrict__ pts4, int64_t n_pts,
+                                                     const double *__restrict__ origin, double strength,
+                                                     double angle_strength, double std, double dx, double dy,
+                                                     double dz, const double *__restrict__ stats_norm,
+                                                     uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_cam + n_pts) return;
+    if (stats_norm) {
+        // add_drift_normalized, src/noise.rs:47-56: dir = std().normalize(), strength *= |std()|
+        const double s0 = stats_norm[3], s1 = stats_norm[4], s2 = stats_norm[5];
+        const double mag = sqrt(dot3(s0, s1, s2, s0, s1, s2));
+        const double inv = 1.0 / mag;
+        dx = s0 * inv; dy = s1 * inv; dz = s2 * inv;
+        strength = strength * mag;
+    }
+    const double ox = origin[0], oy = origin[1], oz = origin[2];
+    if (i < n_cam) {
+        double c[15], ctr[3], z0, z1, dR[9];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+        cm_center(c, c[9], c[10], c[11], ctr);
+        const double ex = ctr[0] - ox, ey = ctr[1] - oy, ez = ctr[2] - oz;
+        const double distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+        normal_pair(seed, kStreamDriftCam, (uint64_t)i, 0, z0, z1);
+        const double va = 1.0 + std * z0;             // angle draw first (src/noise.rs:104-107)
+        const double vt = 1.0 + std * z1;
+        const double angle = angle_strength * va * pow(distance, 1.2);
+        double sn, cs;
+        sincos(angle, &sn, &cs);
+        dR[0] = 1; dR[1] = 0; dR[2] = 0; dR[3] = 0; dR[4] = cs; dR[5] = sn; dR[6] = 0; dR[7] = -sn; dR[8] = cs;
+        transform_cam15(c, dR, dx * strength * vt * distance * distance,
+                        dy * strength * vt * distance * distance, dz * strength * vt * distance * distance);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+    } else {
+        const int64_t j = i - n_cam;
+        double4 p = pts4[j];
+        const double ex = p.x - ox, ey = p.y - oy, ez = p.z - oz;
+        const double distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+        double z0, z1;
+        normal_pair(seed, kStreamDriftPt, (uint64_t)j, 0, z0, z1);
+        const double v = 1.0 + std * z0;
+        p.x = p.x + dx * strength * v * distance * distance;
+        p.y = p.y + dy * strength * v * distance * distance;
+        p.z = p.z + dz * strength * v * distance * distance;
+        pts4[j] = p;
+    }
+}
+
+// add_noise cameras + points, src/noise.rs:129-150
+__global__ __launch_bounds__(kBlock) void k_add_noise_entities(double *__restrict__ cam15, int64_t n_cam,
+                                                              double4 *__restrict__ pts4, int64_t n_pts,
+                                                              const double *__restrict__ stats,
+                                                              double translation_std, double rotation_std,
+                                                              double point_std, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_cam + n_pts) return;
+    if (i < n_cam) {
+        const double bal_std = stats[19];
+        double c[15], a0, a1, a2, rot, b0, b1, b2, tr, dR[9];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 0, a0, a1);
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 1, a2, rot);
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 2, b0, b1);
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 3, b2, tr);
+        const double ia = 1.0 / sqrt(dot3(a0, a1, a2, a0, a1, a2));
+        const double ib = 1.0 / sqrt(dot3(b0, b1, b2, b0, b1, b2));
+        const double ang = 0.0 + rotation_std * rot;
+        const double t = 0.0 + translation_std * tr;
+        cm_from_axis_angle(a0 * ia, a1 * ia, a2 * ia, ang, dR);
+        transform_cam15(c, dR, (b0 * ib) * bal_std * t, (b1 * ib) * bal_std * t, (b2 * ib) * bal_std * t);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+    } else {
+        const int64_t j = i - n_cam;
+        double a0, a1, a2, m;
+        normal_pair(seed, kStreamNoisePt, (uint64_t)j, 0, a0, a1);
+        normal_pair(seed, kStreamNoisePt, (uint64_t)j, 1, a2, m);
+        const double ia = 1.0 / sqrt(dot3(a0, a1, a2, a0, a1, a2));
+        const double mm = 0.0 + point_std * m;
+        double4 p = pts4[j];
+        p.x = p.x + (a0 * ia) * mm; p.y = p.y + (a1 * ia) * mm; p.z = p.z + (a2 * ia) * mm;
+        pts4[j] = p;
+    }
+}
+
+// add_noise observations, src/noise.rs:152-170
+__global__ __launch_bounds__(kBlock) void k_add_noise_observations(double2 *__restrict__ uv, int64_t n,
+                                                                  int64_t obs_base, double observations_std,
+                                                                  uint64_t seed) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= n) return;
+    double nx, ny, z, unused;
+    normal_pair(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 0, nx, ny);
+    normal_pair(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 1, z, unused);
+    const double m = sqrt(nx * nx + ny * ny);
+    const double r = 0.0 + observations_std * z;
+    double2 v = uv[o];
+    v.x = v.x + nx / m * r;
+    v.y = v.y + ny / m * r;
+    uv[o] = v;
+}
+
+// add_sin_noise, src/noise.rs:388-416
+__global__ __launch_bounds__(kBlock) void k_add_sin_noise(double *__restrict__ cam15, int64_t n_cam,
+                                                         double4 *__restrict__ pts4, int64_t n_pts,
+                                                         const double *__restrict__ stats, double dx, double dy,
+                                                         double dz, double nx, double ny, double nz,
+                                                         double strength, double frequency) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_cam + n_pts) return;
+    double d0 = stats[12], d1 = stats[13], d2 = stats[14];
+    if (d0 == 0.0) d0 = 1e-8;
+    if (d1 == 0.0) d1 = 1e-8;
+    if (d2 == 0.0) d2 = 1e-8;
+    const double inv = 1.0 / sqrt(dot3(nx, ny, nz, nx, ny, nz));
+    nx *= inv; ny *= inv; nz *= inv;
+    if (i < n_cam) {
+        double c[15], ctr[3];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+        cm_center(c, c[9], c[10], c[11], ctr);
+        const double s = sin(dot3(ctr[0] / d0, ctr[1] / d1, ctr[2] / d2, dx, dy, dz) * frequency * kPi) * strength;
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        transform_cam15(c, I, nx * s, ny * s, nz * s);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+    } else {
+        const int64_t j = i - n_cam;
+        double4 p = pts4[j];
+        const double s = sin(dot3(p.x / d0, p.y / d1, p.z / d2, dx, dy, dz) * frequency * kPi) * strength;
+        p.x = p.x + nx * s; p.y = p.y + ny * s; p.z = p.z + nz * s;
+        pts4[j] = p;
+    }
+}
+
+}  // namespace c2b

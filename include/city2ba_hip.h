@@ -1,0 +1,178 @@
+/*
+ * city2ba_hip.h -- C ABI of the MI355X (gfx950) hot path of city2ba.
+ *
+ * The reference (tkonolige/city2ba, Rust) has no FFI seam for this path; its extension
+ * points are `trait Camera` (src/baproblem.rs:107-125), the inherent methods of
+ * `BAProblem<C>` (src/baproblem.rs:262-390) and the free functions of src/noise.rs.
+ * Per-point trait calls are far too fine-grained for a device, so this ABI is batched at
+ * BAProblem-method / noise-function granularity.  Each entry point names the reference
+ * item it replaces.  A Rust host binds these with a plain `extern "C"` block
+ * (INTEGRATION.md shows it); nothing here mentions torch, C++ or HIP types.
+ *
+ * Data conventions (all little-endian host order, f64 unless noted)
+ *   cam15   SnavelyCamera in memory (src/baproblem.rs:130-138):
+ *           dir as 9 doubles COLUMN-major (cgmath Matrix3 `as_ref::<[f64;9]>()`),
+ *           loc (t) 3, intrin (f,k1,k2) 3.
+ *   bal9    SnavelyCamera::to_vec order (src/baproblem.rs:189-202): w0 w1 w2 t0 t1 t2 f k1 k2.
+ *   pts3    packed Point3<f64> [n][3];   pts4 = device copy padded to [n][4] (32-B rows,
+ *           one aligned 2x16-B gather per observation).
+ *   CSR     vis_graph: Vec<Vec<(usize,(f64,f64))>> (src/baproblem.rs:256-260) flattened
+ *           camera-major: row_ptr[n_cam+1] (u64), pt_idx[n_obs] (u64 host / u32 device),
+ *           uv[n_obs][2].  cam_idx[n_obs] (u32) is the COO expansion of row_ptr, i.e. the
+ *           camera column of a .bal observation line (src/baproblem.rs:718-722).
+ *   camblk  derived per-camera record, C2B_CAMBLK_DOUBLES doubles:
+ *           R row-major[9] | t[3] | f,k1,k2 | J_l(w) row-major[9] | center[3] | pad.
+ *   Jacobian (NOT in the reference; build-defined): residual r = project(project_world(X))
+ *           - uv_obs (sign of src/baproblem.rs:273).  Jc[n_obs][2][9] row-major, columns in
+ *           to_vec order (w0 w1 w2 t0 t1 t2 f k1 k2); Jp[n_obs][2][3] (d/dX).
+ *
+ * Every function returns C2B_OK or a negative status; c2b_last_error() gives the text.
+ * No exception or abort crosses this boundary.  A context/problem is not thread-safe.
+ */
+#ifndef CITY2BA_HIP_H
+#define CITY2BA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C2B_OK                       0
+#define C2B_ERR_INVALID_ARGUMENT    -1
+#define C2B_ERR_INDEX_OUT_OF_RANGE  -2  /* the asserts of src/baproblem.rs:345-346, 365-369 */
+#define C2B_ERR_HIP                 -3
+#define C2B_ERR_OOM                 -4
+#define C2B_ERR_NO_DEVICE           -5
+
+#define C2B_CAMBLK_DOUBLES 28
+#define C2B_STATS_DOUBLES  20  /* mean[3] std[3] min[3] max[3] dim[3] origin[3] origin_idx |std| */
+
+const char *c2b_version(void);
+const char *c2b_last_error(void);
+int c2b_device_count(int *count);
+
+/* ===================================================================================== *
+ * Level 0 -- stateless launchers.  Every pointer is a DEVICE pointer, every call is
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ * ===================================================================================== */
+
+/* bytes of scratch the reductions below need for a problem with n_obs observations */
+int64_t c2b_workspace_bytes(int64_t n_obs);
+
+/* SnavelyCamera::from_vec / from_rodrigues (src/baproblem.rs:78-90, 180-186) */
+int c2b_cameras_from_bal(const double *bal9, int64_t n_cam, double *cam15, void *stream);
+/* SnavelyCamera::to_vec / to_rodrigues (src/baproblem.rs:93-102, 189-202) */
+int c2b_cameras_to_bal(const double *cam15, int64_t n_cam, double *bal9, void *stream);
+/* derive camblk from the in-memory state; Jacobian columns refer to w = to_rodrigues(R) */
+int c2b_cameras_prepare_state(const double *cam15, int64_t n_cam, double *camblk, void *stream);
+/* derive camblk from 9-vectors; R = from_rodrigues(w), Jacobian columns refer to that w */
+int c2b_cameras_prepare_bal(const double *bal9, int64_t n_cam, double *camblk, void *stream);
+/* pts3 [n][3] -> pts4 [n][4] and back */
+int c2b_points_pad(const double *pts3, int64_t n_pts, double *pts4, void *stream);
+int c2b_points_unpad(const double *pts4, int64_t n_pts, double *pts3, void *stream);
+/* COO expansion of row_ptr: cam_idx[o] = c  iff  row_ptr[c] <= o + obs_base < row_ptr[c+1] */
+int c2b_expand_rows(const uint64_t *row_ptr, int64_t n_cam, int64_t obs_base, int64_t n_obs,
+                    uint32_t *cam_idx, void *stream);
+
+/* Camera::project(Camera::project_world(p)) per observation (src/baproblem.rs:141-151, :272) */
+int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                const uint32_t *pt_idx, int64_t n_obs, double *uv_out, void *stream);
+
+/* Sum over observations of |du|^norm + |dv|^norm, i.e. BAProblem::total_reprojection_error
+ * (src/baproblem.rs:265-279) WITHOUT the final powf(1/norm): the quantity that is
+ * all-reduced across GPUs.  Deterministic two-pass tree (no float atomics). */
+int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                               const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                               double norm, void *workspace, double *out_sum, void *stream);
+
+/* residual + 2x9 camera block + 2x3 point block per observation (no reference equivalent),
+ * fused with the error sum above when out_sum != NULL (pass NULL to skip). */
+int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                          const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                          double *r, double *Jc, double *Jp,
+                          double norm, void *workspace, double *out_sum, void *stream);
+
+/* visibility predicate of the generators (src/synthetic.rs:285-291, 368-375;
+ * src/generate.rs:448-454): keep = |center - p| < max_dist && q.z <= 0 && |u|,|v| <= 1.
+ * uv_out is NaN where project() was not reached. */
+int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                         const uint32_t *pt_idx, int64_t n_pairs, double max_dist,
+                         double *uv_out, uint8_t *keep, void *stream);
+
+/* BAProblem::mean/std/extent/dimensions (src/baproblem.rs:282-337) + add_drift's origin
+ * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES]. */
+int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
+              void *workspace, double *stats, void *stream);
+
+/* noise::add_drift (src/noise.rs:68-116), in place.  `origin` = device pointer to 3 doubles
+ * (stats + 15).  Draws: Philox4x32-10 keyed by (seed; stream, entity, slot) -- the reference
+ * is unseeded, see DESIGN.md. */
+int c2b_add_drift(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *origin,
+                  double strength, double angle_strength, double std, double dir_x, double dir_y,
+                  double dir_z, uint64_t seed, void *stream);
+/* noise::add_drift_normalized (src/noise.rs:47-56): dir and scale come from stats (device) */
+int c2b_add_drift_normalized(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts,
+                             const double *stats, double strength, double angle_strength,
+                             double std, uint64_t seed, void *stream);
+/* noise::add_noise (src/noise.rs:119-177): cameras + points (bal_std = stats[19], device) ... */
+int c2b_add_noise_entities(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts,
+                           const double *stats, double translation_std, double rotation_std,
+                           double point_std, uint64_t seed, void *stream);
+/* ... and every observation (src/noise.rs:152-170); obs_base = global index of uv[0] */
+int c2b_add_noise_observations(double *uv, int64_t n_obs, int64_t obs_base,
+                               double observations_std, uint64_t seed, void *stream);
+/* noise::add_sin_noise (src/noise.rs:388-416); dimensions read from stats (device) */
+int c2b_add_sin_noise(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts,
+                      const double *stats, double dir_x, double dir_y, double dir_z,
+                      double ndir_x, double ndir_y, double ndir_z, double strength,
+                      double frequency, void *stream);
+
+/* contiguous camera ranges with ~equal observation counts (host pointers): the multi-GPU
+ * shard map.  bounds[n_parts+1]; part k owns cameras [bounds[k], bounds[k+1]). */
+int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, int64_t *bounds);
+
+/* ===================================================================================== *
+ * Level 1 -- a BAProblem resident on one device.  Pointers are HOST pointers; calls are
+ * synchronous (results are valid on return).  Mirrors BAProblem<SnavelyCamera>.
+ * ===================================================================================== */
+typedef struct c2b_problem c2b_problem;
+
+int c2b_problem_create(int device, c2b_problem **out);
+void c2b_problem_destroy(c2b_problem *p);
+
+/* BAProblem::from_visibility (src/baproblem.rs:360-376): validates like its asserts */
+int c2b_problem_upload(c2b_problem *p, int64_t n_cam, const double *cams15, int64_t n_pts,
+                       const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx,
+                       const double *uv);
+/* same, cameras as 9-vectors (what from_file_* parses, src/baproblem.rs:605-608) */
+int c2b_problem_upload_bal(c2b_problem *p, int64_t n_cam, const double *bal9, int64_t n_pts,
+                           const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx,
+                           const double *uv);
+int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs);
+/* any of the outputs may be NULL */
+int c2b_problem_download(c2b_problem *p, double *cams15, double *pts3, double *uv);
+int c2b_problem_download_bal(c2b_problem *p, double *bal9);
+
+int c2b_problem_project(c2b_problem *p, double *uv_out);
+int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *out);
+/* Jacobian columns refer to the uploaded 9-vector's w while cameras are unmodified since
+ * c2b_problem_upload_bal, otherwise to w = to_rodrigues(R) (what to_vec would write). */
+int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double *Jp);
+int c2b_problem_stats(c2b_problem *p, double *stats /* C2B_STATS_DOUBLES */);
+int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx,
+                                 const uint32_t *pt_idx, double max_dist, double *uv_out,
+                                 uint8_t *keep);
+int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength, double std,
+                          const double dir[3], uint64_t seed);
+int c2b_problem_add_drift_normalized(c2b_problem *p, double strength, double angle_strength,
+                                     double std, uint64_t seed);
+int c2b_problem_add_noise(c2b_problem *p, double translation_std, double rotation_std,
+                          double point_std, double observations_std, uint64_t seed);
+int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double noise_dir[3],
+                              double strength, double frequency);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CITY2BA_HIP_H */

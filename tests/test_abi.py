@@ -1,0 +1,77 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/city2ba_hip.h
+declares, binds with the declared signatures, and refuses to compute without a device (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def c2b():
+    entry.build()
+    import city2ba_amd
+    return city2ba_amd
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(c2b_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(c2b):
+    from city2ba_amd import _lib
+    names = _header_symbols()
+    assert len(names) >= 35
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "library does not export " + n
+    assert sorted(_lib.SIGNATURES) == names          # the Python binding covers exactly the header
+
+
+def test_header_cites_reference_lines():
+    text = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    assert len(re.findall(r"src/(baproblem|noise|synthetic|generate)\.rs:\d+", text)) >= 15
+
+
+def test_no_cpu_fallback(c2b):
+    if c2b.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(c2b.City2baError) as ei:
+        c2b.BAProblem()
+    assert ei.value.status == -5
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "city2ba_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "city2ba_oracle" not in src and "orc_" not in src, f
+    assert "oracle" not in open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+
+
+def test_workspace_and_partition_host_helpers(c2b):
+    L = c2b.lib()
+    assert L.c2b_workspace_bytes(0) > 0
+    assert L.c2b_workspace_bytes(10_000_000) >= 10_000_000 // 256 * 8
+    counts = np.array([5, 0, 0, 7, 1, 1, 30, 2, 2, 0, 12], dtype=np.uint64)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    for parts in (1, 2, 3, 4, 8, 16):
+        b = np.zeros(parts + 1, dtype=np.int64)
+        rc = L.c2b_partition_cameras(row_ptr.ctypes.data_as(C.c_void_p), len(counts), parts,
+                                     b.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        assert b[0] == 0 and b[-1] == len(counts) and np.all(np.diff(b) >= 0)
+        per = [int(row_ptr[b[k + 1]] - row_ptr[b[k]]) for k in range(parts)]
+        assert sum(per) == int(row_ptr[-1])
+        if parts <= 3:
+            assert max(per) <= int(row_ptr[-1]) / parts + counts.max()
+    assert L.c2b_partition_cameras(None, 3, 2, None) == -1
+    assert b"partition_cameras" in L.c2b_last_error()

@@ -1,0 +1,412 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(city2ba_amd -> ctypes -> libcity2ba_hip.so), against the CPU oracle on the same seeded inputs and
+against the committed golden vectors.
+
+Tolerances (north_star: indices bit-exact, f64 <= 1e-6 relative):
+  * observation indices / keep masks: exact;
+  * projection: BIT-EXACT when k2 == 0 (same IEEE operations in the same order); <= 1e-13 relative
+    otherwise (|p|^4 is n*n on the device, pow(sqrt(n),4) in the reference -- DESIGN.md);
+  * Jacobian, error sums, stats: <= 1e-6 relative required, ~1e-12 asserted;
+  * noise: same Philox draws; device log/sincos/pow differ from glibc by ulps -> 1e-9.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from _problems import grid_cameras_points, grid_candidate_pairs, random_problem
+
+pytestmark = pytest.mark.gpu
+
+IDENT_CAM = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0]
+
+
+@pytest.fixture(scope="module")
+def c2b():
+    import __graft_entry__ as entry
+    entry.build()
+    import city2ba_amd
+    assert city2ba_amd.device_count() > 0, "no HIP device: the gpu tests must run on the GPU box"
+    return city2ba_amd
+
+
+def _upload(c2b, P, bal=False):
+    if bal:
+        return c2b.BAProblem.from_bal(P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    return c2b.BAProblem.from_visibility(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+
+
+def _relerr(a, b, floor=1.0):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own KATs, through the GPU (src/baproblem.rs:64-75, 227-249)
+# ---------------------------------------------------------------------------------------------
+def test_reference_kats_on_gpu(c2b):
+    pts = np.array([[0.0, 0.0, -1.0], [1.0, 3.0, -1.0]])
+    bal = np.array([IDENT_CAM, [3.0, 5.0, -2.0, 0.5, -0.2, 0.1, 1.0, 0.0, 0.0],
+                    [1.0, 2.0, 3.0, 0, 0, 0, 1, 0, 0], [-1.2, 0.0, 1.7, 0, 0, 0, 1, 0, 0]])
+    row_ptr = np.array([0, 1, 2, 2, 2], dtype=np.uint64)
+    ba = c2b.BAProblem.from_bal(bal, pts, row_ptr, np.array([0, 1], dtype=np.uint64), np.zeros((2, 2)))
+    uv = ba.project()
+    assert uv[0, 0] == 0.0 and uv[0, 1] == 0.0                    # test_project: exact
+    cams = ba.cameras()
+    assert np.all(cams[0, :9] == np.eye(3).ravel())               # w = 0 -> identity exactly
+    # rodrigues_idempotent: to_rodrigues(from_rodrigues(v)) ~ v to 1e-10 (device trig)
+    back = ba_bal_roundtrip(c2b, bal)
+    for i in range(4):
+        assert np.linalg.norm(back[i, :3] - bal[i, :3]) < 1e-10
+    # test_project_isomorphic: to_world(project_world(p)) ~ p to 1e-8, with the device's R
+    q = cams[1, :9].reshape(3, 3).T @ pts[1] + cams[1, 9:12]
+    assert np.all(np.abs(O.to_world(cams[1], q) - pts[1]) <= 1e-8)
+
+
+def ba_bal_roundtrip(c2b, bal9):
+    """from_vec on the device, then to_vec on the device (state path, not the cached 9-vector)."""
+    n = len(bal9)
+    ba = c2b.BAProblem.from_bal(bal9, np.zeros((1, 3)), np.zeros(n + 1, dtype=np.uint64), [], np.zeros((0, 2)))
+    cams = ba.cameras()
+    ba2 = c2b.BAProblem.from_visibility(cams, np.zeros((1, 3)), np.zeros(n + 1, dtype=np.uint64), [], np.zeros((0, 2)))
+    return ba2.cameras_bal()
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors (mpmath)
+# ---------------------------------------------------------------------------------------------
+def _golden_problem(golden):
+    bal = np.array([p["bal9"] for p in golden["pairs"]])
+    pts = np.array([p["X"] for p in golden["pairs"]])
+    n = len(bal)
+    row_ptr = np.arange(n + 1, dtype=np.uint64)
+    return bal, pts, row_ptr, np.arange(n, dtype=np.uint64), np.array([p["uv"] for p in golden["pairs"]])
+
+
+def test_golden_projection_and_jacobian(c2b, golden):
+    bal, pts, row_ptr, pt_idx, uv = _golden_problem(golden)
+    ba = c2b.BAProblem.from_bal(bal, pts, row_ptr, pt_idx, uv)
+    got_uv = ba.project()
+    r, Jc, Jp = ba.residual_jacobian()          # bal mode: columns w.r.t. the file's own w
+    Jc = Jc.reshape(-1, 18); Jp = Jp.reshape(-1, 6)
+    for i, pr in enumerate(golden["pairs"]):
+        tol = 1e-9 if pr["kind"] == "nearz" else 1e-12
+        assert _relerr(got_uv[i], pr["uv"], floor=1e-2) < tol, (i, pr["kind"])
+        scale = max(1.0, np.max(np.abs(pr["Jc"])))
+        assert np.max(np.abs(Jc[i] - pr["Jc"])) / scale < 1e-6, (i, pr["kind"])
+        assert np.max(np.abs(Jp[i] - pr["Jp"])) / scale < 1e-6, (i, pr["kind"])
+        if pr["kind"] != "nearz":
+            assert np.max(np.abs(Jc[i] - pr["Jc"])) / scale < 1e-11, (i, pr["kind"])
+            assert np.max(np.abs(Jp[i] - pr["Jp"])) / scale < 1e-11, (i, pr["kind"])
+        assert np.max(np.abs(r[i])) < 1e-9 * max(1.0, np.max(np.abs(pr["uv"])))
+
+
+def test_golden_total_error(c2b, golden):
+    P = golden["problem"]
+    ba = c2b.BAProblem.from_bal(P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv_obs"])
+    for nrm, want in P["err"].items():
+        got = ba.total_reprojection_error(float(nrm))
+        assert abs(got - want) / want < 1e-12, nrm
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle parity on seeded problems, incl. ragged / empty / tile-boundary sizes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_cam,n_pts,opc,seed,empty_every", [
+    (1, 3, 2, 0, 0), (7, 60, 5, 1, 3), (64, 900, 9, 2, 0), (300, 6000, 17, 3, 11), (40, 5000, 64, 4, 0),
+])
+def test_project_bit_exact_without_k2(c2b, n_cam, n_pts, opc, seed, empty_every):
+    P = random_problem(n_cam, n_pts, opc, seed=seed, empty_every=empty_every)
+    P["cams15"][:, 14] = 0.0                                   # k2 = 0 -> no pow() anywhere
+    want = O.project_observations(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"])
+    ba = _upload(c2b, P)
+    got = ba.project()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), "projection must be bit-exact with the CPU oracle when k2 == 0"
+
+
+def test_project_with_k2_within_1e13(c2b):
+    P = random_problem(200, 4000, 15, seed=7, k_scale=5e-2)
+    want = O.project_observations(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"])
+    got = _upload(c2b, P).project()
+    assert _relerr(got, want, floor=1e-3) < 1e-13
+
+
+@pytest.mark.parametrize("norm", [1.0, 2.0, 1.5, 3.0])
+def test_total_reprojection_error(c2b, norm):
+    P = random_problem(150, 3000, 13, seed=11, noise=1e-2, empty_every=9)
+    want = O.total_reprojection_error(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], norm)
+    got = _upload(c2b, P).total_reprojection_error(norm)
+    assert abs(got - want) / want < 1e-12
+
+
+def test_zero_error_by_construction_on_gpu(c2b):
+    """observations written from the device's own project() => error exactly 0."""
+    P = random_problem(100, 2000, 10, seed=13)
+    ba = _upload(c2b, P)
+    uv = ba.project()
+    ba2 = c2b.BAProblem.from_visibility(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], uv)
+    assert ba2.total_reprojection_error(2.0) == 0.0
+    assert ba2.total_reprojection_error(1.0) == 0.0
+    r, _, _ = ba2.residual_jacobian()
+    assert np.all(r == 0.0)
+
+
+@pytest.mark.parametrize("n_cam,n_pts,opc,seed,empty_every", [
+    (1, 1, 1, 0, 0), (5, 100, 13, 1, 2), (33, 700, 8, 2, 0), (257, 8000, 31, 3, 5), (9, 4000, 300, 4, 0),
+])
+def test_residual_jacobian_state_mode(c2b, n_cam, n_pts, opc, seed, empty_every):
+    P = random_problem(n_cam, n_pts, opc, seed=seed, noise=1e-3, empty_every=empty_every)
+    r0, Jc0, Jp0 = O.residual_jacobian(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    r, Jc, Jp = _upload(c2b, P).residual_jacobian()
+    scale = max(1.0, float(np.max(np.abs(Jc0)))) if len(Jc0) else 1.0
+    assert np.max(np.abs(r - r0), initial=0.0) < 1e-12
+    assert np.max(np.abs(Jc.reshape(-1, 18) - Jc0), initial=0.0) / scale < 1e-10
+    assert np.max(np.abs(Jp.reshape(-1, 6) - Jp0), initial=0.0) / scale < 1e-10
+
+
+def test_residual_jacobian_bal_mode(c2b):
+    P = random_problem(120, 2500, 12, seed=5, noise=1e-3)
+    r0, Jc0, Jp0 = O.residual_jacobian_bal(P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    r, Jc, Jp = _upload(c2b, P, bal=True).residual_jacobian()
+    scale = max(1.0, float(np.max(np.abs(Jc0))))
+    assert np.max(np.abs(r - r0)) < 1e-11
+    assert np.max(np.abs(Jc.reshape(-1, 18) - Jc0)) / scale < 1e-10
+    assert np.max(np.abs(Jp.reshape(-1, 6) - Jp0)) / scale < 1e-10
+
+
+def test_jacobian_matches_finite_differences_of_gpu_projection(c2b):
+    """Size-independent property: central differences of the device's own projection in the 9 BAL
+    parameters and in X reproduce the device's analytic blocks."""
+    P = random_problem(20, 300, 6, seed=17)
+    w = P["bal9"][:, :3]
+    keep = np.linalg.norm(w, axis=1) < 2.5                   # stay inside one Rodrigues chart
+    P["bal9"][~keep, :3] *= 0.3
+    ba = c2b.BAProblem.from_bal(P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], np.zeros_like(P["uv"]))
+    _, Jc, Jp = ba.residual_jacobian()
+    counts = np.diff(P["row_ptr"].astype(np.int64))
+    cam_of = np.repeat(np.arange(len(counts)), counts)
+    h = 1e-6
+    for j in range(9):
+        hi = P["bal9"].copy(); hi[:, j] += h
+        lo = P["bal9"].copy(); lo[:, j] -= h
+        up = c2b.BAProblem.from_bal(hi, P["pts"], P["row_ptr"], P["pt_idx"], P["uv"]).project()
+        dn = c2b.BAProblem.from_bal(lo, P["pts"], P["row_ptr"], P["pt_idx"], P["uv"]).project()
+        fd = (up - dn) / (2 * h)
+        assert np.allclose(fd, Jc[:, :, j], rtol=2e-5, atol=2e-6), j
+    for j in range(3):
+        hi = P["pts"].copy(); hi[:, j] += h
+        lo = P["pts"].copy(); lo[:, j] -= h
+        up = c2b.BAProblem.from_bal(P["bal9"], hi, P["row_ptr"], P["pt_idx"], P["uv"]).project()
+        dn = c2b.BAProblem.from_bal(P["bal9"], lo, P["row_ptr"], P["pt_idx"], P["uv"]).project()
+        fd = (up - dn) / (2 * h)
+        assert np.allclose(fd, Jp[:, :, j], rtol=2e-5, atol=2e-6), j
+    del cam_of
+
+
+def test_empty_and_degenerate_inputs(c2b):
+    # no observations at all
+    ba = c2b.BAProblem.from_bal([IDENT_CAM], [[0, 0, -1.0]], [0, 0], [], np.zeros((0, 2)))
+    assert ba.num_observations() == 0 and ba.project().shape == (0, 2)
+    assert ba.total_reprojection_error(2.0) == 0.0
+    r, Jc, Jp = ba.residual_jacobian()
+    assert r.shape == (0, 2) and Jc.shape == (0, 2, 9) and Jp.shape == (0, 2, 3)
+    # z == 0 -> inf/NaN propagate like the reference (not an error)
+    ba = c2b.BAProblem.from_bal([IDENT_CAM], [[1.0, 1.0, 0.0]], [0, 1], [0], [[0.0, 0.0]])
+    uv = ba.project()
+    want = O.project_observations(O.camera_from_bal(IDENT_CAM), [[1.0, 1.0, 0.0]], [0, 1], [0])
+    assert np.all(np.isnan(uv) == np.isnan(want)) and np.all(np.isinf(uv) == np.isinf(want))
+
+
+def test_asserts_become_status_codes(c2b):
+    with pytest.raises(c2b.City2baError) as ei:       # assert!(ci < &points.len()), src/baproblem.rs:368
+        c2b.BAProblem.from_bal([IDENT_CAM], [[0, 0, -1.0]], [0, 1], [1], [[0.0, 0.0]])
+    assert ei.value.status == -2
+    with pytest.raises(c2b.City2baError) as ei:       # assert!(cam_i < cams.len()), src/baproblem.rs:345
+        c2b.BAProblem.new([IDENT_CAM], [[0, 0, -1.0]], [(1, 0, 0.0, 0.0)])
+    assert ei.value.status == -2
+    with pytest.raises(c2b.City2baError) as ei:       # row_ptr must be a prefix sum
+        c2b.BAProblem.from_bal([IDENT_CAM, IDENT_CAM], [[0, 0, -1.0]], [0, 1, 0], [0], [[0.0, 0.0]])
+    assert ei.value.status == -1
+    ba = c2b.BAProblem.from_bal([IDENT_CAM], [[0, 0, -1.0]], [0, 1], [0], [[0.0, 0.0]])
+    with pytest.raises(c2b.City2baError) as ei:       # Normal::new panics on negative std (rand 0.6)
+        c2b.noise.add_noise(ba, -1.0, 0.0, 0.0, 0.0)
+    assert ei.value.status == -1
+
+
+def test_new_keeps_push_order_per_camera(c2b):
+    """BAProblem::new pushes observations per camera in arrival order (src/baproblem.rs:344-348)."""
+    pts = np.array([[0, 0, -2.0], [0.1, 0, -2.0], [0, 0.1, -3.0]])
+    obs = [(1, 2, 0.5, 0.5), (0, 1, 0.1, 0.2), (1, 0, 0.3, 0.4), (0, 0, 0.7, 0.8), (1, 1, 0.9, 1.0)]
+    ba = c2b.BAProblem.new([IDENT_CAM, IDENT_CAM], pts, obs)
+    assert list(ba.row_ptr) == [0, 2, 5]
+    assert list(ba.pt_idx) == [1, 0, 2, 0, 1]
+    assert np.array_equal(ba.observations(), [[0.1, 0.2], [0.7, 0.8], [0.5, 0.5], [0.3, 0.4], [0.9, 1.0]])
+    assert "2 cameras, 3 points, and 5 observations" in str(ba)
+
+
+# ---------------------------------------------------------------------------------------------
+# camera (de)serialisation, stats
+# ---------------------------------------------------------------------------------------------
+def test_from_bal_to_bal_against_oracle(c2b):
+    P = random_problem(500, 10, 0, seed=19)
+    ba = c2b.BAProblem.from_bal(P["bal9"], P["pts"], np.zeros(501, dtype=np.uint64), [], np.zeros((0, 2)))
+    cams = ba.cameras()
+    assert np.max(np.abs(cams - P["cams15"])) < 5e-16 * 4          # device sincos vs glibc: ulps
+    assert np.array_equal(cams[:, 9:], P["cams15"][:, 9:])
+    ba2 = c2b.BAProblem.from_visibility(P["cams15"], P["pts"], np.zeros(501, dtype=np.uint64), [], np.zeros((0, 2)))
+    got = ba2.cameras_bal()
+    want = O.camera_to_bal(P["cams15"])
+    assert np.max(np.abs(got - want)) < 1e-12
+
+
+def test_stats_against_oracle(c2b):
+    P = random_problem(700, 5000, 3, seed=23)
+    ba = _upload(c2b, P)
+    assert _relerr(ba.mean(), O.mean(P["cams15"], P["pts"]), floor=1e-3) < 1e-12
+    assert _relerr(ba.std(), O.std(P["cams15"], P["pts"])) < 1e-12
+    mn, mx = ba.extent()
+    mn0, mx0 = O.extent(P["cams15"], P["pts"])
+    assert np.array_equal(mn, mn0) and np.array_equal(mx, mx0)        # min/max: exact
+    assert np.array_equal(ba.dimensions(), O.dimensions(P["cams15"], P["pts"]))
+    o, idx = ba.drift_origin()
+    o0, idx0 = O.drift_origin(P["cams15"], P["pts"])
+    assert idx == idx0 and np.array_equal(o, o0)                      # index work: exact
+
+
+def test_drift_origin_tie_goes_to_later(c2b):
+    pts = np.array([[1.0, 0, 0], [0.0, 0, 0], [0, 0, 2.0], [0.0, 0.0, 0.0], [3.0, 0, 0]])
+    ba = c2b.BAProblem.from_bal([IDENT_CAM], pts, [0, 0], [], np.zeros((0, 2)))
+    o, idx = ba.drift_origin()
+    assert idx == 1 + 3 and np.all(o == 0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# visibility predicate on the reference's test grid (indices must be bit-exact)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("blocks,cpb,ppb,L", [(3, 10, 20, 5.0), (4, 10, 10, 20.0)])
+def test_visibility_pairs_bit_exact(c2b, blocks, cpb, ppb, L):
+    cams, pts = grid_cameras_points(blocks, cpb=cpb, ppb=ppb, L=L)
+    ci, pi = grid_candidate_pairs(cams, pts, 10.0)
+    uv0, keep0 = O.visibility_pairs(cams, pts, ci, pi, 10.0)
+    ba = c2b.BAProblem.from_visibility(cams, pts, np.zeros(len(cams) + 1, dtype=np.uint64), [], np.zeros((0, 2)))
+    uv, keep = ba.visibility_pairs(ci, pi, 10.0)
+    assert keep0.sum() > 1000
+    assert np.array_equal(keep, keep0), "kept observation indices must match the CPU path exactly"
+    assert np.array_equal(np.isnan(uv), np.isnan(uv0))
+    assert np.array_equal(uv[keep == 1], uv0[keep0 == 1])            # k2 == 0 here: bit-exact uv too
+    # boundary cases exist in this grid (|u| == 1 exactly) and must be kept by <= / >=
+    assert np.any(np.abs(uv0[keep0 == 1]) == 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# noise: same draws as the oracle's Philox scheme, reference inequalities (tests/main.rs:134-195)
+# ---------------------------------------------------------------------------------------------
+def _grid_problem():
+    cams, pts = grid_cameras_points(3, cpb=10, ppb=20, L=5.0)
+    ci, pi = grid_candidate_pairs(cams, pts, 10.0)
+    uv, keep = O.visibility_pairs(cams, pts, ci, pi, 10.0)
+    ci, pi, uv = ci[keep == 1], pi[keep == 1], uv[keep == 1]
+    row_ptr = np.zeros(len(cams) + 1, dtype=np.int64)
+    np.add.at(row_ptr, ci.astype(np.int64) + 1, 1)
+    return dict(cams15=cams, pts=pts, row_ptr=np.cumsum(row_ptr).astype(np.uint64), pt_idx=pi.astype(np.uint64), uv=uv)
+
+
+def test_add_drift_matches_oracle(c2b):
+    P = _grid_problem()
+    d = np.array([0.3, -0.5, 0.8])
+    c0, p0 = O.add_drift(P["cams15"], P["pts"], 1e-3, 2e-3, 0.2, d, seed=42)
+    ba = c2b.noise.add_drift(_upload(c2b, P), 1e-3, 2e-3, 0.2, d, seed=42)
+    assert np.max(np.abs(ba.cameras() - c0)) < 1e-9
+    assert np.max(np.abs(ba.points() - p0)) < 1e-9
+
+
+def test_add_drift_normalized_matches_oracle_and_inequality(c2b):
+    P = _grid_problem()
+    ba = _upload(c2b, P)
+    e0 = ba.total_reprojection_error(2.0)
+    c0, p0 = O.add_drift_normalized(P["cams15"], P["pts"], 0.1, 0.1, 0.1, seed=7)
+    ba = c2b.noise.add_drift_normalized(ba, 0.1, 0.1, 0.1, seed=7)
+    assert np.max(np.abs(ba.cameras() - c0)) < 1e-7          # strength*d^2 amplifies ulps of |std|
+    assert np.max(np.abs(ba.points() - p0)) < 1e-7
+    assert ba.total_reprojection_error(2.0) > e0             # tests/main.rs:134-141
+
+
+def test_add_noise_matches_oracle_and_inequality(c2b):
+    P = _grid_problem()
+    ba = _upload(c2b, P)
+    e0 = ba.total_reprojection_error(2.0)
+    c0, p0, uv0 = O.add_noise(P["cams15"], P["pts"], P["uv"], 0.1, 0.1, 0.1, 0.1, seed=99)
+    ba = c2b.noise.add_noise(ba, 0.1, 0.1, 0.1, 0.1, seed=99)
+    assert np.max(np.abs(ba.cameras() - c0)) < 1e-9
+    assert np.max(np.abs(ba.points() - p0)) < 1e-9
+    assert np.max(np.abs(ba.observations() - uv0)) < 1e-9
+    assert ba.total_reprojection_error(2.0) > e0             # tests/main.rs:143-150
+    e_cpu = O.total_reprojection_error(c0, p0, P["row_ptr"], P["pt_idx"], uv0, 2.0)
+    assert abs(ba.total_reprojection_error(2.0) - e_cpu) / e_cpu < 1e-7
+
+
+def test_add_sin_noise_matches_oracle_and_inequality(c2b):
+    P = _grid_problem()
+    ba = _upload(c2b, P)
+    e0 = ba.total_reprojection_error(2.0)
+    c0, p0 = O.add_sin_noise(P["cams15"], P["pts"], [1.0, 1.0, 0.0], [0.0, 1.0, 0.0], 1.0, 2.0)
+    ba = c2b.noise.add_sin_noise(ba, [1.0, 1.0, 0.0], [0.0, 1.0, 0.0], 1.0, 2.0)
+    assert np.max(np.abs(ba.cameras() - c0)) < 1e-9
+    assert np.max(np.abs(ba.points() - p0)) < 1e-9
+    assert ba.total_reprojection_error(2.0) > e0             # tests/main.rs:188-195
+
+
+def test_zero_strength_noise_only_rounds(c2b):
+    """run_noise always calls add_drift/add_noise, even with all-zero parameters
+    (src/bin/city2ba.rs:305-340): the result differs from the input by rounding only."""
+    P = _grid_problem()
+    ba = c2b.noise.add_noise(c2b.noise.add_drift_normalized(_upload(c2b, P), 0.0, 0.0, 0.0, seed=1), 0, 0, 0, 0, seed=2)
+    assert np.max(np.abs(ba.cameras() - P["cams15"])) < 1e-12
+    assert np.array_equal(ba.points(), P["pts"]) and np.array_equal(ba.observations(), P["uv"])
+    c0, p0 = O.add_drift_normalized(P["cams15"], P["pts"], 0.0, 0.0, 0.0, seed=1)
+    c0, p0, _ = O.add_noise(c0, p0, P["uv"], 0, 0, 0, 0, seed=2)
+    assert np.array_equal(ba.cameras(), c0)                  # pure algebra (no transcendental): bit-exact
+
+
+def test_noise_is_seed_deterministic_and_seed_sensitive(c2b):
+    P = _grid_problem()
+    a = c2b.noise.add_noise(_upload(c2b, P), 0.1, 0.1, 0.1, 0.1, seed=5)
+    b = c2b.noise.add_noise(_upload(c2b, P), 0.1, 0.1, 0.1, 0.1, seed=5)
+    c = c2b.noise.add_noise(_upload(c2b, P), 0.1, 0.1, 0.1, 0.1, seed=6)
+    assert np.array_equal(a.observations(), b.observations()) and np.array_equal(a.cameras(), b.cameras())
+    assert not np.array_equal(a.observations(), c.observations())
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE config sizes; oracle too slow there -> size-independent checks)
+# ---------------------------------------------------------------------------------------------
+def test_large_problem_properties(c2b):
+    rng = np.random.default_rng(31)
+    n_cam, n_pts, per = 40000, 120000, 30
+    P = random_problem(400, 12000, per, seed=37)             # template, tiled 100x with shifted points
+    reps = n_cam // 400
+    cams = np.tile(P["cams15"], (reps, 1))
+    pts = np.tile(P["pts"], (reps, 1))
+    counts = np.tile(np.diff(P["row_ptr"].astype(np.int64)), reps)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    pt_idx = np.concatenate([P["pt_idx"].astype(np.int64) + k * 12000 for k in range(reps)]).astype(np.uint64)
+    n_obs = len(pt_idx)
+    assert n_obs > 1_000_000
+    ba = c2b.BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, np.zeros((n_obs, 2)))
+    uv = ba.project()
+    # periodicity: every replica projects identically (bit-exact), and matches the oracle on replica 0
+    m = int(P["row_ptr"][-1])
+    assert np.array_equal(uv[:m], uv[m:2 * m]) and np.array_equal(uv[:m], uv[-m:])
+    want = O.project_observations(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"])
+    assert _relerr(uv[:m], want, floor=1e-3) < 1e-13
+    # zero error by construction + linear growth of the L1 error under a uniform observation shift
+    ba = c2b.BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv)
+    assert ba.total_reprojection_error(2.0) == 0.0
+    shift = rng.normal(size=2) * 1e-3
+    ba = c2b.BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv + shift)
+    l1 = ba.total_reprojection_error(1.0)
+    assert abs(l1 - n_obs * np.abs(shift).sum()) / l1 < 1e-9
+    r, Jc, Jp = ba.residual_jacobian()
+    assert np.allclose(r, -shift, rtol=0, atol=1e-12)
+    assert np.array_equal(Jc[:m], Jc[m:2 * m]) and np.array_equal(Jp[:m], Jp[-m:])
+    assert np.all(np.isfinite(Jc)) and np.all(np.isfinite(Jp))
