@@ -239,7 +239,7 @@ int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n
     const double4 *p4 = reinterpret_cast<const double4 *>(pts4);
     hipLaunchKernelGGL(k_stats_pass1, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, rec);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold1, dim3(1), dim3(64), 0, S(stream), rec, grid, stats);
+    hipLaunchKernelGGL(k_stats_fold1, dim3(1), dim3(64), 0, S(stream), rec, grid, camblk, n_cam, p4, stats);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_stats_pass2, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, stats, rec);
     LAUNCH_CHECK();

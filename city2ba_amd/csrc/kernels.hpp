@@ -343,7 +343,7 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict_
 }
 
 // ---- stats over camera centers ++ points ------------------------------------------------------------
-// record: [0..2] sum(x/num) | [3..5] min | [6..8] max | [9] best dist | [10] best index | [11..13] best xyz
+// record: [0..2] sum(x/num) | [3..5] min | [6..8] max | [9] best dist | [10] best index
 C2B_DEV void entity_xyz(const double *__restrict__ camblk, int64_t n_cam, const double4 *__restrict__ pts4,
                         int64_t i, double &x, double &y, double &z) {
     if (i < n_cam) {
@@ -355,11 +355,17 @@ C2B_DEV void entity_xyz(const double *__restrict__ camblk, int64_t n_cam, const 
     }
 }
 
-// closest to origin with fold1's semantics (src/noise.rs:80-86): strict <, ties -> later index
-C2B_DEV void argmin_merge(double &bd, double &bi, double &bx, double &by, double &bz, double d,
-                          double i, double x, double y, double z) {
-    const bool take = (bi < 0.0) || (i >= 0.0 && (d < bd || (d == bd && i > bi)));
-    if (take) { bd = d; bi = i; bx = x; by = y; bz = z; }
+// closest to origin with fold1's semantics (src/noise.rs:80-86): strict <, ties -> later index.
+// Only (distance, index) travel through the reduction; the winner's coordinates are re-read by
+// index afterwards.  (Carrying xyz through a branchy merge was miscompiled by hipcc 7.2 -O3: the
+// coordinate moves were emitted on the "no current best" path only.)  Index -1 = no element.
+struct Best { double d, i; };
+C2B_DEV Best best_merge(Best a, Best b) {
+    const bool take = (a.i < 0.0) || (b.i >= 0.0 && (b.d < a.d || (b.d == a.d && b.i > a.i)));
+    Best r;
+    r.d = take ? b.d : a.d;
+    r.i = take ? b.i : a.i;
+    return r;
 }
 
 __global__ __launch_bounds__(kBlock) void k_stats_pass1(const double *__restrict__ camblk, int64_t n_cam,
@@ -370,30 +376,33 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(const double *__restrict
     const double num = (double)n;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double s0 = 0, s1 = 0, s2 = 0, mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
-    double bd = 0, bi = -1.0, bx = 0, by = 0, bz = 0;
+    Best best = {0.0, -1.0};
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         double x, y, z;
         entity_xyz(camblk, n_cam, pts4, i, x, y, z);
         s0 += x / num; s1 += y / num; s2 += z / num;
         mn0 = fmin(mn0, x); mn1 = fmin(mn1, y); mn2 = fmin(mn2, z);
         mx0 = fmax(mx0, x); mx1 = fmax(mx1, y); mx2 = fmax(mx2, z);
-        const double d = sqrt(dot3(x, y, z, x, y, z));
-        argmin_merge(bd, bi, bx, by, bz, d, (double)i, x, y, z);
+        const Best cand = {sqrt(dot3(x, y, z, x, y, z)), (double)i};
+        best = best_merge(best, cand);
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     mn0 = wave_min(mn0); mn1 = wave_min(mn1); mn2 = wave_min(mn2);
     mx0 = wave_max(mx0); mx1 = wave_max(mx1); mx2 = wave_max(mx2);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const double d = __shfl_down(bd, off, 64), i = __shfl_down(bi, off, 64);
-        const double x = __shfl_down(bx, off, 64), y = __shfl_down(by, off, 64), z = __shfl_down(bz, off, 64);
-        argmin_merge(bd, bi, bx, by, bz, d, i, x, y, z);
+        Best o;
+        o.d = __shfl_down(best.d, off, 64);
+        o.i = __shfl_down(best.i, off, 64);
+        best = best_merge(best, o);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
         double *o = sh[wave];
         o[0] = s0; o[1] = s1; o[2] = s2; o[3] = mn0; o[4] = mn1; o[5] = mn2;
-        o[6] = mx0; o[7] = mx1; o[8] = mx2; o[9] = bd; o[10] = bi; o[11] = bx; o[12] = by; o[13] = bz;
+        o[6] = mx0; o[7] = mx1; o[8] = mx2; o[9] = best.d; o[10] = best.i;
+#pragma unroll
+        for (int k = 11; k < kStatRec; ++k) o[k] = 0.0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -401,39 +410,48 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(const double *__restrict
         double t[kStatRec];
 #pragma unroll
         for (int k = 0; k < kStatRec; ++k) t[k] = sh[0][k];
+        Best b = {sh[0][9], sh[0][10]};
         for (int w = 1; w < kWaves; ++w) {
             t[0] += sh[w][0]; t[1] += sh[w][1]; t[2] += sh[w][2];
             for (int k = 3; k < 6; ++k) t[k] = fmin(t[k], sh[w][k]);
             for (int k = 6; k < 9; ++k) t[k] = fmax(t[k], sh[w][k]);
-            argmin_merge(t[9], t[10], t[11], t[12], t[13], sh[w][9], sh[w][10], sh[w][11], sh[w][12], sh[w][13]);
+            const Best o2 = {sh[w][9], sh[w][10]};
+            b = best_merge(b, o2);
         }
+        t[9] = b.d; t[10] = b.i;
 #pragma unroll
         for (int k = 0; k < kStatRec; ++k) o[k] = t[k];
     }
 }
 
-// single workgroup: fold the per-workgroup records -> stats[0..2]=mean, [6..8]=min, [9..11]=max,
-// [12..14]=dim, [15..17]=origin, [18]=origin index
+// single lane: fold the per-workgroup records -> stats[0..2]=mean, [6..8]=min, [9..11]=max,
+// [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin index
 __global__ __launch_bounds__(64) void k_stats_fold1(const double *__restrict__ rec, int n_rec,
+                                                   const double *__restrict__ camblk, int64_t n_cam,
+                                                   const double4 *__restrict__ pts4,
                                                    double *__restrict__ stats) {
     if (threadIdx.x != 0) return;
-    double t[kStatRec];
-    for (int k = 0; k < kStatRec; ++k) t[k] = rec[k];
-    for (int b = 1; b < n_rec; ++b) {
-        const double *r = rec + (int64_t)b * kStatRec;
+    double t[9];
+    for (int k = 0; k < 9; ++k) t[k] = rec[k];
+    Best b = {rec[9], rec[10]};
+    for (int r_ = 1; r_ < n_rec; ++r_) {
+        const double *r = rec + (int64_t)r_ * kStatRec;
         t[0] += r[0]; t[1] += r[1]; t[2] += r[2];
         for (int k = 3; k < 6; ++k) t[k] = fmin(t[k], r[k]);
         for (int k = 6; k < 9; ++k) t[k] = fmax(t[k], r[k]);
-        argmin_merge(t[9], t[10], t[11], t[12], t[13], r[9], r[10], r[11], r[12], r[13]);
+        const Best o = {r[9], r[10]};
+        b = best_merge(b, o);
     }
+    double x = 0, y = 0, z = 0;
+    if (b.i >= 0.0) entity_xyz(camblk, n_cam, pts4, (int64_t)b.i, x, y, z);
     for (int k = 0; k < 3; ++k) {
         stats[k] = t[k];
         stats[6 + k] = t[3 + k];
         stats[9 + k] = t[6 + k];
         stats[12 + k] = t[6 + k] - t[3 + k];
-        stats[15 + k] = t[11 + k];
     }
-    stats[18] = t[10];
+    stats[15] = x; stats[16] = y; stats[17] = z;
+    stats[18] = b.i;
 }
 
 __global__ __launch_bounds__(kBlock) void k_stats_pass2(const double *__restrict__ camblk, int64_t n_cam,

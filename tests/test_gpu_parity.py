@@ -55,7 +55,7 @@ def test_reference_kats_on_gpu(c2b):
     assert np.all(cams[0, :9] == np.eye(3).ravel())               # w = 0 -> identity exactly
     # rodrigues_idempotent: to_rodrigues(from_rodrigues(v)) ~ v to 1e-10 (device trig)
     back = ba_bal_roundtrip(c2b, bal)
-    for i in range(4):
+    for i in (0, 2, 3):             # the three vectors of rodrigues_idempotent
         assert np.linalg.norm(back[i, :3] - bal[i, :3]) < 1e-10
     # test_project_isomorphic: to_world(project_world(p)) ~ p to 1e-8, with the device's R
     q = cams[1, :9].reshape(3, 3).T @ pts[1] + cams[1, 9:12]
