@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement: million observations/s of project + 2x(9+3) Jacobian
+(+ fused L2 error reduce) on a `city2ba synthetic --blocks B` grid, f64, on N MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian (residual, Jc, Jp,
+per-tile error partials) + c2b_error_sum_finish on every rank's shard, then ONE 1-element RCCL
+all-reduce (N > 1).  Inputs are resident in HBM before the timed region.  Strong scaling: the same
+`--blocks 128` problem is sharded over the ranks by contiguous camera ranges (BASELINE.json
+configs[3]); at N = 1 one GPU holds all of it.
+
+Only the `cpu_baseline` leg touches oracle/ (rank 0, N = 1, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_shard(args, rank, world, dev):
+    """This rank's shard of `synthetic --blocks B` (defaults of src/bin/city2ba.rs:113-152), on device."""
+    import numpy as np
+    import torch
+    from city2ba_amd import device as D
+    from city2ba_amd import dist as Dist
+    from city2ba_amd import synthetic as S
+
+    B, max_dist, L, inset = args.blocks, 10.0, 20.0, 1.0
+    pos, dirs, pts = S.grid_layout(B)
+    n_cam, n_pts = len(pos), len(pts)
+    bounds = Dist.camera_count_bounds(n_cam, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+
+    pts4 = D.points_pad(torch.from_numpy(pts).to(dev))
+    cam15 = D.cameras_from_position_direction(torch.from_numpy(pos[lo:hi]).to(dev),
+                                              torch.from_numpy(dirs[lo:hi]).to(dev))
+    camblk = D.cameras_prepare_state(cam15)
+    centers = camblk[:, 24:27].contiguous().cpu().numpy()
+
+    threads = max(1, (os.cpu_count() or 8) // max(1, min(world, 8)))
+    ci, pi = S.candidate_pairs(centers, pts, max_dist, occlusion=True, block_length=L, block_inset=inset,
+                               n_threads=threads)
+    n_cand = len(ci)
+    ci_d = torch.from_numpy(ci.view(np.int32)).to(dev)
+    pi_d = torch.from_numpy(pi.view(np.int32)).to(dev)
+    uv_c = torch.empty((n_cand, 2), dtype=torch.float64, device=dev)
+    keep = torch.empty(n_cand, dtype=torch.uint8, device=dev)
+    D.visibility_pairs(camblk, pts4, ci_d, pi_d, max_dist, uv_c, keep)
+    m = keep.bool()
+    cam_idx = ci_d[m].contiguous()
+    pt_idx = pi_d[m].contiguous()
+    uv = uv_c[m].contiguous()
+    del ci_d, pi_d, uv_c, keep, m
+    n_obs = int(cam_idx.shape[0])
+    # observation noise so that the reduced error is a non-trivial number (seeded, shard-independent)
+    obs_base, n_obs_total = Dist.exclusive_offset(n_obs)
+    D.add_noise_observations(uv, obs_base, 1e-3, seed=20243)
+    torch.cuda.synchronize()
+    return dict(camblk=camblk, cam15=cam15, pts4=pts4, cam_idx=cam_idx, pt_idx=pt_idx, uv=uv, n_obs=n_obs,
+                n_obs_total=n_obs_total, n_cam=n_cam, n_pts=n_pts, n_cam_local=hi - lo, n_candidates=n_cand,
+                pts_host=pts)
+
+
+def algorithmic_bytes(n_obs, n_cam, n_pts):
+    """SURVEY section 8(d), residual+Jacobian: each camera and point read once, 4-B device indices."""
+    return n_obs * (4 + 16 + 16 + 192) + (n_cam + 1) * 8 + n_cam * 72 + n_pts * 24
+
+
+def cpu_baseline(sh, seconds):
+    """The oracle (C restatement of the reference CPU path + its Jacobian), one thread, on a camera-range
+    prefix of the same workload.  Baseline, not target."""
+    import numpy as np
+    import oracle as O
+    cam_idx = sh["cam_idx"].cpu().numpy().astype(np.int64)
+    target = min(len(cam_idx), 2_000_000)
+    c_end = int(cam_idx[target - 1]) + 1
+    n = int(np.searchsorted(cam_idx, c_end, side="left"))
+    counts = np.bincount(cam_idx[:n], minlength=c_end)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    pt_idx = sh["pt_idx"][:n].cpu().numpy().astype(np.uint64)
+    uv = sh["uv"][:n].cpu().numpy()
+    cams15 = sh["cam15"][:c_end].cpu().numpy()
+    pts = np.ascontiguousarray(sh["pts_host"])
+    r, Jc, Jp = np.empty((n, 2)), np.empty((n, 18)), np.empty((n, 6))
+    O.lib()
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        O.bench_residual_jacobian(cams15, pts, row_ptr, pt_idx, uv, r, Jc, Jp)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or passes >= 200:
+            break
+    return {"value": round(n * passes / el / 1e6, 4), "unit": "Mobs/s", "cores": 1, "kind": "port",
+            "sample": "oracle/ C restatement (orc_bench_residual_jacobian: project + 2x12 Jacobian + L2 sum), "
+                      "first %d cameras / %d observations of the same grid, %d passes in %.1f s, 1 thread"
+                      % (c_end, n, passes, el)}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    (profiles/, produced by tools/profile_bench.sh with the guide's gfx950 FETCH_SIZE correction)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get("traffic_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.build_hip()
+    from city2ba_amd import device as D
+    from city2ba_amd import dist as Dist
+
+    rank, local_rank, world = Dist.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sh = build_shard(args, rank, world, dev)
+    n = sh["n_obs"]
+    r = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
+    Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    ws = D.workspace(n, dev)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws)
+        if ev is not None:
+            ev[1].record()
+        D.error_sum_finish(ws, n, err)
+        Dist.all_reduce_sum_(err)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_err = Dist.finish_error(err.item(), 2.0)
+
+    kern_ms = sorted(a.elapsed_time(b) for a, b in events)
+    kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+    if rank == 0:
+        n_total = sh["n_obs_total"]
+        value = n_total * args.steps / elapsed / 1e6
+        alg = algorithmic_bytes(n, sh["n_cam_local"], sh["n_pts"])
+        achieved = alg / kern_avg_s / 1e9
+        out = {
+            "metric": "million observations/sec (project+Jacobian)",
+            "value": round(value, 3), "unit": "Mobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "city2ba synthetic --blocks %d (cpb=10 ppb=10 block-length=20 inset=1 max-dist=10): "
+                            "residual + 2x(9+3) Jacobian + fused L2 error reduce, f64; 1-scalar all-reduce when N>1"
+                            % args.blocks,
+                "blocks": args.blocks, "n_cameras": sh["n_cam"], "n_points": sh["n_pts"],
+                "n_observations": n_total, "n_candidates_rank0": sh["n_candidates"],
+                "occlusion": True, "cull": False,
+                "sharding": "contiguous camera ranges (n_cam/N each), points replicated, outputs sharded",
+                "total_L2_error": total_err,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_residual_jacobian<true>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic() if (world == 1 and args.blocks == 128) else None,
+                "algorithmic_bytes_per_launch": alg, "observations_per_launch": n,
+                "bytes_per_observation": round(alg / max(n, 1), 2),
+                "kernel_avg_us": round(kern_avg_s * 1e6, 2), "kernel_min_us": round(kern_ms[0] * 1e3, 2),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sh, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,12 +34,14 @@ SIGNATURES = {
     "c2b_cameras_to_bal": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_prepare_state": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_prepare_bal": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_cameras_from_position_direction": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "c2b_points_pad": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_points_unpad": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_expand_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "c2b_project": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "c2b_reprojection_error_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
-    "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp]),
+    "c2b_error_sum_finish": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
@@ -48,6 +50,14 @@ SIGNATURES = {
     "c2b_add_noise_observations": (_int, [_vp, _i64, _i64, _d, _u64, _vp]),
     "c2b_add_sin_noise": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _d, _d, _vp]),
     "c2b_partition_cameras": (_int, [_vp, _i64, _int, _vp]),
+    "c2b_synthetic_grid_sizes": (_int, [_i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "c2b_synthetic_grid_layout": (_int, [_i64, _i64, _i64, _d, _d, _d, _d, _vp, _vp, _vp]),
+    "c2b_synthetic_line_layout": (_int, [_i64, _i64, _d, _d, _d, _d, _vp, _vp, _vp]),
+    "c2b_candidate_pairs": (_int, [_vp, _i64, _vp, _i64, _d, _i64, _i64, _int, _d, _d, _int, C.POINTER(_vp)]),
+    "c2b_pairs_count": (_i64, [_vp]),
+    "c2b_pairs_cam_idx": (_vp, [_vp]),
+    "c2b_pairs_pt_idx": (_vp, [_vp]),
+    "c2b_pairs_free": (None, [_vp]),
     "c2b_problem_create": (_int, [_int, C.POINTER(_vp)]),
     "c2b_problem_destroy": (None, [_vp]),
     "c2b_problem_upload": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),

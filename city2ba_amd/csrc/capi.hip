@@ -13,6 +13,7 @@
 #include <new>
 #include <vector>
 
+#include "host_synthetic.hpp"
 #include "kernels.hpp"
 
 using namespace c2b;
@@ -104,6 +105,17 @@ int c2b_cameras_prepare_bal(const double *bal9, int64_t n, double *camblk, void 
     return C2B_OK;
 }
 
+int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, int64_t n, double *cam15,
+                                        void *stream) {
+    if (n < 0 || (n && (!pos3 || !dir9 || !cam15)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_from_position_direction: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_cameras_from_position_direction, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), pos3, dir9,
+                       n, cam15);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
 int c2b_points_pad(const double *pts3, int64_t n, double *pts4, void *stream) {
     if (n < 0 || (n && (!pts3 || !pts4))) return fail(C2B_ERR_INVALID_ARGUMENT, "points_pad: bad arguments");
     if (!n) return C2B_OK;
@@ -181,34 +193,38 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
 
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                           const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
-                          double *Jp, double norm, void *workspace, double *out_sum, void *stream) {
+                          double *Jp, double norm, void *workspace, void *stream) {
     int rc = check_obs_args("residual_jacobian", camblk, pts4, cam_idx, pt_idx, n_obs);
     if (rc) return rc;
-    if (!n_obs) {
-        if (out_sum) HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream)));
-        return C2B_OK;
-    }
+    if (!n_obs) return C2B_OK;
     if (!uv_obs || !r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: NULL buffer");
     if (!aligned16(uv_obs) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
         return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: uv/r/Jc/Jp must be 16-byte aligned");
-    if (out_sum && !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: workspace is NULL");
     const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
-    double *partials = workspace ? reinterpret_cast<double *>(workspace) + kWsStatsDoubles : nullptr;
-    if (out_sum) {
+    if (workspace) {
+        double *partials = reinterpret_cast<double *>(workspace) + kWsStatsDoubles;
         hipLaunchKernelGGL(k_residual_jacobian<true>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
                            reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
                            reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
                            reinterpret_cast<double2 *>(r), Jc, Jp, partials);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, S(stream), partials, tiles, out_sum);
-        LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(k_residual_jacobian<false>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
                            reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
                            reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
                            reinterpret_cast<double2 *>(r), Jc, Jp, (double *)nullptr);
-        LAUNCH_CHECK();
     }
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, void *stream) {
+    if (n_obs < 0 || !out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: bad arguments");
+    if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
+    if (!workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: workspace is NULL");
+    const double *partials = reinterpret_cast<const double *>(workspace) + kWsStatsDoubles;
+    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, S(stream), partials, tiles, out_sum);
+    LAUNCH_CHECK();
     return C2B_OK;
 }
 
@@ -337,6 +353,74 @@ int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, i
     bounds[n_parts] = n_cam;
     return C2B_OK;
 }
+
+/* ------------------------------- host-side generator pieces -------------------------- */
+
+int c2b_synthetic_grid_sizes(int64_t cpb, int64_t ppb, int64_t blocks, int64_t *n_cam, int64_t *n_pts) {
+    if (cpb < 0 || ppb < 0 || blocks < 0 || !n_cam || !n_pts)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "synthetic_grid_sizes: bad arguments");
+    c2b_host::grid_sizes(cpb, ppb, blocks, n_cam, n_pts);
+    return C2B_OK;
+}
+
+int c2b_synthetic_grid_layout(int64_t cpb, int64_t ppb, int64_t blocks, double block_length, double block_inset,
+                              double camera_height, double point_height, double *cam_pos3, double *cam_dir9,
+                              double *pts3) {
+    if (cpb < 0 || ppb < 0 || blocks < 0 || !cam_pos3 || !cam_dir9 || !pts3)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "synthetic_grid_layout: bad arguments");
+    // assert!(block_inset * 2. < block_length, ...), src/synthetic.rs:177
+    if (!(block_inset * 2.0 < block_length))
+        return fail(C2B_ERR_INVALID_ARGUMENT,
+                    "Block inset (%g) must be less than half the block length (%g), to not violate physical constraints.",
+                    block_inset, block_length);
+    c2b_host::grid_layout(cpb, ppb, blocks, block_length, block_inset, camera_height, point_height, cam_pos3,
+                          cam_dir9, pts3);
+    return C2B_OK;
+}
+
+int c2b_synthetic_line_layout(int64_t n_cam, int64_t n_pts, double length, double point_offset, double camera_height,
+                              double point_height, double *cam_pos3, double *cam_dir9, double *pts3) {
+    if (n_cam < 0 || n_pts < 0 || (n_cam && (!cam_pos3 || !cam_dir9)) || (n_pts && !pts3))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "synthetic_line_layout: bad arguments");
+    c2b_host::line_layout(n_cam, n_pts, length, point_offset, camera_height, point_height, cam_pos3, cam_dir9, pts3);
+    return C2B_OK;
+}
+
+struct c2b_pairs {
+    c2b_host::Pairs v;
+};
+
+int c2b_candidate_pairs(const double *centers3, int64_t n_cam, const double *pts3, int64_t n_pts, double max_dist,
+                        int64_t cam_lo, int64_t cam_hi, int occlusion, double block_length, double block_inset,
+                        int n_threads, c2b_pairs **out) {
+    if (!out) return fail(C2B_ERR_INVALID_ARGUMENT, "candidate_pairs: out is NULL");
+    *out = nullptr;
+    if (n_cam < 0 || n_pts < 0 || cam_lo < 0 || cam_hi > n_cam || cam_lo > cam_hi || (n_cam && !centers3) ||
+        (n_pts && !pts3) || !(max_dist >= 0.0))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "candidate_pairs: bad arguments");
+    if (n_cam >= ((int64_t)1 << 32) || n_pts >= ((int64_t)1 << 32))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "candidate_pairs: indices are 32-bit");
+    if (occlusion && !(block_length > 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "candidate_pairs: block_length must be > 0");
+    c2b_pairs *p = new (std::nothrow) c2b_pairs();
+    if (!p) return fail(C2B_ERR_OOM, "candidate_pairs: host allocation failed");
+    try {
+        c2b_host::candidate_pairs(centers3, pts3, n_pts, max_dist, cam_lo, cam_hi, occlusion != 0, block_length,
+                                  block_inset, n_threads, &p->v);
+    } catch (const std::bad_alloc &) {
+        delete p;
+        return fail(C2B_ERR_OOM, "candidate_pairs: out of host memory");
+    } catch (const std::exception &e) {
+        delete p;
+        return fail(C2B_ERR_INVALID_ARGUMENT, "candidate_pairs: %s", e.what());
+    }
+    *out = p;
+    return C2B_OK;
+}
+
+int64_t c2b_pairs_count(const c2b_pairs *p) { return p ? (int64_t)p->v.cam.size() : 0; }
+const uint32_t *c2b_pairs_cam_idx(const c2b_pairs *p) { return p ? p->v.cam.data() : nullptr; }
+const uint32_t *c2b_pairs_pt_idx(const c2b_pairs *p) { return p ? p->v.pt.data() : nullptr; }
+void c2b_pairs_free(c2b_pairs *p) { delete p; }
 
 /* ------------------------------- level 1 --------------------------------------------- */
 
@@ -568,7 +652,7 @@ int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double 
     if (e == hipSuccess) e = hipMalloc((void **)&d_Jp, sizeof(double) * 6 * p->n_obs);
     if (e == hipSuccess) {
         rc = c2b_residual_jacobian(p->camblk, p->pts4, p->cam_idx, p->pt_idx, p->uv, p->n_obs, d_r, d_Jc, d_Jp, 2.0,
-                                   nullptr, nullptr, p->stream);
+                                   nullptr, p->stream);
         if (!rc) {
             e = hipMemcpyAsync(r, d_r, sizeof(double) * 2 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(Jc, d_Jc, sizeof(double) * 18 * p->n_obs, hipMemcpyDeviceToHost, p->stream);

@@ -98,6 +98,22 @@ __global__ void k_cameras_prepare(const double *__restrict__ in, int64_t n, doub
     for (int k = 0; k < kCamBlk; ++k) o[k] = blk[k];
 }
 
+// Camera::from_position_direction, src/baproblem.rs:153-159: loc = -1.0 * dir.rotate_point(position)
+__global__ void k_cameras_from_position_direction(const double *__restrict__ pos, const double *__restrict__ dir,
+                                                  int64_t n, double *__restrict__ cam15) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double R[9], v[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = dir[9 * i + k];
+    cm_mat_vec(R, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], v);
+    double *o = cam15 + 15 * i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = R[k];
+    o[9] = -1.0 * v[0]; o[10] = -1.0 * v[1]; o[11] = -1.0 * v[2];
+    o[12] = 1.0; o[13] = 0.0; o[14] = 0.0;
+}
+
 __global__ void k_points_pad(const double *__restrict__ p3, int64_t n, double4 *__restrict__ p4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

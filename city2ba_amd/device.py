@@ -1,0 +1,134 @@
+"""Level-0 launchers over torch CUDA(=HIP) tensors.
+
+torch is plumbing here: it owns device memory, the current stream and torch.distributed (RCCL).
+Every function forwards raw device pointers + the current stream handle to the C ABI
+(include/city2ba_hip.h); nothing is computed by torch ops."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, name
+
+
+def workspace(n_obs, device):
+    nbytes = L.lib().c2b_workspace_bytes(int(n_obs))
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+
+
+def cameras_from_bal(bal9):
+    _chk(bal9, torch.float64, "bal9")
+    n = bal9.shape[0]
+    cam15 = torch.empty((n, 15), dtype=torch.float64, device=bal9.device)
+    L.check(L.lib().c2b_cameras_from_bal(_p(bal9), n, _p(cam15), _stream()))
+    return cam15
+
+
+def cameras_to_bal(cam15):
+    _chk(cam15, torch.float64, "cam15")
+    n = cam15.shape[0]
+    bal9 = torch.empty((n, 9), dtype=torch.float64, device=cam15.device)
+    L.check(L.lib().c2b_cameras_to_bal(_p(cam15), n, _p(bal9), _stream()))
+    return bal9
+
+
+def cameras_prepare_state(cam15, out=None):
+    _chk(cam15, torch.float64, "cam15")
+    n = cam15.shape[0]
+    blk = out if out is not None else torch.empty((n, L.CAMBLK_DOUBLES), dtype=torch.float64, device=cam15.device)
+    L.check(L.lib().c2b_cameras_prepare_state(_p(cam15), n, _p(blk), _stream()))
+    return blk
+
+
+def cameras_prepare_bal(bal9, out=None):
+    _chk(bal9, torch.float64, "bal9")
+    n = bal9.shape[0]
+    blk = out if out is not None else torch.empty((n, L.CAMBLK_DOUBLES), dtype=torch.float64, device=bal9.device)
+    L.check(L.lib().c2b_cameras_prepare_bal(_p(bal9), n, _p(blk), _stream()))
+    return blk
+
+
+def points_pad(pts3):
+    _chk(pts3, torch.float64, "pts3")
+    n = pts3.shape[0]
+    pts4 = torch.empty((n, 4), dtype=torch.float64, device=pts3.device)
+    L.check(L.lib().c2b_points_pad(_p(pts3), n, _p(pts4), _stream()))
+    return pts4
+
+
+def expand_rows(row_ptr, n_obs, obs_base=0):
+    _chk(row_ptr, torch.int64, "row_ptr")       # u64 values < 2^63 share the int64 bit pattern
+    n_cam = row_ptr.shape[0] - 1
+    cam_idx = torch.empty(n_obs, dtype=torch.int32, device=row_ptr.device)
+    L.check(L.lib().c2b_expand_rows(_p(row_ptr), n_cam, int(obs_base), int(n_obs), _p(cam_idx), _stream()))
+    return cam_idx
+
+
+def project(camblk, pts4, cam_idx, pt_idx, uv_out):
+    L.check(L.lib().c2b_project(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), cam_idx.shape[0], _p(uv_out),
+                                _stream()))
+    return uv_out
+
+
+def reprojection_error_sum(camblk, pts4, cam_idx, pt_idx, uv, norm, ws, out_sum):
+    L.check(L.lib().c2b_reprojection_error_sum(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv),
+                                               cam_idx.shape[0], float(norm), _p(ws), _p(out_sum), _stream()))
+    return out_sum
+
+
+def residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None):
+    """ws != None -> the kernel also leaves per-tile error partials in ws (see error_sum_finish)."""
+    L.check(L.lib().c2b_residual_jacobian(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv), cam_idx.shape[0],
+                                          _p(r), _p(Jc), _p(Jp), float(norm), _p(ws), _stream()))
+
+
+def error_sum_finish(ws, n_obs, out_sum):
+    L.check(L.lib().c2b_error_sum_finish(_p(ws), int(n_obs), _p(out_sum), _stream()))
+    return out_sum
+
+
+def cameras_from_position_direction(pos3, dir9):
+    _chk(pos3, torch.float64, "pos3")
+    _chk(dir9, torch.float64, "dir9")
+    n = pos3.shape[0]
+    cam15 = torch.empty((n, 15), dtype=torch.float64, device=pos3.device)
+    L.check(L.lib().c2b_cameras_from_position_direction(_p(pos3), _p(dir9), n, _p(cam15), _stream()))
+    return cam15
+
+
+def visibility_pairs(camblk, pts4, cam_idx, pt_idx, max_dist, uv_out, keep):
+    L.check(L.lib().c2b_visibility_pairs(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), cam_idx.shape[0],
+                                         float(max_dist), _p(uv_out), _p(keep), _stream()))
+
+
+def stats(camblk, pts4, ws, out=None):
+    out = out if out is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=camblk.device)
+    L.check(L.lib().c2b_stats(_p(camblk), camblk.shape[0], _p(pts4), pts4.shape[0], _p(ws), _p(out), _stream()))
+    return out
+
+
+def add_drift_normalized(cam15, pts4, stats_, strength, angle_strength, std, seed):
+    L.check(L.lib().c2b_add_drift_normalized(_p(cam15), cam15.shape[0], _p(pts4), pts4.shape[0], _p(stats_),
+                                             float(strength), float(angle_strength), float(std), int(seed), _stream()))
+
+
+def add_noise_entities(cam15, pts4, stats_, translation_std, rotation_std, point_std, seed):
+    L.check(L.lib().c2b_add_noise_entities(_p(cam15), cam15.shape[0], _p(pts4), pts4.shape[0], _p(stats_),
+                                           float(translation_std), float(rotation_std), float(point_std), int(seed),
+                                           _stream()))
+
+
+def add_noise_observations(uv, obs_base, observations_std, seed):
+    L.check(L.lib().c2b_add_noise_observations(_p(uv), uv.shape[0], int(obs_base), float(observations_std),
+                                               int(seed), _stream()))

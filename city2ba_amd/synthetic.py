@@ -1,0 +1,62 @@
+"""Host-side mirror of synthetic.rs over the C ABI: layout and candidate search run in the native
+host code (csrc/host_synthetic.hpp), from_position_direction and the visibility predicate
+(src/synthetic.rs:285-291) on the GPU.  cull() is not applied yet."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def grid_sizes(num_blocks, cameras_per_block=10, points_per_block=10):
+    a, b = C.c_int64(), C.c_int64()
+    L.check(L.lib().c2b_synthetic_grid_sizes(cameras_per_block, points_per_block, num_blocks, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def grid_layout(num_blocks, cameras_per_block=10, points_per_block=10, block_length=20.0, block_inset=1.0,
+                camera_height=1.0, point_height=1.0):
+    """camera positions [n,3], directions [n,9] (col-major), points [n,3]: src/synthetic.rs:178-258."""
+    n_cam, n_pts = grid_sizes(num_blocks, cameras_per_block, points_per_block)
+    pos, dirs, pts = np.empty((n_cam, 3)), np.empty((n_cam, 9)), np.empty((n_pts, 3))
+    L.check(L.lib().c2b_synthetic_grid_layout(cameras_per_block, points_per_block, num_blocks, float(block_length),
+                                              float(block_inset), float(camera_height), float(point_height),
+                                              _ptr(pos), _ptr(dirs), _ptr(pts)))
+    return pos, dirs, pts
+
+
+def line_layout(num_cameras, num_points, length, point_offset, camera_height, point_height):
+    """src/synthetic.rs:323-344"""
+    pos, dirs, pts = np.empty((num_cameras, 3)), np.empty((num_cameras, 9)), np.empty((num_points, 3))
+    L.check(L.lib().c2b_synthetic_line_layout(num_cameras, num_points, float(length), float(point_offset),
+                                              float(camera_height), float(point_height), _ptr(pos), _ptr(dirs),
+                                              _ptr(pts)))
+    return pos, dirs, pts
+
+
+def candidate_pairs(centers, pts, max_dist, cam_lo=0, cam_hi=None, occlusion=False, block_length=20.0,
+                    block_inset=1.0, n_threads=None):
+    """(cam_idx u32, pt_idx u32): rstar's locate_within_distance (src/synthetic.rs:277-280) replaced by
+    cell binning, optionally filtered by hits_building (:52-124).  Camera-major, ascending point index."""
+    centers = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, 3)
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    cam_hi = len(centers) if cam_hi is None else cam_hi
+    n_threads = n_threads or max(1, min(16, os.cpu_count() or 1))
+    h = C.c_void_p()
+    L.check(L.lib().c2b_candidate_pairs(_ptr(centers), len(centers), _ptr(pts), len(pts), float(max_dist), int(cam_lo),
+                                        int(cam_hi), int(bool(occlusion)), float(block_length), float(block_inset),
+                                        int(n_threads), C.byref(h)))
+    try:
+        n = L.lib().c2b_pairs_count(h)
+        if n == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        ci = np.ctypeslib.as_array(C.cast(L.lib().c2b_pairs_cam_idx(h), C.POINTER(C.c_uint32)), shape=(n,)).copy()
+        pi = np.ctypeslib.as_array(C.cast(L.lib().c2b_pairs_pt_idx(h), C.POINTER(C.c_uint32)), shape=(n,)).copy()
+    finally:
+        L.lib().c2b_pairs_free(h)
+    return ci, pi

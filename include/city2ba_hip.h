@@ -68,6 +68,9 @@ int c2b_cameras_to_bal(const double *cam15, int64_t n_cam, double *bal9, void *s
 int c2b_cameras_prepare_state(const double *cam15, int64_t n_cam, double *camblk, void *stream);
 /* derive camblk from 9-vectors; R = from_rodrigues(w), Jacobian columns refer to that w */
 int c2b_cameras_prepare_bal(const double *bal9, int64_t n_cam, double *camblk, void *stream);
+/* Camera::from_position_direction (src/baproblem.rs:153-159): pos [n][3], dir [n][9] col-major */
+int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, int64_t n_cam,
+                                        double *cam15, void *stream);
 /* pts3 [n][3] -> pts4 [n][4] and back */
 int c2b_points_pad(const double *pts3, int64_t n_pts, double *pts4, void *stream);
 int c2b_points_unpad(const double *pts4, int64_t n_pts, double *pts3, void *stream);
@@ -86,12 +89,15 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
                                const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
                                double norm, void *workspace, double *out_sum, void *stream);
 
-/* residual + 2x9 camera block + 2x3 point block per observation (no reference equivalent),
- * fused with the error sum above when out_sum != NULL (pass NULL to skip). */
+/* residual + 2x9 camera block + 2x3 point block per observation (no reference equivalent).
+ * With workspace != NULL the kernel also leaves one partial of sum |du|^norm + |dv|^norm per
+ * 256-observation tile in the workspace (fused error reduce); c2b_error_sum_finish folds them. */
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                           const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
                           double *r, double *Jc, double *Jp,
-                          double norm, void *workspace, double *out_sum, void *stream);
+                          double norm, void *workspace, void *stream);
+/* fixed-order fold of the per-tile partials left by c2b_residual_jacobian -> out_sum[0] */
+int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, void *stream);
 
 /* visibility predicate of the generators (src/synthetic.rs:285-291, 368-375;
  * src/generate.rs:448-454): keep = |center - p| < max_dist && q.z <= 0 && |u|,|v| <= 1.
@@ -131,6 +137,38 @@ int c2b_add_sin_noise(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts,
 /* contiguous camera ranges with ~equal observation counts (host pointers): the multi-GPU
  * shard map.  bounds[n_parts+1]; part k owns cameras [bounds[k], bounds[k+1]). */
 int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, int64_t *bounds);
+
+/* ===================================================================================== *
+ * Host-side generator pieces around the device predicate (HOST pointers, CPU, synchronous).
+ * These are the callers either side of the hot path, in C++ because the
+ * reference's generator is compiled code; they never touch the GPU.
+ * ===================================================================================== */
+
+/* synthetic_grid's camera / point counts: 4*cpb*B*(B+1), 12*ppb*B*(B+1) (src/synthetic.rs:179-258) */
+int c2b_synthetic_grid_sizes(int64_t cameras_per_block, int64_t points_per_block, int64_t blocks,
+                             int64_t *n_cam, int64_t *n_pts);
+/* layout loops of synthetic_grid (src/synthetic.rs:178-258) in the reference's push and arithmetic
+ * order: camera positions [n_cam][3], directions [n_cam][9] (col-major Basis3), points [n_pts][3] */
+int c2b_synthetic_grid_layout(int64_t cameras_per_block, int64_t points_per_block, int64_t blocks,
+                              double block_length, double block_inset, double camera_height,
+                              double point_height, double *cam_pos3, double *cam_dir9, double *pts3);
+/* layout of synthetic_line (src/synthetic.rs:323-344) */
+int c2b_synthetic_line_layout(int64_t n_cam, int64_t n_pts, double length, double point_offset,
+                              double camera_height, double point_height, double *cam_pos3,
+                              double *cam_dir9, double *pts3);
+
+/* Candidate (camera, point) pairs for cameras [cam_lo, cam_hi): squared distance from the camera
+ * centre <= max_dist^2 (rstar locate_within_distance, src/synthetic.rs:277-280), camera-major,
+ * ascending point index per camera; with occlusion != 0, pairs whose sight line crosses a building
+ * are dropped (hits_building, src/synthetic.rs:52-124, incl. its end-point quirk at :93). */
+typedef struct c2b_pairs c2b_pairs;
+int c2b_candidate_pairs(const double *centers3, int64_t n_cam, const double *pts3, int64_t n_pts,
+                        double max_dist, int64_t cam_lo, int64_t cam_hi, int occlusion,
+                        double block_length, double block_inset, int n_threads, c2b_pairs **out);
+int64_t c2b_pairs_count(const c2b_pairs *p);
+const uint32_t *c2b_pairs_cam_idx(const c2b_pairs *p);
+const uint32_t *c2b_pairs_pt_idx(const c2b_pairs *p);
+void c2b_pairs_free(c2b_pairs *p);
 
 /* ===================================================================================== *
  * Level 1 -- a BAProblem resident on one device.  Pointers are HOST pointers; calls are

@@ -1,4 +1,6 @@
 """Seeded synthetic BA problems shared by the CPU and GPU tests (inputs only)."""
+import math
+
 import numpy as np
 
 import oracle as O
@@ -90,3 +92,107 @@ def grid_candidate_pairs(cams15, pts, max_dist):
         cam_idx.append(np.full(len(sel), c, dtype=np.uint32))
         pt_idx.append(sel.astype(np.uint32))
     return np.concatenate(cam_idx), np.concatenate(pt_idx)
+
+
+# ---- numpy restatement of the grid layout / candidate search (independent of the C++ host code) ----
+def _basis_y(deg):
+    """Basis3::from_angle_y(Deg(deg)) as col-major 9 (cgmath: Deg -> Rad is deg * (PI/180));
+    libm sin/cos like Rust's f64::sin_cos."""
+    th = deg * (math.pi / 180.0)
+    s, c = math.sin(th), math.cos(th)
+    return np.array([c, 0.0, -s, 0.0, 1.0, 0.0, s, 0.0, c])
+
+
+def np_grid_layout(num_blocks, cpb=10, ppb=10, block_length=20.0, block_inset=1.0, camera_height=1.0,
+                point_height=1.0):
+    """cams15 [4*cpb*B*(B+1), 15] and pts [12*ppb*B*(B+1), 3] in the reference's push order."""
+    B, L, ins = int(num_blocks), float(block_length), float(block_inset)
+    assert ins * 2.0 < L, "Block inset must be less than half the block length"
+    bx, by, i, k = np.meshgrid(np.arange(B + 1), np.arange(B + 1), np.arange(cpb), np.arange(4), indexing="ij")
+    bx, by, i, k = bx.ravel(), by.ravel(), i.ravel(), k.ravel()
+    horiz = k < 2
+    ok = np.where(horiz, bx != B, by != B)
+    bx, by, i, k, horiz = bx[ok], by[ok], i[ok], k[ok], horiz[ok]
+    off_x, off_z = L * bx.astype(np.float64), L * by.astype(np.float64)
+    along = i.astype(np.float64) / float(cpb) * L
+    px = np.where(horiz, off_x + along, off_x)
+    pz = np.where(horiz, off_z, off_z + along)
+    py = np.full_like(px, float(camera_height))
+    dirs = np.stack([_basis_y(-90.0), _basis_y(90.0), _basis_y(180.0), np.array([1.0, 0, 0, 0, 1, 0, 0, 0, 1])])
+    R = dirs[k]                                               # [n, 9] col-major
+    # from_position_direction (src/baproblem.rs:153-159): loc = -1.0 * (dir . pos), dot = (a+b)+c
+    t = np.stack([-1.0 * ((R[:, 0] * px + R[:, 3] * py) + R[:, 6] * pz),
+                  -1.0 * ((R[:, 1] * px + R[:, 4] * py) + R[:, 7] * pz),
+                  -1.0 * ((R[:, 2] * px + R[:, 5] * py) + R[:, 8] * pz)], axis=1)
+    intr = np.tile(np.array([1.0, 0.0, 0.0]), (len(px), 1))
+    cams15 = np.ascontiguousarray(np.concatenate([R, t, intr], axis=1))
+
+    step = (L - ins * 2.0) / float(ppb)
+    bx, by, i, k = np.meshgrid(np.arange(B + 1), np.arange(B + 1), np.arange(ppb), np.arange(12), indexing="ij")
+    bx, by, i, k = bx.ravel(), by.ravel(), i.ravel(), k.ravel()
+    horiz = k < 6
+    ok = np.where(horiz, bx != B, by != B)
+    bx, by, i, k, horiz = bx[ok], by[ok], i[ok], k[ok], horiz[ok]
+    off_x, off_z = L * bx.astype(np.float64), L * by.astype(np.float64)
+    kk = k % 6
+    base = np.where(horiz, off_x, off_z) + ins + i.astype(np.float64) * step     # loc_x / loc_z
+    along = np.where(kk < 2, base, base + step / 2.0)
+    other0 = np.where(horiz, off_z, off_x)
+    lateral = np.select([kk == 0, kk == 1, kk == 2, kk == 3, kk == 4, kk == 5],
+                        [other0 - ins, other0 + ins, other0 - ins, other0 + ins,
+                         other0 - ins / 2.0, other0 + ins / 2.0])
+    y = np.where(kk < 2, float(point_height), 0.0)
+    x = np.where(horiz, along, lateral)
+    z = np.where(horiz, lateral, along)
+    pts = np.ascontiguousarray(np.stack([x, y, z], axis=1))
+    return cams15, pts
+
+
+def np_candidate_pairs(centers, pts, max_dist, cam_lo=0, cam_hi=None, chunk=100_000):
+    """(cam, point) pairs with |center - p|^2 <= max_dist^2 (rstar's locate_within_distance takes the
+    squared radius, src/synthetic.rs:277-280), camera-major, ascending point index per camera.
+    Uniform-cell binning over (x, z)."""
+    cam_hi = len(centers) if cam_hi is None else cam_hi
+    cs = float(max_dist)
+    x0 = min(pts[:, 0].min(), centers[:, 0].min()) - cs
+    z0 = min(pts[:, 2].min(), centers[:, 2].min()) - cs
+    pcx = np.floor((pts[:, 0] - x0) / cs).astype(np.int64)
+    pcz = np.floor((pts[:, 2] - z0) / cs).astype(np.int64)
+    ncz = int(pcz.max()) + 3
+    ncx = int(pcx.max()) + 3
+    cell = pcx * ncz + pcz
+    order = np.argsort(cell, kind="stable")
+    sorted_cell = cell[order]
+    starts = np.searchsorted(sorted_cell, np.arange(ncx * ncz + 1))
+    out_c, out_p = [], []
+    r2 = max_dist * max_dist
+    for lo in range(cam_lo, cam_hi, chunk):
+        hi = min(lo + chunk, cam_hi)
+        c = centers[lo:hi]
+        ccx = np.floor((c[:, 0] - x0) / cs).astype(np.int64)
+        ccz = np.floor((c[:, 2] - z0) / cs).astype(np.int64)
+        cams, pidx = [], []
+        for dx in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                cid = (ccx + dx) * ncz + (ccz + dz)
+                s, e = starts[cid], starts[cid + 1]
+                ln = e - s
+                tot = int(ln.sum())
+                if tot == 0:
+                    continue
+                rep = np.repeat(np.arange(lo, hi), ln)
+                first = np.repeat(np.cumsum(ln) - ln, ln)
+                pos = np.arange(tot) - first + np.repeat(s, ln)
+                cams.append(rep)
+                pidx.append(order[pos])
+        cams = np.concatenate(cams)
+        pidx = np.concatenate(pidx)
+        d = pts[pidx] - centers[cams]
+        keep = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2] <= r2
+        cams, pidx = cams[keep], pidx[keep]
+        o = np.lexsort((pidx, cams))
+        out_c.append(cams[o].astype(np.int32))
+        out_p.append(pidx[o].astype(np.int32))
+    if not out_c:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32)
+    return np.concatenate(out_c), np.concatenate(out_p)
