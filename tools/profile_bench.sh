@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): rocprofv3 kernel trace + stats, then the HBM PMC counters in their own
+# passes (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+#   usage: tools/profile_bench.sh <tag> [bench args...]
+# Output: gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write}/ + summary files written by summarize_prof.py.
+TAG=${1:-r01}; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+ARGS="${@:---steps 10 --warmup 2 --no-cpu-baseline}"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
+echo "trace rc=$?"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
+echo "pmc_fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
+echo "pmc_write rc=$?"
+python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$TAG"
