@@ -44,8 +44,71 @@ inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)((n + b - 1) / b); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// workspace layout: [0, kRedBlocks*kStatRec) stats records | then one partial per observation tile
+// workspace layout (doubles): [stats records: kRedBlocks*kStatRec] [stage-1 sums: kSumBlocks]
+//                            [error partials: one per 64-observation wave tile]
 constexpr int64_t kWsStatsDoubles = (int64_t)kRedBlocks * kStatRec;
+constexpr int64_t kWsPartials = kWsStatsDoubles + kSumBlocks;
+
+// residual+Jacobian kernel variant (tuning knob, not part of the ABI): 0 = workgroup-tiled kernel,
+// 1.. = wave-centric kernel <WPB, SPLIT, NT> (see launch_jacobian)
+int g_jac_variant = 9;
+
+int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) {
+    double *ws = reinterpret_cast<double *>(workspace);
+    const double *partials = ws + kWsPartials;
+    double *stage = ws + kWsStatsDoubles;
+    int64_t chunk = (count + kSumBlocks - 1) / kSumBlocks;
+    if (chunk < 256) chunk = 256;
+    const int blocks = (int)((count + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_sum_stage1, dim3(blocks), dim3(256), 0, st, partials, count, chunk, stage);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(kSumBlocks), 0, st, (const double *)stage, blocks, out_sum);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0>
+void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                         const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
+                         double *partials, hipStream_t st) {
+    const int64_t wave_tiles = (n_obs + 63) / 64;
+    const int64_t btiles = (wave_tiles + WPB - 1) / WPB;
+    hipLaunchKernelGGL((k_residual_jacobian_w<WITH_ERR, WPB, SPLIT, NT, ABL>), dim3((unsigned)btiles), dim3(WPB * 64), 0, st,
+                       camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
+                       reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r),
+                       Jc, Jp, partials);
+}
+
+template <bool WITH_ERR>
+void launch_jacobian(int variant, const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                            const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
+                            double *Jp, double norm, double *partials, hipStream_t st) {
+#define C2B_W(WPB, SPLIT, NT) launch_jac_w<WITH_ERR, WPB, SPLIT, NT>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st)
+    switch (variant) {
+        case 1: C2B_W(4, 2, false); break;
+        case 2: C2B_W(4, 2, true); break;
+        case 3: C2B_W(4, 1, false); break;
+        case 4: C2B_W(1, 2, false); break;
+        case 5: C2B_W(1, 2, true); break;
+        case 6: C2B_W(2, 2, true); break;
+        case 7: C2B_W(4, 1, true); break;
+        case 8: C2B_W(1, 1, true); break;
+        default:
+        case 9: C2B_W(8, 2, true); break;
+        case 10: C2B_W(16, 2, true); break;
+        case 20: launch_jac_w<WITH_ERR, 4, 2, true, 1>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+        case 21: launch_jac_w<WITH_ERR, 4, 2, true, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+        case 0: {
+            const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
+            hipLaunchKernelGGL(k_residual_jacobian<WITH_ERR>, dim3((unsigned)tiles), dim3(kBlock), 0, st, camblk,
+                               reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
+                               reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
+                               reinterpret_cast<double2 *>(r), Jc, Jp, partials);
+            break;
+        }
+    }
+#undef C2B_W
+}
 
 }  // namespace
 
@@ -65,9 +128,12 @@ int c2b_device_count(int *count) {
 
 int64_t c2b_workspace_bytes(int64_t n_obs) {
     if (n_obs < 0) n_obs = 0;
-    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
-    return (kWsStatsDoubles + tiles + 16) * (int64_t)sizeof(double);
+    const int64_t wave_tiles = (n_obs + 63) / 64;
+    return (kWsPartials + wave_tiles + 16) * (int64_t)sizeof(double);
 }
+
+// hidden tuning hook (tools/tune_jac.py); not declared in the public header
+int c2b_tune_set_jacobian_variant(int v) { g_jac_variant = v; return C2B_OK; }
 
 /* ------------------------------- level 0 --------------------------------------------- */
 
@@ -179,16 +245,14 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
     if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
     if (!uv_obs || !aligned16(uv_obs) || !workspace)
         return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: uv_obs/workspace NULL or misaligned");
-    double *partials = reinterpret_cast<double *>(workspace) + kWsStatsDoubles;
+    double *partials = reinterpret_cast<double *>(workspace) + kWsPartials;
     const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_observations<MODE_ERROR>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
                        reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm, 0.0, (double2 *)nullptr,
                        (uint8_t *)nullptr, partials);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, S(stream), partials, tiles, out_sum);
-    LAUNCH_CHECK();
-    return C2B_OK;
+    return launch_sum(workspace, tiles, out_sum, S(stream));
 }
 
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
@@ -200,18 +264,13 @@ int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32
     if (!uv_obs || !r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: NULL buffer");
     if (!aligned16(uv_obs) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
         return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: uv/r/Jc/Jp must be 16-byte aligned");
-    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
     if (workspace) {
-        double *partials = reinterpret_cast<double *>(workspace) + kWsStatsDoubles;
-        hipLaunchKernelGGL(k_residual_jacobian<true>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
-                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
-                           reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
-                           reinterpret_cast<double2 *>(r), Jc, Jp, partials);
+        double *partials = reinterpret_cast<double *>(workspace) + kWsPartials;
+        launch_jacobian<true>(g_jac_variant, camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials,
+                              S(stream));
     } else {
-        hipLaunchKernelGGL(k_residual_jacobian<false>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
-                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
-                           reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
-                           reinterpret_cast<double2 *>(r), Jc, Jp, (double *)nullptr);
+        launch_jacobian<false>(g_jac_variant, camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr,
+                               S(stream));
     }
     LAUNCH_CHECK();
     return C2B_OK;
@@ -221,11 +280,8 @@ int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, 
     if (n_obs < 0 || !out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: bad arguments");
     if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
     if (!workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: workspace is NULL");
-    const double *partials = reinterpret_cast<const double *>(workspace) + kWsStatsDoubles;
-    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, S(stream), partials, tiles, out_sum);
-    LAUNCH_CHECK();
-    return C2B_OK;
+    const int64_t count = g_jac_variant == 0 ? (n_obs + kBlock - 1) / kBlock : (n_obs + 63) / 64;
+    return launch_sum(const_cast<void *>(workspace), count, out_sum, S(stream));
 }
 
 int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_t *cam_idx,

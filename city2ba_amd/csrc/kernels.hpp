@@ -341,19 +341,197 @@ __global__ __launch_bounds__(kBlock) void k_residual_jacobian(
     }
 }
 
-// fixed-order sum of n partials by one 1024-lane workgroup
-__global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ partials, int64_t n,
-                                                      double *__restrict__ out) {
-    __shared__ double sRed[16];
+// ---- residual + Jacobian, wave-centric form -------------------------------------------------------
+// Every wave owns 64 consecutive observations and never synchronises with another wave: it stages
+// the (typically 3-4) cameras its observations touch in a wave-private LDS tile, transposes its
+// Jacobian blocks through a wave-private slab (optionally in two half-wave rounds to halve the slab)
+// and leaves one error partial.  No workgroup barrier => the memory round trips of one wave overlap
+// the arithmetic of its neighbours, and LDS per wave drops from 12 KB to 6.9 KB (20 waves per CU).
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+C2B_DEV void store16(char *dst, const double2 v) {
+    if (NT) {
+        d2_t t; t.x = v.x; t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(dst));
+    } else {
+        *reinterpret_cast<double2 *>(dst) = v;
+    }
+}
+
+constexpr int kCamW = 12;                      // cameras staged per wave (12 x 192 B)
+
+template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0>   // ABL: timing-only ablations (tools/)
+__global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
+    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
+    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
+    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm,
+    double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
+    double *__restrict__ partials) {
+    constexpr int kSlab = 64 * 144 / SPLIT;
+    constexpr int kCamBytes = kCamW * kCamHot * 8;
+    __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wt = xcd_tile(blockIdx.x, n_btiles) * WPB + wave;     // this wave's 64-observation tile
+    const int64_t wave0 = wt * 64;
+    if (wave0 >= n) return;                                              // wave-uniform
+    const int64_t o = wave0 + lane;
+    const bool valid = o < n;
+    const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
+
+    uint32_t ci = 0, pi = 0;
+    double2 ob = make_double2(0, 0);
+    if (valid) { ci = cam_idx[o]; pi = pt_idx[o]; ob = uv_obs[o]; }
+    double4 X = make_double4(0, 0, -1, 0);
+    if (valid) X = pts4[pi];
+
+    // wave-private camera tile
+    double *sCam = reinterpret_cast<double *>(smem + wave * (kSlab + kCamBytes) + kSlab);
+    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci);
+    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci, n_wave - 1, 64));
+    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
+    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
+    for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
+        const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
+        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+        *reinterpret_cast<double2 *>(sCam + k * kCamHot + 2 * j) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t local = ci - c_first;
+    const double *cam = (valid && local < n_staged) ? (sCam + local * kCamHot) : (camblk + (int64_t)ci * kCamBlk);
+    Proj p;
+    if (ABL == 2) {        // memory-only build: keep every load live, skip the arithmetic
+        p.qx = X.x + cam[0]; p.qy = X.y + cam[9]; p.qz = X.z + cam[12]; p.px = cam[15]; p.py = cam[23];
+        p.n = ob.x; p.rad = ob.y; p.u = X.x; p.v = X.y;
+    } else {
+        p = project_obs(cam, X.x, X.y, X.z);
+    }
+    const double r0 = p.u - ob.x, r1 = p.v - ob.y;
+
+    const double f = cam[12], k1 = cam[13], k2 = cam[14];
+    double iz = ABL == 2 ? p.qz : __builtin_amdgcn_rcp(p.qz);
+    iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
+    iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
+    const double s = -f * iz;
+    const double c = fma(4.0 * k2, p.n, 2.0 * k1);
+    const double cpx = c * p.px;
+    const double B00 = fma(cpx, p.px, p.rad), B01 = cpx * p.py, B11 = fma(c * p.py, p.py, p.rad);
+    const double g = fma(c, p.n, p.rad);
+    const double a00 = s * B00, a01 = s * B01, a02 = s * p.px * g;
+    const double a10 = s * B01, a11 = s * B11, a12 = s * p.py * g;
+    const double yx = p.qx - cam[9], yy = p.qy - cam[10], yz = p.qz - cam[11];
+    const double v0x = fma(yy, a02, -yz * a01), v0y = fma(yz, a00, -yx * a02), v0z = fma(yx, a01, -yy * a00);
+    const double v1x = fma(yy, a12, -yz * a11), v1y = fma(yz, a10, -yx * a12), v1z = fma(yx, a11, -yy * a10);
+    const double *Jl = cam + kJl;
+    double jc[18], jp[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        jc[j] = fma(v0z, Jl[6 + j], fma(v0y, Jl[3 + j], v0x * Jl[j]));
+        jc[9 + j] = fma(v1z, Jl[6 + j], fma(v1y, Jl[3 + j], v1x * Jl[j]));
+        jp[j] = fma(a02, cam[6 + j], fma(a01, cam[3 + j], a00 * cam[j]));
+        jp[3 + j] = fma(a12, cam[6 + j], fma(a11, cam[3 + j], a10 * cam[j]));
+    }
+    jc[3] = a00; jc[4] = a01; jc[5] = a02;
+    jc[12] = a10; jc[13] = a11; jc[14] = a12;
+    const double fn = f * p.n, fnn = fn * p.n;
+    jc[6] = p.rad * p.px;  jc[15] = p.rad * p.py;
+    jc[7] = fn * p.px;     jc[16] = fn * p.py;
+    jc[8] = fnn * p.px;    jc[17] = fnn * p.py;
+    if (ABL == 2) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) jc[k] = p.qx + k;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) jp[k] = p.qy + k;
+    }
+
+    if (valid) store16<NT>(reinterpret_cast<char *>(r_out + o), make_double2(r0, r1));
+    if (ABL == 1) {        // load+compute-only build: fold the Jacobian into one value, no slab / no stores
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) acc += jc[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += jp[k];
+        if (acc == 1.2345e300) Jc[o] = acc;
+        return;
+    }
+
+    char *slab = smem + wave * (kSlab + kCamBytes);
+    constexpr int kHalf = 64 / SPLIT;                 // lanes per transposition round
+#pragma unroll
+    for (int h = 0; h < SPLIT; ++h) {
+        if (SPLIT == 1 || (lane / kHalf) == h) {
+            double2 *w = reinterpret_cast<double2 *>(slab + (lane % kHalf) * 144);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = make_double2(jc[2 * k], jc[2 * k + 1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        char *dst = reinterpret_cast<char *>(Jc) + (wave0 + h * kHalf) * 144;
+        int nv = n_wave - h * kHalf;
+        nv = nv < 0 ? 0 : (nv > kHalf ? kHalf : nv);
+        const int bytes = nv * 144;
+        constexpr int kIters = (kHalf * 144 + 1023) / 1024;
+#pragma unroll
+        for (int k = 0; k < kIters; ++k) {
+            const int off = (k * 64 + lane) * 16;
+            if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+        double2 *w = reinterpret_cast<double2 *>(slab + lane * 48);      // 64 x 48 B = 3 KB <= slab
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] = make_double2(jp[2 * k], jp[2 * k + 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        char *dst = reinterpret_cast<char *>(Jp) + wave0 * 48;
+        const int bytes = n_wave * 48;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int off = (k * 64 + lane) * 16;
+            if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
+        }
+    }
+
+    if (WITH_ERR) {
+        const double e = valid ? abs_pow(r0, norm) + abs_pow(r1, norm) : 0.0;
+        const double w = wave_sum(e);
+        if (lane == 0) partials[wt] = w;
+    }
+}
+
+// Fixed-order two-stage sum of n partials: stage 1 = up to kSumBlocks workgroups, each summing one
+// contiguous chunk; stage 2 = one workgroup summing the stage-1 results.  Deterministic.
+constexpr int kSumBlocks = 512;
+
+__global__ __launch_bounds__(256) void k_sum_stage1(const double *__restrict__ partials, int64_t n, int64_t chunk,
+                                                   double *__restrict__ out) {
+    __shared__ double sRed[4];
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t hi = lo + chunk < n ? lo + chunk : n;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += partials[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += partials[i];
     const double w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+}
+
+__global__ __launch_bounds__(kSumBlocks) void k_sum_stage2(const double *__restrict__ partials, int n,
+                                                          double *__restrict__ out) {
+    __shared__ double sRed[kSumBlocks / 64];
+    const double v = (int)threadIdx.x < n ? partials[threadIdx.x] : 0.0;
+    const double w = wave_sum(v);
     if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = w;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += sRed[i];
+        for (int i = 0; i < kSumBlocks / 64; ++i) t += sRed[i];
         out[0] = t;
     }
 }
