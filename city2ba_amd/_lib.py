@@ -58,6 +58,12 @@ SIGNATURES = {
     "c2b_pairs_cam_idx": (_vp, [_vp]),
     "c2b_pairs_pt_idx": (_vp, [_vp]),
     "c2b_pairs_free": (None, [_vp]),
+    "c2b_cull": (_int, [C.POINTER(_i64), _vp, _int, C.POINTER(_i64), _vp, _vp, _vp, _vp, _int]),
+    "c2b_bal_read": (_int, [C.c_char_p, C.POINTER(_vp)]),
+    "c2b_bal_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "c2b_bal_copy": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "c2b_bal_close": (None, [_vp]),
+    "c2b_bal_write": (_int, [C.c_char_p, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "c2b_problem_create": (_int, [_int, C.POINTER(_vp)]),
     "c2b_problem_destroy": (None, [_vp]),
     "c2b_problem_upload": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -65,6 +71,8 @@ SIGNATURES = {
     "c2b_problem_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "c2b_problem_download": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_download_bal": (_int, [_vp, _vp]),
+    "c2b_problem_from_position_direction": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "c2b_problem_centers": (_int, [_vp, _vp]),
     "c2b_problem_project": (_int, [_vp, _vp]),
     "c2b_problem_total_reprojection_error": (_int, [_vp, _d, C.POINTER(_d)]),
     "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),

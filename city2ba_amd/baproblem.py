@@ -186,6 +186,41 @@ class BAProblem:
         s = self._stats()
         return s[15:18].copy(), int(s[18])
 
+    def _cameras_from_position_direction(self, pos, dirs):
+        """Camera::from_position_direction (src/baproblem.rs:153-159), batched on this problem's device."""
+        pos, dirs = _f64(pos, (-1, 3)), _f64(dirs, (-1, 9))
+        out = np.empty((len(pos), 15))
+        L.check(L.lib().c2b_problem_from_position_direction(self._h, len(pos), _ptr(pos), _ptr(dirs), _ptr(out)))
+        return out
+
+    def _camera_centers(self):
+        """Camera::center (src/baproblem.rs:161-163) of every camera [n,3]"""
+        out = np.empty((self.num_cameras(), 3))
+        L.check(L.lib().c2b_problem_centers(self._h, _ptr(out)))
+        return out
+
+    # ---- host-side rows: cull and file IO (C++ host code behind the same ABI) -----------------------
+    def cull(self, faithful=True):
+        """BAProblem::cull (src/baproblem.rs:538-549): largest connected component + cameras with > 3
+        observations / points with > 1, to a fixed point.  Returns a NEW device problem."""
+        cams = self.cameras()
+        pts = self.points()
+        uv = self.observations()
+        row_ptr = self._row_ptr.copy()
+        pt_idx = self._pt_idx.copy()
+        cams, pts, row_ptr, pt_idx, uv = cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful)
+        return BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv)
+
+    @classmethod
+    def from_file(cls, path, device=0):
+        """BAProblem::from_file (src/baproblem.rs:697-706): .bal text or .bbal binary by extension."""
+        bal9, pts, row_ptr, pt_idx, uv = read_bal(path)
+        return cls.from_bal(bal9, pts, row_ptr, pt_idx, uv, device)
+
+    def write(self, path):
+        """BAProblem::write (src/baproblem.rs:768-785)"""
+        write_bal(path, self.cameras_bal(), self.points(), self._row_ptr, self._pt_idx, self.observations())
+
     def visibility_pairs(self, cam_idx, pt_idx, max_dist):
         """predicate of the generator loops (src/synthetic.rs:285-291; src/generate.rs:448-454)"""
         cam_idx = np.ascontiguousarray(cam_idx, dtype=np.uint32)
@@ -198,3 +233,50 @@ class BAProblem:
         L.check(L.lib().c2b_problem_visibility_pairs(self._h, n, _ptr(cam_idx), _ptr(pt_idx), float(max_dist),
                                                      _ptr(uv), _ptr(keep)))
         return uv, keep
+
+
+# ---- host-array helpers over the C ABI (no GPU involved) ------------------------------------------------
+def cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful=True):
+    """c2b_cull on numpy arrays; cams is [n, stride] (cam15 or bal9 rows).  Returns the culled copies."""
+    cams = np.array(cams, dtype=np.float64, order="C", copy=True)
+    cams = cams.reshape(len(cams), -1) if cams.size else cams.reshape(0, cams.shape[-1] if cams.ndim == 2 else 15)
+    pts = np.array(pts, dtype=np.float64, order="C", copy=True).reshape(-1, 3)
+    row_ptr = np.array(row_ptr, dtype=np.uint64, order="C", copy=True)
+    pt_idx = np.array(pt_idx, dtype=np.uint64, order="C", copy=True)
+    uv = np.array(uv, dtype=np.float64, order="C", copy=True).reshape(-1, 2)
+    if len(row_ptr) != len(cams) + 1:
+        raise L.City2baError(L.ERR_INVALID_ARGUMENT, "row_ptr must have n_cameras + 1 entries")
+    stride = cams.shape[1] if cams.ndim == 2 and len(cams) else 0
+    nc, npts = C.c_int64(len(cams)), C.c_int64(len(pts))
+    L.check(L.lib().c2b_cull(C.byref(nc), _ptr(cams), int(stride), C.byref(npts), _ptr(pts), _ptr(row_ptr),
+                             _ptr(pt_idx), _ptr(uv), int(bool(faithful))))
+    n_obs = int(row_ptr[nc.value])
+    return (cams[:nc.value].copy(), pts[:npts.value].copy(), row_ptr[:nc.value + 1].copy(), pt_idx[:n_obs].copy(),
+            uv[:n_obs].copy())
+
+
+def read_bal(path):
+    """(bal9 [n,9], pts [m,3], row_ptr, pt_idx, uv) from a .bal / .bbal file."""
+    h = C.c_void_p()
+    L.check(L.lib().c2b_bal_read(str(path).encode(), C.byref(h)))
+    try:
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().c2b_bal_sizes(h, C.byref(a), C.byref(b), C.byref(c)))
+        bal9, pts = np.empty((a.value, 9)), np.empty((b.value, 3))
+        row_ptr = np.empty(a.value + 1, dtype=np.uint64)
+        pt_idx = np.empty(c.value, dtype=np.uint64)
+        uv = np.empty((c.value, 2))
+        L.check(L.lib().c2b_bal_copy(h, _ptr(bal9), _ptr(pts), _ptr(row_ptr), _ptr(pt_idx), _ptr(uv)))
+    finally:
+        L.lib().c2b_bal_close(h)
+    return bal9, pts, row_ptr, pt_idx, uv
+
+
+def write_bal(path, bal9, pts, row_ptr, pt_idx, uv):
+    bal9 = _f64(bal9, (-1, 9))
+    pts = _f64(pts, (-1, 3))
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint64)
+    uv = _f64(uv, (-1, 2))
+    L.check(L.lib().c2b_bal_write(str(path).encode(), len(bal9), _ptr(bal9), len(pts), _ptr(pts), _ptr(row_ptr),
+                                  _ptr(pt_idx), _ptr(uv)))

@@ -1,0 +1,273 @@
+// city2ba (MI355X build) -- command line with the reference's subcommands and flag names
+// (src/bin/city2ba.rs:113-260), written against the C ABI only (include/city2ba_hip.h), i.e. exactly
+// what a Rust host would call.
+//
+//   city2ba synthetic OUT [--blocks N --cameras-per-block N --points-per-block N --max-dist X
+//                          --camera-height X --point-height X --block-inset X --block-length X]
+//   city2ba synthetic-line OUT [--cameras N --points N --max-dist X --camera-height X --point-height X
+//                               --point-offset X --length X]
+//   city2ba noise IN OUT [--rotation-std X --translation-std X --point-std X --observation-std X
+//                         --drift-std X --drift-strength X --fixed-drift --drift-angle X
+//                         --sin-strength X --sin-frequency X] [--seed N]
+//
+// Not provided: `generate` and `ply` (Embree ray casting / PLY export are outside the hot-path scope) and the
+// index-shuffling noise flags (--mismatch-chance > 0, --drop-features < 1, --split-landmarks, --join-landmarks).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/city2ba_hip.h"
+
+namespace {
+
+[[noreturn]] void die(const std::string &msg) {
+    std::fprintf(stderr, "Error: %s\n", msg.c_str());
+    std::exit(1);
+}
+
+void ck(int rc) {
+    if (rc != C2B_OK) die(c2b_last_error());
+}
+
+// Rust `{:.2e}`: "1.23e-5", "0.00e0"
+std::string sci2(double v) {
+    if (v != v) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    if (v == 0.0) return "0.00e0";
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.2e", v);
+    std::string s(buf);
+    const size_t e = s.find('e');
+    const int ex = std::atoi(s.c_str() + e + 1);
+    return s.substr(0, e) + "e" + std::to_string(ex);
+}
+
+struct Args {
+    std::vector<std::string> positional;
+    std::map<std::string, std::string> opt;
+    bool has(const std::string &k) const { return opt.count(k) != 0; }
+    double f(const std::string &k, double dflt) const {
+        auto it = opt.find(k);
+        if (it == opt.end()) return dflt;
+        char *end = nullptr;
+        const double v = std::strtod(it->second.c_str(), &end);
+        if (end == it->second.c_str() || *end) die("Invalid value for '--" + k + " <" + k + ">': invalid float literal");
+        return v;
+    }
+    int64_t i(const std::string &k, int64_t dflt) const {
+        auto it = opt.find(k);
+        if (it == opt.end()) return dflt;
+        char *end = nullptr;
+        const long long v = std::strtoll(it->second.c_str(), &end, 10);
+        if (end == it->second.c_str() || *end || v < 0) die("Invalid value for '--" + k + " <" + k + ">': invalid digit found in string");
+        return (int64_t)v;
+    }
+};
+
+Args parse(int argc, char **argv, int first, const std::vector<std::string> &flags, const std::vector<std::string> &values) {
+    Args a;
+    for (int k = first; k < argc; ++k) {
+        std::string s = argv[k];
+        if (s.rfind("--", 0) == 0) {
+            std::string key = s.substr(2), val;
+            const size_t eq = key.find('=');
+            bool has_val = false;
+            if (eq != std::string::npos) { val = key.substr(eq + 1); key = key.substr(0, eq); has_val = true; }
+            bool is_flag = false, is_value = false;
+            for (auto &f : flags) if (f == key) is_flag = true;
+            for (auto &v : values) if (v == key) is_value = true;
+            if (is_flag) { a.opt[key] = "1"; continue; }
+            if (!is_value) die("Found argument '--" + key + "' which wasn't expected, or isn't valid in this context");
+            if (!has_val) {
+                if (k + 1 >= argc) die("The argument '--" + key + " <" + key + ">' requires a value but none was supplied");
+                val = argv[++k];
+            }
+            a.opt[key] = val;
+        } else {
+            a.positional.push_back(s);
+        }
+    }
+    return a;
+}
+
+struct HostProblem {
+    int64_t n_cam = 0, n_pts = 0;
+    std::vector<double> cams15, pts, uv;
+    std::vector<uint64_t> row_ptr, pt_idx;
+};
+
+// shared tail of synthetic_grid / synthetic_line: visibility (device predicate) then cull (host)
+HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, const std::vector<double> &dir,
+                                const std::vector<double> &pts, double max_dist, bool occlusion, double L, double inset) {
+    const int64_t n_cam = (int64_t)pos.size() / 3, n_pts = (int64_t)pts.size() / 3;
+    HostProblem hp;
+    hp.n_cam = n_cam; hp.n_pts = n_pts; hp.pts = pts;
+    hp.cams15.resize((size_t)n_cam * 15);
+    ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), hp.cams15.data()));
+    std::vector<uint64_t> empty_rows((size_t)n_cam + 1, 0);
+    ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), n_pts, pts.data(), empty_rows.data(), nullptr, nullptr));
+    std::vector<double> centers((size_t)n_cam * 3);
+    ck(c2b_problem_centers(p, centers.data()));
+    c2b_pairs *pairs = nullptr;
+    const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    ck(c2b_candidate_pairs(centers.data(), n_cam, pts.data(), n_pts, max_dist, 0, n_cam, occlusion ? 1 : 0, L, inset, threads, &pairs));
+    const int64_t n_pairs = c2b_pairs_count(pairs);
+    std::vector<double> uv((size_t)n_pairs * 2);
+    std::vector<uint8_t> keep((size_t)n_pairs);
+    ck(c2b_problem_visibility_pairs(p, n_pairs, c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, uv.data(), keep.data()));
+    const uint32_t *ci = c2b_pairs_cam_idx(pairs), *pi = c2b_pairs_pt_idx(pairs);
+    hp.row_ptr.assign((size_t)n_cam + 1, 0);
+    for (int64_t k = 0; k < n_pairs; ++k)
+        if (keep[(size_t)k]) {
+            ++hp.row_ptr[(size_t)ci[k] + 1];
+            hp.pt_idx.push_back(pi[k]);
+            hp.uv.push_back(uv[2 * (size_t)k]);
+            hp.uv.push_back(uv[2 * (size_t)k + 1]);
+        }
+    for (int64_t c = 0; c < n_cam; ++c) hp.row_ptr[(size_t)c + 1] += hp.row_ptr[(size_t)c];
+    c2b_pairs_free(pairs);
+    // .cull(), src/synthetic.rs:299
+    ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(), 1));
+    hp.cams15.resize((size_t)hp.n_cam * 15);
+    hp.pts.resize((size_t)hp.n_pts * 3);
+    hp.row_ptr.resize((size_t)hp.n_cam + 1);
+    const size_t n_obs = (size_t)hp.row_ptr[(size_t)hp.n_cam];
+    hp.pt_idx.resize(n_obs);
+    hp.uv.resize(2 * n_obs);
+    return hp;
+}
+
+void display_and_write(c2b_problem *p, const HostProblem &hp, const std::string &out) {
+    ck(c2b_problem_upload(p, hp.n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+    std::printf("Bundle Adjustment Problem with %lld cameras, %lld points, and %lld observations\n", (long long)hp.n_cam,
+                (long long)hp.n_pts, (long long)hp.pt_idx.size());
+    std::vector<double> bal9((size_t)hp.n_cam * 9);
+    ck(c2b_problem_download_bal(p, bal9.data()));
+    ck(c2b_bal_write(out.c_str(), hp.n_cam, bal9.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+}
+
+int run_synthetic(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, {}, {"cameras-per-block", "points-per-block", "max-dist", "camera-height",
+                                             "point-height", "block-inset", "block-length", "blocks", "device"});
+    if (a.positional.size() != 1) die("The following required arguments were not provided:\n    <OUTPUT>");
+    const int64_t cpb = a.i("cameras-per-block", 10), ppb = a.i("points-per-block", 10), B = a.i("blocks", 5);
+    const double max_dist = a.f("max-dist", 10), cam_h = a.f("camera-height", 1), pt_h = a.f("point-height", 1);
+    const double inset = a.f("block-inset", 1), L = a.f("block-length", 20);
+    int64_t n_cam, n_pts;
+    ck(c2b_synthetic_grid_sizes(cpb, ppb, B, &n_cam, &n_pts));
+    std::vector<double> pos((size_t)n_cam * 3), dir((size_t)n_cam * 9), pts((size_t)n_pts * 3);
+    ck(c2b_synthetic_grid_layout(cpb, ppb, B, L, inset, cam_h, pt_h, pos.data(), dir.data(), pts.data()));
+    c2b_problem *p = nullptr;
+    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    const HostProblem hp = visibility_and_cull(p, pos, dir, pts, max_dist, true, L, inset);
+    display_and_write(p, hp, a.positional[0]);
+    c2b_problem_destroy(p);
+    return 0;
+}
+
+int run_synthetic_line(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, {}, {"cameras", "points", "max-dist", "camera-height", "point-height",
+                                             "point-offset", "length", "device"});
+    if (a.positional.size() != 1) die("The following required arguments were not provided:\n    <OUTPUT>");
+    const int64_t n_cam = a.i("cameras", 10), n_pts = a.i("points", 10);
+    std::vector<double> pos((size_t)n_cam * 3), dir((size_t)n_cam * 9), pts((size_t)n_pts * 3);
+    ck(c2b_synthetic_line_layout(n_cam, n_pts, a.f("length", 20), a.f("point-offset", 1), a.f("camera-height", 1),
+                                 a.f("point-height", 1), pos.data(), dir.data(), pts.data()));
+    c2b_problem *p = nullptr;
+    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    const HostProblem hp = visibility_and_cull(p, pos, dir, pts, a.f("max-dist", 10), false, 1.0, 0.0);
+    display_and_write(p, hp, a.positional[0]);
+    c2b_problem_destroy(p);
+    return 0;
+}
+
+int run_noise(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, {"fixed-drift"},
+                         {"rotation-std", "translation-std", "point-std", "observation-std", "drift-std", "drift-strength",
+                          "drift-angle", "mismatch-chance", "drop-features", "split-landmarks", "join-landmarks",
+                          "sin-strength", "sin-frequency", "seed", "device"});
+    if (a.positional.size() != 2) die("The following required arguments were not provided:\n    <FILE> <OUT>");
+    if (a.f("mismatch-chance", 0.0) > 0.0 || a.f("drop-features", 1.0) < 1.0 || a.f("split-landmarks", 0.0) > 0.0 ||
+        a.f("join-landmarks", 0.0) > 0.0)
+        die("--mismatch-chance / --drop-features / --split-landmarks / --join-landmarks are index-shuffling noise "
+            "(src/noise.rs:179-378), outside this build's scope");
+    uint64_t seed;
+    if (a.has("seed")) seed = (uint64_t)a.i("seed", 0);
+    else { std::random_device rd; seed = ((uint64_t)rd() << 32) ^ rd(); }   // the reference: unseeded thread_rng()
+
+    c2b_balfile *f = nullptr;
+    ck(c2b_bal_read(a.positional[0].c_str(), &f));
+    int64_t n_cam, n_pts, n_obs;
+    ck(c2b_bal_sizes(f, &n_cam, &n_pts, &n_obs));
+    std::vector<double> bal9((size_t)n_cam * 9), pts((size_t)n_pts * 3), uv((size_t)n_obs * 2);
+    std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs);
+    ck(c2b_bal_copy(f, bal9.data(), pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    c2b_bal_close(f);
+
+    c2b_problem *p = nullptr;
+    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    double l1, l2;
+    ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
+    ck(c2b_problem_total_reprojection_error(p, 2.0, &l2));
+    std::printf("Initial error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
+
+    // src/bin/city2ba.rs:305-316: drift is ALWAYS applied, even with zero strength
+    if (a.has("fixed-drift")) {
+        double stats[C2B_STATS_DOUBLES];
+        ck(c2b_problem_stats(p, stats));
+        ck(c2b_problem_add_drift(p, a.f("drift-strength", 0), a.f("drift-angle", 0), a.f("drift-std", 0), stats + 3, seed));
+    } else {
+        ck(c2b_problem_add_drift_normalized(p, a.f("drift-strength", 0), a.f("drift-angle", 0), a.f("drift-std", 0), seed));
+    }
+    if (a.f("sin-strength", 0) > 0.0) {        // :318-333
+        const double dx[3] = {1, 0, 0}, dz[3] = {0, 0, 1}, up[3] = {0, 1, 0};
+        ck(c2b_problem_add_sin_noise(p, dx, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
+        ck(c2b_problem_add_sin_noise(p, dz, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
+    }
+    ck(c2b_problem_add_noise(p, a.f("translation-std", 0), a.f("rotation-std", 0), a.f("point-std", 0),
+                             a.f("observation-std", 0), seed + 1));      // :334-340, always
+    std::printf("BA Problem with %lld cameras, %lld points, %lld correspondences\n", (long long)n_cam, (long long)n_pts,
+                (long long)n_obs);
+    ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
+    ck(c2b_problem_total_reprojection_error(p, 2.0, &l2));
+    std::printf("Final error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
+    ck(c2b_problem_download_bal(p, bal9.data()));
+    ck(c2b_problem_download(p, nullptr, pts.data(), uv.data()));
+    ck(c2b_bal_write(a.positional[1].c_str(), n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    c2b_problem_destroy(p);
+    return 0;
+}
+
+void usage() {
+    std::printf("city2ba (MI355X build, %s)\nTools for generating synthetic bundle adjustment problems.\n\n"
+                "USAGE:\n    city2ba <SUBCOMMAND>\n\nSUBCOMMANDS:\n"
+                "    synthetic         Generate a synthetic bundle adjustment problem from an grid of city blocks.\n"
+                "    synthetic-line    Generate a synthetic bundle adjustment problem on a line.\n"
+                "    noise             Add noise to a bundle adjustment problem.\n"
+                "    generate, ply     not provided by this build (Embree / PLY are outside the hot-path scope)\n",
+                c2b_version());
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2 || !std::strcmp(argv[1], "--help") || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "help")) {
+        usage();
+        return argc < 2 ? 1 : 0;
+    }
+    const std::string sub = argv[1];
+    if (sub == "synthetic") return run_synthetic(argc, argv);
+    if (sub == "synthetic-line") return run_synthetic_line(argc, argv);
+    if (sub == "noise") return run_noise(argc, argv);
+    if (sub == "generate" || sub == "ply")
+        die("subcommand '" + sub + "' needs Embree ray casting / PLY export, which this hot-path build does not provide");
+    die("The subcommand '" + sub + "' wasn't recognized");
+}

@@ -13,6 +13,7 @@
 #include <new>
 #include <vector>
 
+#include "host_baproblem.hpp"
 #include "host_synthetic.hpp"
 #include "kernels.hpp"
 
@@ -478,6 +479,111 @@ const uint32_t *c2b_pairs_cam_idx(const c2b_pairs *p) { return p ? p->v.cam.data
 const uint32_t *c2b_pairs_pt_idx(const c2b_pairs *p) { return p ? p->v.pt.data() : nullptr; }
 void c2b_pairs_free(c2b_pairs *p) { delete p; }
 
+int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
+             uint64_t *pt_idx, double *uv, int faithful) {
+    if (!n_cam || !n_pts || !row_ptr || *n_cam < 0 || *n_pts < 0 || cam_stride < 0 || (*n_cam && cam_stride && !cams) ||
+        (*n_pts && !pts3))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "cull: bad arguments");
+    const int64_t n_obs = (int64_t)row_ptr[*n_cam];
+    if (n_obs && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "cull: NULL observations");
+    for (int64_t o = 0; o < n_obs; ++o)
+        if (pt_idx[o] >= (uint64_t)*n_pts) return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "cull: point index out of range");
+    try {
+        c2b_host::Graph g;
+        g.n_cam = *n_cam; g.n_pts = *n_pts; g.stride = cam_stride;
+        g.cams.assign(cams, cams + (size_t)*n_cam * cam_stride);
+        g.pts.assign(pts3, pts3 + (size_t)*n_pts * 3);
+        g.row_ptr.assign(row_ptr, row_ptr + *n_cam + 1);
+        g.pt_idx.assign(pt_idx, pt_idx + n_obs);
+        g.uv.assign(uv, uv + 2 * n_obs);
+        const c2b_host::Graph c = c2b_host::cull(g, faithful != 0);
+        std::copy(c.cams.begin(), c.cams.end(), cams);
+        std::copy(c.pts.begin(), c.pts.end(), pts3);
+        std::copy(c.row_ptr.begin(), c.row_ptr.end(), row_ptr);
+        std::copy(c.pt_idx.begin(), c.pt_idx.end(), pt_idx);
+        std::copy(c.uv.begin(), c.uv.end(), uv);
+        *n_cam = c.n_cam;
+        *n_pts = c.n_pts;
+    } catch (const std::bad_alloc &) {
+        return fail(C2B_ERR_OOM, "cull: out of host memory");
+    }
+    return C2B_OK;
+}
+
+struct c2b_balfile {
+    c2b_host::Graph g;
+};
+
+int c2b_bal_read(const char *path, c2b_balfile **out) {
+    if (!path || !out) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_read: bad arguments");
+    *out = nullptr;
+    const std::string ext = c2b_host::extension(path);
+    if (ext != "bal" && ext != "bbal") return fail(C2B_ERR_INVALID_ARGUMENT, "unknown file extension %s", ext.c_str());
+    c2b_balfile *f = new (std::nothrow) c2b_balfile();
+    if (!f) return fail(C2B_ERR_OOM, "bal_read: host allocation failed");
+    std::string err;
+    bool ok = false;
+    try {
+        ok = ext == "bal" ? c2b_host::read_text(path, f->g, &err) : c2b_host::read_binary(path, f->g, &err);
+    } catch (const std::bad_alloc &) {
+        err = "out of host memory";
+    }
+    if (!ok) {
+        delete f;
+        const bool range = err.find("assertion failed") != std::string::npos || err.find("out of range") != std::string::npos;
+        return fail(range ? C2B_ERR_INDEX_OUT_OF_RANGE : C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    }
+    *out = f;
+    return C2B_OK;
+}
+
+int c2b_bal_sizes(const c2b_balfile *f, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs) {
+    if (!f) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_sizes: file is NULL");
+    if (n_cam) *n_cam = f->g.n_cam;
+    if (n_pts) *n_pts = f->g.n_pts;
+    if (n_obs) *n_obs = f->g.n_obs();
+    return C2B_OK;
+}
+
+int c2b_bal_copy(const c2b_balfile *f, double *bal9, double *pts3, uint64_t *row_ptr, uint64_t *pt_idx, double *uv) {
+    if (!f) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_copy: file is NULL");
+    if (bal9) std::copy(f->g.cams.begin(), f->g.cams.end(), bal9);
+    if (pts3) std::copy(f->g.pts.begin(), f->g.pts.end(), pts3);
+    if (row_ptr) std::copy(f->g.row_ptr.begin(), f->g.row_ptr.end(), row_ptr);
+    if (pt_idx) std::copy(f->g.pt_idx.begin(), f->g.pt_idx.end(), pt_idx);
+    if (uv) std::copy(f->g.uv.begin(), f->g.uv.end(), uv);
+    return C2B_OK;
+}
+
+void c2b_bal_close(c2b_balfile *f) { delete f; }
+
+int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
+                  const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    if (!path || n_cam < 0 || n_pts < 0 || !row_ptr || (n_cam && !bal9) || (n_pts && !pts3))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "bal_write: bad arguments");
+    const std::string ext = c2b_host::extension(path);
+    if (ext.empty()) return fail(C2B_ERR_INVALID_ARGUMENT, "file does not have an extension");
+    if (ext != "bal" && ext != "bbal") return fail(C2B_ERR_INVALID_ARGUMENT, "unknown file extension %s", ext.c_str());
+    const int64_t n_obs = (int64_t)row_ptr[n_cam];
+    if (n_obs && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_write: NULL observations");
+    std::string err;
+    bool ok = false;
+    try {
+        c2b_host::Graph g;
+        g.n_cam = n_cam; g.n_pts = n_pts; g.stride = 9;
+        g.cams.assign(bal9, bal9 + (size_t)n_cam * 9);
+        g.pts.assign(pts3, pts3 + (size_t)n_pts * 3);
+        g.row_ptr.assign(row_ptr, row_ptr + n_cam + 1);
+        g.pt_idx.assign(pt_idx, pt_idx + n_obs);
+        g.uv.assign(uv, uv + 2 * n_obs);
+        ok = ext == "bal" ? c2b_host::write_text(path, g, &err) : c2b_host::write_binary(path, g, &err);
+    } catch (const std::bad_alloc &) {
+        err = "out of host memory";
+    }
+    if (!ok) return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    return C2B_OK;
+}
+
 /* ------------------------------- level 1 --------------------------------------------- */
 
 struct c2b_problem {
@@ -659,6 +765,48 @@ int c2b_problem_download_bal(c2b_problem *p, double *bal9) {
         if (rc) return rc;
     }
     HIP_TRY(hipMemcpyAsync(bal9, p->bal9, sizeof(double) * 9 * p->n_cam, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+}
+
+int c2b_problem_from_position_direction(c2b_problem *p, int64_t n_cam, const double *pos3, const double *dir9,
+                                        double *cams15) {
+    if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_from_position_direction: problem is NULL");
+    if (n_cam < 0 || (n_cam && (!pos3 || !dir9 || !cams15)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_from_position_direction: bad arguments");
+    if (!n_cam) return C2B_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    double *d_pos = nullptr, *d_dir = nullptr, *d_cam = nullptr;
+    int rc = C2B_OK;
+    hipError_t e = hipMalloc((void **)&d_pos, sizeof(double) * 3 * n_cam);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_dir, sizeof(double) * 9 * n_cam);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cam, sizeof(double) * 15 * n_cam);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pos, pos3, sizeof(double) * 3 * n_cam, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dir, dir9, sizeof(double) * 9 * n_cam, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) {
+        rc = c2b_cameras_from_position_direction(d_pos, d_dir, n_cam, d_cam, p->stream);
+        if (!rc) e = hipMemcpyAsync(cams15, d_cam, sizeof(double) * 15 * n_cam, hipMemcpyDeviceToHost, p->stream);
+        hipError_t e2 = hipStreamSynchronize(p->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    if (d_pos) (void)hipFree(d_pos);
+    if (d_dir) (void)hipFree(d_dir);
+    if (d_cam) (void)hipFree(d_cam);
+    if (rc) return rc;
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_from_position_direction: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+int c2b_problem_centers(c2b_problem *p, double *centers3) {
+    NEED_UPLOADED(p, "problem_centers");
+    if (!p->n_cam) return C2B_OK;
+    if (!centers3) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_centers: centers3 is NULL");
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    // camblk rows are 28 doubles; the center sits at [24..26]
+    HIP_TRY(hipMemcpy2DAsync(centers3, 3 * sizeof(double), p->camblk + kCenter, kCamBlk * sizeof(double),
+                             3 * sizeof(double), (size_t)p->n_cam, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
 }

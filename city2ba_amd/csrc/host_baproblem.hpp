@@ -1,0 +1,358 @@
+// host_baproblem.hpp -- host-side (CPU, C++) rows next to the hot path:
+//   * cull() = largest_connected_component + remove_singletons + subset, iterated to a fixed point
+//     (src/baproblem.rs:392-550), on the flat CSR form of vis_graph;
+//   * .bal (text) and .bbal (big-endian binary) reader / writer (src/baproblem.rs:580-786).
+// Irregular integer graph work and file IO: they run once per problem on the host, like in the
+// reference.  Camera payloads are opaque rows of `stride` doubles (cam15 or bal9).
+#pragma once
+#include <algorithm>
+#include <charconv>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace c2b_host {
+
+struct Graph {
+    int64_t n_cam = 0, n_pts = 0;
+    int stride = 15;                 // doubles per camera row
+    std::vector<double> cams, pts;   // [n_cam*stride], [n_pts*3]
+    std::vector<uint64_t> row_ptr;   // [n_cam+1]
+    std::vector<uint64_t> pt_idx;    // [n_obs]
+    std::vector<double> uv;          // [n_obs*2]
+    int64_t n_obs() const { return (int64_t)pt_idx.size(); }
+};
+
+// BAProblem::subset, src/baproblem.rs:394-423
+inline Graph subset(const Graph &g, const std::vector<int64_t> &ci, const std::vector<int64_t> &pi) {
+    Graph o;
+    o.stride = g.stride;
+    o.n_cam = (int64_t)ci.size();
+    o.n_pts = (int64_t)pi.size();
+    o.cams.resize((size_t)o.n_cam * g.stride);
+    o.pts.resize((size_t)o.n_pts * 3);
+    for (size_t k = 0; k < ci.size(); ++k)
+        std::copy(&g.cams[(size_t)ci[k] * g.stride], &g.cams[(size_t)(ci[k] + 1) * g.stride], &o.cams[k * g.stride]);
+    std::vector<int64_t> point_indices((size_t)g.n_pts, -1);
+    for (size_t k = 0; k < pi.size(); ++k) {
+        std::copy(&g.pts[(size_t)pi[k] * 3], &g.pts[(size_t)pi[k] * 3 + 3], &o.pts[k * 3]);
+        point_indices[(size_t)pi[k]] = (int64_t)k;
+    }
+    o.row_ptr.assign(1, 0);
+    for (int64_t c : ci) {
+        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) {
+            const int64_t ni = point_indices[(size_t)g.pt_idx[(size_t)e]];
+            if (ni >= 0) {
+                o.pt_idx.push_back((uint64_t)ni);
+                o.uv.push_back(g.uv[2 * (size_t)e]);
+                o.uv.push_back(g.uv[2 * (size_t)e + 1]);
+            }
+        }
+        o.row_ptr.push_back((uint64_t)o.pt_idx.size());
+    }
+    return o;
+}
+
+// remove_singletons, src/baproblem.rs:426-453: cameras need > 3 observations, points > 1; the point
+// counts are taken over ALL cameras, including the ones being removed (reference TODO at :437).
+inline Graph remove_singletons(const Graph &g) {
+    std::vector<int64_t> ci, pi;
+    for (int64_t c = 0; c < g.n_cam; ++c)
+        if (g.row_ptr[(size_t)c + 1] - g.row_ptr[(size_t)c] > 3) ci.push_back(c);
+    std::vector<int64_t> count((size_t)g.n_pts, 0);
+    for (uint64_t p : g.pt_idx) ++count[(size_t)p];
+    for (int64_t p = 0; p < g.n_pts; ++p)
+        if (count[(size_t)p] > 1) pi.push_back(p);
+    return subset(g, ci, pi);
+}
+
+struct UnionFind {
+    std::vector<int64_t> parent, rank_;
+    explicit UnionFind(int64_t n) : parent((size_t)n), rank_((size_t)n, 0) { std::iota(parent.begin(), parent.end(), 0); }
+    int64_t find(int64_t x) {
+        while (parent[(size_t)x] != x) {
+            parent[(size_t)x] = parent[(size_t)parent[(size_t)x]];
+            x = parent[(size_t)x];
+        }
+        return x;
+    }
+    void unite(int64_t a, int64_t b) {
+        a = find(a); b = find(b);
+        if (a == b) return;
+        if (rank_[(size_t)a] < rank_[(size_t)b]) std::swap(a, b);
+        parent[(size_t)b] = a;
+        if (rank_[(size_t)a] == rank_[(size_t)b]) ++rank_[(size_t)a];
+    }
+};
+
+// largest_connected_component, src/baproblem.rs:456-534.
+//   * Tie between equally large components: the reference takes HashMap iteration order
+//     (nondeterministic, :483-488); here the component with the smallest member index wins.
+//   * `faithful` keeps the reference's observation filter `sets[x.0] == lcc_id` (:523), which indexes the
+//     camera-first union-find array with a POINT index: an observation of point j is dropped when element j of
+//     that array (camera j, or point j - n_cam) lies outside the largest component.  With faithful = false the
+//     filter tests the observed point itself.
+inline Graph largest_connected_component(const Graph &g, bool faithful) {
+    if (g.n_cam == 0) return g;
+    const int64_t nc = g.n_cam, np = g.n_pts;
+    UnionFind uf(nc + np);
+    for (int64_t c = 0; c < nc; ++c)
+        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e)
+            uf.unite(c, nc + (int64_t)g.pt_idx[(size_t)e]);
+    std::vector<int64_t> sets((size_t)(nc + np));
+    for (int64_t i = 0; i < nc + np; ++i) sets[(size_t)i] = uf.find(i);
+    // canonical id of a set = its smallest member
+    std::vector<int64_t> canon((size_t)(nc + np), -1), size((size_t)(nc + np), 0);
+    for (int64_t i = 0; i < nc + np; ++i) {
+        const int64_t r = sets[(size_t)i];
+        if (canon[(size_t)r] < 0) canon[(size_t)r] = i;
+        ++size[(size_t)r];
+    }
+    int64_t lcc = -1, best = -1, best_canon = -1;
+    for (int64_t r = 0; r < nc + np; ++r)
+        if (size[(size_t)r] > 0 && (size[(size_t)r] > best || (size[(size_t)r] == best && canon[(size_t)r] < best_canon))) {
+            best = size[(size_t)r]; lcc = r; best_canon = canon[(size_t)r];
+        }
+    Graph o;
+    o.stride = g.stride;
+    std::vector<int64_t> point_map((size_t)np, -1);
+    for (int64_t p = 0; p < np; ++p)
+        if (sets[(size_t)(nc + p)] == lcc) {
+            point_map[(size_t)p] = o.n_pts++;
+            o.pts.insert(o.pts.end(), &g.pts[(size_t)p * 3], &g.pts[(size_t)p * 3 + 3]);
+        }
+    o.row_ptr.assign(1, 0);
+    for (int64_t c = 0; c < nc; ++c) {
+        if (sets[(size_t)c] != lcc) continue;
+        ++o.n_cam;
+        o.cams.insert(o.cams.end(), &g.cams[(size_t)c * g.stride], &g.cams[(size_t)(c + 1) * g.stride]);
+        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) {
+            const int64_t p = (int64_t)g.pt_idx[(size_t)e];
+            const bool keep = faithful ? sets[(size_t)p] == lcc : sets[(size_t)(nc + p)] == lcc;
+            if (!keep) continue;
+            o.pt_idx.push_back((uint64_t)point_map[(size_t)p]);   // p is in the component (camera c observes it)
+            o.uv.push_back(g.uv[2 * (size_t)e]);
+            o.uv.push_back(g.uv[2 * (size_t)e + 1]);
+        }
+        o.row_ptr.push_back((uint64_t)o.pt_idx.size());
+    }
+    return o;
+}
+
+// cull, src/baproblem.rs:538-549
+inline Graph cull(const Graph &g, bool faithful) {
+    int64_t nc = g.n_cam, np = g.n_pts;
+    Graph c = remove_singletons(largest_connected_component(g, faithful));
+    while (c.n_cam != nc || c.n_pts != np) {
+        nc = c.n_cam; np = c.n_pts;
+        c = remove_singletons(largest_connected_component(c, faithful));
+    }
+    return c;
+}
+
+// ---- .bal / .bbal -----------------------------------------------------------------------------------
+// Rust's `{}` for f64: shortest digits that round-trip, never an exponent, "1" for 1.0, "-0", "NaN", "inf".
+inline void fmt_f64(double v, std::string &out) {
+    if (v != v) { out += "NaN"; return; }
+    char buf[400];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    out.append(buf, r.ptr);
+}
+
+// write_text, src/baproblem.rs:709-733 (cameras: 9 values on ONE line, space-joined)
+inline bool write_text(const char *path, const Graph &g, std::string *err) {
+    if (g.stride != 9) { *err = "write_text needs bal9 camera rows"; return false; }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { *err = std::string("cannot create ") + path; return false; }
+    std::string s;
+    s.reserve(1 << 20);
+    s += std::to_string(g.n_cam) + " " + std::to_string(g.n_pts) + " " + std::to_string(g.n_obs()) + "\n";
+    auto flush = [&](bool force) {
+        if (force || s.size() > (1u << 20)) { std::fwrite(s.data(), 1, s.size(), f); s.clear(); }
+    };
+    for (int64_t c = 0; c < g.n_cam; ++c)
+        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) {
+            s += std::to_string(c); s += ' ';
+            s += std::to_string(g.pt_idx[(size_t)e]); s += ' ';
+            fmt_f64(g.uv[2 * (size_t)e], s); s += ' ';
+            fmt_f64(g.uv[2 * (size_t)e + 1], s); s += '\n';
+            flush(false);
+        }
+    for (int64_t c = 0; c < g.n_cam; ++c) {
+        for (int k = 0; k < 9; ++k) { if (k) s += ' '; fmt_f64(g.cams[(size_t)c * 9 + k], s); }
+        s += '\n';
+        flush(false);
+    }
+    for (int64_t p = 0; p < g.n_pts; ++p) {
+        fmt_f64(g.pts[(size_t)p * 3], s); s += ' ';
+        fmt_f64(g.pts[(size_t)p * 3 + 1], s); s += ' ';
+        fmt_f64(g.pts[(size_t)p * 3 + 2], s); s += '\n';
+        flush(false);
+    }
+    flush(true);
+    const bool ok = std::fclose(f) == 0;
+    if (!ok) *err = std::string("write failed: ") + path;
+    return ok;
+}
+
+inline void put_be64(std::string &s, uint64_t v) {
+    char b[8];
+    for (int i = 0; i < 8; ++i) b[i] = (char)(v >> (56 - 8 * i));
+    s.append(b, 8);
+}
+inline void put_bef64(std::string &s, double d) {
+    uint64_t v;
+    std::memcpy(&v, &d, 8);
+    put_be64(s, v);
+}
+
+// write_binary, src/baproblem.rs:736-764
+inline bool write_binary(const char *path, const Graph &g, std::string *err) {
+    if (g.stride != 9) { *err = "write_binary needs bal9 camera rows"; return false; }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { *err = std::string("cannot create ") + path; return false; }
+    std::string s;
+    put_be64(s, (uint64_t)g.n_cam); put_be64(s, (uint64_t)g.n_pts); put_be64(s, (uint64_t)g.n_obs());
+    auto flush = [&](bool force) {
+        if (force || s.size() > (1u << 20)) { std::fwrite(s.data(), 1, s.size(), f); s.clear(); }
+    };
+    for (int64_t c = 0; c < g.n_cam; ++c) {
+        put_be64(s, g.row_ptr[(size_t)c + 1] - g.row_ptr[(size_t)c]);
+        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) {
+            put_be64(s, g.pt_idx[(size_t)e]);
+            put_bef64(s, g.uv[2 * (size_t)e]);
+            put_bef64(s, g.uv[2 * (size_t)e + 1]);
+        }
+        flush(false);
+    }
+    for (double v : g.cams) { put_bef64(s, v); flush(false); }
+    for (double v : g.pts) { put_bef64(s, v); flush(false); }
+    flush(true);
+    const bool ok = std::fclose(f) == 0;
+    if (!ok) *err = std::string("write failed: ") + path;
+    return ok;
+}
+
+inline bool read_all(const char *path, std::string &buf, std::string *err) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { *err = std::string("cannot open ") + path; return false; }
+    char tmp[1 << 16];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
+    std::fclose(f);
+    return true;
+}
+
+// from_file_text, src/baproblem.rs:580-628: unsigned/float tokens separated by any whitespace; observations
+// are (camera, point, u, v) tuples in file order and are pushed per camera like BAProblem::new (:342-355).
+inline bool read_text(const char *path, Graph &g, std::string *err) {
+    std::string buf;
+    if (!read_all(path, buf, err)) return false;
+    const char *p = buf.c_str(), *end = p + buf.size();
+    auto skip = [&]() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; };
+    auto get_u = [&](uint64_t &v) -> bool {
+        skip();
+        if (p >= end || *p < '0' || *p > '9') return false;
+        v = 0;
+        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0');
+        return true;
+    };
+    auto get_d = [&](double &v) -> bool {
+        skip();
+        if (p >= end) return false;
+        char *q = nullptr;
+        v = std::strtod(p, &q);
+        if (q == p) return false;
+        p = q;
+        return true;
+    };
+    uint64_t nc, np, no;
+    if (!get_u(nc) || !get_u(np) || !get_u(no)) { *err = "ParseError: bad header"; return false; }
+    std::vector<uint64_t> oc((size_t)no), op((size_t)no);
+    std::vector<double> ou((size_t)no * 2);
+    for (uint64_t i = 0; i < no; ++i)
+        if (!get_u(oc[(size_t)i]) || !get_u(op[(size_t)i]) || !get_d(ou[2 * (size_t)i]) || !get_d(ou[2 * (size_t)i + 1])) {
+            *err = "ParseError: bad observation " + std::to_string(i);
+            return false;
+        }
+    g.stride = 9;
+    g.n_cam = (int64_t)nc; g.n_pts = (int64_t)np;
+    g.cams.resize((size_t)nc * 9);
+    g.pts.resize((size_t)np * 3);
+    for (double &v : g.cams) if (!get_d(v)) { *err = "ParseError: bad camera block"; return false; }
+    for (double &v : g.pts) if (!get_d(v)) { *err = "ParseError: bad point block"; return false; }
+    // BAProblem::new: asserts then per-camera push in file order
+    std::vector<uint64_t> count((size_t)nc + 1, 0);
+    for (uint64_t i = 0; i < no; ++i) {
+        if (oc[(size_t)i] >= nc) { *err = "assertion failed: cam_i < cams.len()"; return false; }
+        if (op[(size_t)i] >= np) { *err = "assertion failed: p_i < points.len()"; return false; }
+        ++count[(size_t)oc[(size_t)i] + 1];
+    }
+    g.row_ptr.assign((size_t)nc + 1, 0);
+    for (uint64_t c = 0; c < nc; ++c) g.row_ptr[(size_t)c + 1] = g.row_ptr[(size_t)c] + count[(size_t)c + 1];
+    std::vector<uint64_t> fill(g.row_ptr.begin(), g.row_ptr.end() - 1);
+    g.pt_idx.resize((size_t)no);
+    g.uv.resize((size_t)no * 2);
+    for (uint64_t i = 0; i < no; ++i) {
+        const uint64_t d = fill[(size_t)oc[(size_t)i]]++;
+        g.pt_idx[(size_t)d] = op[(size_t)i];
+        g.uv[2 * (size_t)d] = ou[2 * (size_t)i];
+        g.uv[2 * (size_t)d + 1] = ou[2 * (size_t)i + 1];
+    }
+    return true;
+}
+
+// from_file_binary, src/baproblem.rs:632-693
+inline bool read_binary(const char *path, Graph &g, std::string *err) {
+    std::string buf;
+    if (!read_all(path, buf, err)) return false;
+    size_t pos = 0;
+    auto get64 = [&](uint64_t &v) -> bool {
+        if (pos + 8 > buf.size()) return false;
+        v = 0;
+        for (int i = 0; i < 8; ++i) v = (v << 8) | (uint8_t)buf[pos + i];
+        pos += 8;
+        return true;
+    };
+    auto getf = [&](double &d) -> bool {
+        uint64_t v;
+        if (!get64(v)) return false;
+        std::memcpy(&d, &v, 8);
+        return true;
+    };
+    uint64_t nc, np, no;
+    if (!get64(nc) || !get64(np) || !get64(no)) { *err = "Binary parse error"; return false; }
+    g.stride = 9;
+    g.n_cam = (int64_t)nc; g.n_pts = (int64_t)np;
+    g.row_ptr.assign(1, 0);
+    for (uint64_t c = 0; c < nc; ++c) {
+        uint64_t k;
+        if (!get64(k)) { *err = "Binary parse error"; return false; }
+        for (uint64_t i = 0; i < k; ++i) {
+            uint64_t p; double u, v;
+            if (!get64(p) || !getf(u) || !getf(v)) { *err = "Binary parse error"; return false; }
+            g.pt_idx.push_back(p); g.uv.push_back(u); g.uv.push_back(v);
+        }
+        g.row_ptr.push_back((uint64_t)g.pt_idx.size());
+    }
+    g.cams.resize((size_t)nc * 9);
+    g.pts.resize((size_t)np * 3);
+    for (double &v : g.cams) if (!getf(v)) { *err = "Binary parse error"; return false; }
+    for (double &v : g.pts) if (!getf(v)) { *err = "Binary parse error"; return false; }
+    for (uint64_t p : g.pt_idx) if (p >= np) { *err = "Binary parse error: point index out of range"; return false; }
+    return true;
+}
+
+inline std::string extension(const char *path) {
+    const std::string s(path);
+    const size_t dot = s.find_last_of('.'), slash = s.find_last_of('/');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
+    return s.substr(dot + 1);
+}
+
+}  // namespace c2b_host

@@ -60,3 +60,40 @@ def candidate_pairs(centers, pts, max_dist, cam_lo=0, cam_hi=None, occlusion=Fal
     finally:
         L.lib().c2b_pairs_free(h)
     return ci, pi
+
+
+def _visibility_problem(pos, dirs, pts, max_dist, occlusion, block_length, block_inset, cull, device):
+    """Shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:260-299, 346-380)."""
+    from .baproblem import BAProblem
+    n_cam = len(pos)
+    empty_rows = np.zeros(n_cam + 1, dtype=np.uint64)
+    # from_position_direction on the device; cameras only, no observations yet
+    stage = BAProblem(device)
+    cam15 = stage._cameras_from_position_direction(pos, dirs)
+    ba = BAProblem.from_visibility(cam15, pts, empty_rows, [], np.zeros((0, 2)), device)
+    s = ba._camera_centers()
+    ci, pi = candidate_pairs(s, pts, max_dist, occlusion=occlusion, block_length=block_length,
+                             block_inset=block_inset)
+    uv, keep = ba.visibility_pairs(ci, pi, max_dist)
+    k = keep == 1
+    ci, pi, uv = ci[k], pi[k], uv[k]
+    row_ptr = np.zeros(n_cam + 1, dtype=np.uint64)
+    row_ptr[1:] = np.cumsum(np.bincount(ci.astype(np.int64), minlength=n_cam))
+    out = BAProblem.from_visibility(cam15, pts, row_ptr, pi.astype(np.uint64), uv, device)
+    return out.cull() if cull else out
+
+
+def synthetic_grid(num_cameras_per_block, num_points_per_block, num_blocks, block_length, block_inset,
+                   camera_height, point_height, max_dist, verbose=False, cull=True, device=0):
+    """synthetic_grid (src/synthetic.rs:163-300), same argument order.  In-camera observation order is
+    ascending point index (the reference's is rstar's traversal order)."""
+    pos, dirs, pts = grid_layout(num_blocks, num_cameras_per_block, num_points_per_block, block_length,
+                                 block_inset, camera_height, point_height)
+    return _visibility_problem(pos, dirs, pts, max_dist, True, block_length, block_inset, cull, device)
+
+
+def synthetic_line(num_cameras, num_points, length, point_offset, camera_height, point_height, max_dist,
+                   verbose=False, cull=True, device=0):
+    """synthetic_line (src/synthetic.rs:313-381)"""
+    pos, dirs, pts = line_layout(num_cameras, num_points, length, point_offset, camera_height, point_height)
+    return _visibility_problem(pos, dirs, pts, max_dist, False, 1.0, 0.0, cull, device)

@@ -170,6 +170,27 @@ const uint32_t *c2b_pairs_cam_idx(const c2b_pairs *p);
 const uint32_t *c2b_pairs_pt_idx(const c2b_pairs *p);
 void c2b_pairs_free(c2b_pairs *p);
 
+/* BAProblem::cull (src/baproblem.rs:538-549) = largest_connected_component + remove_singletons to a
+ * fixed point, IN PLACE on host arrays (outputs are subsets, so they fit).  Camera rows are opaque
+ * `cam_stride` doubles.  On return *n_cam / *n_pts hold the new counts and row_ptr[*n_cam] the new
+ * observation count.  faithful != 0 keeps the reference's observation filter at :523 (it indexes the
+ * camera-first union-find array with a point index); ties between equally large components go to the one
+ * with the smallest member (the reference: HashMap order). */
+int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
+             uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful);
+
+/* BAProblem::from_file (src/baproblem.rs:697-706): ".bal" text / ".bbal" big-endian binary by extension.
+ * Cameras come back as 9-vectors (upload them with c2b_problem_upload_bal = from_vec). */
+typedef struct c2b_balfile c2b_balfile;
+int c2b_bal_read(const char *path, c2b_balfile **out);
+int c2b_bal_sizes(const c2b_balfile *f, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs);
+int c2b_bal_copy(const c2b_balfile *f, double *bal9, double *pts3, uint64_t *row_ptr, uint64_t *pt_idx,
+                 double *uv);
+void c2b_bal_close(c2b_balfile *f);
+/* BAProblem::write (src/baproblem.rs:768-785); bal9 = to_vec of every camera (c2b_problem_download_bal) */
+int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
+                  const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv);
+
 /* ===================================================================================== *
  * Level 1 -- a BAProblem resident on one device.  Pointers are HOST pointers; calls are
  * synchronous (results are valid on return).  Mirrors BAProblem<SnavelyCamera>.
@@ -191,6 +212,13 @@ int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int6
 /* any of the outputs may be NULL */
 int c2b_problem_download(c2b_problem *p, double *cams15, double *pts3, double *uv);
 int c2b_problem_download_bal(c2b_problem *p, double *bal9);
+
+/* Camera::from_position_direction (src/baproblem.rs:153-159) for n cameras on p's device:
+ * pos3 [n][3], dir9 [n][9] col-major -> cams15 [n][15].  Does not change the problem. */
+int c2b_problem_from_position_direction(c2b_problem *p, int64_t n_cam, const double *pos3,
+                                        const double *dir9, double *cams15);
+/* Camera::center (src/baproblem.rs:161-163) of every camera of the problem -> centers3 [n_cam][3] */
+int c2b_problem_centers(c2b_problem *p, double *centers3);
 
 int c2b_problem_project(c2b_problem *p, double *uv_out);
 int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *out);
