@@ -229,8 +229,8 @@ int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_id
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
     if (!uv_out || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "project: uv_out NULL or misaligned");
-    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_observations<MODE_PROJECT>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+    const int64_t tiles = ((n_obs + 63) / 64 + kObsWPB - 1) / kObsWPB;
+    hipLaunchKernelGGL(k_observations<MODE_PROJECT>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_obs,
                        tiles, 0.0, 0.0, reinterpret_cast<double2 *>(uv_out), (uint8_t *)nullptr, (double *)nullptr);
     LAUNCH_CHECK();
@@ -247,13 +247,14 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
     if (!uv_obs || !aligned16(uv_obs) || !workspace)
         return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: uv_obs/workspace NULL or misaligned");
     double *partials = reinterpret_cast<double *>(workspace) + kWsPartials;
-    const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_observations<MODE_ERROR>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+    const int64_t wave_tiles = (n_obs + 63) / 64;
+    const int64_t tiles = (wave_tiles + kObsWPB - 1) / kObsWPB;
+    hipLaunchKernelGGL(k_observations<MODE_ERROR>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
                        reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm, 0.0, (double2 *)nullptr,
                        (uint8_t *)nullptr, partials);
     LAUNCH_CHECK();
-    return launch_sum(workspace, tiles, out_sum, S(stream));
+    return launch_sum(workspace, wave_tiles, out_sum, S(stream));
 }
 
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
@@ -292,8 +293,8 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
     if (rc) return rc;
     if (!n_pairs) return C2B_OK;
     if (!uv_out || !keep || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_pairs: NULL/misaligned output");
-    const int64_t tiles = (n_pairs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_observations<MODE_VISIBILITY>, dim3((unsigned)tiles), dim3(kBlock), 0, S(stream), camblk,
+    const int64_t tiles = ((n_pairs + 63) / 64 + kObsWPB - 1) / kObsWPB;
+    hipLaunchKernelGGL(k_observations<MODE_VISIBILITY>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_pairs,
                        tiles, 0.0, max_dist, reinterpret_cast<double2 *>(uv_out), keep, (double *)nullptr);
     LAUNCH_CHECK();
@@ -312,11 +313,11 @@ int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n
     const double4 *p4 = reinterpret_cast<const double4 *>(pts4);
     hipLaunchKernelGGL(k_stats_pass1, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, rec);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold1, dim3(1), dim3(64), 0, S(stream), rec, grid, camblk, n_cam, p4, stats);
+    hipLaunchKernelGGL(k_stats_fold1, dim3(1), dim3(kRedBlocks), 0, S(stream), rec, grid, camblk, n_cam, p4, stats);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_stats_pass2, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, stats, rec);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold2, dim3(1), dim3(64), 0, S(stream), rec, grid, n, stats);
+    hipLaunchKernelGGL(k_stats_fold2, dim3(1), dim3(kRedBlocks), 0, S(stream), rec, grid, n, stats);
     LAUNCH_CHECK();
     return C2B_OK;
 }

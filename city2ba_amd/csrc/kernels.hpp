@@ -161,62 +161,83 @@ C2B_DEV uint32_t stage_cameras(const double *__restrict__ camblk, const uint32_t
     return c_first;
 }
 
+// ---- wave-private camera tile ------------------------------------------------------------------------
+// A wave's 64 consecutive observations touch a short run of consecutive cameras (3-4 on the grid).  The
+// wave copies the first HOT doubles of those records into its own LDS tile and every lane then reads its
+// camera by ds_read broadcast.  Lanes whose camera is outside the staged run (unsorted cam_idx, or more
+// than kCamW cameras in 64 observations) read global memory instead: correct, just slower.
+constexpr int kCamW = 12;                      // cameras staged per wave
+
+template <int HOT>
+C2B_DEV const double *wave_camera(const double *__restrict__ camblk, uint32_t ci, bool valid, int n_wave, int lane,
+                                  double *sCam) {
+    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci);
+    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci, n_wave - 1, 64));
+    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
+    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
+    for (int ch = lane; ch < (int)n_staged * (HOT / 2); ch += 64) {
+        const int k = ch / (HOT / 2), j = ch % (HOT / 2);
+        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+        *reinterpret_cast<double2 *>(sCam + k * HOT + 2 * j) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t local = ci - c_first;
+    return (valid && local < n_staged) ? (sCam + local * HOT) : (camblk + (int64_t)ci * kCamBlk);
+}
+
 // ---- project / error / visibility: the light per-observation kernels ----------------------------
+// Wave-centric like the Jacobian kernel; they need R, t, intrinsics only (15 doubles, staged as 16).
 enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2 };
+constexpr int kObsWPB = 8;                     // waves per workgroup
+constexpr int kCamLight = 16;
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_observations(
+__global__ __launch_bounds__(kObsWPB * 64) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
-    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_tiles, double norm, double max_dist,
+    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) double sCam[kCamTile * kCamHot];
-    __shared__ double sRed[kWaves];
-    const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
-    const int64_t tile0 = tile * kBlock;
-    const int64_t o = tile0 + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double sCamAll[kObsWPB * kCamW * kCamLight];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wt = xcd_tile(blockIdx.x, n_btiles) * kObsWPB + wave;
+    const int64_t wave0 = wt * 64;
+    if (wave0 >= n) return;                                              // wave-uniform
+    const int64_t o = wave0 + lane;
     const bool valid = o < n;
+    const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
 
     uint32_t ci = 0, pi = 0;
     if (valid) { ci = cam_idx[o]; pi = pt_idx[o]; }
     double4 X = make_double4(0, 0, -1, 0);
     if (valid) X = pts4[pi];
+    double2 ob = make_double2(0, 0);
+    if (MODE == MODE_ERROR && valid) ob = uv_obs[o];
 
-    uint32_t n_staged;
-    const uint32_t c_first = stage_cameras(camblk, cam_idx, tile0, n, sCam, n_staged);
-    __syncthreads();
+    const double *cam = wave_camera<kCamLight>(camblk, ci, valid, n_wave, lane, sCamAll + wave * kCamW * kCamLight);
 
     double e = 0.0;
     if (valid) {
-        const uint32_t local = ci - c_first;
-        const bool in_lds = local < n_staged;
-        const double *cam = in_lds ? (sCam + local * kCamHot) : (camblk + (int64_t)ci * kCamBlk);
+        const Proj p = project_obs(cam, X.x, X.y, X.z);
         if (MODE == MODE_VISIBILITY) {
             // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1
             const double *g = camblk + (int64_t)ci * kCamBlk + kCenter;
             const double dx = g[0] - X.x, dy = g[1] - X.y, dz = g[2] - X.z;
             const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
-            const Proj p = project_obs(cam, X.x, X.y, X.z);
             const bool front = dist < max_dist && p.qz <= 0.0;
             const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
             uv_out[o] = front ? make_double2(p.u, p.v) : make_double2(nan, nan);
             keep[o] = k ? 1 : 0;
+        } else if (MODE == MODE_PROJECT) {
+            uv_out[o] = make_double2(p.u, p.v);
         } else {
-            const Proj p = project_obs(cam, X.x, X.y, X.z);
-            if (MODE == MODE_PROJECT) {
-                uv_out[o] = make_double2(p.u, p.v);
-            } else {
-                const double2 ob = uv_obs[o];
-                e = abs_pow(p.u - ob.x, norm) + abs_pow(p.v - ob.y, norm);
-            }
+            e = abs_pow(p.u - ob.x, norm) + abs_pow(p.v - ob.y, norm);
         }
     }
     if (MODE == MODE_ERROR) {
         const double w = wave_sum(e);
-        if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = w;
-        __syncthreads();
-        if (threadIdx.x == 0) partials[tile] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+        if (lane == 0) partials[wt] = w;
     }
 }
 
@@ -359,8 +380,6 @@ C2B_DEV void store16(char *dst, const double2 v) {
     }
 }
 
-constexpr int kCamW = 12;                      // cameras staged per wave (12 x 192 B)
-
 template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0>   // ABL: timing-only ablations (tools/)
 __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
@@ -388,20 +407,7 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
 
     // wave-private camera tile
     double *sCam = reinterpret_cast<double *>(smem + wave * (kSlab + kCamBytes) + kSlab);
-    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci);
-    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci, n_wave - 1, 64));
-    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
-    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
-    for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
-        const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
-        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
-        *reinterpret_cast<double2 *>(sCam + k * kCamHot + 2 * j) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    const uint32_t local = ci - c_first;
-    const double *cam = (valid && local < n_staged) ? (sCam + local * kCamHot) : (camblk + (int64_t)ci * kCamBlk);
+    const double *cam = wave_camera<kCamHot>(camblk, ci, valid, n_wave, lane, sCam);
     Proj p;
     if (ABL == 2) {        // memory-only build: keep every load live, skip the arithmetic
         p.qx = X.x + cam[0]; p.qy = X.y + cam[9]; p.qz = X.z + cam[12]; p.px = cam[15]; p.py = cam[23];
@@ -618,22 +624,43 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(const double *__restrict
     }
 }
 
-// single lane: fold the per-workgroup records -> stats[0..2]=mean, [6..8]=min, [9..11]=max,
-// [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin index
-__global__ __launch_bounds__(64) void k_stats_fold1(const double *__restrict__ rec, int n_rec,
-                                                   const double *__restrict__ camblk, int64_t n_cam,
-                                                   const double4 *__restrict__ pts4,
-                                                   double *__restrict__ stats) {
+// one 1024-lane workgroup (record t on lane t; kRedBlocks <= 1024): fold the per-workgroup records ->
+// stats[0..2]=mean, [6..8]=min, [9..11]=max, [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin index.
+// Fixed shuffle / LDS order => deterministic.
+__global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__restrict__ rec, int n_rec,
+                                                          const double *__restrict__ camblk, int64_t n_cam,
+                                                          const double4 *__restrict__ pts4,
+                                                          double *__restrict__ stats) {
+    __shared__ double sh[kRedBlocks / 64][12];
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double t[9] = {0, 0, 0, inf, inf, inf, -inf, -inf, -inf};
+    Best b = {0.0, -1.0};
+    if ((int)threadIdx.x < n_rec) {
+        const double *r = rec + (int64_t)threadIdx.x * kStatRec;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t[k] = r[k];
+        b.d = r[9]; b.i = r[10];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t[k] = wave_sum(t[k]); t[3 + k] = wave_min(t[3 + k]); t[6 + k] = wave_max(t[6 + k]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.d = __shfl_down(b.d, off, 64);
+        o.i = __shfl_down(b.i, off, 64);
+        b = best_merge(b, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sh[wave][k] = t[k];
+        sh[wave][9] = b.d; sh[wave][10] = b.i; sh[wave][11] = 0.0;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    double t[9];
-    for (int k = 0; k < 9; ++k) t[k] = rec[k];
-    Best b = {rec[9], rec[10]};
-    for (int r_ = 1; r_ < n_rec; ++r_) {
-        const double *r = rec + (int64_t)r_ * kStatRec;
-        t[0] += r[0]; t[1] += r[1]; t[2] += r[2];
-        for (int k = 3; k < 6; ++k) t[k] = fmin(t[k], r[k]);
-        for (int k = 6; k < 9; ++k) t[k] = fmax(t[k], r[k]);
-        const Best o = {r[9], r[10]};
+    for (int w = 1; w < kRedBlocks / 64; ++w) {
+        for (int k = 0; k < 3; ++k) { t[k] += sh[w][k]; t[3 + k] = fmin(t[3 + k], sh[w][3 + k]); t[6 + k] = fmax(t[6 + k], sh[w][6 + k]); }
+        const Best o = {sh[w][9], sh[w][10]};
         b = best_merge(b, o);
     }
     double x = 0, y = 0, z = 0;
@@ -670,14 +697,20 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass2(const double *__restrict
     }
 }
 
-__global__ __launch_bounds__(64) void k_stats_fold2(const double *__restrict__ rec, int n_rec, int64_t n_ent,
-                                                   double *__restrict__ stats) {
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(kRedBlocks) void k_stats_fold2(const double *__restrict__ rec, int n_rec, int64_t n_ent,
+                                                          double *__restrict__ stats) {
+    __shared__ double sh[kRedBlocks / 64][3];
     double t0 = 0, t1 = 0, t2 = 0;
-    for (int b = 0; b < n_rec; ++b) {
-        const double *r = rec + (int64_t)b * kStatRec;
-        t0 += r[0]; t1 += r[1]; t2 += r[2];
+    if ((int)threadIdx.x < n_rec) {
+        const double *r = rec + (int64_t)threadIdx.x * kStatRec;
+        t0 = r[0]; t1 = r[1]; t2 = r[2];
     }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[wave][0] = t0; sh[wave][1] = t1; sh[wave][2] = t2; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int w = 1; w < kRedBlocks / 64; ++w) { t0 += sh[w][0]; t1 += sh[w][1]; t2 += sh[w][2]; }
     const double num = (double)n_ent;
     const double a = sqrt(t0 / num), b = sqrt(t1 / num), c = sqrt(t2 / num);
     stats[3] = a; stats[4] = b; stats[5] = c;

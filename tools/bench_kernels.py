@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Per-kernel timings of the whole hot path on the bench workload (one process, HIP events).
+   python tools/bench_kernels.py [--blocks 128] [--reps 20]
+Prints one JSON object; algorithmic bytes follow SURVEY section 8(d)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from city2ba_amd import device as D  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--blocks", type=int, default=128)
+ap.add_argument("--reps", type=int, default=20)
+a = ap.parse_args()
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+sh = bench.build_shard(argparse.Namespace(blocks=a.blocks), 0, 1, dev)
+n, n_cam, n_pts = sh["n_obs"], sh["n_cam"], sh["n_pts"]
+camblk, pts4, cam_idx, pt_idx, uv, cam15 = sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], sh["cam15"]
+ws = D.workspace(n, dev)
+err = torch.zeros(1, dtype=torch.float64, device=dev)
+uv_out = torch.empty_like(uv)
+entity_bytes = n_cam * 72 + n_pts * 24
+
+
+def timed(fn, reps=a.reps):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+
+out = {"blocks": a.blocks, "n_obs": n, "n_cameras": n_cam, "n_points": n_pts, "kernels": {}}
+
+
+def report(name, secs, units, alg_bytes, unit_name):
+    out["kernels"][name] = {"us": round(secs * 1e6, 1), "G%s/s" % unit_name: round(units / secs / 1e9, 3),
+                            "alg_GB/s": round(alg_bytes / secs / 1e9, 1), "frac_hbm_peak": round(alg_bytes / secs / 8e12, 4)}
+
+
+t = timed(lambda: D.project(camblk, pts4, cam_idx, pt_idx, uv_out))
+report("project", t, n, n * (4 + 16) + entity_bytes, "obs")
+for norm in (2.0, 1.0, 1.5):
+    t = timed(lambda: D.reprojection_error_sum(camblk, pts4, cam_idx, pt_idx, uv, norm, ws, err))
+    report("error_sum(norm=%g)" % norm, t, n, n * (4 + 16) + entity_bytes, "obs")
+r = torch.empty((n, 2), dtype=torch.float64, device=dev)
+Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
+Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
+t = timed(lambda: D.residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, 2.0, ws))
+report("residual_jacobian+err", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
+t = timed(lambda: D.error_sum_finish(ws, n, err))
+report("error_sum_finish", t, n / 64, n / 64 * 8, "partials")
+del r, Jc, Jp
+
+# visibility predicate on a candidate list of the same size class as the generator's
+keep = torch.empty(n, dtype=torch.uint8, device=dev)
+t = timed(lambda: D.visibility_pairs(camblk, pts4, cam_idx, pt_idx, 10.0, uv_out, keep))
+report("visibility_pairs", t, n, n * (8 + 16 + 1) + entity_bytes, "pairs")
+
+uv2 = uv.clone()
+t = timed(lambda: D.add_noise_observations(uv2, 0, 1e-6, 7))
+report("add_noise_observations", t, n, n * 32, "obs")
+
+st = torch.empty(20, dtype=torch.float64, device=dev)
+t = timed(lambda: D.stats(camblk, pts4, ws, st))
+report("stats(mean,std,extent,origin)", t, n_cam + n_pts, 2 * (n_cam * 24 + n_pts * 24), "entities")
+t = timed(lambda: D.cameras_prepare_state(cam15, camblk))
+report("cameras_prepare_state", t, n_cam, n_cam * (120 + 224), "cams")
+bal9 = D.cameras_to_bal(cam15)
+t = timed(lambda: D.cameras_to_bal(cam15))
+report("cameras_to_bal", t, n_cam, n_cam * (120 + 72), "cams")
+t = timed(lambda: D.cameras_from_bal(bal9))
+report("cameras_from_bal", t, n_cam, n_cam * (120 + 72), "cams")
+c2, p2 = cam15.clone(), pts4.clone()
+t = timed(lambda: D.add_drift_normalized(c2, p2, st, 1e-9, 1e-9, 0.1, 3))
+report("add_drift_normalized", t, n_cam + n_pts, 2 * (n_cam * 120 + n_pts * 24), "entities")
+t = timed(lambda: D.add_noise_entities(c2, p2, st, 1e-9, 1e-9, 1e-9, 4))
+report("add_noise_entities", t, n_cam + n_pts, 2 * (n_cam * 120 + n_pts * 24), "entities")
+print(json.dumps(out, indent=1))
