@@ -43,6 +43,9 @@ SIGNATURES = {
     "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp]),
     "c2b_error_sum_finish": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
+    "c2b_visibility_dense_tiles": (_i64, [_i64]),
+    "c2b_visibility_dense_count": (_int, [_vp, _i64, _vp, _i64, _d, _vp, _vp, _vp, _vp]),
+    "c2b_visibility_dense_fill": (_int, [_vp, _i64, _vp, _i64, _d, _vp, _vp, _vp, _vp, _vp]),
     "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
     "c2b_add_drift_normalized": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
@@ -78,6 +81,8 @@ SIGNATURES = {
     "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_stats": (_int, [_vp, _vp]),
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),
+    "c2b_problem_visibility_dense": (_int, [_vp, _d, _vp]),
+    "c2b_problem_visibility_dense_fetch": (_int, [_vp, _vp, _vp]),
     "c2b_problem_add_drift": (_int, [_vp, _d, _d, _d, _vp, _u64]),
     "c2b_problem_add_drift_normalized": (_int, [_vp, _d, _d, _d, _u64]),
     "c2b_problem_add_noise": (_int, [_vp, _d, _d, _d, _d, _u64]),

@@ -186,6 +186,19 @@ class BAProblem:
         s = self._stats()
         return s[15:18].copy(), int(s[18])
 
+    def visibility_graph(self, max_dist):
+        """The camera x point sweep of generate::visibility_graph (src/generate.rs:424-481) WITHOUT the
+        Embree occlusion filter: every camera of the problem against every point.  Returns the CSR graph
+        (row_ptr u64, pt_idx u64, uv) with points in ascending order per camera, like the reference's push order."""
+        n_cam = self.num_cameras()
+        row_ptr = np.zeros(n_cam + 1, dtype=np.uint64)
+        L.check(L.lib().c2b_problem_visibility_dense(self._h, float(max_dist), _ptr(row_ptr)))
+        n = int(row_ptr[-1])
+        pt_idx = np.empty(n, dtype=np.uint64)
+        uv = np.empty((n, 2))
+        L.check(L.lib().c2b_problem_visibility_dense_fetch(self._h, _ptr(pt_idx), _ptr(uv)))
+        return row_ptr, pt_idx, uv
+
     def _cameras_from_position_direction(self, pos, dirs):
         """Camera::from_position_direction (src/baproblem.rs:153-159), batched on this problem's device."""
         pos, dirs = _f64(pos, (-1, 3)), _f64(dirs, (-1, 9))

@@ -412,6 +412,74 @@ int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, i
     return C2B_OK;
 }
 
+int64_t c2b_visibility_dense_tiles(int64_t n_pts) { return n_pts <= 0 ? 0 : (n_pts + kDenseTile - 1) / kDenseTile; }
+
+static void dense_grid(int64_t n_cam, int64_t n_tiles, dim3 *grid, int64_t *cams_per_chunk) {
+    const int64_t bx = (n_tiles + kDenseWPB - 1) / kDenseWPB;
+    // enough waves to fill 256 CUs a few times over, camera chunks in multiples of the LDS tile
+    int64_t chunks = (16384 + n_tiles - 1) / (n_tiles > 0 ? n_tiles : 1);
+    const int64_t max_chunks = (n_cam + kDenseCamTile - 1) / kDenseCamTile;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks > 65535) chunks = 65535;
+    if (chunks < 1) chunks = 1;
+    int64_t per = (n_cam + chunks - 1) / chunks;
+    per = (per + kDenseCamTile - 1) / kDenseCamTile * kDenseCamTile;
+    chunks = (n_cam + per - 1) / per;
+    *grid = dim3((unsigned)bx, (unsigned)chunks);
+    *cams_per_chunk = per;
+}
+
+static int dense_check(const char *who, const void *camblk, int64_t n_cam, const void *pts4, int64_t n_pts) {
+    if (n_cam < 0 || n_pts < 0 || (n_cam && !camblk) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: bad arguments", who);
+    if (n_pts >= ((int64_t)1 << 32)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: point indices are 32-bit", who);
+    if ((n_cam && !aligned16(camblk)) || (n_pts && !aligned16(pts4))) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: camblk/pts4 must be 16-byte aligned", who);
+    return C2B_OK;
+}
+
+int c2b_visibility_dense_count(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, double max_dist,
+                               uint32_t *tile_counts, uint64_t *cam_total, uint64_t *row_ptr, void *stream) {
+    int rc = dense_check("visibility_dense_count", camblk, n_cam, pts4, n_pts);
+    if (rc) return rc;
+    if (!row_ptr) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_dense_count: row_ptr is NULL");
+    const int64_t n_tiles = c2b_visibility_dense_tiles(n_pts);
+    if (!n_cam || !n_tiles) {
+        HIP_TRY(hipMemsetAsync(row_ptr, 0, sizeof(uint64_t) * (size_t)(n_cam + 1), S(stream)));
+        return C2B_OK;
+    }
+    if (!tile_counts || !cam_total) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_dense_count: NULL scratch");
+    dim3 grid;
+    int64_t per;
+    dense_grid(n_cam, n_tiles, &grid, &per);
+    hipLaunchKernelGGL(k_visibility_dense<false>, grid, dim3(kDenseWPB * 64), 0, S(stream), camblk, n_cam, per,
+                       reinterpret_cast<const double4 *>(pts4), n_pts, n_tiles, max_dist, tile_counts,
+                       (const uint64_t *)nullptr, (uint32_t *)nullptr, (double2 *)nullptr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_dense_row_scan, dim3((unsigned)n_cam), dim3(256), 0, S(stream), tile_counts, n_tiles, cam_total);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_dense_cam_scan, dim3(1), dim3(256), 0, S(stream), (const uint64_t *)cam_total, n_cam, row_ptr);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_visibility_dense_fill(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, double max_dist,
+                              const uint32_t *tile_offsets, const uint64_t *row_ptr, uint32_t *pt_idx, double *uv,
+                              void *stream) {
+    int rc = dense_check("visibility_dense_fill", camblk, n_cam, pts4, n_pts);
+    if (rc) return rc;
+    const int64_t n_tiles = c2b_visibility_dense_tiles(n_pts);
+    if (!n_cam || !n_tiles) return C2B_OK;
+    if (!tile_offsets || !row_ptr || !pt_idx || !uv || !aligned16(uv))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_dense_fill: NULL/misaligned buffer");
+    dim3 grid;
+    int64_t per;
+    dense_grid(n_cam, n_tiles, &grid, &per);
+    hipLaunchKernelGGL(k_visibility_dense<true>, grid, dim3(kDenseWPB * 64), 0, S(stream), camblk, n_cam, per,
+                       reinterpret_cast<const double4 *>(pts4), n_pts, n_tiles, max_dist,
+                       const_cast<uint32_t *>(tile_offsets), row_ptr, pt_idx, reinterpret_cast<double2 *>(uv));
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
 /* ------------------------------- host-side generator pieces -------------------------- */
 
 int c2b_synthetic_grid_sizes(int64_t cpb, int64_t ppb, int64_t blocks, int64_t *n_cam, int64_t *n_pts) {
@@ -597,11 +665,16 @@ struct c2b_problem {
     double *stats = nullptr, *scalar = nullptr;
     bool bal_valid = false;     // bal9 still describes the cameras (no mutation since upload_bal)
     bool blk_valid = false;     // camblk matches cam15 (and bal_valid mode)
+    uint32_t *dense_pt = nullptr;   // survivors of the last dense visibility sweep
+    double *dense_uv = nullptr;
+    int64_t dense_n = 0;
 };
 
 static void free_buffers(c2b_problem *p) {
-    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar};
+    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar,
+                    p->dense_pt, p->dense_uv};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->dense_pt = nullptr; p->dense_uv = nullptr; p->dense_n = 0;
     p->cam15 = p->bal9 = p->camblk = p->pts4 = p->uv = nullptr;
     p->cam_idx = p->pt_idx = nullptr;
     p->ws = nullptr; p->stats = p->scalar = nullptr;
@@ -925,6 +998,66 @@ int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t
     if (d_k) (void)hipFree(d_k);
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_pairs: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr) {
+    NEED_UPLOADED(p, "problem_visibility_dense");
+    if (!row_ptr) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense: row_ptr is NULL");
+    if (!(max_dist >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense: max_dist must be >= 0");
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    if (p->dense_pt) { (void)hipFree(p->dense_pt); p->dense_pt = nullptr; }
+    if (p->dense_uv) { (void)hipFree(p->dense_uv); p->dense_uv = nullptr; }
+    p->dense_n = 0;
+    const int64_t n_tiles = c2b_visibility_dense_tiles(p->n_pts);
+    const int64_t cells = p->n_cam * n_tiles;
+    if (cells > ((int64_t)1 << 33))
+        return fail(C2B_ERR_INVALID_ARGUMENT,
+                    "problem_visibility_dense: %lld cameras x %lld point tiles is too large for the dense sweep; "
+                    "use candidate pairs + c2b_problem_visibility_pairs", (long long)p->n_cam, (long long)n_tiles);
+    uint32_t *d_counts = nullptr;
+    uint64_t *d_tot = nullptr, *d_row = nullptr;
+    hipError_t e = hipMalloc((void **)&d_counts, sizeof(uint32_t) * (size_t)(cells ? cells : 4));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tot, sizeof(uint64_t) * (size_t)(p->n_cam + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_row, sizeof(uint64_t) * (size_t)(p->n_cam + 1));
+    if (e == hipSuccess) {
+        rc = c2b_visibility_dense_count(p->camblk, p->n_cam, p->pts4, p->n_pts, max_dist, d_counts, d_tot, d_row, p->stream);
+        if (!rc) e = hipMemcpyAsync(row_ptr, d_row, sizeof(uint64_t) * (size_t)(p->n_cam + 1), hipMemcpyDeviceToHost, p->stream);
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (!rc && e == hipSuccess) {
+            const int64_t total = (int64_t)row_ptr[p->n_cam];
+            e = hipMalloc((void **)&p->dense_pt, sizeof(uint32_t) * (size_t)(total ? total : 4));
+            if (e == hipSuccess) e = hipMalloc((void **)&p->dense_uv, sizeof(double) * 2 * (size_t)(total ? total : 1));
+            if (e == hipSuccess && total) {
+                rc = c2b_visibility_dense_fill(p->camblk, p->n_cam, p->pts4, p->n_pts, max_dist, d_counts, d_row, p->dense_pt,
+                                               p->dense_uv, p->stream);
+                if (!rc) e = hipStreamSynchronize(p->stream);
+            }
+            if (!rc && e == hipSuccess) p->dense_n = total;
+        }
+    }
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_tot) (void)hipFree(d_tot);
+    if (d_row) (void)hipFree(d_row);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double *uv) {
+    NEED_UPLOADED(p, "problem_visibility_dense_fetch");
+    if (!p->dense_pt || !p->dense_uv) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_fetch: no sweep result");
+    const int64_t n = p->dense_n;
+    if (!n) return C2B_OK;
+    if (uv) HIP_TRY(hipMemcpyAsync(uv, p->dense_uv, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, p->stream));
+    if (pt_idx) {
+        std::vector<uint32_t> tmp((size_t)n);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), p->dense_pt, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (int64_t i = 0; i < n; ++i) pt_idx[i] = tmp[(size_t)i];
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
 }
 

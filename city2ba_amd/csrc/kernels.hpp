@@ -858,3 +858,171 @@ __global__ __launch_bounds__(kBlock) void k_add_sin_noise(double *__restrict__ c
 }
 
 }  // namespace c2b
+
+// =====================================================================================================
+// Dense visibility sweep: every camera x every point, the O(C*P) loop of the mesh generator
+// (visibility_graph, src/generate.rs:446-469) without its Embree occlusion stream.  Kept observations
+// come out per camera in ascending point order, exactly like the reference's `for (i, point) in
+// points.iter().enumerate()` push order.
+//
+// Mapping: a wave owns a tile of 256 consecutive points (4 per lane, in registers for the whole kernel)
+// and walks a chunk of cameras staged 64 at a time in LDS (18 doubles each, read by broadcast).  The
+// common case -- the point is farther than max_dist -- costs 8 f64 operations per pair; only survivors
+// run project_world / project.  Pass 1 counts survivors per (camera, tile); a row scan turns counts into
+// offsets; pass 2 repeats the predicate and writes (point index, uv) at offset + wave-prefix rank.
+// =====================================================================================================
+namespace c2b {
+
+constexpr int kDensePPL = 4;                       // points per lane
+constexpr int kDenseTile = 64 * kDensePPL;         // points per wave tile
+constexpr int kDenseWPB = 4;                       // waves per workgroup
+constexpr int kDenseCamTile = 64;                  // cameras staged per LDS round
+constexpr int kDenseRec = 18;                      // center3 | R9 (row-major) | t3 | f,k1,k2
+
+C2B_DEV int wave_excl_scan(int v, int lane, int &total) {
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
+    const double *__restrict__ camblk, int64_t n_cam, int64_t cams_per_chunk, const double4 *__restrict__ pts4,
+    int64_t n_pts, int64_t n_tiles, double max_dist, uint32_t *__restrict__ tile_counts,
+    const uint64_t *__restrict__ row_ptr, uint32_t *__restrict__ pt_out, double2 *__restrict__ uv_out) {
+    __shared__ double sCam[kDenseCamTile * kDenseRec];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * kDenseWPB + wave;
+    const int64_t p0 = tile * kDenseTile + (int64_t)lane * kDensePPL;      // this lane's first point
+    const bool wave_live = tile < n_tiles;
+
+    double X[kDensePPL], Y[kDensePPL], Z[kDensePPL];
+    bool pv[kDensePPL];
+#pragma unroll
+    for (int j = 0; j < kDensePPL; ++j) {
+        pv[j] = wave_live && p0 + j < n_pts;
+        const double4 p = pv[j] ? pts4[p0 + j] : make_double4(0, 0, 0, 0);
+        X[j] = p.x; Y[j] = p.y; Z[j] = p.z;
+    }
+    const double m2 = max_dist * max_dist;
+    const double m2_lo = m2 * (1.0 - 0x1.0p-50), m2_hi = m2 * (1.0 + 0x1.0p-50);
+
+    const int64_t c_begin = (int64_t)blockIdx.y * cams_per_chunk;
+    const int64_t c_end = c_begin + cams_per_chunk < n_cam ? c_begin + cams_per_chunk : n_cam;
+    for (int64_t cb = c_begin; cb < c_end; cb += kDenseCamTile) {
+        const int nc = c_end - cb < kDenseCamTile ? (int)(c_end - cb) : kDenseCamTile;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nc * kDenseRec; e += kDenseWPB * 64) {
+            const int k = e / kDenseRec, f = e % kDenseRec;
+            const double *src = camblk + (cb + k) * kCamBlk;
+            sCam[e] = f < 3 ? src[kCenter + f] : src[f - 3];         // center | R, t, intrinsics (camblk[0..14])
+        }
+        __syncthreads();
+        if (!wave_live) continue;
+        for (int k = 0; k < nc; ++k) {
+            const double *cam = sCam + k * kDenseRec;
+            const double cx = cam[0], cy = cam[1], cz = cam[2];
+            unsigned keep_bits = 0;
+            double u[kDensePPL], v[kDensePPL];
+#pragma unroll
+            for (int j = 0; j < kDensePPL; ++j) {
+                // (camera.center() - point).magnitude() < max_dist, src/generate.rs:450
+                const double dx = cx - X[j], dy = cy - Y[j], dz = cz - Z[j];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                u[j] = 0.0; v[j] = 0.0;
+                if (pv[j] && d2 < m2_hi) {
+                    bool near = d2 < m2_lo;
+                    if (!near) near = sqrt(d2) < max_dist;               // exact decision on the boundary band
+                    if (near) {
+                        const Proj p = project_obs(cam + 3, X[j], Y[j], Z[j]);
+                        if (p.qz <= 0.0 && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0) {
+                            keep_bits |= 1u << j;
+                            u[j] = p.u; v[j] = p.v;
+                        }
+                    }
+                }
+            }
+            const int mine = __popc(keep_bits);
+            if (!__any(mine != 0)) {
+                if (!FILL && lane == 0) tile_counts[(cb + k) * n_tiles + tile] = 0;
+                continue;
+            }
+            int total;
+            const int before = wave_excl_scan(mine, lane, total);
+            if (!FILL) {
+                if (lane == 0) tile_counts[(cb + k) * n_tiles + tile] = (uint32_t)total;
+            } else {
+                int64_t dst = (int64_t)row_ptr[cb + k] + tile_counts[(cb + k) * n_tiles + tile] + before;
+#pragma unroll
+                for (int j = 0; j < kDensePPL; ++j)
+                    if (keep_bits & (1u << j)) {
+                        pt_out[dst] = (uint32_t)(p0 + j);
+                        uv_out[dst] = make_double2(u[j], v[j]);
+                        ++dst;
+                    }
+            }
+        }
+    }
+}
+
+// per camera: exclusive scan of its row of tile counts (in place) + row total
+__global__ __launch_bounds__(256) void k_dense_row_scan(uint32_t *__restrict__ tile_counts, int64_t n_tiles,
+                                                       uint64_t *__restrict__ cam_total) {
+    __shared__ int sWave[4];
+    __shared__ int sCarry;
+    uint32_t *row = tile_counts + (int64_t)blockIdx.x * n_tiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sCarry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < n_tiles ? (int)row[i] : 0;
+        int total;
+        const int ex = wave_excl_scan(v, lane, total);
+        if (lane == 0) sWave[wave] = total;
+        __syncthreads();
+        int off = sCarry;
+        for (int w = 0; w < wave; ++w) off += sWave[w];
+        if (i < n_tiles) row[i] = (uint32_t)(off + ex);
+        __syncthreads();
+        if (threadIdx.x == 0) sCarry += (sWave[0] + sWave[1]) + (sWave[2] + sWave[3]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cam_total[blockIdx.x] = (uint64_t)sCarry;
+}
+
+// row_ptr[0..n_cam] = exclusive scan of cam_total (one workgroup; n_cam is small next to n_cam * n_tiles)
+__global__ __launch_bounds__(256) void k_dense_cam_scan(const uint64_t *__restrict__ cam_total, int64_t n_cam,
+                                                       uint64_t *__restrict__ row_ptr) {
+    __shared__ long long sWave[4];
+    __shared__ long long sCarry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sCarry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_cam; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const long long v = i < n_cam ? (long long)cam_total[i] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) sWave[wave] = inc;
+        __syncthreads();
+        long long off = sCarry;
+        for (int w = 0; w < wave; ++w) off += sWave[w];
+        if (i < n_cam) row_ptr[i] = (uint64_t)(off + inc - v);
+        __syncthreads();
+        if (threadIdx.x == 0) sCarry += (sWave[0] + sWave[1]) + (sWave[2] + sWave[3]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_ptr[n_cam] = (uint64_t)sCarry;
+}
+
+}  // namespace c2b

@@ -106,6 +106,20 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
                          const uint32_t *pt_idx, int64_t n_pairs, double max_dist,
                          double *uv_out, uint8_t *keep, void *stream);
 
+/* The O(cameras x points) sweep of the mesh generator (visibility_graph, src/generate.rs:446-469)
+ * WITHOUT its Embree occlusion stream: every camera against every point with the predicate above,
+ * survivors per camera in ascending point order (the reference's push order).  Two passes:
+ *   _count: survivors per (camera, 256-point tile) -> tile_counts[n_cam * tiles] (turned into per-camera
+ *           exclusive offsets in place) and row_ptr[n_cam + 1]; cam_total[n_cam] is scratch;
+ *   _fill:  after the caller has read row_ptr[n_cam] and allocated pt_idx / uv of that size. */
+int64_t c2b_visibility_dense_tiles(int64_t n_pts);
+int c2b_visibility_dense_count(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
+                               double max_dist, uint32_t *tile_counts, uint64_t *cam_total,
+                               uint64_t *row_ptr, void *stream);
+int c2b_visibility_dense_fill(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
+                              double max_dist, const uint32_t *tile_offsets, const uint64_t *row_ptr,
+                              uint32_t *pt_idx, double *uv, void *stream);
+
 /* BAProblem::mean/std/extent/dimensions (src/baproblem.rs:282-337) + add_drift's origin
  * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES]. */
 int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
@@ -229,6 +243,11 @@ int c2b_problem_stats(c2b_problem *p, double *stats /* C2B_STATS_DOUBLES */);
 int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx,
                                  const uint32_t *pt_idx, double max_dist, double *uv_out,
                                  uint8_t *keep);
+/* dense sweep (src/generate.rs:446-469, no occlusion) over the problem's cameras and points: writes
+ * row_ptr[n_cam + 1] and keeps the survivors on the device; _fetch copies pt_idx[row_ptr[n_cam]] and
+ * uv[row_ptr[n_cam]][2] out (either may be NULL). */
+int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr);
+int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double *uv);
 int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength, double std,
                           const double dir[3], uint64_t seed);
 int c2b_problem_add_drift_normalized(c2b_problem *p, double strength, double angle_strength,
