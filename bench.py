@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blocks", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -114,6 +115,45 @@ def cpu_baseline(sh, seconds):
             "sample": "oracle/ C restatement (orc_bench_residual_jacobian: project + 2x12 Jacobian + L2 sum), "
                       "first %d cameras / %d observations of the same grid, %d passes in %.1f s, 1 thread"
                       % (c_end, n, passes, el)}
+
+
+def other_configs(dev):
+    """BASELINE.json's smaller single-GPU configurations, reported next to the headline (not `value`):
+    configs[1] `--blocks 4` project-only (a latency test: 0.6 MB of data) and configs[2] `--blocks 32`
+    residual + Jacobian (0.29 GB per launch; fits the 256 MB Infinity Cache)."""
+    import argparse as _ap
+    import torch
+    from city2ba_amd import device as D
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps * 1e-3
+
+    res = {}
+    s4 = build_shard(_ap.Namespace(blocks=4), 0, 1, dev)
+    uv4 = torch.empty_like(s4["uv"])
+    t = timed(lambda: D.project(s4["camblk"], s4["pts4"], s4["cam_idx"], s4["pt_idx"], uv4), 500)
+    res["blocks4_project_only"] = {"n_observations": s4["n_obs"], "us_per_launch": round(t * 1e6, 2),
+                                   "Mobs/s": round(s4["n_obs"] / t / 1e6, 1)}
+    s32 = build_shard(_ap.Namespace(blocks=32), 0, 1, dev)
+    n = s32["n_obs"]
+    r = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
+    Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    ws = D.workspace(n, dev)
+    t = timed(lambda: D.residual_jacobian(s32["camblk"], s32["pts4"], s32["cam_idx"], s32["pt_idx"], s32["uv"], r, Jc, Jp,
+                                          2.0, ws), 200)
+    alg = algorithmic_bytes(n, s32["n_cam"], s32["n_pts"])
+    res["blocks32_residual_jacobian"] = {"n_observations": n, "us_per_launch": round(t * 1e6, 2),
+                                         "Mobs/s": round(n / t / 1e6, 1), "algorithmic_GB/s": round(alg / t / 1e9, 1)}
+    return res
 
 
 def pmc_traffic():
@@ -221,6 +261,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sh, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and args.blocks == 128 and not args.no_extras:
+            out["other_configs"] = other_configs(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

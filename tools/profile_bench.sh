@@ -6,7 +6,7 @@
 TAG=${1:-r01}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-ARGS="${@:---steps 10 --warmup 2 --no-cpu-baseline}"
+ARGS="${@:---steps 50 --warmup 5 --no-cpu-baseline --no-extras}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
