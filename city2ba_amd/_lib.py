@@ -52,6 +52,13 @@ SIGNATURES = {
     "c2b_add_noise_entities": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
     "c2b_add_noise_observations": (_int, [_vp, _i64, _i64, _d, _u64, _vp]),
     "c2b_add_sin_noise": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _d, _d, _vp]),
+    "c2b_convert_f64_to_f32": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_convert_f32_to_f64": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_stats_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "c2b_add_drift_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
+    "c2b_add_drift_normalized_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
+    "c2b_add_noise_entities_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
+    "c2b_add_sin_noise_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _d, _d, _vp]),
     "c2b_partition_cameras": (_int, [_vp, _i64, _int, _vp]),
     "c2b_synthetic_grid_sizes": (_int, [_i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "c2b_synthetic_grid_layout": (_int, [_i64, _i64, _i64, _d, _d, _d, _d, _vp, _vp, _vp]),

@@ -25,19 +25,27 @@ constexpr double kEps = 2.220446049250313e-16;   // f64::EPSILON
 constexpr double kPi = 3.14159265358979323846;
 
 // ---- small vector helpers (cgmath evaluation order) ----------------------------------
-C2B_DEV double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+// Templated on the scalar so that the f32 extension (BASELINE config 5) shares the algebra; the f64
+// instantiations are what every parity statement refers to.
+C2B_DEV void sincos_t(double a, double *s, double *c) { sincos(a, s, c); }
+C2B_DEV void sincos_t(float a, float *s, float *c) { sincosf(a, s, c); }
+
+template <typename T>
+C2B_DEV T dot3(T ax, T ay, T az, T bx, T by, T bz) {
     return (ax * bx + ay * by) + az * bz;
 }
 
 // col-major 3x3 (cam15 state): m[3*c + r]
-C2B_DEV void cm_mat_vec(const double *m, double x, double y, double z, double o[3]) {
+template <typename T>
+C2B_DEV void cm_mat_vec(const T *m, T x, T y, T z, T o[3]) {
     o[0] = dot3(m[0], m[3], m[6], x, y, z);
     o[1] = dot3(m[1], m[4], m[7], x, y, z);
     o[2] = dot3(m[2], m[5], m[8], x, y, z);
 }
 
 // out = a * b, all col-major; out[c][r] = a.row(r) . b.col(c)
-C2B_DEV void cm_mat_mul(const double *a, const double *b, double *o) {
+template <typename T>
+C2B_DEV void cm_mat_mul(const T *a, const T *b, T *o) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -46,29 +54,31 @@ C2B_DEV void cm_mat_mul(const double *a, const double *b, double *o) {
 }
 
 // -(R^-1 t) with cgmath's Matrix3::invert (cross products / determinant), src/baproblem.rs:161-163
-C2B_DEV void cm_center(const double *m, double tx, double ty, double tz, double c[3]) {
-    const double m00 = m[0], m01 = m[1], m02 = m[2];   // column 0 (c, r)
-    const double m10 = m[3], m11 = m[4], m12 = m[5];   // column 1
-    const double m20 = m[6], m21 = m[7], m22 = m[8];   // column 2
-    const double det = m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02) +
-                       m20 * (m01 * m12 - m11 * m02);
+template <typename T>
+C2B_DEV void cm_center(const T *m, T tx, T ty, T tz, T c[3]) {
+    const T m00 = m[0], m01 = m[1], m02 = m[2];   // column 0 (c, r)
+    const T m10 = m[3], m11 = m[4], m12 = m[5];   // column 1
+    const T m20 = m[6], m21 = m[7], m22 = m[8];   // column 2
+    const T det = m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02) +
+                  m20 * (m01 * m12 - m11 * m02);
     // rows of the inverse: (c1 x c2)/det, (c2 x c0)/det, (c0 x c1)/det
-    const double a0 = (m11 * m22 - m12 * m21) / det, a1 = (m12 * m20 - m10 * m22) / det,
-                 a2 = (m10 * m21 - m11 * m20) / det;
-    const double b0 = (m21 * m02 - m22 * m01) / det, b1 = (m22 * m00 - m20 * m02) / det,
-                 b2 = (m20 * m01 - m21 * m00) / det;
-    const double c0 = (m01 * m12 - m02 * m11) / det, c1 = (m02 * m10 - m00 * m12) / det,
-                 c2 = (m00 * m11 - m01 * m10) / det;
+    const T a0 = (m11 * m22 - m12 * m21) / det, a1 = (m12 * m20 - m10 * m22) / det,
+            a2 = (m10 * m21 - m11 * m20) / det;
+    const T b0 = (m21 * m02 - m22 * m01) / det, b1 = (m22 * m00 - m20 * m02) / det,
+            b2 = (m20 * m01 - m21 * m00) / det;
+    const T c0 = (m01 * m12 - m02 * m11) / det, c1 = (m02 * m10 - m00 * m12) / det,
+            c2 = (m00 * m11 - m01 * m10) / det;
     c[0] = -dot3(a0, a1, a2, tx, ty, tz);
     c[1] = -dot3(b0, b1, b2, tx, ty, tz);
     c[2] = -dot3(c0, c1, c2, tx, ty, tz);
 }
 
 // Matrix3::from_axis_angle, col-major out
-C2B_DEV void cm_from_axis_angle(double ax, double ay, double az, double angle, double *o) {
-    double s, c;
-    sincos(angle, &s, &c);
-    const double k = 1.0 - c;
+template <typename T>
+C2B_DEV void cm_from_axis_angle(T ax, T ay, T az, T angle, T *o) {
+    T s, c;
+    sincos_t(angle, &s, &c);
+    const T k = T(1.0) - c;
     o[0] = k * ax * ax + c;       o[1] = k * ax * ay + s * az;  o[2] = k * ax * az - s * ay;
     o[3] = k * ax * ay - s * az;  o[4] = k * ay * ay + c;       o[5] = k * ay * az + s * ax;
     o[6] = k * ax * az + s * ay;  o[7] = k * ay * az - s * ax;  o[8] = k * az * az + c;
@@ -144,14 +154,15 @@ C2B_DEV void to_rodrigues(const double *Rcm, double w[3]) {
 }
 
 // Camera::transform, src/baproblem.rs:165-171 (new loc uses the OLD dir), in place on cam15
-C2B_DEV void transform_cam15(double *cam, const double *dRcm, double dx, double dy, double dz) {
-    double c[3], v[3], nr[9];
+template <typename T>
+C2B_DEV void transform_cam15(T *cam, const T *dRcm, T dx, T dy, T dz) {
+    T c[3], v[3], nr[9];
     cm_center(cam, cam[9], cam[10], cam[11], c);
     cm_mat_vec(cam, c[0] + dx, c[1] + dy, c[2] + dz, v);
     cm_mat_mul(cam, dRcm, nr);
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam[i] = nr[i];
-    cam[9] = -1.0 * v[0]; cam[10] = -1.0 * v[1]; cam[11] = -1.0 * v[2];
+    cam[9] = T(-1.0) * v[0]; cam[10] = T(-1.0) * v[1]; cam[11] = T(-1.0) * v[2];
 }
 
 // Left Jacobian of SO(3), J_l(w) = I + a [w]x + b [w]x^2 (row-major out).  Build-defined

@@ -111,6 +111,68 @@ void launch_jacobian(int variant, const double *camblk, const double *pts4, cons
 #undef C2B_W
 }
 
+template <typename Src>
+int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStream_t st) {
+    double *rec = reinterpret_cast<double *>(workspace);
+    int grid = (int)((n + kBlock - 1) / kBlock);
+    if (grid > kRedBlocks) grid = kRedBlocks;
+    hipLaunchKernelGGL(k_stats_pass1<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, rec);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_fold1<Src>, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, src, stats);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_pass2<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, (const double *)stats, rec);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_fold2, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, n, stats);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+template <typename T>
+int drift_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts, const double *origin,
+               const double *stats_norm, double strength, double angle_strength, double std, double dx, double dy,
+               double dz, uint64_t seed, hipStream_t st) {
+    if (n_cam < 0 || n_pts < 0 || !origin || (n_cam && !cam15) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s: bad arguments", who);
+    if (!(std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: std must be >= 0 (rand's Normal::new panics)", who);
+    const int64_t n = n_cam + n_pts;
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_add_drift<T>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam15, n_cam,
+                       reinterpret_cast<typename V4<T>::type *>(pts4), n_pts, origin, strength, angle_strength, std, dx,
+                       dy, dz, stats_norm, seed);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+template <typename T>
+int noise_entities_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts, const double *stats,
+                        double translation_std, double rotation_std, double point_std, uint64_t seed, hipStream_t st) {
+    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s: bad arguments", who);
+    if (!(translation_std >= 0.0) || !(rotation_std >= 0.0) || !(point_std >= 0.0))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise: standard deviations must be >= 0");
+    const int64_t n = n_cam + n_pts;
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_add_noise_entities<T>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam15, n_cam,
+                       reinterpret_cast<typename V4<T>::type *>(pts4), n_pts, stats, translation_std, rotation_std,
+                       point_std, seed);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+template <typename T>
+int sin_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts, const double *stats, double dx, double dy,
+             double dz, double nx, double ny, double nz, double strength, double frequency, hipStream_t st) {
+    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s: bad arguments", who);
+    const int64_t n = n_cam + n_pts;
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_add_sin_noise<T>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam15, n_cam,
+                       reinterpret_cast<typename V4<T>::type *>(pts4), n_pts, stats, dx, dy, dz, nx, ny, nz, strength,
+                       frequency);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -304,20 +366,33 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
 int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, void *workspace,
               double *stats, void *stream) {
     if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: bad arguments");
-    const int64_t n = n_cam + n_pts;
-    if (n == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: empty problem (the reference's fold1().unwrap() panics)");
+    if (n_cam + n_pts == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: empty problem (the reference's fold1().unwrap() panics)");
     if ((n_cam && !camblk) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: NULL input");
-    double *rec = reinterpret_cast<double *>(workspace);
-    int grid = (int)((n + kBlock - 1) / kBlock);
-    if (grid > kRedBlocks) grid = kRedBlocks;
-    const double4 *p4 = reinterpret_cast<const double4 *>(pts4);
-    hipLaunchKernelGGL(k_stats_pass1, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, rec);
+    const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
+    return stats_impl(src, n_cam + n_pts, workspace, stats, S(stream));
+}
+
+int c2b_stats_f32(const float *cam15, int64_t n_cam, const float *pts4, int64_t n_pts, void *workspace,
+                  double *stats, void *stream) {
+    if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_f32: bad arguments");
+    if (n_cam + n_pts == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_f32: empty problem");
+    if ((n_cam && !cam15) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_f32: NULL input");
+    const SrcState32 src{cam15, reinterpret_cast<const float4 *>(pts4), n_cam};
+    return stats_impl(src, n_cam + n_pts, workspace, stats, S(stream));
+}
+
+int c2b_convert_f64_to_f32(const double *src, int64_t n, float *dst, void *stream) {
+    if (n < 0 || (n && (!src || !dst))) return fail(C2B_ERR_INVALID_ARGUMENT, "convert_f64_to_f32: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), src, n, dst);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold1, dim3(1), dim3(kRedBlocks), 0, S(stream), rec, grid, camblk, n_cam, p4, stats);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_pass2, dim3(grid), dim3(kBlock), 0, S(stream), camblk, n_cam, p4, n_pts, stats, rec);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold2, dim3(1), dim3(kRedBlocks), 0, S(stream), rec, grid, n, stats);
+    return C2B_OK;
+}
+
+int c2b_convert_f32_to_f64(const float *src, int64_t n, double *dst, void *stream) {
+    if (n < 0 || (n && (!src || !dst))) return fail(C2B_ERR_INVALID_ARGUMENT, "convert_f32_to_f64: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), src, n, dst);
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -325,45 +400,39 @@ int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n
 int c2b_add_drift(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *origin,
                   double strength, double angle_strength, double std, double dir_x, double dir_y, double dir_z,
                   uint64_t seed, void *stream) {
-    if (n_cam < 0 || n_pts < 0 || !origin || (n_cam && !cam15) || (n_pts && !pts4))
-        return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift: bad arguments");
-    if (!(std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift: std must be >= 0 (rand's Normal::new panics)");
-    const int64_t n = n_cam + n_pts;
-    if (!n) return C2B_OK;
-    hipLaunchKernelGGL(k_add_drift, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
-                       reinterpret_cast<double4 *>(pts4), n_pts, origin, strength, angle_strength, std, dir_x, dir_y,
-                       dir_z, (const double *)nullptr, seed);
-    LAUNCH_CHECK();
-    return C2B_OK;
+    return drift_impl<double>("add_drift", cam15, n_cam, pts4, n_pts, origin, nullptr, strength, angle_strength, std,
+                              dir_x, dir_y, dir_z, seed, S(stream));
 }
-
+int c2b_add_drift_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *origin,
+                      double strength, double angle_strength, double std, double dir_x, double dir_y, double dir_z,
+                      uint64_t seed, void *stream) {
+    return drift_impl<float>("add_drift_f32", cam15, n_cam, pts4, n_pts, origin, nullptr, strength, angle_strength, std,
+                             dir_x, dir_y, dir_z, seed, S(stream));
+}
 int c2b_add_drift_normalized(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats,
                              double strength, double angle_strength, double std, uint64_t seed, void *stream) {
-    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
-        return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized: bad arguments");
-    if (!(std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized: std must be >= 0");
-    const int64_t n = n_cam + n_pts;
-    if (!n) return C2B_OK;
-    hipLaunchKernelGGL(k_add_drift, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
-                       reinterpret_cast<double4 *>(pts4), n_pts, stats + 15, strength, angle_strength, std, 0.0, 0.0,
-                       0.0, stats, seed);
-    LAUNCH_CHECK();
-    return C2B_OK;
+    if (!stats) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized: stats is NULL");
+    return drift_impl<double>("add_drift_normalized", cam15, n_cam, pts4, n_pts, stats + 15, stats, strength,
+                              angle_strength, std, 0.0, 0.0, 0.0, seed, S(stream));
+}
+int c2b_add_drift_normalized_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats,
+                                 double strength, double angle_strength, double std, uint64_t seed, void *stream) {
+    if (!stats) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized_f32: stats is NULL");
+    return drift_impl<float>("add_drift_normalized_f32", cam15, n_cam, pts4, n_pts, stats + 15, stats, strength,
+                             angle_strength, std, 0.0, 0.0, 0.0, seed, S(stream));
 }
 
 int c2b_add_noise_entities(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats,
                            double translation_std, double rotation_std, double point_std, uint64_t seed,
                            void *stream) {
-    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
-        return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_entities: bad arguments");
-    if (!(translation_std >= 0.0) || !(rotation_std >= 0.0) || !(point_std >= 0.0))
-        return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise: standard deviations must be >= 0");
-    const int64_t n = n_cam + n_pts;
-    if (!n) return C2B_OK;
-    hipLaunchKernelGGL(k_add_noise_entities, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
-                       reinterpret_cast<double4 *>(pts4), n_pts, stats, translation_std, rotation_std, point_std, seed);
-    LAUNCH_CHECK();
-    return C2B_OK;
+    return noise_entities_impl<double>("add_noise_entities", cam15, n_cam, pts4, n_pts, stats, translation_std,
+                                       rotation_std, point_std, seed, S(stream));
+}
+int c2b_add_noise_entities_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats,
+                               double translation_std, double rotation_std, double point_std, uint64_t seed,
+                               void *stream) {
+    return noise_entities_impl<float>("add_noise_entities_f32", cam15, n_cam, pts4, n_pts, stats, translation_std,
+                                      rotation_std, point_std, seed, S(stream));
 }
 
 int c2b_add_noise_observations(double *uv, int64_t n_obs, int64_t obs_base, double observations_std, uint64_t seed,
@@ -381,15 +450,14 @@ int c2b_add_noise_observations(double *uv, int64_t n_obs, int64_t obs_base, doub
 int c2b_add_sin_noise(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats, double dir_x,
                       double dir_y, double dir_z, double ndir_x, double ndir_y, double ndir_z, double strength,
                       double frequency, void *stream) {
-    if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
-        return fail(C2B_ERR_INVALID_ARGUMENT, "add_sin_noise: bad arguments");
-    const int64_t n = n_cam + n_pts;
-    if (!n) return C2B_OK;
-    hipLaunchKernelGGL(k_add_sin_noise, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n_cam,
-                       reinterpret_cast<double4 *>(pts4), n_pts, stats, dir_x, dir_y, dir_z, ndir_x, ndir_y, ndir_z,
-                       strength, frequency);
-    LAUNCH_CHECK();
-    return C2B_OK;
+    return sin_impl<double>("add_sin_noise", cam15, n_cam, pts4, n_pts, stats, dir_x, dir_y, dir_z, ndir_x, ndir_y, ndir_z,
+                            strength, frequency, S(stream));
+}
+int c2b_add_sin_noise_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats, double dir_x,
+                          double dir_y, double dir_z, double ndir_x, double ndir_y, double ndir_z, double strength,
+                          double frequency, void *stream) {
+    return sin_impl<float>("add_sin_noise_f32", cam15, n_cam, pts4, n_pts, stats, dir_x, dir_y, dir_z, ndir_x, ndir_y,
+                           ndir_z, strength, frequency, S(stream));
 }
 
 int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, int64_t *bounds) {

@@ -544,16 +544,42 @@ __global__ __launch_bounds__(kSumBlocks) void k_sum_stage2(const double *__restr
 
 // ---- stats over camera centers ++ points ------------------------------------------------------------
 // record: [0..2] sum(x/num) | [3..5] min | [6..8] max | [9] best dist | [10] best index
-C2B_DEV void entity_xyz(const double *__restrict__ camblk, int64_t n_cam, const double4 *__restrict__ pts4,
-                        int64_t i, double &x, double &y, double &z) {
-    if (i < n_cam) {
-        const double *c = camblk + i * kCamBlk + kCenter;
-        x = c[0]; y = c[1]; z = c[2];
-    } else {
-        const double4 p = pts4[i - n_cam];
-        x = p.x; y = p.y; z = p.z;
+//
+// Entity sources.  f64 problems read the camera centre from the derived camblk record; the f32 extension
+// (BASELINE config 5) has no camblk and derives the centre from its f32 state on the fly.  Accumulation is
+// always f64.
+template <typename T> struct V4;
+template <> struct V4<double> { typedef double4 type; };
+template <> struct V4<float> { typedef float4 type; };
+
+struct SrcBlk {                                  // f64: camblk centres + pts4
+    const double *camblk; const double4 *pts; int64_t n_cam;
+    C2B_DEV void get(int64_t i, double &x, double &y, double &z) const {
+        if (i < n_cam) {
+            const double *c = camblk + i * kCamBlk + kCenter;
+            x = c[0]; y = c[1]; z = c[2];
+        } else {
+            const double4 p = pts[i - n_cam];
+            x = p.x; y = p.y; z = p.z;
+        }
     }
-}
+};
+struct SrcState32 {                              // f32: cam15 (float) + pts4 (float)
+    const float *cam15; const float4 *pts; int64_t n_cam;
+    C2B_DEV void get(int64_t i, double &x, double &y, double &z) const {
+        if (i < n_cam) {
+            const float *c = cam15 + 15 * i;
+            float m[9], ctr[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m[k] = c[k];
+            cm_center(m, c[9], c[10], c[11], ctr);
+            x = ctr[0]; y = ctr[1]; z = ctr[2];
+        } else {
+            const float4 p = pts[i - n_cam];
+            x = p.x; y = p.y; z = p.z;
+        }
+    }
+};
 
 // closest to origin with fold1's semantics (src/noise.rs:80-86): strict <, ties -> later index.
 // Only (distance, index) travel through the reduction; the winner's coordinates are re-read by
@@ -568,18 +594,16 @@ C2B_DEV Best best_merge(Best a, Best b) {
     return r;
 }
 
-__global__ __launch_bounds__(kBlock) void k_stats_pass1(const double *__restrict__ camblk, int64_t n_cam,
-                                                       const double4 *__restrict__ pts4, int64_t n_pts,
-                                                       double *__restrict__ rec) {
+template <typename Src>
+__global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, double *__restrict__ rec) {
     __shared__ double sh[kWaves][kStatRec];
-    const int64_t n = n_cam + n_pts;
     const double num = (double)n;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double s0 = 0, s1 = 0, s2 = 0, mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
     Best best = {0.0, -1.0};
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         double x, y, z;
-        entity_xyz(camblk, n_cam, pts4, i, x, y, z);
+        src.get(i, x, y, z);
         s0 += x / num; s1 += y / num; s2 += z / num;
         mn0 = fmin(mn0, x); mn1 = fmin(mn1, y); mn2 = fmin(mn2, z);
         mx0 = fmax(mx0, x); mx1 = fmax(mx1, y); mx2 = fmax(mx2, z);
@@ -627,9 +651,8 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(const double *__restrict
 // one 1024-lane workgroup (record t on lane t; kRedBlocks <= 1024): fold the per-workgroup records ->
 // stats[0..2]=mean, [6..8]=min, [9..11]=max, [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin index.
 // Fixed shuffle / LDS order => deterministic.
-__global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__restrict__ rec, int n_rec,
-                                                          const double *__restrict__ camblk, int64_t n_cam,
-                                                          const double4 *__restrict__ pts4,
+template <typename Src>
+__global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__restrict__ rec, int n_rec, Src src,
                                                           double *__restrict__ stats) {
     __shared__ double sh[kRedBlocks / 64][12];
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
@@ -664,7 +687,7 @@ __global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__rest
         b = best_merge(b, o);
     }
     double x = 0, y = 0, z = 0;
-    if (b.i >= 0.0) entity_xyz(camblk, n_cam, pts4, (int64_t)b.i, x, y, z);
+    if (b.i >= 0.0) src.get((int64_t)b.i, x, y, z);
     for (int k = 0; k < 3; ++k) {
         stats[k] = t[k];
         stats[6 + k] = t[3 + k];
@@ -675,16 +698,15 @@ __global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__rest
     stats[18] = b.i;
 }
 
-__global__ __launch_bounds__(kBlock) void k_stats_pass2(const double *__restrict__ camblk, int64_t n_cam,
-                                                       const double4 *__restrict__ pts4, int64_t n_pts,
-                                                       const double *__restrict__ stats, double *__restrict__ rec) {
+template <typename Src>
+__global__ __launch_bounds__(kBlock) void k_stats_pass2(Src src, int64_t n, const double *__restrict__ stats,
+                                                       double *__restrict__ rec) {
     __shared__ double sh[kWaves][3];
-    const int64_t n = n_cam + n_pts;
     const double m0 = stats[0], m1 = stats[1], m2 = stats[2];
     double s0 = 0, s1 = 0, s2 = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         double x, y, z;
-        entity_xyz(camblk, n_cam, pts4, i, x, y, z);
+        src.get(i, x, y, z);
         s0 += (x - m0) * (x - m0); s1 += (y - m1) * (y - m1); s2 += (z - m2) * (z - m2);
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -718,12 +740,16 @@ __global__ __launch_bounds__(kRedBlocks) void k_stats_fold2(const double *__rest
 }
 
 // ---- noise kernels -------------------------------------------------------------------------------------
+// Templated on the state scalar T (double = the parity path; float = config-5 extension).  Draws are always
+// the f64 Philox/Box-Muller normals, rounded to T, so the f32 results track the f64 ones to f32 accuracy.
+
 // add_drift, src/noise.rs:68-116.  One lane per entity (cameras first, then points).
-__global__ __launch_bounds__(kBlock) void k_add_drift(double *__restrict__ cam15, int64_t n_cam,
-                                                     double4 *__restrict__ pts4, int64_t n_pts,
-                                                     const double *__restrict__ origin, double strength,
-                                                     double angle_strength, double std, double dx, double dy,
-                                                     double dz, const double *__restrict__ stats_norm,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_add_drift(T *__restrict__ cam15, int64_t n_cam,
+                                                     typename V4<T>::type *__restrict__ pts4, int64_t n_pts,
+                                                     const double *__restrict__ origin, double strength_d,
+                                                     double angle_strength_d, double std_d, double dx_d, double dy_d,
+                                                     double dz_d, const double *__restrict__ stats_norm,
                                                      uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
@@ -732,23 +758,25 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(double *__restrict__ cam15
         const double s0 = stats_norm[3], s1 = stats_norm[4], s2 = stats_norm[5];
         const double mag = sqrt(dot3(s0, s1, s2, s0, s1, s2));
         const double inv = 1.0 / mag;
-        dx = s0 * inv; dy = s1 * inv; dz = s2 * inv;
-        strength = strength * mag;
+        dx_d = s0 * inv; dy_d = s1 * inv; dz_d = s2 * inv;
+        strength_d = strength_d * mag;
     }
-    const double ox = origin[0], oy = origin[1], oz = origin[2];
+    const T dx = (T)dx_d, dy = (T)dy_d, dz = (T)dz_d, strength = (T)strength_d, angle_strength = (T)angle_strength_d;
+    const T ox = (T)origin[0], oy = (T)origin[1], oz = (T)origin[2];
     if (i < n_cam) {
-        double c[15], ctr[3], z0, z1, dR[9];
+        T c[15], ctr[3], dR[9];
+        double z0, z1;
 #pragma unroll
         for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
         cm_center(c, c[9], c[10], c[11], ctr);
-        const double ex = ctr[0] - ox, ey = ctr[1] - oy, ez = ctr[2] - oz;
-        const double distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+        const T ex = ctr[0] - ox, ey = ctr[1] - oy, ez = ctr[2] - oz;
+        const T distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
         normal_pair(seed, kStreamDriftCam, (uint64_t)i, 0, z0, z1);
-        const double va = 1.0 + std * z0;             // angle draw first (src/noise.rs:104-107)
-        const double vt = 1.0 + std * z1;
-        const double angle = angle_strength * va * pow(distance, 1.2);
-        double sn, cs;
-        sincos(angle, &sn, &cs);
+        const T va = (T)(1.0 + std_d * z0);             // angle draw first (src/noise.rs:104-107)
+        const T vt = (T)(1.0 + std_d * z1);
+        const T angle = angle_strength * va * pow(distance, (T)1.2);
+        T sn, cs;
+        sincos_t(angle, &sn, &cs);
         dR[0] = 1; dR[1] = 0; dR[2] = 0; dR[3] = 0; dR[4] = cs; dR[5] = sn; dR[6] = 0; dR[7] = -sn; dR[8] = cs;
         transform_cam15(c, dR, dx * strength * vt * distance * distance,
                         dy * strength * vt * distance * distance, dz * strength * vt * distance * distance);
@@ -756,12 +784,12 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(double *__restrict__ cam15
         for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
     } else {
         const int64_t j = i - n_cam;
-        double4 p = pts4[j];
-        const double ex = p.x - ox, ey = p.y - oy, ez = p.z - oz;
-        const double distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+        typename V4<T>::type p = pts4[j];
+        const T ex = p.x - ox, ey = p.y - oy, ez = p.z - oz;
+        const T distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
         double z0, z1;
         normal_pair(seed, kStreamDriftPt, (uint64_t)j, 0, z0, z1);
-        const double v = 1.0 + std * z0;
+        const T v = (T)(1.0 + std_d * z0);
         p.x = p.x + dx * strength * v * distance * distance;
         p.y = p.y + dy * strength * v * distance * distance;
         p.z = p.z + dz * strength * v * distance * distance;
@@ -770,28 +798,31 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(double *__restrict__ cam15
 }
 
 // add_noise cameras + points, src/noise.rs:129-150
-__global__ __launch_bounds__(kBlock) void k_add_noise_entities(double *__restrict__ cam15, int64_t n_cam,
-                                                              double4 *__restrict__ pts4, int64_t n_pts,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ cam15, int64_t n_cam,
+                                                              typename V4<T>::type *__restrict__ pts4, int64_t n_pts,
                                                               const double *__restrict__ stats,
                                                               double translation_std, double rotation_std,
                                                               double point_std, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
     if (i < n_cam) {
-        const double bal_std = stats[19];
-        double c[15], a0, a1, a2, rot, b0, b1, b2, tr, dR[9];
+        const T bal_std = (T)stats[19];
+        T c[15], dR[9];
+        double a0, a1, a2, rot, b0, b1, b2, tr;
 #pragma unroll
         for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
         normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 0, a0, a1);
         normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 1, a2, rot);
         normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 2, b0, b1);
         normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 3, b2, tr);
-        const double ia = 1.0 / sqrt(dot3(a0, a1, a2, a0, a1, a2));
-        const double ib = 1.0 / sqrt(dot3(b0, b1, b2, b0, b1, b2));
-        const double ang = 0.0 + rotation_std * rot;
-        const double t = 0.0 + translation_std * tr;
-        cm_from_axis_angle(a0 * ia, a1 * ia, a2 * ia, ang, dR);
-        transform_cam15(c, dR, (b0 * ib) * bal_std * t, (b1 * ib) * bal_std * t, (b2 * ib) * bal_std * t);
+        const T A0 = (T)a0, A1 = (T)a1, A2 = (T)a2, B0 = (T)b0, B1 = (T)b1, B2 = (T)b2;
+        const T ia = (T)1.0 / sqrt(dot3(A0, A1, A2, A0, A1, A2));
+        const T ib = (T)1.0 / sqrt(dot3(B0, B1, B2, B0, B1, B2));
+        const T ang = (T)(0.0 + rotation_std * rot);
+        const T t = (T)(0.0 + translation_std * tr);
+        cm_from_axis_angle(A0 * ia, A1 * ia, A2 * ia, ang, dR);
+        transform_cam15(c, dR, (B0 * ib) * bal_std * t, (B1 * ib) * bal_std * t, (B2 * ib) * bal_std * t);
 #pragma unroll
         for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
     } else {
@@ -799,10 +830,11 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(double *__restric
         double a0, a1, a2, m;
         normal_pair(seed, kStreamNoisePt, (uint64_t)j, 0, a0, a1);
         normal_pair(seed, kStreamNoisePt, (uint64_t)j, 1, a2, m);
-        const double ia = 1.0 / sqrt(dot3(a0, a1, a2, a0, a1, a2));
-        const double mm = 0.0 + point_std * m;
-        double4 p = pts4[j];
-        p.x = p.x + (a0 * ia) * mm; p.y = p.y + (a1 * ia) * mm; p.z = p.z + (a2 * ia) * mm;
+        const T A0 = (T)a0, A1 = (T)a1, A2 = (T)a2;
+        const T ia = (T)1.0 / sqrt(dot3(A0, A1, A2, A0, A1, A2));
+        const T mm = (T)(0.0 + point_std * m);
+        typename V4<T>::type p = pts4[j];
+        p.x = p.x + (A0 * ia) * mm; p.y = p.y + (A1 * ia) * mm; p.z = p.z + (A2 * ia) * mm;
         pts4[j] = p;
     }
 }
@@ -825,36 +857,50 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_observations(double2 *__re
 }
 
 // add_sin_noise, src/noise.rs:388-416
-__global__ __launch_bounds__(kBlock) void k_add_sin_noise(double *__restrict__ cam15, int64_t n_cam,
-                                                         double4 *__restrict__ pts4, int64_t n_pts,
-                                                         const double *__restrict__ stats, double dx, double dy,
-                                                         double dz, double nx, double ny, double nz,
-                                                         double strength, double frequency) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_add_sin_noise(T *__restrict__ cam15, int64_t n_cam,
+                                                         typename V4<T>::type *__restrict__ pts4, int64_t n_pts,
+                                                         const double *__restrict__ stats, double dx_d, double dy_d,
+                                                         double dz_d, double nx_d, double ny_d, double nz_d,
+                                                         double strength_d, double frequency_d) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
-    double d0 = stats[12], d1 = stats[13], d2 = stats[14];
-    if (d0 == 0.0) d0 = 1e-8;
-    if (d1 == 0.0) d1 = 1e-8;
-    if (d2 == 0.0) d2 = 1e-8;
-    const double inv = 1.0 / sqrt(dot3(nx, ny, nz, nx, ny, nz));
+    double e0 = stats[12], e1 = stats[13], e2 = stats[14];
+    if (e0 == 0.0) e0 = 1e-8;
+    if (e1 == 0.0) e1 = 1e-8;
+    if (e2 == 0.0) e2 = 1e-8;
+    const T d0 = (T)e0, d1 = (T)e1, d2 = (T)e2;
+    T nx = (T)nx_d, ny = (T)ny_d, nz = (T)nz_d;
+    const T dx = (T)dx_d, dy = (T)dy_d, dz = (T)dz_d, strength = (T)strength_d, frequency = (T)frequency_d;
+    const T inv = (T)1.0 / sqrt(dot3(nx, ny, nz, nx, ny, nz));
     nx *= inv; ny *= inv; nz *= inv;
     if (i < n_cam) {
-        double c[15], ctr[3];
+        T c[15], ctr[3];
 #pragma unroll
         for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
         cm_center(c, c[9], c[10], c[11], ctr);
-        const double s = sin(dot3(ctr[0] / d0, ctr[1] / d1, ctr[2] / d2, dx, dy, dz) * frequency * kPi) * strength;
-        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const T s = sin(dot3(ctr[0] / d0, ctr[1] / d1, ctr[2] / d2, dx, dy, dz) * frequency * (T)kPi) * strength;
+        const T I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         transform_cam15(c, I, nx * s, ny * s, nz * s);
 #pragma unroll
         for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
     } else {
         const int64_t j = i - n_cam;
-        double4 p = pts4[j];
-        const double s = sin(dot3(p.x / d0, p.y / d1, p.z / d2, dx, dy, dz) * frequency * kPi) * strength;
+        typename V4<T>::type p = pts4[j];
+        const T s = sin(dot3(p.x / d0, p.y / d1, p.z / d2, dx, dy, dz) * frequency * (T)kPi) * strength;
         p.x = p.x + nx * s; p.y = p.y + ny * s; p.z = p.z + nz * s;
         pts4[j] = p;
     }
+}
+
+// f64 <-> f32 state conversion for the config-5 extension (element-wise, n scalars)
+__global__ void k_f64_to_f32(const double *__restrict__ a, int64_t n, float *__restrict__ b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (float)a[i];
+}
+__global__ void k_f32_to_f64(const float *__restrict__ a, int64_t n, double *__restrict__ b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (double)a[i];
 }
 
 }  // namespace c2b

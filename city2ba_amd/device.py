@@ -132,3 +132,50 @@ def add_noise_entities(cam15, pts4, stats_, translation_std, rotation_std, point
 def add_noise_observations(uv, obs_base, observations_std, seed):
     L.check(L.lib().c2b_add_noise_observations(_p(uv), uv.shape[0], int(obs_base), float(observations_std),
                                                int(seed), _stream()))
+
+
+# ---- f32 extension (BASELINE configs[4]): the same entity kernels over a float state ---------------------
+def to_f32(t):
+    _chk(t, torch.float64, "to_f32 input")
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    L.check(L.lib().c2b_convert_f64_to_f32(_p(t), t.numel(), _p(out), _stream()))
+    return out
+
+
+def to_f64(t):
+    _chk(t, torch.float32, "to_f64 input")
+    out = torch.empty(t.shape, dtype=torch.float64, device=t.device)
+    L.check(L.lib().c2b_convert_f32_to_f64(_p(t), t.numel(), _p(out), _stream()))
+    return out
+
+
+def stats_f32(cam15_f32, pts4_f32, ws, out=None):
+    out = out if out is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=cam15_f32.device)
+    L.check(L.lib().c2b_stats_f32(_p(cam15_f32), cam15_f32.shape[0], _p(pts4_f32), pts4_f32.shape[0], _p(ws), _p(out),
+                                  _stream()))
+    return out
+
+
+def add_drift_f32(cam15, pts4, stats_, strength, angle_strength, std, dir_, seed):
+    L.check(L.lib().c2b_add_drift_f32(_p(cam15), cam15.shape[0], _p(pts4), pts4.shape[0],
+                                      C.c_void_p(stats_.data_ptr() + 15 * 8), float(strength), float(angle_strength),
+                                      float(std), float(dir_[0]), float(dir_[1]), float(dir_[2]), int(seed), _stream()))
+
+
+def add_drift_normalized_f32(cam15, pts4, stats_, strength, angle_strength, std, seed):
+    L.check(L.lib().c2b_add_drift_normalized_f32(_p(cam15), cam15.shape[0], _p(pts4), pts4.shape[0], _p(stats_),
+                                                 float(strength), float(angle_strength), float(std), int(seed),
+                                                 _stream()))
+
+
+def add_noise_entities_f32(cam15, pts4, stats_, translation_std, rotation_std, point_std, seed):
+    L.check(L.lib().c2b_add_noise_entities_f32(_p(cam15), cam15.shape[0], _p(pts4), pts4.shape[0], _p(stats_),
+                                               float(translation_std), float(rotation_std), float(point_std),
+                                               int(seed), _stream()))
+
+
+def add_sin_noise_f32(cam15, pts4, stats_, dir_, noise_dir, strength, frequency):
+    L.check(L.lib().c2b_add_sin_noise_f32(_p(cam15), cam15.shape[0], _p(pts4), pts4.shape[0], _p(stats_),
+                                          float(dir_[0]), float(dir_[1]), float(dir_[2]), float(noise_dir[0]),
+                                          float(noise_dir[1]), float(noise_dir[2]), float(strength), float(frequency),
+                                          _stream()))

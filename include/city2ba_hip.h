@@ -148,6 +148,26 @@ int c2b_add_sin_noise(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts,
                       double ndir_x, double ndir_y, double ndir_z, double strength,
                       double frequency, void *stream);
 
+/* ---- f32 extension (BASELINE.json configs[4]).  The reference has NO f32 compute path:
+ * these run the same kernels over a float state -- cam15 / pts4 stored as float -- with the draws and
+ * the statistics kept in f64; results track the f64 path to f32 accuracy (tested at an f32 tolerance). */
+int c2b_convert_f64_to_f32(const double *src, int64_t n, float *dst, void *stream);
+int c2b_convert_f32_to_f64(const float *src, int64_t n, double *dst, void *stream);
+int c2b_stats_f32(const float *cam15, int64_t n_cam, const float *pts4, int64_t n_pts, void *workspace,
+                  double *stats, void *stream);
+int c2b_add_drift_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *origin,
+                      double strength, double angle_strength, double std, double dir_x, double dir_y,
+                      double dir_z, uint64_t seed, void *stream);
+int c2b_add_drift_normalized_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts,
+                                 const double *stats, double strength, double angle_strength,
+                                 double std, uint64_t seed, void *stream);
+int c2b_add_noise_entities_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts,
+                               const double *stats, double translation_std, double rotation_std,
+                               double point_std, uint64_t seed, void *stream);
+int c2b_add_sin_noise_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats,
+                          double dir_x, double dir_y, double dir_z, double ndir_x, double ndir_y,
+                          double ndir_z, double strength, double frequency, void *stream);
+
 /* contiguous camera ranges with ~equal observation counts (host pointers): the multi-GPU
  * shard map.  bounds[n_parts+1]; part k owns cameras [bounds[k], bounds[k+1]). */
 int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, int64_t *bounds);
