@@ -182,11 +182,19 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs (tools/rehearse_multirank.sh): on a 1-GPU box the N-rank code path can be exercised with
+    # every rank on GPU 0 and gloo for the two tiny collectives.  Never set by the driver: real runs are one
+    # rank per GPU over nccl (= RCCL over xGMI).
+    backend = os.environ.get("C2B_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("C2B_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     sh = build_shard(args, rank, world, dev)
     n = sh["n_obs"]
@@ -221,7 +229,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_err = Dist.finish_error(err.item(), 2.0)

@@ -62,7 +62,13 @@ def all_reduce_sum_(t, group=None):
     """In-place sum all-reduce of a (1-element) tensor; a no-op for a single process."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.is_cuda and dist.get_backend(group) != "nccl":
+            # gloo (single-GPU rehearsal of the multi-rank path): stage the scalar through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 

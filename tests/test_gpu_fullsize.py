@@ -1,0 +1,75 @@
+"""Full-size properties at BASELINE.json's headline configuration (synthetic --blocks 128: 19.3 M observations,
+2.8 GB of camera Jacobian -- byte offsets beyond 2^31), where the oracle is too slow to run over everything:
+  * tiling independence: the first / last 200k observations computed alone equal the same rows of the full launch;
+  * r == project - uv (bit-exact) on every observation, via the separate projection kernel;
+  * fused error partials == the stand-alone error kernel == sum of r^2 (to rounding);
+  * the oracle on a 20k-observation window in the middle of the problem."""
+import argparse
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_blocks128_properties():
+    import __graft_entry__ as entry
+    entry.build()
+    import torch
+    import bench
+    from city2ba_amd import device as D
+    dev = torch.device("cuda", 0)
+    sh = bench.build_shard(argparse.Namespace(blocks=128), 0, 1, dev)
+    n = sh["n_obs"]
+    assert n > 19_000_000 and n * 144 > 2 ** 31
+    camblk, pts4, ci, pi, uv = sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"]
+    r = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    Jc = torch.full((n, 18), float("nan"), dtype=torch.float64, device=dev)
+    Jp = torch.full((n, 6), float("nan"), dtype=torch.float64, device=dev)
+    ws = D.workspace(n, dev)
+    e_fused = torch.zeros(1, dtype=torch.float64, device=dev)
+    D.residual_jacobian(camblk, pts4, ci, pi, uv, r, Jc, Jp, 2.0, ws)
+    D.error_sum_finish(ws, n, e_fused)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(Jc).all()) and bool(torch.isfinite(Jp).all())      # every row written, incl. the tail
+
+    # r == project - uv, bit-exact, everywhere
+    proj = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    D.project(camblk, pts4, ci, pi, proj)
+    assert torch.equal(r, proj - uv)
+
+    # error: fused partials == stand-alone kernel; both == sum r^2 up to summation order
+    e_alone = torch.zeros(1, dtype=torch.float64, device=dev)
+    D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, e_alone)
+    torch.cuda.synchronize()
+    assert e_fused.item() == e_alone.item()
+    assert abs(e_fused.item() - float((r * r).sum().item())) / e_fused.item() < 1e-11
+
+    # tiling independence at both ends (different tile origin => different wave / XCD assignment)
+    for lo, hi in ((0, 200_000), (n - 200_003, n)):
+        m = hi - lo
+        r2 = torch.empty((m, 2), dtype=torch.float64, device=dev)
+        Jc2 = torch.empty((m, 18), dtype=torch.float64, device=dev)
+        Jp2 = torch.empty((m, 6), dtype=torch.float64, device=dev)
+        D.residual_jacobian(camblk, pts4, ci[lo:hi].contiguous(), pi[lo:hi].contiguous(), uv[lo:hi].contiguous(),
+                            r2, Jc2, Jp2, 2.0, None)
+        torch.cuda.synchronize()
+        assert torch.equal(r2, r[lo:hi]) and torch.equal(Jc2, Jc[lo:hi]) and torch.equal(Jp2, Jp[lo:hi])
+
+    # the oracle on a window in the middle
+    lo = n // 2
+    hi = lo + 20_000
+    cams15 = sh["cam15"].cpu().numpy()
+    pts = sh["pts_host"]
+    ci_h = ci[lo:hi].cpu().numpy().astype(np.int64)
+    c0, c1 = int(ci_h[0]), int(ci_h[-1]) + 1
+    counts = np.bincount(ci_h - c0, minlength=c1 - c0)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    r0, Jc0, Jp0 = O.residual_jacobian(cams15[c0:c1], pts, row_ptr, pi[lo:hi].cpu().numpy().astype(np.uint64),
+                                       uv[lo:hi].cpu().numpy())
+    assert np.max(np.abs(r[lo:hi].cpu().numpy() - r0)) < 1e-12
+    scale = max(1.0, float(np.max(np.abs(Jc0))))
+    assert np.max(np.abs(Jc[lo:hi].cpu().numpy() - Jc0)) / scale < 1e-10
+    assert np.max(np.abs(Jp[lo:hi].cpu().numpy() - Jp0)) / scale < 1e-10
