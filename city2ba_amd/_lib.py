@@ -109,6 +109,29 @@ class City2baError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  libcity2ba_hip.so links ROCm's; with
+    both loaded a process holds two HIP runtimes and whichever initialises second can fail ("no ROCm-capable
+    device", "No HIP GPUs are available") depending on import order.  When torch is installed its runtime is
+    therefore opened first, globally, so that this library binds to the same copy torch will use.  Hosts without
+    torch (the Rust binding) simply get ROCm's runtime."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -116,6 +139,7 @@ def lib():
             raise ImportError(
                 "city2ba_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)          # AttributeError here = header/library mismatch

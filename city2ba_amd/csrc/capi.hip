@@ -41,7 +41,12 @@ int fail(int code, const char *fmt, ...) {
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
-inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// Every launch passes its stream through S(): clearing the thread's sticky error there means the
+// hipGetLastError() after the launch reports THIS launch, not a stale error left by another library.
+inline hipStream_t S(void *s) {
+    (void)hipGetLastError();
+    return reinterpret_cast<hipStream_t>(s);
+}
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)((n + b - 1) / b); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
