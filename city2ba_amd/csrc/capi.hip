@@ -57,7 +57,7 @@ constexpr int64_t kWsPartials = kWsStatsDoubles + kSumBlocks;
 
 // residual+Jacobian kernel variant (tuning knob, not part of the ABI): 0 = workgroup-tiled kernel,
 // 1.. = wave-centric kernel <WPB, SPLIT, NT> (see launch_jacobian)
-int g_jac_variant = 9;
+int g_jac_variant = 13;
 
 int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) {
     double *ws = reinterpret_cast<double *>(workspace);
@@ -73,13 +73,13 @@ int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) 
     return C2B_OK;
 }
 
-template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0>
+template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1>
 void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                          const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                          double *partials, hipStream_t st) {
     const int64_t wave_tiles = (n_obs + 63) / 64;
-    const int64_t btiles = (wave_tiles + WPB - 1) / WPB;
-    hipLaunchKernelGGL((k_residual_jacobian_w<WITH_ERR, WPB, SPLIT, NT, ABL>), dim3((unsigned)btiles), dim3(WPB * 64), 0, st,
+    const int64_t btiles = (wave_tiles + WPB * OPL - 1) / (WPB * OPL);
+    hipLaunchKernelGGL((k_residual_jacobian_w<WITH_ERR, WPB, SPLIT, NT, ABL, OPL>), dim3((unsigned)btiles), dim3(WPB * 64), 0, st,
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
                        reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r),
                        Jc, Jp, partials);
@@ -91,19 +91,21 @@ void launch_jacobian(int variant, const double *camblk, const double *pts4, cons
                             double *Jp, double norm, double *partials, hipStream_t st) {
 #define C2B_W(WPB, SPLIT, NT) launch_jac_w<WITH_ERR, WPB, SPLIT, NT>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st)
     switch (variant) {
-        case 1: C2B_W(4, 2, false); break;
-        case 2: C2B_W(4, 2, true); break;
-        case 3: C2B_W(4, 1, false); break;
-        case 4: C2B_W(1, 2, false); break;
-        case 5: C2B_W(1, 2, true); break;
-        case 6: C2B_W(2, 2, true); break;
-        case 7: C2B_W(4, 1, true); break;
-        case 8: C2B_W(1, 1, true); break;
+        case 2: C2B_W(4, 2, true); break;                    // 256-thread workgroups, one tile per wave
+        case 9: C2B_W(8, 2, true); break;                    // 512-thread
+        case 10: C2B_W(16, 2, true); break;                  // 1024-thread
+        case 11: launch_jac_w<WITH_ERR, 16, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
         default:
-        case 9: C2B_W(8, 2, true); break;
-        case 10: C2B_W(16, 2, true); break;
-        case 20: launch_jac_w<WITH_ERR, 4, 2, true, 1>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
-        case 21: launch_jac_w<WITH_ERR, 4, 2, true, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+        case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // shipped
+        case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no Jacobian stores
+        case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no arithmetic
+        case 30: case 31: case 32: {      // store-pattern-only timing builds
+            const int64_t wt = (n_obs + 63) / 64;
+            if (variant == 30) { const int64_t bt = (wt + 7) / 8; hipLaunchKernelGGL((k_store_pattern<true, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
+            if (variant == 31) { const int64_t bt = (wt + 7) / 8; hipLaunchKernelGGL((k_store_pattern<false, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
+            if (variant == 32) { const int64_t bt = (wt + 3) / 4; hipLaunchKernelGGL((k_store_pattern<true, 4>), dim3((unsigned)bt), dim3(256), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
+            break;
+        }
         case 0: {
             const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
             hipLaunchKernelGGL(k_residual_jacobian<WITH_ERR>, dim3((unsigned)tiles), dim3(kBlock), 0, st, camblk,

@@ -363,11 +363,12 @@ __global__ __launch_bounds__(kBlock) void k_residual_jacobian(
 }
 
 // ---- residual + Jacobian, wave-centric form -------------------------------------------------------
-// Every wave owns 64 consecutive observations and never synchronises with another wave: it stages
-// the (typically 3-4) cameras its observations touch in a wave-private LDS tile, transposes its
-// Jacobian blocks through a wave-private slab (optionally in two half-wave rounds to halve the slab)
-// and leaves one error partial.  No workgroup barrier => the memory round trips of one wave overlap
-// the arithmetic of its neighbours, and LDS per wave drops from 12 KB to 6.9 KB (20 waves per CU).
+// Every wave owns OPL consecutive tiles of 64 observations and never synchronises with another wave: it
+// stages the (typically 3-7) cameras its observations touch in a wave-private LDS tile, transposes its
+// Jacobian blocks through a wave-private slab (in SPLIT rounds to shrink the slab) and leaves one error
+// partial per tile.  With OPL = 2 each lane carries two observations: both tiles' index / uv loads, then
+// both point gathers, are issued up front, so the second tile's memory latency hides behind the first
+// tile's arithmetic and stores (the index -> gather chain is two dependent round trips per tile otherwise).
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 template <bool NT>
@@ -380,34 +381,10 @@ C2B_DEV void store16(char *dst, const double2 v) {
     }
 }
 
-template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0>   // ABL: timing-only ablations (tools/)
-__global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
-    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
-    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
-    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm,
-    double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
-    double *__restrict__ partials) {
-    constexpr int kSlab = 64 * 144 / SPLIT;
-    constexpr int kCamBytes = kCamW * kCamHot * 8;
-    __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wt = xcd_tile(blockIdx.x, n_btiles) * WPB + wave;     // this wave's 64-observation tile
-    const int64_t wave0 = wt * 64;
-    if (wave0 >= n) return;                                              // wave-uniform
-    const int64_t o = wave0 + lane;
-    const bool valid = o < n;
-    const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
-
-    uint32_t ci = 0, pi = 0;
-    double2 ob = make_double2(0, 0);
-    if (valid) { ci = cam_idx[o]; pi = pt_idx[o]; ob = uv_obs[o]; }
-    double4 X = make_double4(0, 0, -1, 0);
-    if (valid) X = pts4[pi];
-
-    // wave-private camera tile
-    double *sCam = reinterpret_cast<double *>(smem + wave * (kSlab + kCamBytes) + kSlab);
-    const double *cam = wave_camera<kCamHot>(camblk, ci, valid, n_wave, lane, sCam);
+// one observation: projection (reference order) + the 2x9 / 2x3 blocks (explicit FMAs)
+template <int ABL>
+C2B_DEV void jacobian_obs(const double *cam, const double4 X, const double2 ob, double &r0, double &r1,
+                          double jc[18], double jp[6]) {
     Proj p;
     if (ABL == 2) {        // memory-only build: keep every load live, skip the arithmetic
         p.qx = X.x + cam[0]; p.qy = X.y + cam[9]; p.qz = X.z + cam[12]; p.px = cam[15]; p.py = cam[23];
@@ -415,24 +392,24 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
     } else {
         p = project_obs(cam, X.x, X.y, X.z);
     }
-    const double r0 = p.u - ob.x, r1 = p.v - ob.y;
-
+    r0 = p.u - ob.x; r1 = p.v - ob.y;
     const double f = cam[12], k1 = cam[13], k2 = cam[14];
+    // -1/z by v_rcp_f64 + two Newton steps (~full precision, cheaper than an IEEE divide)
     double iz = ABL == 2 ? p.qz : __builtin_amdgcn_rcp(p.qz);
     iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
     iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
-    const double s = -f * iz;
-    const double c = fma(4.0 * k2, p.n, 2.0 * k1);
+    const double s = -f * iz;                                   // f * (-1/z)
+    const double c = fma(4.0 * k2, p.n, 2.0 * k1);              // 2 * d rad / d n
     const double cpx = c * p.px;
     const double B00 = fma(cpx, p.px, p.rad), B01 = cpx * p.py, B11 = fma(c * p.py, p.py, p.rad);
     const double g = fma(c, p.n, p.rad);
     const double a00 = s * B00, a01 = s * B01, a02 = s * p.px * g;
     const double a10 = s * B01, a11 = s * B11, a12 = s * p.py * g;
+    // y = R X (= q - t);  v_i = y x a_i;  Jw_i = v_i^T J_l
     const double yx = p.qx - cam[9], yy = p.qy - cam[10], yz = p.qz - cam[11];
     const double v0x = fma(yy, a02, -yz * a01), v0y = fma(yz, a00, -yx * a02), v0z = fma(yx, a01, -yy * a00);
     const double v1x = fma(yy, a12, -yz * a11), v1y = fma(yz, a10, -yx * a12), v1z = fma(yx, a11, -yy * a10);
     const double *Jl = cam + kJl;
-    double jc[18], jp[6];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         jc[j] = fma(v0z, Jl[6 + j], fma(v0y, Jl[3 + j], v0x * Jl[j]));
@@ -452,61 +429,132 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
 #pragma unroll
         for (int k = 0; k < 6; ++k) jp[k] = p.qy + k;
     }
+}
 
-    if (valid) store16<NT>(reinterpret_cast<char *>(r_out + o), make_double2(r0, r1));
-    if (ABL == 1) {        // load+compute-only build: fold the Jacobian into one value, no slab / no stores
-        double acc = 0.0;
+template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1>   // ABL: timing-only ablations (tools/)
+__global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
+    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
+    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
+    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm,
+    double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
+    double *__restrict__ partials) {
+    constexpr int kSlab = 64 * 144 / SPLIT;
+    constexpr int kCamBytes = kCamW * kCamHot * 8;
+    __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * WPB + wave) * OPL;   // this wave's first 64-observation tile
+    const int64_t base = wt0 * 64;
+    if (base >= n) return;                                                     // wave-uniform
+
+    // ---- all loads of all OPL tiles up front: indices + uv, then the dependent point gathers ----
+    uint32_t ci[OPL], pi[OPL];
+    double2 ob[OPL];
+    double4 X[OPL];
+    bool valid[OPL];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) acc += jc[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc += jp[k];
-        if (acc == 1.2345e300) Jc[o] = acc;
-        return;
+    for (int t = 0; t < OPL; ++t) {
+        const int64_t o = base + t * 64 + lane;
+        valid[t] = o < n;
+        ci[t] = 0; pi[t] = 0; ob[t] = make_double2(0, 0);
+        if (valid[t]) { ci[t] = cam_idx[o]; pi[t] = pt_idx[o]; ob[t] = uv_obs[o]; }
     }
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) {
+        X[t] = make_double4(0, 0, -1, 0);
+        if (valid[t]) X[t] = pts4[pi[t]];
+    }
+
+    // ---- wave-private camera tile covering every tile of this wave ----
+    double *sCam = reinterpret_cast<double *>(smem + wave * (kSlab + kCamBytes) + kSlab);
+    const int64_t n_here = n - base < 64 * OPL ? n - base : 64 * OPL;          // valid observations of this wave
+    const int last_t = (int)((n_here - 1) >> 6), last_l = (int)((n_here - 1) & 63);
+    uint32_t ci_last = ci[0];
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) if (t == last_t) ci_last = ci[t];
+    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
+    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci_last, last_l, 64));
+    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
+    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
+    for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
+        const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
+        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+        *reinterpret_cast<double2 *>(sCam + k * kCamHot + 2 * j) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     char *slab = smem + wave * (kSlab + kCamBytes);
     constexpr int kHalf = 64 / SPLIT;                 // lanes per transposition round
 #pragma unroll
-    for (int h = 0; h < SPLIT; ++h) {
-        if (SPLIT == 1 || (lane / kHalf) == h) {
-            double2 *w = reinterpret_cast<double2 *>(slab + (lane % kHalf) * 144);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) w[k] = make_double2(jc[2 * k], jc[2 * k + 1]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        char *dst = reinterpret_cast<char *>(Jc) + (wave0 + h * kHalf) * 144;
-        int nv = n_wave - h * kHalf;
-        nv = nv < 0 ? 0 : (nv > kHalf ? kHalf : nv);
-        const int bytes = nv * 144;
-        constexpr int kIters = (kHalf * 144 + 1023) / 1024;
-#pragma unroll
-        for (int k = 0; k < kIters; ++k) {
-            const int off = (k * 64 + lane) * 16;
-            if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    {
-        double2 *w = reinterpret_cast<double2 *>(slab + lane * 48);      // 64 x 48 B = 3 KB <= slab
-#pragma unroll
-        for (int k = 0; k < 3; ++k) w[k] = make_double2(jp[2 * k], jp[2 * k + 1]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        char *dst = reinterpret_cast<char *>(Jp) + wave0 * 48;
-        const int bytes = n_wave * 48;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int off = (k * 64 + lane) * 16;
-            if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
-        }
-    }
+    for (int t = 0; t < OPL; ++t) {
+        const int64_t wave0 = base + t * 64;
+        if (wave0 >= n) break;                                                 // wave-uniform
+        const int64_t o = wave0 + lane;
+        const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
+        const uint32_t local = ci[t] - c_first;
+        const double *cam = (valid[t] && local < n_staged) ? (sCam + local * kCamHot)
+                                                           : (camblk + (int64_t)ci[t] * kCamBlk);
+        double r0, r1, jc[18], jp[6];
+        jacobian_obs<ABL>(cam, X[t], ob[t], r0, r1, jc, jp);
 
-    if (WITH_ERR) {
-        const double e = valid ? abs_pow(r0, norm) + abs_pow(r1, norm) : 0.0;
-        const double w = wave_sum(e);
-        if (lane == 0) partials[wt] = w;
+        // residual: 16 B per lane, already coalesced
+        if (valid[t]) store16<NT>(reinterpret_cast<char *>(r_out + o), make_double2(r0, r1));
+        if (ABL == 1) {        // load+compute-only build: fold the Jacobian into one value, no slab / no stores
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) acc += jc[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc += jp[k];
+            if (acc == 1.2345e300) Jc[o] = acc;
+            continue;
+        }
+
+        // transpose through the wave-private slab, leave as contiguous 1-KiB stores of whole 128-B lines
+#pragma unroll
+        for (int h = 0; h < SPLIT; ++h) {
+            if (SPLIT == 1 || (lane / kHalf) == h) {
+                double2 *w = reinterpret_cast<double2 *>(slab + (lane % kHalf) * 144);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) w[k] = make_double2(jc[2 * k], jc[2 * k + 1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            char *dst = reinterpret_cast<char *>(Jc) + (wave0 + h * kHalf) * 144;
+            int nv = n_wave - h * kHalf;
+            nv = nv < 0 ? 0 : (nv > kHalf ? kHalf : nv);
+            const int bytes = nv * 144;
+            constexpr int kIters = (kHalf * 144 + 1023) / 1024;
+#pragma unroll
+            for (int k = 0; k < kIters; ++k) {
+                const int off = (k * 64 + lane) * 16;
+                if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            double2 *w = reinterpret_cast<double2 *>(slab + lane * 48);      // 64 x 48 B = 3 KB <= slab
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[k] = make_double2(jp[2 * k], jp[2 * k + 1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            char *dst = reinterpret_cast<char *>(Jp) + wave0 * 48;
+            const int bytes = n_wave * 48;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int off = (k * 64 + lane) * 16;
+                if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        if (WITH_ERR) {
+            const double e = valid[t] ? abs_pow(r0, norm) + abs_pow(r1, norm) : 0.0;
+            const double w = wave_sum(e);
+            if (lane == 0) partials[wt0 + t] = w;
+        }
     }
 }
 
@@ -1071,4 +1119,24 @@ __global__ __launch_bounds__(256) void k_dense_cam_scan(const uint64_t *__restri
     if (threadIdx.x == 0) row_ptr[n_cam] = (uint64_t)sCarry;
 }
 
+}  // namespace c2b
+
+// ---- timing-only: the Jacobian kernel's store pattern with no loads, no LDS, no arithmetic (tools/tune_jac.py) ----
+namespace c2b {
+template <bool NT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n_btiles, double2 *__restrict__ r_out,
+                                                           double *__restrict__ Jc, double *__restrict__ Jp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wt = xcd_tile(blockIdx.x, n_btiles) * WPB + wave;
+    const int64_t wave0 = wt * 64;
+    if (wave0 + 64 > n) return;
+    const double2 v = make_double2((double)lane, (double)wave);
+    store16<NT>(reinterpret_cast<char *>(r_out + wave0 + lane), v);
+    char *dc = reinterpret_cast<char *>(Jc) + wave0 * 144;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) store16<NT>(dc + (k * 64 + lane) * 16, v);
+    char *dp = reinterpret_cast<char *>(Jp) + wave0 * 48;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
+}
 }  // namespace c2b
