@@ -55,8 +55,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 constexpr int64_t kWsStatsDoubles = (int64_t)kRedBlocks * kStatRec;
 constexpr int64_t kWsPartials = kWsStatsDoubles + kSumBlocks;
 
-// residual+Jacobian kernel variant (tuning knob, not part of the ABI): 0 = workgroup-tiled kernel,
-// 1.. = wave-centric kernel <WPB, SPLIT, NT> (see launch_jacobian)
+// residual+Jacobian kernel variant (tuning knob of tools/tune_jac.py, not part of the ABI): see launch_jacobian
 int g_jac_variant = 13;
 
 int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) {
@@ -104,14 +103,6 @@ void launch_jacobian(int variant, const double *camblk, const double *pts4, cons
             if (variant == 30) { const int64_t bt = (wt + 7) / 8; hipLaunchKernelGGL((k_store_pattern<true, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
             if (variant == 31) { const int64_t bt = (wt + 7) / 8; hipLaunchKernelGGL((k_store_pattern<false, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
             if (variant == 32) { const int64_t bt = (wt + 3) / 4; hipLaunchKernelGGL((k_store_pattern<true, 4>), dim3((unsigned)bt), dim3(256), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
-            break;
-        }
-        case 0: {
-            const int64_t tiles = (n_obs + kBlock - 1) / kBlock;
-            hipLaunchKernelGGL(k_residual_jacobian<WITH_ERR>, dim3((unsigned)tiles), dim3(kBlock), 0, st, camblk,
-                               reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
-                               reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm,
-                               reinterpret_cast<double2 *>(r), Jc, Jp, partials);
             break;
         }
     }
@@ -298,7 +289,7 @@ int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_id
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
     if (!uv_out || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "project: uv_out NULL or misaligned");
-    const int64_t tiles = ((n_obs + 63) / 64 + kObsWPB - 1) / kObsWPB;
+    const int64_t tiles = ((n_obs + 63) / 64 + kObsWPB * kObsOPL - 1) / (kObsWPB * kObsOPL);
     hipLaunchKernelGGL(k_observations<MODE_PROJECT>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_obs,
                        tiles, 0.0, 0.0, reinterpret_cast<double2 *>(uv_out), (uint8_t *)nullptr, (double *)nullptr);
@@ -317,7 +308,7 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
         return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: uv_obs/workspace NULL or misaligned");
     double *partials = reinterpret_cast<double *>(workspace) + kWsPartials;
     const int64_t wave_tiles = (n_obs + 63) / 64;
-    const int64_t tiles = (wave_tiles + kObsWPB - 1) / kObsWPB;
+    const int64_t tiles = (wave_tiles + kObsWPB * kObsOPL - 1) / (kObsWPB * kObsOPL);
     hipLaunchKernelGGL(k_observations<MODE_ERROR>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
                        reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm, 0.0, (double2 *)nullptr,
@@ -351,7 +342,7 @@ int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, 
     if (n_obs < 0 || !out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: bad arguments");
     if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
     if (!workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: workspace is NULL");
-    const int64_t count = g_jac_variant == 0 ? (n_obs + kBlock - 1) / kBlock : (n_obs + 63) / 64;
+    const int64_t count = (n_obs + 63) / 64;       // one partial per 64-observation tile
     return launch_sum(const_cast<void *>(workspace), count, out_sum, S(stream));
 }
 
@@ -362,7 +353,7 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
     if (rc) return rc;
     if (!n_pairs) return C2B_OK;
     if (!uv_out || !keep || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_pairs: NULL/misaligned output");
-    const int64_t tiles = ((n_pairs + 63) / 64 + kObsWPB - 1) / kObsWPB;
+    const int64_t tiles = ((n_pairs + 63) / 64 + kObsWPB * kObsOPL - 1) / (kObsWPB * kObsOPL);
     hipLaunchKernelGGL(k_observations<MODE_VISIBILITY>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_pairs,
                        tiles, 0.0, max_dist, reinterpret_cast<double2 *>(uv_out), keep, (double *)nullptr);

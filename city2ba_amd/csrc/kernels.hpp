@@ -1,27 +1,27 @@
 // kernels.hpp -- gfx950 kernels of the city2ba hot path (included by capi.hip only).
 //
 // Design (MI355X: 256 CUs / 8 XCDs, wave64, 160 KB LDS per CU, HBM-bound stores):
-//   * one observation per lane; 256-lane workgroups walk the camera-major observation list,
-//     so a workgroup touches a short contiguous run of cameras: their 192-B hot records are
-//     staged once in LDS and every lane reads its camera by ds_read broadcast;
+//   * per-observation kernels are wave-centric: a wave owns two consecutive tiles of 64 observations
+//     (two per lane) of the camera-major observation list and never synchronises with another wave;
+//     all loads of both tiles are issued before any arithmetic;
+//   * a wave's observations touch a short run of consecutive cameras: their hot records are staged
+//     once in a wave-private LDS tile and every lane reads its camera by ds_read broadcast;
 //   * point gather = two aligned 16-B loads from the padded [n][4] point table (L2/MALL
-//     resident: 47.5 MB at --blocks 128);
+//     resident: 63 MB at --blocks 128);
 //   * the 2x9 / 2x3 Jacobian blocks are transposed through wave-private LDS (144-B and 48-B
 //     lane strides are bank-conflict-free for ds_write_b128) and leave as 1-KiB-per-instruction
-//     contiguous global stores -- the kernel's 208 B/observation of output is what binds it
-//     to HBM;
+//     contiguous non-temporal stores -- the kernel's 208 B/observation of output binds it to HBM;
 //   * tile -> workgroup map is XCD-aware: the 8 XCDs each stream a contiguous eighth of the
 //     observation list so that a camera's / point's neighbours hit the same 4 MiB L2;
-//   * reductions are wave shuffles -> LDS -> per-workgroup partial -> fixed-order second pass
+//   * reductions are wave shuffles -> per-tile partial -> fixed-order two-stage fold
 //     (no float atomics: run-to-run reproducible).
 #pragma once
 #include "camera_math.hpp"
 
 namespace c2b {
 
-constexpr int kBlock = 256;          // lanes per workgroup (4 waves)
+constexpr int kBlock = 256;          // lanes per workgroup of the per-entity kernels (4 waves)
 constexpr int kWaves = kBlock / 64;
-constexpr int kCamTile = 64;         // cameras staged in LDS per workgroup (12 KB)
 constexpr int kRedBlocks = 1024;     // grid of the entity reductions
 constexpr int kStatRec = 16;         // doubles per stats partial record
 
@@ -140,27 +140,6 @@ __global__ void k_expand_rows(const uint64_t *__restrict__ row_ptr, int64_t n_ca
     cam_idx[o] = (uint32_t)(lo - 1);
 }
 
-// ---- camera staging: the run of cameras a tile touches -> LDS -----------------------------------
-// Returns the first camera of the tile; lanes whose camera falls outside the staged run read
-// global memory instead (unsorted cam_idx or > kCamTile cameras per tile: correct, just slower).
-C2B_DEV uint32_t stage_cameras(const double *__restrict__ camblk, const uint32_t *__restrict__ cam_idx,
-                               int64_t tile0, int64_t n, double *sCam, uint32_t &n_staged) {
-    const int64_t last = (tile0 + kBlock < n ? tile0 + kBlock : n) - 1;
-    const uint32_t c_first = __builtin_amdgcn_readfirstlane(cam_idx[tile0]);
-    const uint32_t c_last = __builtin_amdgcn_readfirstlane(cam_idx[last]);
-    uint32_t cnt = c_last >= c_first ? c_last - c_first + 1 : 1;
-    if (cnt > (uint32_t)kCamTile) cnt = kCamTile;
-    n_staged = cnt;
-    // kCamHot doubles = 12 x 16 B per camera
-    const int chunks = (int)cnt * (kCamHot / 2);
-    for (int ch = threadIdx.x; ch < chunks; ch += kBlock) {
-        const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
-        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
-        *reinterpret_cast<double2 *>(sCam + k * kCamHot + 2 * j) = v;
-    }
-    return c_first;
-}
-
 // ---- wave-private camera tile ------------------------------------------------------------------------
 // A wave's 64 consecutive observations touch a short run of consecutive cameras (3-4 on the grid).  The
 // wave copies the first HOT doubles of those records into its own LDS tile and every lane then reads its
@@ -192,173 +171,88 @@ enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2 };
 constexpr int kObsWPB = 8;                     // waves per workgroup
 constexpr int kCamLight = 16;
 
+constexpr int kObsOPL = 2;                     // observations per lane (both tiles' loads issued up front)
+
 template <int MODE>
 __global__ __launch_bounds__(kObsWPB * 64) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ partials) {
+    constexpr int OPL = kObsOPL;
     __shared__ __attribute__((aligned(16))) double sCamAll[kObsWPB * kCamW * kCamLight];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wt = xcd_tile(blockIdx.x, n_btiles) * kObsWPB + wave;
-    const int64_t wave0 = wt * 64;
-    if (wave0 >= n) return;                                              // wave-uniform
-    const int64_t o = wave0 + lane;
-    const bool valid = o < n;
-    const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
+    const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * kObsWPB + wave) * OPL;
+    const int64_t base = wt0 * 64;
+    if (base >= n) return;                                               // wave-uniform
 
-    uint32_t ci = 0, pi = 0;
-    if (valid) { ci = cam_idx[o]; pi = pt_idx[o]; }
-    double4 X = make_double4(0, 0, -1, 0);
-    if (valid) X = pts4[pi];
-    double2 ob = make_double2(0, 0);
-    if (MODE == MODE_ERROR && valid) ob = uv_obs[o];
+    uint32_t ci[OPL], pi[OPL];
+    double2 ob[OPL];
+    double4 X[OPL];
+    bool valid[OPL];
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) {
+        const int64_t o = base + t * 64 + lane;
+        valid[t] = o < n;
+        ci[t] = 0; pi[t] = 0; ob[t] = make_double2(0, 0);
+        if (valid[t]) { ci[t] = cam_idx[o]; pi[t] = pt_idx[o]; }
+        if (MODE == MODE_ERROR && valid[t]) ob[t] = uv_obs[o];
+    }
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) {
+        X[t] = make_double4(0, 0, -1, 0);
+        if (valid[t]) X[t] = pts4[pi[t]];
+    }
 
-    const double *cam = wave_camera<kCamLight>(camblk, ci, valid, n_wave, lane, sCamAll + wave * kCamW * kCamLight);
+    // wave-private camera tile covering both tiles
+    double *sCam = sCamAll + wave * kCamW * kCamLight;
+    const int64_t n_here = n - base < 64 * OPL ? n - base : 64 * OPL;
+    const int last_t = (int)((n_here - 1) >> 6), last_l = (int)((n_here - 1) & 63);
+    uint32_t ci_last = ci[0];
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) if (t == last_t) ci_last = ci[t];
+    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
+    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci_last, last_l, 64));
+    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
+    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
+    for (int ch = lane; ch < (int)n_staged * (kCamLight / 2); ch += 64) {
+        const int k = ch / (kCamLight / 2), j = ch % (kCamLight / 2);
+        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+        *reinterpret_cast<double2 *>(sCam + k * kCamLight + 2 * j) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    double e = 0.0;
-    if (valid) {
-        const Proj p = project_obs(cam, X.x, X.y, X.z);
-        if (MODE == MODE_VISIBILITY) {
-            // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1
-            const double *g = camblk + (int64_t)ci * kCamBlk + kCenter;
-            const double dx = g[0] - X.x, dy = g[1] - X.y, dz = g[2] - X.z;
-            const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
-            const bool front = dist < max_dist && p.qz <= 0.0;
-            const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
-            const double nan = __longlong_as_double(0x7ff8000000000000LL);
-            uv_out[o] = front ? make_double2(p.u, p.v) : make_double2(nan, nan);
-            keep[o] = k ? 1 : 0;
-        } else if (MODE == MODE_PROJECT) {
-            uv_out[o] = make_double2(p.u, p.v);
-        } else {
-            e = abs_pow(p.u - ob.x, norm) + abs_pow(p.v - ob.y, norm);
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) {
+        const int64_t wave0 = base + t * 64;
+        if (wave0 >= n) break;                                           // wave-uniform
+        const int64_t o = wave0 + lane;
+        double e = 0.0;
+        if (valid[t]) {
+            const uint32_t local = ci[t] - c_first;
+            const double *cam = local < n_staged ? (sCam + local * kCamLight) : (camblk + (int64_t)ci[t] * kCamBlk);
+            const Proj p = project_obs(cam, X[t].x, X[t].y, X[t].z);
+            if (MODE == MODE_VISIBILITY) {
+                // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1
+                const double *g = camblk + (int64_t)ci[t] * kCamBlk + kCenter;
+                const double dx = g[0] - X[t].x, dy = g[1] - X[t].y, dz = g[2] - X[t].z;
+                const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
+                const bool front = dist < max_dist && p.qz <= 0.0;
+                const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
+                const double nan = __longlong_as_double(0x7ff8000000000000LL);
+                uv_out[o] = front ? make_double2(p.u, p.v) : make_double2(nan, nan);
+                keep[o] = k ? 1 : 0;
+            } else if (MODE == MODE_PROJECT) {
+                uv_out[o] = make_double2(p.u, p.v);
+            } else {
+                e = abs_pow(p.u - ob[t].x, norm) + abs_pow(p.v - ob[t].y, norm);
+            }
         }
-    }
-    if (MODE == MODE_ERROR) {
-        const double w = wave_sum(e);
-        if (lane == 0) partials[wt] = w;
-    }
-}
-
-// ---- residual + Jacobian (+ fused error partials) ------------------------------------------------
-// LDS per workgroup: cameras 12 KB + 4 wave-private transposition slabs of 9 KB = 48 KB
-//   -> 3 workgroups (12 waves) per CU.
-constexpr int kSlabBytes = 64 * 144;   // one wave's 64 x (2x9) doubles
-
-template <bool WITH_ERR>
-__global__ __launch_bounds__(kBlock) void k_residual_jacobian(
-    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
-    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
-    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_tiles, double norm,
-    double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
-    double *__restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) double sCam[kCamTile * kCamHot];
-    __shared__ __attribute__((aligned(16))) char sSlab[kWaves * kSlabBytes];
-    __shared__ double sRed[kWaves];
-
-    const int64_t tile = xcd_tile(blockIdx.x, n_tiles);
-    const int64_t tile0 = tile * kBlock;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wave0 = tile0 + wave * 64;          // first observation of this wave
-    const int64_t o = wave0 + lane;
-    const bool valid = o < n;
-
-    uint32_t ci = 0, pi = 0;
-    double2 ob = make_double2(0, 0);
-    if (valid) { ci = cam_idx[o]; pi = pt_idx[o]; ob = uv_obs[o]; }
-    double4 X = make_double4(0, 0, -1, 0);
-    if (valid) X = pts4[pi];
-
-    uint32_t n_staged;
-    const uint32_t c_first = stage_cameras(camblk, cam_idx, tile0, n, sCam, n_staged);
-    __syncthreads();
-
-    const uint32_t local = ci - c_first;
-    const double *cam = (valid && local < n_staged) ? (sCam + local * kCamHot)
-                                                    : (camblk + (int64_t)ci * kCamBlk);
-    const Proj p = project_obs(cam, X.x, X.y, X.z);
-    const double r0 = p.u - ob.x, r1 = p.v - ob.y;
-
-    // ---- Jacobian (explicit FMAs; no reference arithmetic to mirror) ----
-    const double f = cam[12], k1 = cam[13], k2 = cam[14];
-    // -1/z by v_rcp_f64 + two Newton steps (~full precision, cheaper than an IEEE divide)
-    double iz = __builtin_amdgcn_rcp(p.qz);
-    iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
-    iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
-    const double s = -f * iz;                                   // f * (-1/z)
-    const double c = fma(4.0 * k2, p.n, 2.0 * k1);              // d rad / d n * 2
-    const double cpx = c * p.px;
-    const double B00 = fma(cpx, p.px, p.rad), B01 = cpx * p.py, B11 = fma(c * p.py, p.py, p.rad);
-    const double g = fma(c, p.n, p.rad);
-    const double a00 = s * B00, a01 = s * B01, a02 = s * p.px * g;
-    const double a10 = s * B01, a11 = s * B11, a12 = s * p.py * g;
-    // y = R X  (= q - t)
-    const double yx = p.qx - cam[9], yy = p.qy - cam[10], yz = p.qz - cam[11];
-    // v_i = y x a_i ;  Jw_i = v_i^T J_l
-    const double v0x = fma(yy, a02, -yz * a01), v0y = fma(yz, a00, -yx * a02), v0z = fma(yx, a01, -yy * a00);
-    const double v1x = fma(yy, a12, -yz * a11), v1y = fma(yz, a10, -yx * a12), v1z = fma(yx, a11, -yy * a10);
-    const double *Jl = cam + kJl;
-    double jc[18], jp[6];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        jc[j] = fma(v0z, Jl[6 + j], fma(v0y, Jl[3 + j], v0x * Jl[j]));
-        jc[9 + j] = fma(v1z, Jl[6 + j], fma(v1y, Jl[3 + j], v1x * Jl[j]));
-        jp[j] = fma(a02, cam[6 + j], fma(a01, cam[3 + j], a00 * cam[j]));
-        jp[3 + j] = fma(a12, cam[6 + j], fma(a11, cam[3 + j], a10 * cam[j]));
-    }
-    jc[3] = a00; jc[4] = a01; jc[5] = a02;
-    jc[12] = a10; jc[13] = a11; jc[14] = a12;
-    const double fn = f * p.n, fnn = fn * p.n;
-    jc[6] = p.rad * p.px;  jc[15] = p.rad * p.py;
-    jc[7] = fn * p.px;     jc[16] = fn * p.py;
-    jc[8] = fnn * p.px;    jc[17] = fnn * p.py;
-
-    // ---- residual: 16 B per lane, already coalesced ----
-    if (valid) r_out[o] = make_double2(r0, r1);
-
-    // ---- transpose through the wave-private slab, leave as contiguous 1-KiB stores ----
-    char *slab = sSlab + wave * kSlabBytes;
-    const int64_t n_wave = n - wave0 < 64 ? (n - wave0 > 0 ? n - wave0 : 0) : 64;  // valid lanes
-    {
-        double2 *w = reinterpret_cast<double2 *>(slab + lane * 144);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) w[k] = make_double2(jc[2 * k], jc[2 * k + 1]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        char *dst = reinterpret_cast<char *>(Jc) + wave0 * 144;
-        const int64_t bytes = n_wave * 144;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int off = (k * 64 + lane) * 16;
-            const double2 v = *reinterpret_cast<const double2 *>(slab + off);
-            if (off < bytes) *reinterpret_cast<double2 *>(dst + off) = v;
+        if (MODE == MODE_ERROR) {
+            const double w = wave_sum(e);
+            if (lane == 0) partials[wt0 + t] = w;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    {
-        double2 *w = reinterpret_cast<double2 *>(slab + lane * 48);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) w[k] = make_double2(jp[2 * k], jp[2 * k + 1]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        char *dst = reinterpret_cast<char *>(Jp) + wave0 * 48;
-        const int64_t bytes = n_wave * 48;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int off = (k * 64 + lane) * 16;
-            const double2 v = *reinterpret_cast<const double2 *>(slab + off);
-            if (off < bytes) *reinterpret_cast<double2 *>(dst + off) = v;
-        }
-    }
-
-    if (WITH_ERR) {
-        const double e = valid ? abs_pow(r0, norm) + abs_pow(r1, norm) : 0.0;
-        const double w = wave_sum(e);
-        if (lane == 0) sRed[wave] = w;
-        __syncthreads();
-        if (threadIdx.x == 0) partials[tile] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
     }
 }
 

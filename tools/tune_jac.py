@@ -17,7 +17,7 @@ from city2ba_amd import device as D  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--blocks", type=int, default=128)
-ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8")
+ap.add_argument("--variants", default="13,9,10,11,2,20,21,30")
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=10)
 a = ap.parse_args()
