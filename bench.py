@@ -8,7 +8,8 @@
 
 One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian (residual, Jc, Jp,
 per-tile error partials) + c2b_error_sum_finish on every rank's shard, then ONE 1-element RCCL
-all-reduce (N > 1).  Inputs are resident in HBM before the timed region.  Strong scaling: the same
+all-reduce (N > 1; fold + all-reduce run on a side stream and overlap the next pass, all of it
+completed inside the timed region).  Inputs are resident in HBM before the timed region.  Strong scaling: the same
 `--blocks 128` problem is sharded over the ranks by contiguous camera ranges (BASELINE.json
 configs[3]); at N = 1 one GPU holds all of it.
 
@@ -258,17 +259,42 @@ def main():
     r = torch.empty((n, 2), dtype=torch.float64, device=dev)
     Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
     Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
-    ws = D.workspace(n, dev)
+    # The reduced scalar of step k is not an input of step k+1, so the fixed-order fold and the 8-byte all-reduce run
+    # on a side stream and overlap the next pass of the Jacobian kernel (collectives overlapped with compute on
+    # separate HIP streams).  The error partials are double-buffered so pass k+1 never overwrites what fold k reads.
+    ws2 = [D.workspace(n, dev), D.workspace(n, dev)]
     err = torch.zeros(1, dtype=torch.float64, device=dev)
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=dev)
+    fold_done = [None, None]
+    counter = [0]
 
     def step(ev=None):
+        if world == 1:                             # nothing to overlap: plain in-order step on one stream
+            if ev is not None:
+                ev[0].record()
+            D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws2[0])
+            if ev is not None:
+                ev[1].record()
+            D.error_sum_finish(ws2[0], n, err)
+            return
+        k = counter[0] & 1
+        counter[0] += 1
+        if fold_done[k] is not None:
+            main.wait_event(fold_done[k])          # workspace k is free again (its fold ran a whole pass ago)
         if ev is not None:
             ev[0].record()
-        D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws)
+        D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws2[k])
         if ev is not None:
             ev[1].record()
-        D.error_sum_finish(ws, n, err)
-        Dist.all_reduce_sum_(err)
+        produced = torch.cuda.Event()
+        produced.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(produced)
+            D.error_sum_finish(ws2[k], n, err)
+            Dist.all_reduce_sum_(err)
+            fold_done[k] = torch.cuda.Event()
+            fold_done[k].record(side)
 
     for _ in range(args.warmup):
         step()
@@ -328,7 +354,7 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and args.blocks == 128 and not args.no_extras:
             out["other_configs"] = other_configs(dev)
-            out["other_configs"]["blocks128_uniform_random_point_gather"] = adversarial_gather(sh, r, Jc, Jp, ws)
+            out["other_configs"]["blocks128_uniform_random_point_gather"] = adversarial_gather(sh, r, Jc, Jp, ws2[0])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
