@@ -1,0 +1,84 @@
+"""Level-0 (device pointers, torch as the memory owner) edge cases that the CSR-based Level-1 API cannot produce:
+observations in arbitrary (unsorted) camera order -- the kernels promise correctness there through their
+global-memory fallback -- and many cameras per wave (more than the 12-camera LDS tile)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from _problems import random_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as entry
+    entry.build()
+    import torch
+    import city2ba_amd
+    from city2ba_amd import device as D
+    assert city2ba_amd.device_count() > 0
+    return dict(torch=torch, D=D, dev=torch.device("cuda", 0))
+
+
+def _device_problem(env, P, order):
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    counts = np.diff(P["row_ptr"].astype(np.int64))
+    cam_of = np.repeat(np.arange(len(counts)), counts)
+    cam15 = torch.from_numpy(P["cams15"]).to(dev)
+    camblk = D.cameras_prepare_state(cam15)
+    pts4 = D.points_pad(torch.from_numpy(P["pts"]).to(dev))
+    ci = torch.from_numpy(cam_of[order].astype(np.int32)).to(dev)
+    pi = torch.from_numpy(P["pt_idx"].astype(np.int64)[order].astype(np.int32)).to(dev)
+    uv = torch.from_numpy(np.ascontiguousarray(P["uv"][order])).to(dev)
+    return camblk, pts4, ci, pi, uv
+
+
+@pytest.mark.parametrize("n_cam,n_pts,opc,seed", [(200, 3000, 9, 1), (900, 4000, 2, 2), (37, 2000, 40, 3)])
+def test_unsorted_observation_order(env, n_cam, n_pts, opc, seed):
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    P = random_problem(n_cam, n_pts, opc, seed=seed, noise=1e-3)
+    n = len(P["pt_idx"])
+    rng = np.random.default_rng(seed)
+    order = rng.permutation(n)                           # arbitrary COO order: cameras jump on every lane
+    camblk, pts4, ci, pi, uv = _device_problem(env, P, order)
+    r = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
+    Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    ws = D.workspace(n, dev)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    D.residual_jacobian(camblk, pts4, ci, pi, uv, r, Jc, Jp, 2.0, ws)
+    D.error_sum_finish(ws, n, err)
+    proj = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    D.project(camblk, pts4, ci, pi, proj)
+    e2 = torch.zeros(1, dtype=torch.float64, device=dev)
+    D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, e2)
+    torch.cuda.synchronize()
+    r0, Jc0, Jp0 = O.residual_jacobian(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    scale = max(1.0, float(np.max(np.abs(Jc0))))
+    assert np.max(np.abs(r.cpu().numpy() - r0[order])) < 1e-12
+    assert np.max(np.abs(Jc.cpu().numpy() - Jc0[order])) / scale < 1e-10
+    assert np.max(np.abs(Jp.cpu().numpy() - Jp0[order])) / scale < 1e-10
+    want_uv = O.project_observations(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"])[order]
+    assert np.max(np.abs(proj.cpu().numpy() - want_uv) / np.maximum(np.abs(want_uv), 1e-3)) < 1e-13
+    want_e = float(np.sum(r0 * r0))
+    assert abs(err.item() - want_e) / want_e < 1e-11 and abs(e2.item() - want_e) / want_e < 1e-11
+
+
+def test_sorted_and_unsorted_launches_agree_bitwise(env):
+    """The LDS-tile path (sorted) and the global fallback (unsorted) read the same camera records: same bits."""
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    P = random_problem(150, 3000, 12, seed=9, noise=1e-3)
+    n = len(P["pt_idx"])
+    order = np.random.default_rng(4).permutation(n)
+    outs = []
+    for o in (np.arange(n), order):
+        camblk, pts4, ci, pi, uv = _device_problem(env, P, o)
+        r = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
+        Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
+        D.residual_jacobian(camblk, pts4, ci, pi, uv, r, Jc, Jp, 2.0, None)
+        torch.cuda.synchronize()
+        outs.append((r.cpu().numpy(), Jc.cpu().numpy(), Jp.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a[order], b)
