@@ -55,6 +55,9 @@ int c2b_device_count(int *count);
 /* ===================================================================================== *
  * Level 0 -- stateless launchers.  Every pointer is a DEVICE pointer, every call is
  * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ * Indices are NOT validated here (they live on the device): cam_idx[i] < n_cam and
+ * pt_idx[i] < n_pts are the caller's contract; Level 1 validates like the reference's asserts.
+ * Observations may come in any order; camera-major (CSR) order is the fast path.
  * ===================================================================================== */
 
 /* bytes of scratch the reductions below need for a problem with n_obs observations */
@@ -91,7 +94,7 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
 
 /* residual + 2x9 camera block + 2x3 point block per observation (no reference equivalent).
  * With workspace != NULL the kernel also leaves one partial of sum |du|^norm + |dv|^norm per
- * 256-observation tile in the workspace (fused error reduce); c2b_error_sum_finish folds them. */
+ * 64-observation tile in the workspace (fused error reduce); c2b_error_sum_finish folds them. */
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                           const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
                           double *r, double *Jc, double *Jp,
