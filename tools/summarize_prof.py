@@ -24,13 +24,20 @@ def kernel_stats(root):
 
 
 def pmc_per_kernel(root, counter):
-    """average counter value per dispatch, per kernel name"""
+    """average counter value per dispatch, per kernel name (counter=None: every counter, keyed (kernel, counter))"""
     path = find(root, "*counter_collection.csv")
     acc = {}
     if not path:
         return acc
     with open(path) as fh:
         for row in csv.DictReader(fh):
+            if counter is None:
+                k = (row.get("Kernel_Name", "?"), row.get("Counter_Name"))
+                v = float(row.get("Counter_Value", "0") or 0)
+                s = acc.setdefault(k, [0.0, 0])
+                s[0] += v
+                s[1] += 1
+                continue
             if row.get("Counter_Name") != counter:
                 continue
             k = row.get("Kernel_Name", "?")
@@ -84,11 +91,23 @@ def main():
             summary["traffic_uncorrected_bytes_per_launch"] = int((f + w) * 1024)
             summary["traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of %s; separate --pmc passes" % name
         summary["dominant_kernel"] = dom
+    sq = pmc_per_kernel(os.path.join(out, "pmc_sq"), None)
+    sq_dom = {c: round(v[0], 1) for (k, c), v in sq.items() if "residual_jacobian" in k}
+    if sq_dom:
+        wc = sq_dom.get("SQ_WAVE_CYCLES") or 0
+        summary["sq_counters_dominant_kernel"] = sq_dom
+        if wc:
+            summary["sq_derived"] = {
+                "lds_bank_conflict_frac_of_lds_active": round(sq_dom.get("SQ_LDS_BANK_CONFLICT", 0) / max(sq_dom.get("SQ_LDS_IDX_ACTIVE", 1), 1), 4),
+                "wait_any_frac_of_wave_cycles": round(sq_dom.get("SQ_WAIT_ANY", 0) / wc, 4),
+                "active_inst_any_frac": round(sq_dom.get("SQ_ACTIVE_INST_ANY", 0) / wc, 4),
+                "active_inst_valu_frac": round(sq_dom.get("SQ_ACTIVE_INST_VALU", 0) / wc, 4),
+            }
     summary["bench_trace"] = bench_line(os.path.join(out, "trace.log"))
     summary["bench_pmc_fetch"] = bench_line(os.path.join(out, "pmc_fetch.log"))
     with open(os.path.join(out, "%s_summary.json" % tag), "w") as fh:
         json.dump(summary, fh, indent=1)
-    print(json.dumps({k: summary.get(k) for k in ("dominant_kernel", "traffic_bytes_per_launch")}, indent=1))
+    print(json.dumps({k: summary.get(k) for k in ("dominant_kernel", "traffic_bytes_per_launch", "sq_counters_dominant_kernel", "sq_derived")}, indent=1))
     for k in summary["kernels"][:8]:
         print("%-90s calls=%d avg=%.1f us  %.1f%%" % (k["name"][:90], k["calls"], k["avg_ns"] / 1e3, k["pct"]))
 
