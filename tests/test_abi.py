@@ -35,6 +35,35 @@ def test_library_exports_every_declared_symbol(c2b):
     assert sorted(_lib.SIGNATURES) == names          # the Python binding covers exactly the header
 
 
+def test_header_is_plain_c_and_links(c2b, tmp_path):
+    """The boundary is a C ABI: the header must compile as strict C99 and a C program must link and run against
+    the shared library (host-only entry points; no GPU needed)."""
+    import subprocess
+    from city2ba_amd import _lib
+    src = tmp_path / "use_abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "city2ba_hip.h"
+int main(void) {
+    int64_t n_cam = 0, n_pts = 0;
+    int rc = c2b_synthetic_grid_sizes(10, 10, 4, &n_cam, &n_pts);
+    printf("%s rc=%d cams=%lld pts=%lld ws=%lld\n", c2b_version(), rc, (long long)n_cam, (long long)n_pts,
+           (long long)c2b_workspace_bytes(1000));
+    rc = c2b_partition_cameras(0, 1, 1, 0);
+    printf("bad-args rc=%d msg=%s\n", rc, c2b_last_error());
+    return (n_cam == 800 && n_pts == 2400 && rc == C2B_ERR_INVALID_ARGUMENT) ? 0 : 1;
+}
+''')
+    exe = tmp_path / "use_abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L" + libdir, "-lcity2ba_hip", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "cams=800 pts=2400" in out.stdout and "bad-args rc=-1" in out.stdout
+
+
 def test_header_cites_reference_lines():
     text = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
     assert len(re.findall(r"src/(baproblem|noise|synthetic|generate)\.rs:\d+", text)) >= 15
