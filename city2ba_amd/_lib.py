@@ -35,6 +35,9 @@ SIGNATURES = {
     "c2b_cameras_prepare_state": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_prepare_bal": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_from_position_direction": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "c2b_project_world": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "c2b_to_world": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "c2b_cameras_transform": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "c2b_points_pad": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_points_unpad": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_expand_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),

@@ -243,6 +243,31 @@ int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, 
     return C2B_OK;
 }
 
+int c2b_project_world(const double *cam15, const uint32_t *cam_idx, const double *p3, int64_t n, double *out3,
+                      void *stream) {
+    if (n < 0 || (n && (!cam15 || !cam_idx || !p3 || !out3))) return fail(C2B_ERR_INVALID_ARGUMENT, "project_world: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_camera_point_map<false>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, cam_idx, p3, n, out3);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_to_world(const double *cam15, const uint32_t *cam_idx, const double *p3, int64_t n, double *out3, void *stream) {
+    if (n < 0 || (n && (!cam15 || !cam_idx || !p3 || !out3))) return fail(C2B_ERR_INVALID_ARGUMENT, "to_world: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_camera_point_map<true>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, cam_idx, p3, n, out3);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_cameras_transform(double *cam15, const double *delta_dir9, const double *delta_loc3, int64_t n, void *stream) {
+    if (n < 0 || (n && (!cam15 || !delta_dir9 || !delta_loc3))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_transform: bad arguments");
+    if (!n) return C2B_OK;
+    hipLaunchKernelGGL(k_cameras_transform, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, delta_dir9, delta_loc3, n);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
 int c2b_points_pad(const double *pts3, int64_t n, double *pts4, void *stream) {
     if (n < 0 || (n && (!pts3 || !pts4))) return fail(C2B_ERR_INVALID_ARGUMENT, "points_pad: bad arguments");
     if (!n) return C2B_OK;

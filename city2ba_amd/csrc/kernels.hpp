@@ -1034,3 +1034,60 @@ __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n
     for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
 }
 }  // namespace c2b
+
+// ---- the remaining Camera trait methods as batched kernels (src/baproblem.rs:141-143, 165-175) ----------------
+namespace c2b {
+
+// rows of cgmath's Matrix3::invert (cross products / determinant), as in cm_center
+template <typename T>
+C2B_DEV void cm_inverse_rows(const T *m, T a[3], T b[3], T c[3]) {
+    const T m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    const T det = m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02) + m20 * (m01 * m12 - m11 * m02);
+    a[0] = (m11 * m22 - m12 * m21) / det; a[1] = (m12 * m20 - m10 * m22) / det; a[2] = (m10 * m21 - m11 * m20) / det;
+    b[0] = (m21 * m02 - m22 * m01) / det; b[1] = (m22 * m00 - m20 * m02) / det; b[2] = (m20 * m01 - m21 * m00) / det;
+    c[0] = (m01 * m12 - m02 * m11) / det; c[1] = (m02 * m10 - m00 * m12) / det; c[2] = (m00 * m11 - m01 * m10) / det;
+}
+
+// Camera::project_world (to_world = false) / Camera::to_world (true) for pair i = (camera cam_idx[i], point i)
+template <bool TO_WORLD>
+__global__ void k_camera_point_map(const double *__restrict__ cam15, const uint32_t *__restrict__ cam_idx,
+                                   const double *__restrict__ p3, int64_t n, double *__restrict__ out3) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double c[15];
+    const double *src = cam15 + 15 * (int64_t)cam_idx[i];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) c[k] = src[k];
+    const double x = p3[3 * i], y = p3[3 * i + 1], z = p3[3 * i + 2];
+    if (TO_WORLD) {
+        // dir.invert().rotate_point(p - loc), src/baproblem.rs:173-175
+        double a[3], b[3], cc[3];
+        cm_inverse_rows(c, a, b, cc);
+        const double dx = x - c[9], dy = y - c[10], dz = z - c[11];
+        out3[3 * i] = dot3(a[0], a[1], a[2], dx, dy, dz);
+        out3[3 * i + 1] = dot3(b[0], b[1], b[2], dx, dy, dz);
+        out3[3 * i + 2] = dot3(cc[0], cc[1], cc[2], dx, dy, dz);
+    } else {
+        // dir.rotate_point(p) + loc, src/baproblem.rs:141-143
+        double v[3];
+        cm_mat_vec(c, x, y, z, v);
+        out3[3 * i] = v[0] + c[9]; out3[3 * i + 1] = v[1] + c[10]; out3[3 * i + 2] = v[2] + c[11];
+    }
+}
+
+// Camera::transform (src/baproblem.rs:165-171) for every camera with its own delta_dir [n][9] / delta_loc [n][3]
+__global__ void k_cameras_transform(double *__restrict__ cam15, const double *__restrict__ dR9,
+                                    const double *__restrict__ dloc3, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double c[15], d[9];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = dR9[9 * i + k];
+    transform_cam15(c, d, dloc3[3 * i], dloc3[3 * i + 1], dloc3[3 * i + 2]);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+}
+
+}  // namespace c2b

@@ -179,3 +179,21 @@ def add_sin_noise_f32(cam15, pts4, stats_, dir_, noise_dir, strength, frequency)
                                           float(dir_[0]), float(dir_[1]), float(dir_[2]), float(noise_dir[0]),
                                           float(noise_dir[1]), float(noise_dir[2]), float(strength), float(frequency),
                                           _stream()))
+
+
+# ---- the remaining Camera trait methods, batched (src/baproblem.rs:141-143, 165-175) ------------------------
+def project_world(cam15, cam_idx, p3):
+    out = torch.empty_like(p3)
+    L.check(L.lib().c2b_project_world(_p(cam15), _p(cam_idx), _p(p3), p3.shape[0], _p(out), _stream()))
+    return out
+
+
+def to_world(cam15, cam_idx, p3):
+    out = torch.empty_like(p3)
+    L.check(L.lib().c2b_to_world(_p(cam15), _p(cam_idx), _p(p3), p3.shape[0], _p(out), _stream()))
+    return out
+
+
+def cameras_transform(cam15, delta_dir9, delta_loc3):
+    L.check(L.lib().c2b_cameras_transform(_p(cam15), _p(delta_dir9), _p(delta_loc3), cam15.shape[0], _stream()))
+    return cam15

@@ -74,6 +74,16 @@ int c2b_cameras_prepare_bal(const double *bal9, int64_t n_cam, double *camblk, v
 /* Camera::from_position_direction (src/baproblem.rs:153-159): pos [n][3], dir [n][9] col-major */
 int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, int64_t n_cam,
                                         double *cam15, void *stream);
+/* Camera::project_world (src/baproblem.rs:141-143) and Camera::to_world (:173-175), batched over pairs:
+ * pair i = (camera cam_idx[i], point p3[i]) -> out3[i] */
+int c2b_project_world(const double *cam15, const uint32_t *cam_idx, const double *p3, int64_t n,
+                      double *out3, void *stream);
+int c2b_to_world(const double *cam15, const uint32_t *cam_idx, const double *p3, int64_t n,
+                 double *out3, void *stream);
+/* Camera::transform (src/baproblem.rs:165-171) of every camera, in place: dir' = dir * delta_dir[i],
+ * loc' = -dir * (center + delta_loc[i]) (the OLD dir, like the reference) */
+int c2b_cameras_transform(double *cam15, const double *delta_dir9, const double *delta_loc3, int64_t n_cam,
+                          void *stream);
 /* pts3 [n][3] -> pts4 [n][4] and back */
 int c2b_points_pad(const double *pts3, int64_t n_pts, double *pts4, void *stream);
 int c2b_points_unpad(const double *pts4, int64_t n_pts, double *pts3, void *stream);

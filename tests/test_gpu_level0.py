@@ -82,3 +82,38 @@ def test_sorted_and_unsorted_launches_agree_bitwise(env):
         outs.append((r.cpu().numpy(), Jc.cpu().numpy(), Jp.cpu().numpy()))
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a[order], b)
+
+
+def test_camera_trait_methods_batched(env):
+    """project_world / to_world / transform as stand-alone batched calls: bit-exact with the oracle (pure IEEE
+    algebra, no transcendental), and the reference's test_project_isomorphic (src/baproblem.rs:244-249) on the device."""
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    P = random_problem(64, 500, 0, seed=12)
+    rng = np.random.default_rng(3)
+    n = 2000
+    ci = rng.integers(0, 64, n).astype(np.int32)
+    p = rng.uniform(-20, 20, (n, 3))
+    cam15 = torch.from_numpy(P["cams15"]).to(dev)
+    ci_d, p_d = torch.from_numpy(ci).to(dev), torch.from_numpy(p).to(dev)
+    q = D.project_world(cam15, ci_d, p_d)
+    back = D.to_world(cam15, ci_d, q)
+    torch.cuda.synchronize()
+    want_q = np.array([O.project_world(P["cams15"][c], x) for c, x in zip(ci, p)])
+    want_back = np.array([O.to_world(P["cams15"][c], x) for c, x in zip(ci, want_q)])
+    assert np.array_equal(q.cpu().numpy(), want_q)
+    assert np.array_equal(back.cpu().numpy(), want_back)
+    assert np.max(np.abs(back.cpu().numpy() - p)) < 1e-8                     # test_project_isomorphic's tolerance
+    # the reference's own KAT
+    kat = O.camera_from_bal([3.0, 5.0, -2.0, 0.5, -0.2, 0.1, 1.0, 0.0, 0.0])
+    c1 = torch.from_numpy(kat).to(dev)
+    z = torch.zeros(1, dtype=torch.int32, device=dev)
+    pk = torch.tensor([[1.0, 3.0, -1.0]], dtype=torch.float64, device=dev)
+    assert float((D.to_world(c1, z, D.project_world(c1, z, pk)) - pk).abs().max()) <= 1e-8
+    # transform: per-camera deltas
+    dR = np.array([O.basis_from_axis_angle(a / np.linalg.norm(a), th) for a, th in
+                   zip(rng.normal(size=(64, 3)), rng.uniform(-1, 1, 64))])
+    dl = rng.normal(size=(64, 3))
+    moved = D.cameras_transform(cam15.clone(), torch.from_numpy(dR).to(dev), torch.from_numpy(dl).to(dev))
+    torch.cuda.synchronize()
+    want = np.array([O.transform(P["cams15"][i], dR[i], dl[i]) for i in range(64)])
+    assert np.array_equal(moved.cpu().numpy(), want)
