@@ -152,3 +152,30 @@ def test_cli_synthetic_line_and_errors(cli, tmp_path):
     assert r.returncode != 0 and "unknown file extension" in r.stderr
     r = _run(cli, "generate", "a.obj", "b.bal")
     assert r.returncode != 0 and "Embree" in r.stderr
+
+
+def test_cli_noise_equals_python_host_path(c2b, cli, tmp_path):
+    """Two independent hosts over the same C ABI (C++ CLI, Python mirror), same seed => identical problems
+    (run_noise order, src/bin/city2ba.rs:305-340: drift always, optional sin pair, add_noise always)."""
+    src = tmp_path / "g.bbal"
+    assert _run(cli, "synthetic", src, "--blocks", "3").returncode == 0
+    out = tmp_path / "n.bbal"
+    r = _run(cli, "noise", src, out, "--drift-strength", "0.001", "--drift-angle", "0.002", "--drift-std", "0.1",
+             "--sin-strength", "0.05", "--sin-frequency", "2", "--rotation-std", "0.01", "--translation-std", "0.02",
+             "--point-std", "0.03", "--observation-std", "0.004", "--seed", "5")
+    assert r.returncode == 0, r.stderr
+    got = c2b.BAProblem.from_file(out)
+    ba = c2b.BAProblem.from_file(src)
+    ba = c2b.noise.add_drift_normalized(ba, 0.001, 0.002, 0.1, seed=5)
+    ba = c2b.noise.add_sin_noise(ba, [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], 0.05, 2.0)
+    ba = c2b.noise.add_sin_noise(ba, [0.0, 0.0, 1.0], [0.0, 1.0, 0.0], 0.05, 2.0)
+    ba = c2b.noise.add_noise(ba, 0.02, 0.01, 0.03, 0.004, seed=6)
+    assert np.array_equal(got.points(), ba.points()) and np.array_equal(got.observations(), ba.observations())
+    # cameras went through to_vec -> file -> from_vec once more on the CLI side
+    assert np.max(np.abs(got.cameras() - ba.cameras())) < 1e-12
+    assert np.array_equal(got.cameras_bal(), ba.cameras_bal())
+    l2 = ba.total_reprojection_error(2.0)
+    assert ("Final error: " in r.stdout) and l2 > 0
+    # fixed-drift variant parses and runs
+    r2 = _run(cli, "noise", src, tmp_path / "f.bal", "--fixed-drift", "--drift-strength", "1e-6", "--seed", "1")
+    assert r2.returncode == 0 and "Final error" in r2.stdout
