@@ -49,6 +49,7 @@ SIGNATURES = {
     "c2b_visibility_dense_tiles": (_i64, [_i64]),
     "c2b_visibility_dense_count": (_int, [_vp, _i64, _vp, _i64, _d, _vp, _vp, _vp, _vp]),
     "c2b_visibility_dense_fill": (_int, [_vp, _i64, _vp, _i64, _d, _vp, _vp, _vp, _vp, _vp]),
+    "c2b_occlusion_filter": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
     "c2b_add_drift_normalized": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
@@ -71,12 +72,25 @@ SIGNATURES = {
     "c2b_pairs_cam_idx": (_vp, [_vp]),
     "c2b_pairs_pt_idx": (_vp, [_vp]),
     "c2b_pairs_free": (None, [_vp]),
+    "c2b_obj_load": (_int, [C.c_char_p, C.POINTER(_vp)]),
+    "c2b_obj_model_count": (_i64, [_vp]),
+    "c2b_obj_model_name": (C.c_char_p, [_vp, _i64]),
+    "c2b_obj_model_sizes": (_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
+    "c2b_obj_model_copy": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_obj_move_to_origin": (_int, [_vp, _i64]),
+    "c2b_obj_triangles": (_int, [_vp, _i64, _vp, C.POINTER(_i64)]),
+    "c2b_obj_free": (None, [_vp]),
+    "c2b_generate_cameras_path": (_int, [_vp, _i64, _i64, _d, _u64, _vp, _vp]),
+    "c2b_generate_cameras_poisson": (_int, [_vp, _i64, _i64, _d, _d, _u64, _i64, _vp, _vp, C.POINTER(_i64)]),
+    "c2b_modify_intrinsics": (_int, [_vp, _i64, _vp, _vp, _u64]),
+    "c2b_generate_world_points": (_int, [_vp, _i64, _vp, _i64, _i64, _d, _u64, _vp, C.POINTER(_i64)]),
     "c2b_cull": (_int, [C.POINTER(_i64), _vp, _int, C.POINTER(_i64), _vp, _vp, _vp, _vp, _int]),
     "c2b_bal_read": (_int, [C.c_char_p, C.POINTER(_vp)]),
     "c2b_bal_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "c2b_bal_copy": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "c2b_bal_close": (None, [_vp]),
     "c2b_bal_write": (_int, [C.c_char_p, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_ply_write": (_int, [C.c_char_p, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_problem_create": (_int, [_int, C.POINTER(_vp)]),
     "c2b_problem_destroy": (None, [_vp]),
     "c2b_problem_upload": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -93,6 +107,7 @@ SIGNATURES = {
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),
     "c2b_problem_visibility_dense": (_int, [_vp, _d, _vp]),
     "c2b_problem_visibility_dense_fetch": (_int, [_vp, _vp, _vp]),
+    "c2b_problem_visibility_dense_occlude": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_problem_add_drift": (_int, [_vp, _d, _d, _d, _vp, _u64]),
     "c2b_problem_add_drift_normalized": (_int, [_vp, _d, _d, _d, _u64]),
     "c2b_problem_add_noise": (_int, [_vp, _d, _d, _d, _d, _u64]),

@@ -186,13 +186,17 @@ class BAProblem:
         s = self._stats()
         return s[15:18].copy(), int(s[18])
 
-    def visibility_graph(self, max_dist):
-        """The camera x point sweep of generate::visibility_graph (src/generate.rs:424-481) WITHOUT the
-        Embree occlusion filter: every camera of the problem against every point.  Returns the CSR graph
+    def visibility_graph(self, max_dist, triangles=None):
+        """The camera x point sweep of generate::visibility_graph (src/generate.rs:424-481): every camera of
+        the problem against every point; with `triangles` ([n,9] f32 mesh) the survivors also pass the occlusion
+        rays of :455-476 (brute force over the triangles on the device in place of Embree).  Returns the CSR graph
         (row_ptr u64, pt_idx u64, uv) with points in ascending order per camera, like the reference's push order."""
         n_cam = self.num_cameras()
         row_ptr = np.zeros(n_cam + 1, dtype=np.uint64)
         L.check(L.lib().c2b_problem_visibility_dense(self._h, float(max_dist), _ptr(row_ptr)))
+        if triangles is not None:
+            tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
+            L.check(L.lib().c2b_problem_visibility_dense_occlude(self._h, _ptr(tri), len(tri), _ptr(row_ptr)))
         n = int(row_ptr[-1])
         pt_idx = np.empty(n, dtype=np.uint64)
         uv = np.empty((n, 2))

@@ -10,8 +10,13 @@
 //                         --drift-std X --drift-strength X --fixed-drift --drift-angle X
 //                         --sin-strength X --sin-frequency X] [--seed N]
 //
-// Not provided: `generate` and `ply` (Embree ray casting / PLY export are outside the hot-path scope) and the
-// index-shuffling noise flags (--mismatch-chance > 0, --drop-features < 1, --split-landmarks, --join-landmarks).
+//   city2ba generate FILE OUT [--cameras N --intrinsics-start x,y,z --intrinsics-end x,y,z --points N --max-dist X
+//                              --ground X --height X --no-lcc --move-to-origin --path NAME --step-size X] [--seed N]
+//   city2ba ply IN OUT
+//
+// Not provided: the index-shuffling noise flags (--mismatch-chance > 0, --drop-features < 1, --split-landmarks,
+// --join-landmarks).  `generate` casts its rays by brute force over the triangles instead of through Embree.
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -246,13 +251,163 @@ int run_noise(int argc, char **argv) {
     return 0;
 }
 
+// parse_vec3, src/bin/city2ba.rs:20-31: "x,y,z"
+void parse_vec3(const Args &a, const std::string &k, double out[3]) {
+    auto it = a.opt.find(k);
+    if (it == a.opt.end()) return;
+    const std::string &s = it->second;
+    size_t pos = 0;
+    for (int c = 0; c < 3; ++c) {
+        const size_t comma = c < 2 ? s.find(',', pos) : s.size();
+        if (comma == std::string::npos) die("Invalid value for '--" + k + " <" + k + ">': expected x,y,z");
+        const std::string tok = s.substr(pos, comma - pos);
+        char *end = nullptr;
+        out[c] = std::strtod(tok.c_str(), &end);
+        if (end == tok.c_str() || *end) die("Invalid value for '--" + k + " <" + k + ">': invalid float literal");
+        pos = comma + 1;
+    }
+}
+
+// Rust `{}` of an f64: shortest digits that round-trip, never scientific
+std::string display_f64(double v) {
+    if (v != v) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    char buf[400];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
+}
+
+// run_generate, src/bin/city2ba.rs:480-573.  Ray casts: brute force over the mesh's triangles (host for camera
+// placement, the device occlusion kernel for the visibility graph) in place of Embree.
+int run_generate(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, {"no-lcc", "move-to-origin"},
+                         {"cameras", "intrinsics-start", "intrinsics-end", "points", "max-dist", "ground", "height", "path",
+                          "step-size", "seed", "device"});
+    if (a.positional.size() != 2) die("The following required arguments were not provided:\n    <FILE> <OUT>");
+    if (a.has("path") && a.has("ground")) die("The argument '--path <path>' cannot be used with '--ground <ground>'");
+    const int64_t num_cameras = a.i("cameras", 100), num_points = a.i("points", 1000);
+    const double max_dist = a.f("max-dist", 100), ground = a.f("ground", 0), height = a.f("height", 1);
+    const double step_size = a.f("step-size", 0);
+    double istart[3] = {1, 0, 0}, iend[3] = {1, 0, 0};
+    parse_vec3(a, "intrinsics-start", istart);
+    parse_vec3(a, "intrinsics-end", iend);
+    uint64_t seed;
+    if (a.has("seed")) seed = (uint64_t)a.i("seed", 0);
+    else { std::random_device rd; seed = ((uint64_t)rd() << 32) ^ rd(); }   // the reference: unseeded thread_rng()
+
+    c2b_obj *obj = nullptr;
+    ck(c2b_obj_load(a.positional[0].c_str(), &obj));
+    int64_t path_model = -1;
+    if (a.has("path")) {
+        const std::string want = a.opt.at("path");
+        std::string names;
+        for (int64_t m = 0; m < c2b_obj_model_count(obj); ++m) {
+            const std::string name = c2b_obj_model_name(obj, m);
+            if (name == want && path_model < 0) path_model = m;
+            names += (m ? ", " : "") + name;
+        }
+        if (path_model < 0) die("Could not find a path named " + want + ". Available model names are " + names);
+    }
+    if (a.has("move-to-origin")) ck(c2b_obj_move_to_origin(obj, path_model));
+    int64_t n_tri = 0;
+    ck(c2b_obj_triangles(obj, path_model, nullptr, &n_tri));
+    std::vector<float> tri((size_t)n_tri * 9 + 1);
+    ck(c2b_obj_triangles(obj, path_model, tri.data(), &n_tri));
+
+    int64_t n_cam = 0;
+    std::vector<double> pos, dir;
+    if (path_model >= 0) {
+        n_cam = num_cameras;
+        pos.resize((size_t)n_cam * 3 + 1); dir.resize((size_t)n_cam * 9 + 1);
+        ck(c2b_generate_cameras_path(obj, path_model, num_cameras, step_size, seed, pos.data(), dir.data()));
+    } else {
+        ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, 0, nullptr, nullptr, &n_cam));
+        pos.resize((size_t)n_cam * 3 + 1); dir.resize((size_t)n_cam * 9 + 1);
+        ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, n_cam, pos.data(), dir.data(), &n_cam));
+    }
+    c2b_obj_free(obj);
+    std::printf("Generated %lld cameras\n", (long long)n_cam);
+
+    c2b_problem *p = nullptr;
+    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    HostProblem hp;
+    hp.n_cam = n_cam;
+    hp.cams15.resize((size_t)n_cam * 15 + 1);
+    if (n_cam) ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), hp.cams15.data()));
+    ck(c2b_modify_intrinsics(hp.cams15.data(), n_cam, istart, iend, seed + 1));
+    std::printf("Modified intrinsics\n");
+
+    std::vector<double> centers((size_t)n_cam * 3 + 1);
+    std::vector<uint64_t> rows((size_t)n_cam + 1, 0);
+    if (n_cam) {
+        ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), 0, nullptr, rows.data(), nullptr, nullptr));
+        ck(c2b_problem_centers(p, centers.data()));
+    }
+    hp.pts.resize((size_t)num_points * 3 + 1);
+    ck(c2b_generate_world_points(tri.data(), n_tri, centers.data(), n_cam, num_points, max_dist, seed + 2, hp.pts.data(), &hp.n_pts));
+    std::printf("Generated %lld world points\n", (long long)hp.n_pts);
+
+    // visibility_graph, src/generate.rs:424-481: dense (camera, point) sweep, then the occlusion rays
+    ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), rows.data(), nullptr, nullptr));
+    hp.row_ptr.assign((size_t)n_cam + 1, 0);
+    ck(c2b_problem_visibility_dense(p, max_dist, hp.row_ptr.data()));
+    ck(c2b_problem_visibility_dense_occlude(p, tri.data(), n_tri, hp.row_ptr.data()));
+    const size_t n_edges = (size_t)hp.row_ptr[(size_t)n_cam];
+    hp.pt_idx.resize(n_edges + 1); hp.uv.resize(2 * n_edges + 2);
+    ck(c2b_problem_visibility_dense_fetch(p, hp.pt_idx.data(), hp.uv.data()));
+    std::printf("Computed visibility graph with %zu edges\n", n_edges);
+
+    if (!a.has("no-lcc"))
+        ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(), 1));
+    if (hp.n_cam == 0 || hp.n_pts == 0) die("EmptyProblem(\"No cameras remain\")");
+    hp.cams15.resize((size_t)hp.n_cam * 15);
+    hp.pts.resize((size_t)hp.n_pts * 3);
+    hp.row_ptr.resize((size_t)hp.n_cam + 1);
+    const size_t n_obs = (size_t)hp.row_ptr[(size_t)hp.n_cam];
+    hp.pt_idx.resize(n_obs); hp.uv.resize(2 * n_obs);
+    std::printf("Computed LCC with %lld cameras, %lld points, %zu edges\n", (long long)hp.n_cam, (long long)hp.n_pts, n_obs);
+
+    ck(c2b_problem_upload(p, hp.n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+    double l1 = 0;
+    ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
+    std::printf("Total reprojection error: %s\n", display_f64(l1).c_str());
+    std::vector<double> bal9((size_t)hp.n_cam * 9);
+    ck(c2b_problem_download_bal(p, bal9.data()));
+    ck(c2b_bal_write(a.positional[1].c_str(), hp.n_cam, bal9.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+    c2b_problem_destroy(p);
+    return 0;
+}
+
+// run_ply, src/bin/city2ba.rs:441-445
+int run_ply(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, {}, {"device"});
+    if (a.positional.size() != 2) die("The following required arguments were not provided:\n    <FILE> <OUT>");
+    c2b_balfile *f = nullptr;
+    ck(c2b_bal_read(a.positional[0].c_str(), &f));
+    int64_t n_cam, n_pts, n_obs;
+    ck(c2b_bal_sizes(f, &n_cam, &n_pts, &n_obs));
+    std::vector<double> bal9((size_t)n_cam * 9 + 1), pts((size_t)n_pts * 3 + 1), uv((size_t)n_obs * 2 + 1);
+    std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs + 1);
+    ck(c2b_bal_copy(f, bal9.data(), pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    c2b_bal_close(f);
+    c2b_problem *p = nullptr;
+    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    std::vector<double> centers((size_t)n_cam * 3 + 1);
+    ck(c2b_problem_centers(p, centers.data()));
+    c2b_problem_destroy(p);
+    ck(c2b_ply_write(a.positional[1].c_str(), n_cam, centers.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data()));
+    return 0;
+}
+
 void usage() {
     std::printf("city2ba (MI355X build, %s)\nTools for generating synthetic bundle adjustment problems.\n\n"
                 "USAGE:\n    city2ba <SUBCOMMAND>\n\nSUBCOMMANDS:\n"
                 "    synthetic         Generate a synthetic bundle adjustment problem from an grid of city blocks.\n"
                 "    synthetic-line    Generate a synthetic bundle adjustment problem on a line.\n"
                 "    noise             Add noise to a bundle adjustment problem.\n"
-                "    generate, ply     not provided by this build (Embree / PLY are outside the hot-path scope)\n",
+                "    generate          Generate a synthetic bundle adjustment problem from a 3D model.\n"
+                "    ply               Convert a .bal or .bbal to a .ply for visualization.\n",
                 c2b_version());
 }
 
@@ -267,7 +422,7 @@ int main(int argc, char **argv) {
     if (sub == "synthetic") return run_synthetic(argc, argv);
     if (sub == "synthetic-line") return run_synthetic_line(argc, argv);
     if (sub == "noise") return run_noise(argc, argv);
-    if (sub == "generate" || sub == "ply")
-        die("subcommand '" + sub + "' needs Embree ray casting / PLY export, which this hot-path build does not provide");
+    if (sub == "generate") return run_generate(argc, argv);
+    if (sub == "ply") return run_ply(argc, argv);
     die("The subcommand '" + sub + "' wasn't recognized");
 }

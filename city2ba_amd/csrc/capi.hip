@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "host_baproblem.hpp"
+#include "host_generate.hpp"
 #include "host_synthetic.hpp"
 #include "kernels.hpp"
 
@@ -386,6 +387,18 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
     return C2B_OK;
 }
 
+int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                         int64_t n_obs, const float *tri9, int64_t n_tri, uint8_t *keep, void *stream) {
+    int rc = check_obs_args("occlusion_filter", camblk, pts4, cam_idx, pt_idx, n_obs);
+    if (rc) return rc;
+    if (!n_obs) return C2B_OK;
+    if (!keep || n_tri < 0 || (n_tri && !tri9)) return fail(C2B_ERR_INVALID_ARGUMENT, "occlusion_filter: bad arguments");
+    hipLaunchKernelGGL(k_occlusion, dim3(blocks_for(n_obs)), dim3(kBlock), 0, S(stream), camblk,
+                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, n_obs, tri9, n_tri, keep);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
 int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, void *workspace,
               double *stats, void *stream) {
     if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: bad arguments");
@@ -639,6 +652,124 @@ const uint32_t *c2b_pairs_cam_idx(const c2b_pairs *p) { return p ? p->v.cam.data
 const uint32_t *c2b_pairs_pt_idx(const c2b_pairs *p) { return p ? p->v.pt.data() : nullptr; }
 void c2b_pairs_free(c2b_pairs *p) { delete p; }
 
+/* ---- mesh generator, host side ---- */
+struct c2b_obj {
+    std::vector<c2b_host::ObjModel> models;
+};
+
+int c2b_obj_load(const char *path, c2b_obj **out) {
+    if (!path || !out) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_load: bad arguments");
+    *out = nullptr;
+    c2b_obj *o = new (std::nothrow) c2b_obj();
+    if (!o) return fail(C2B_ERR_OOM, "obj_load: host allocation failed");
+    std::string err;
+    bool ok = false;
+    try {
+        ok = c2b_host::load_obj(path, o->models, &err);
+    } catch (const std::bad_alloc &) {
+        err = "out of host memory";
+    }
+    if (!ok) { delete o; return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str()); }
+    *out = o;
+    return C2B_OK;
+}
+
+int64_t c2b_obj_model_count(const c2b_obj *o) { return o ? (int64_t)o->models.size() : 0; }
+
+const char *c2b_obj_model_name(const c2b_obj *o, int64_t m) {
+    return (o && m >= 0 && m < (int64_t)o->models.size()) ? o->models[(size_t)m].name.c_str() : nullptr;
+}
+
+int c2b_obj_model_sizes(const c2b_obj *o, int64_t m, int64_t *n_positions, int64_t *n_indices, int *is_lines) {
+    if (!o || m < 0 || m >= (int64_t)o->models.size()) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_model_sizes: bad model index");
+    const c2b_host::ObjModel &mod = o->models[(size_t)m];
+    if (n_positions) *n_positions = (int64_t)(mod.positions.size() / 3);
+    if (n_indices) *n_indices = (int64_t)mod.indices.size();
+    if (is_lines) *is_lines = mod.lines ? 1 : 0;
+    return C2B_OK;
+}
+
+int c2b_obj_model_copy(const c2b_obj *o, int64_t m, float *positions3, uint32_t *indices) {
+    if (!o || m < 0 || m >= (int64_t)o->models.size()) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_model_copy: bad model index");
+    const c2b_host::ObjModel &mod = o->models[(size_t)m];
+    if (positions3) std::copy(mod.positions.begin(), mod.positions.end(), positions3);
+    if (indices) std::copy(mod.indices.begin(), mod.indices.end(), indices);
+    return C2B_OK;
+}
+
+int c2b_obj_move_to_origin(c2b_obj *o, int64_t skip_model) {
+    if (!o) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_move_to_origin: obj is NULL");
+    c2b_host::move_to_origin(o->models, skip_model);
+    return C2B_OK;
+}
+
+int c2b_obj_triangles(const c2b_obj *o, int64_t skip_model, float *tri9, int64_t *n_tri) {
+    if (!o || !n_tri) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_triangles: bad arguments");
+    std::vector<c2b_host::ObjModel> use;
+    for (int64_t m = 0; m < (int64_t)o->models.size(); ++m)
+        if (m != skip_model) use.push_back(o->models[(size_t)m]);
+    std::vector<float> t;
+    c2b_host::triangles_of(use, t);
+    *n_tri = (int64_t)(t.size() / 9);
+    if (tri9) std::copy(t.begin(), t.end(), tri9);
+    return C2B_OK;
+}
+
+void c2b_obj_free(c2b_obj *o) { delete o; }
+
+int c2b_generate_cameras_path(const c2b_obj *o, int64_t path_model, int64_t num_cameras, double step_size, uint64_t seed,
+                              double *cam_pos3, double *cam_dir9) {
+    if (!o || path_model < 0 || path_model >= (int64_t)o->models.size() || num_cameras < 0 || (num_cameras && (!cam_pos3 || !cam_dir9)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "generate_cameras_path: bad arguments");
+    const c2b_host::ObjModel &path = o->models[(size_t)path_model];
+    if (!path.lines) return fail(C2B_ERR_INVALID_ARGUMENT, "generate_cameras_path: model '%s' is not a polyline", path.name.c_str());
+    c2b_host::CameraSamples cs;
+    std::string err;
+    double total = 0;
+    const bool ok = step_size <= 0.0 ? c2b_host::cameras_path(path, num_cameras, seed, cs, &err)
+                                     : c2b_host::cameras_path_step(path, num_cameras, step_size, cs, &err, &total);
+    if (!ok) return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    std::copy(cs.pos.begin(), cs.pos.end(), cam_pos3);
+    std::copy(cs.dir.begin(), cs.dir.end(), cam_dir9);
+    return C2B_OK;
+}
+
+int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_points, double height, double ground,
+                                 uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out) {
+    if (!tri9 || n_tri <= 0 || num_points < 0 || capacity < 0 || !n_out || (capacity && (!cam_pos3 || !cam_dir9)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "generate_cameras_poisson: bad arguments");
+    const std::vector<float> tri(tri9, tri9 + 9 * n_tri);
+    c2b_host::CameraSamples cs;
+    c2b_host::cameras_poisson(tri, num_points, height, ground, seed, cs);
+    const int64_t n = std::min<int64_t>((int64_t)cs.size(), capacity);
+    if (n) {
+        std::copy(cs.pos.begin(), cs.pos.begin() + 3 * n, cam_pos3);
+        std::copy(cs.dir.begin(), cs.dir.begin() + 9 * n, cam_dir9);
+    }
+    *n_out = (int64_t)cs.size();
+    return C2B_OK;
+}
+
+int c2b_modify_intrinsics(double *cams15, int64_t n_cam, const double start[3], const double end[3], uint64_t seed) {
+    if (n_cam < 0 || (n_cam && !cams15) || !start || !end) return fail(C2B_ERR_INVALID_ARGUMENT, "modify_intrinsics: bad arguments");
+    c2b_host::modify_intrinsics(cams15, n_cam, start, end, seed);
+    return C2B_OK;
+}
+
+int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *centers3, int64_t n_cam, int64_t num_points,
+                              double max_dist, uint64_t seed, double *pts3, int64_t *n_out) {
+    if (!tri9 || n_tri < 0 || n_cam < 0 || (n_cam && !centers3) || num_points < 0 || !n_out || (num_points && !pts3))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "generate_world_points: bad arguments");
+    const std::vector<float> tri(tri9, tri9 + 9 * n_tri);
+    std::vector<double> pts;
+    std::string err;
+    if (!c2b_host::world_points_uniform(tri, centers3, n_cam, num_points, max_dist, seed, pts, &err))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    std::copy(pts.begin(), pts.end(), pts3);
+    *n_out = (int64_t)(pts.size() / 3);
+    return C2B_OK;
+}
+
 int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
              uint64_t *pt_idx, double *uv, int faithful) {
     if (!n_cam || !n_pts || !row_ptr || *n_cam < 0 || *n_pts < 0 || cam_stride < 0 || (*n_cam && cam_stride && !cams) ||
@@ -744,6 +875,17 @@ int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n
     return C2B_OK;
 }
 
+int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,
+                  const uint64_t *row_ptr, const uint64_t *pt_idx) {
+    if (!path || n_cam < 0 || n_pts < 0 || (n_cam && (!centers3 || !row_ptr)) || (n_pts && !pts3))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "ply_write: bad arguments");
+    if (n_cam && row_ptr[n_cam] && !pt_idx) return fail(C2B_ERR_INVALID_ARGUMENT, "ply_write: pt_idx is NULL");
+    std::string err;
+    if (!c2b_host::write_ply(path, n_cam, centers3, n_pts, pts3, row_ptr, pt_idx, &err))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    return C2B_OK;
+}
+
 /* ------------------------------- level 1 --------------------------------------------- */
 
 struct c2b_problem {
@@ -758,14 +900,21 @@ struct c2b_problem {
     bool blk_valid = false;     // camblk matches cam15 (and bal_valid mode)
     uint32_t *dense_pt = nullptr;   // survivors of the last dense visibility sweep
     double *dense_uv = nullptr;
+    uint64_t *dense_row = nullptr;  // its CSR row pointer [n_cam + 1], kept for the occlusion filter
     int64_t dense_n = 0;
 };
 
+static void free_dense(c2b_problem *p) {
+    if (p->dense_pt) (void)hipFree(p->dense_pt);
+    if (p->dense_uv) (void)hipFree(p->dense_uv);
+    if (p->dense_row) (void)hipFree(p->dense_row);
+    p->dense_pt = nullptr; p->dense_uv = nullptr; p->dense_row = nullptr; p->dense_n = 0;
+}
+
 static void free_buffers(c2b_problem *p) {
-    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar,
-                    p->dense_pt, p->dense_uv};
+    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    p->dense_pt = nullptr; p->dense_uv = nullptr; p->dense_n = 0;
+    free_dense(p);
     p->cam15 = p->bal9 = p->camblk = p->pts4 = p->uv = nullptr;
     p->cam_idx = p->pt_idx = nullptr;
     p->ws = nullptr; p->stats = p->scalar = nullptr;
@@ -1098,9 +1247,7 @@ int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_
     if (!(max_dist >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense: max_dist must be >= 0");
     int rc = ensure_camblk(p);
     if (rc) return rc;
-    if (p->dense_pt) { (void)hipFree(p->dense_pt); p->dense_pt = nullptr; }
-    if (p->dense_uv) { (void)hipFree(p->dense_uv); p->dense_uv = nullptr; }
-    p->dense_n = 0;
+    free_dense(p);
     const int64_t n_tiles = c2b_visibility_dense_tiles(p->n_pts);
     const int64_t cells = p->n_cam * n_tiles;
     if (cells > ((int64_t)1 << 33))
@@ -1125,14 +1272,77 @@ int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_
                                                p->dense_uv, p->stream);
                 if (!rc) e = hipStreamSynchronize(p->stream);
             }
-            if (!rc && e == hipSuccess) p->dense_n = total;
+            if (!rc && e == hipSuccess) { p->dense_n = total; p->dense_row = d_row; d_row = nullptr; }
         }
     }
     if (d_counts) (void)hipFree(d_counts);
     if (d_tot) (void)hipFree(d_tot);
     if (d_row) (void)hipFree(d_row);
+    if (rc || e != hipSuccess) free_dense(p);
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int64_t n_tri, uint64_t *row_ptr) {
+    NEED_UPLOADED(p, "problem_visibility_dense_occlude");
+    if (!p->dense_pt || !p->dense_uv || !p->dense_row)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: no sweep result");
+    if (!row_ptr || n_tri < 0 || (n_tri && !tri9)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: bad arguments");
+    const int64_t n = p->dense_n, n_cam = p->n_cam;
+    std::vector<uint64_t> row((size_t)n_cam + 1);
+    HIP_TRY(hipMemcpyAsync(row.data(), p->dense_row, sizeof(uint64_t) * row.size(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!n || !n_tri) { std::copy(row.begin(), row.end(), row_ptr); return C2B_OK; }
+    float *d_tri = nullptr;
+    uint32_t *d_cam = nullptr;
+    uint8_t *d_keep = nullptr;
+    std::vector<uint8_t> keep((size_t)n);
+    std::vector<uint32_t> pt((size_t)n);
+    std::vector<double> uv((size_t)n * 2);
+    int rc = C2B_OK;
+    hipError_t e = hipMalloc((void **)&d_tri, sizeof(float) * 9 * (size_t)n_tri);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cam, sizeof(uint32_t) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_keep, (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tri, tri9, sizeof(float) * 9 * (size_t)n_tri, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) {
+        rc = c2b_expand_rows(p->dense_row, n_cam, 0, n, d_cam, p->stream);
+        if (!rc) rc = c2b_occlusion_filter(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_tri, n_tri, d_keep, p->stream);
+        if (!rc) {
+            e = hipMemcpyAsync(keep.data(), d_keep, (size_t)n, hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(pt.data(), p->dense_pt, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(uv.data(), p->dense_uv, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, p->stream);
+        }
+        hipError_t e2 = hipStreamSynchronize(p->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    if (!rc && e == hipSuccess) {
+        // stable compaction of the survivor lists (per-camera order of the sweep is kept) and the new row pointer
+        int64_t w = 0;
+        std::vector<uint64_t> nrow((size_t)n_cam + 1, 0);
+        for (int64_t c = 0; c < n_cam; ++c) {
+            nrow[(size_t)c] = (uint64_t)w;
+            for (uint64_t i = row[(size_t)c]; i < row[(size_t)c + 1]; ++i)
+                if (keep[(size_t)i]) {
+                    pt[(size_t)w] = pt[(size_t)i];
+                    uv[2 * (size_t)w] = uv[2 * (size_t)i];
+                    uv[2 * (size_t)w + 1] = uv[2 * (size_t)i + 1];
+                    ++w;
+                }
+        }
+        nrow[(size_t)n_cam] = (uint64_t)w;
+        e = hipMemcpyAsync(p->dense_row, nrow.data(), sizeof(uint64_t) * nrow.size(), hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess && w) e = hipMemcpyAsync(p->dense_pt, pt.data(), sizeof(uint32_t) * (size_t)w, hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess && w) e = hipMemcpyAsync(p->dense_uv, uv.data(), sizeof(double) * 2 * (size_t)w, hipMemcpyHostToDevice, p->stream);
+        hipError_t e2 = hipStreamSynchronize(p->stream);
+        if (e == hipSuccess) e = e2;
+        if (e == hipSuccess) { p->dense_n = w; std::copy(nrow.begin(), nrow.end(), row_ptr); }
+    }
+    if (d_tri) (void)hipFree(d_tri);
+    if (d_cam) (void)hipFree(d_cam);
+    if (d_keep) (void)hipFree(d_keep);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense_occlude: %s", hipGetErrorString(e));
     return C2B_OK;
 }
 

@@ -200,6 +200,47 @@ inline bool write_text(const char *path, const Graph &g, std::string *err) {
     return ok;
 }
 
+inline void fmt_f32(float v, std::string &out) {
+    if (v != v) { out += "NaN"; return; }
+    char buf[128];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    out.append(buf, r.ptr);
+}
+
+// write_cameras, src/bin/city2ba.rs:359-439 (ply-rs ASCII writer: header, then one line per element with the
+// properties in declaration order, space separated)
+inline bool write_ply(const char *path, int64_t n_cam, const double *centers, int64_t n_pts, const double *pts,
+                      const uint64_t *row_ptr, const uint64_t *pt_idx, std::string *err) {
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { *err = std::string("cannot create ") + path; return false; }
+    const uint64_t n_obs = n_cam ? row_ptr[(size_t)n_cam] : 0;
+    std::string s;
+    s.reserve(1 << 20);
+    s += "ply\nformat ascii 1.0\nelement vertex " + std::to_string(n_cam + n_pts) + "\n";
+    s += "property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n";
+    s += "element edge " + std::to_string(n_obs) + "\nproperty int vertex1\nproperty int vertex2\nend_header\n";
+    auto flush = [&](bool force) {
+        if (force || s.size() > (1u << 20)) { std::fwrite(s.data(), 1, s.size(), f); s.clear(); }
+    };
+    auto vertex = [&](const double *p, const char *rgb) {
+        for (int k = 0; k < 3; ++k) { fmt_f32((float)p[k], s); s += ' '; }
+        s += rgb;
+        flush(false);
+    };
+    for (int64_t c = 0; c < n_cam; ++c) vertex(centers + 3 * c, "255 0 0\n");
+    for (int64_t p = 0; p < n_pts; ++p) vertex(pts + 3 * p, "0 255 0\n");
+    for (int64_t c = 0; c < n_cam; ++c)
+        for (uint64_t e = row_ptr[(size_t)c]; e < row_ptr[(size_t)c + 1]; ++e) {
+            s += std::to_string((int32_t)c); s += ' ';
+            s += std::to_string((int32_t)(pt_idx[(size_t)e] + (uint64_t)n_cam)); s += '\n';
+            flush(false);
+        }
+    flush(true);
+    const bool ok = std::fclose(f) == 0;
+    if (!ok) *err = std::string("write failed: ") + path;
+    return ok;
+}
+
 inline void put_be64(std::string &s, uint64_t v) {
     char b[8];
     for (int i = 0; i < 8; ++i) b[i] = (char)(v >> (56 - 8 * i));

@@ -1091,3 +1091,61 @@ __global__ void k_cameras_transform(double *__restrict__ cam15, const double *__
 }
 
 }  // namespace c2b
+
+// ---- occlusion test of the mesh generator: brute-force stand-in for Embree's occluded_stream_aos ---------------
+// (src/generate.rs:455-476).  Per kept observation a f32 ray from the camera centre towards the point, tfar =
+// |dir| - 1e-6; occluded iff any triangle is hit with 0 < t <= tfar.  Triangles are staged 256 at a time in LDS and
+// read by broadcast (every lane tests the same triangle).  Embree's own intersector (BVH traversal order, its
+// watertight / SIMD arithmetic) is not reproducible; rays grazing an edge may be classified differently.
+namespace c2b {
+
+constexpr int kOccTile = 256;     // triangles per LDS round (9 KB)
+
+__global__ __launch_bounds__(kBlock) void k_occlusion(const double *__restrict__ camblk, const double4 *__restrict__ pts4,
+                                                     const uint32_t *__restrict__ cam_idx,
+                                                     const uint32_t *__restrict__ pt_idx, int64_t n,
+                                                     const float *__restrict__ tri9, int64_t n_tri,
+                                                     uint8_t *__restrict__ keep) {
+    __shared__ float sTri[kOccTile * 9];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, tfar = -1.0f;
+    if (valid) {
+        const double *c = camblk + (int64_t)cam_idx[i] * kCamBlk + kCenter;
+        const double4 p = pts4[pt_idx[i]];
+        const double ex = p.x - c[0], ey = p.y - c[1], ez = p.z - c[2];        // point - camera.center()
+        const double mag = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+        const double inv = 1.0 / mag;                                          // dir.normalize() = dir * (1/|dir|)
+        ox = (float)c[0]; oy = (float)c[1]; oz = (float)c[2];
+        dx = (float)(ex * inv); dy = (float)(ey * inv); dz = (float)(ez * inv);
+        tfar = (float)mag - 1e-6f;
+    }
+    bool occluded = false;
+    for (int64_t base = 0; base < n_tri; base += kOccTile) {
+        const int nt = n_tri - base < kOccTile ? (int)(n_tri - base) : kOccTile;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nt * 9; e += kBlock) sTri[e] = tri9[base * 9 + e];
+        __syncthreads();
+        if (!valid || occluded) continue;
+        for (int t = 0; t < nt; ++t) {
+            const float *q = sTri + 9 * t;
+            const float e1x = q[3] - q[0], e1y = q[4] - q[1], e1z = q[5] - q[2];
+            const float e2x = q[6] - q[0], e2y = q[7] - q[1], e2z = q[8] - q[2];
+            const float px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+            const float det = e1x * px + e1y * py + e1z * pz;
+            if (det == 0.0f) continue;
+            const float inv = 1.0f / det;
+            const float tx = ox - q[0], ty = oy - q[1], tz = oz - q[2];
+            const float u = (tx * px + ty * py + tz * pz) * inv;
+            if (u < 0.0f || u > 1.0f) continue;
+            const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+            const float w = (dx * qx + dy * qy + dz * qz) * inv;
+            if (w < 0.0f || u + w > 1.0f) continue;
+            const float th = (e2x * qx + e2y * qy + e2z * qz) * inv;
+            if (th > 0.0f && th <= tfar) { occluded = true; break; }
+        }
+    }
+    if (valid) keep[i] = occluded ? 0 : 1;
+}
+
+}  // namespace c2b

@@ -133,6 +133,13 @@ int c2b_visibility_dense_fill(const double *camblk, int64_t n_cam, const double 
                               double max_dist, const uint32_t *tile_offsets, const uint64_t *row_ptr,
                               uint32_t *pt_idx, double *uv, void *stream);
 
+/* Occlusion test of the mesh generator (src/generate.rs:455-476) with a brute-force stand-in for Embree's
+ * occluded stream: per observation a f32 ray from the camera centre towards the point, tfar = |dir| - 1e-6;
+ * keep[i] = 0 iff some triangle of tri9 [n_tri][9] (device, f32) is hit with 0 < t <= tfar. */
+int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                         const uint32_t *pt_idx, int64_t n_obs, const float *tri9, int64_t n_tri,
+                         uint8_t *keep, void *stream);
+
 /* BAProblem::mean/std/extent/dimensions (src/baproblem.rs:282-337) + add_drift's origin
  * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES]. */
 int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
@@ -217,6 +224,42 @@ const uint32_t *c2b_pairs_cam_idx(const c2b_pairs *p);
 const uint32_t *c2b_pairs_pt_idx(const c2b_pairs *p);
 void c2b_pairs_free(c2b_pairs *p);
 
+/* ---- mesh generator (src/generate.rs), host side.  Embree is replaced by brute-force f32 ray / triangle
+ * tests; every sampler takes a seed where the reference draws from an unseeded thread_rng(). ---- */
+
+/* tobj::load_obj conventions (tobj 0.1.12): one model per `o`/`g` that owns faces or lines, f32 positions
+ * re-indexed per model, polygons fan-triangulated, `l` polylines as index pairs. */
+typedef struct c2b_obj c2b_obj;
+int c2b_obj_load(const char *path, c2b_obj **out);
+int64_t c2b_obj_model_count(const c2b_obj *o);
+const char *c2b_obj_model_name(const c2b_obj *o, int64_t model);
+/* is_lines: 1 when the model is a polyline (indices are segment pairs), 0 for triangles */
+int c2b_obj_model_sizes(const c2b_obj *o, int64_t model, int64_t *n_positions, int64_t *n_indices, int *is_lines);
+int c2b_obj_model_copy(const c2b_obj *o, int64_t model, float *positions3, uint32_t *indices);
+/* move_to_origin (src/generate.rs:484-527), in place, over every model except `skip_model` (-1: none):
+ * run_generate (src/bin/city2ba.rs:493-513) takes the --path model out of the list before the move */
+int c2b_obj_move_to_origin(c2b_obj *o, int64_t skip_model);
+/* triangles of every non-polyline model except `skip_model` (-1: none) as packed f32 [n_tri][9];
+ * call with tri9 == NULL to get the count */
+int c2b_obj_triangles(const c2b_obj *o, int64_t skip_model, float *tri9, int64_t *n_tri);
+void c2b_obj_free(c2b_obj *o);
+
+/* generate_cameras_path (step_size <= 0, src/generate.rs:109-148) / generate_cameras_path_step (:152-213) along
+ * polyline model `path_model`: positions [num_cameras][3], directions [num_cameras][9] (col-major Basis3) */
+int c2b_generate_cameras_path(const c2b_obj *o, int64_t path_model, int64_t num_cameras, double step_size,
+                              uint64_t seed, double *cam_pos3, double *cam_dir9);
+/* generate_cameras_poisson (:217-280) over triangles tri9: Poisson-disk x-z samples, downward ray casts, the
+ * `pt[2] < lower_y + ground` filter of :264, random yaw.  *n_out = the number of cameras generated; the first
+ * min(*n_out, capacity) are written (same seed => same cameras, so call with capacity 0 to size the buffers). */
+int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_points, double height, double ground,
+                                 uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out);
+/* modify_intrinsics (:530-544) */
+int c2b_modify_intrinsics(double *cams15, int64_t n_cam, const double start[3], const double end[3], uint64_t seed);
+/* generate_world_points_uniform (:356-420): area-weighted samples on the triangles that lie within max_dist of
+ * some camera centre; fails like the reference's panics (no cameras / too many rejections) */
+int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *centers3, int64_t n_cam,
+                              int64_t num_points, double max_dist, uint64_t seed, double *pts3, int64_t *n_out);
+
 /* BAProblem::cull (src/baproblem.rs:538-549) = largest_connected_component + remove_singletons to a
  * fixed point, IN PLACE on host arrays (outputs are subsets, so they fit).  Camera rows are opaque
  * `cam_stride` doubles.  On return *n_cam / *n_pts hold the new counts and row_ptr[*n_cam] the new
@@ -237,6 +280,10 @@ void c2b_bal_close(c2b_balfile *f);
 /* BAProblem::write (src/baproblem.rs:768-785); bal9 = to_vec of every camera (c2b_problem_download_bal) */
 int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
                   const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv);
+/* write_cameras of the `ply` subcommand (src/bin/city2ba.rs:359-439): ASCII PLY with one red vertex per camera
+ * centre, one green vertex per point (f32) and one edge per observation (camera, n_cam + point) */
+int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,
+                  const uint64_t *row_ptr, const uint64_t *pt_idx);
 
 /* ===================================================================================== *
  * Level 1 -- a BAProblem resident on one device.  Pointers are HOST pointers; calls are
@@ -281,6 +328,9 @@ int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t
  * uv[row_ptr[n_cam]][2] out (either may be NULL). */
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr);
 int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double *uv);
+/* filter the survivors of the last dense sweep through c2b_occlusion_filter against host triangles
+ * tri9 [n_tri][9] (f32); rewrites row_ptr[n_cam + 1]; a following _fetch returns the filtered lists */
+int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int64_t n_tri, uint64_t *row_ptr);
 int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength, double std,
                           const double dir[3], uint64_t seed);
 int c2b_problem_add_drift_normalized(c2b_problem *p, double strength, double angle_strength,

@@ -1,6 +1,6 @@
 """GPU end-to-end tests that read like the reference's own tests/main.rs: the library tests over
 test_grid() = synthetic_grid(10, 20, 3, 5., 1., 1., 1., 10.) (:130-195), test_line (:197-201) and the CLI
-tests (:11-63) against the C++ command line.  `generate`-based CLI tests (:65-128) need Embree: out of scope."""
+tests (:11-63) against the C++ command line.  The `generate`-based CLI tests (:65-128) are in test_gpu_generate.py."""
 import os
 import subprocess
 
@@ -150,8 +150,8 @@ def test_cli_synthetic_line_and_errors(cli, tmp_path):
     assert r.returncode != 0 and "Block inset" in r.stderr            # assert at src/synthetic.rs:177
     r = _run(cli, "synthetic", tmp_path / "bad.xyz")
     assert r.returncode != 0 and "unknown file extension" in r.stderr
-    r = _run(cli, "generate", "a.obj", "b.bal")
-    assert r.returncode != 0 and "Embree" in r.stderr
+    r = _run(cli, "generate", tmp_path / "a.obj", tmp_path / "b.bal")
+    assert r.returncode != 0 and "Could not open file" in r.stderr     # src/bin/city2ba.rs:482-485
 
 
 def test_cli_noise_equals_python_host_path(c2b, cli, tmp_path):
