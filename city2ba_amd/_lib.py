@@ -85,6 +85,10 @@ SIGNATURES = {
     "c2b_modify_intrinsics": (_int, [_vp, _i64, _vp, _vp, _u64]),
     "c2b_generate_world_points": (_int, [_vp, _i64, _vp, _i64, _i64, _d, _u64, _vp, C.POINTER(_i64)]),
     "c2b_cull": (_int, [C.POINTER(_i64), _vp, _int, C.POINTER(_i64), _vp, _vp, _vp, _vp, _int]),
+    "c2b_add_incorrect_correspondences": (_int, [_i64, _vp, _vp, _vp, _d, _u64]),
+    "c2b_drop_features": (_int, [_i64, _vp, _vp, _vp, _d, _u64]),
+    "c2b_split_landmarks": (_int, [C.POINTER(_i64), _vp, _i64, _i64, _vp, _d, _u64]),
+    "c2b_join_landmarks": (_int, [_i64, _vp, _i64, _vp, _d, _u64]),
     "c2b_bal_read": (_int, [C.c_char_p, C.POINTER(_vp)]),
     "c2b_bal_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "c2b_bal_copy": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

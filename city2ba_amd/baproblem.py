@@ -30,6 +30,7 @@ class BAProblem:
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
+        self._device = int(device)
         L.check(L.lib().c2b_problem_create(int(device), C.byref(self._h)))
         self._row_ptr = np.zeros(1, dtype=np.uint64)
         self._pt_idx = np.zeros(0, dtype=np.uint64)
@@ -226,7 +227,7 @@ class BAProblem:
         row_ptr = self._row_ptr.copy()
         pt_idx = self._pt_idx.copy()
         cams, pts, row_ptr, pt_idx, uv = cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful)
-        return BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv)
+        return BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv, self._device)
 
     @classmethod
     def from_file(cls, path, device=0):

@@ -8,14 +8,15 @@
 //                               --point-offset X --length X]
 //   city2ba noise IN OUT [--rotation-std X --translation-std X --point-std X --observation-std X
 //                         --drift-std X --drift-strength X --fixed-drift --drift-angle X
-//                         --sin-strength X --sin-frequency X] [--seed N]
+//                         --sin-strength X --sin-frequency X --mismatch-chance X --drop-features X
+//                         --split-landmarks X --join-landmarks X] [--seed N]
 //
 //   city2ba generate FILE OUT [--cameras N --intrinsics-start x,y,z --intrinsics-end x,y,z --points N --max-dist X
 //                              --ground X --height X --no-lcc --move-to-origin --path NAME --step-size X] [--seed N]
 //   city2ba ply IN OUT
 //
-// Not provided: the index-shuffling noise flags (--mismatch-chance > 0, --drop-features < 1, --split-landmarks,
-// --join-landmarks).  `generate` casts its rays by brute force over the triangles instead of through Embree.
+// `generate` casts its rays by brute force over the triangles instead of through Embree.  Every random draw is
+// seeded (--seed; default: std::random_device) where the reference uses thread_rng().
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -199,10 +200,6 @@ int run_noise(int argc, char **argv) {
                           "drift-angle", "mismatch-chance", "drop-features", "split-landmarks", "join-landmarks",
                           "sin-strength", "sin-frequency", "seed", "device"});
     if (a.positional.size() != 2) die("The following required arguments were not provided:\n    <FILE> <OUT>");
-    if (a.f("mismatch-chance", 0.0) > 0.0 || a.f("drop-features", 1.0) < 1.0 || a.f("split-landmarks", 0.0) > 0.0 ||
-        a.f("join-landmarks", 0.0) > 0.0)
-        die("--mismatch-chance / --drop-features / --split-landmarks / --join-landmarks are index-shuffling noise "
-            "(src/noise.rs:179-378), outside this build's scope");
     uint64_t seed;
     if (a.has("seed")) seed = (uint64_t)a.i("seed", 0);
     else { std::random_device rd; seed = ((uint64_t)rd() << 32) ^ rd(); }   // the reference: unseeded thread_rng()
@@ -211,8 +208,11 @@ int run_noise(int argc, char **argv) {
     ck(c2b_bal_read(a.positional[0].c_str(), &f));
     int64_t n_cam, n_pts, n_obs;
     ck(c2b_bal_sizes(f, &n_cam, &n_pts, &n_obs));
-    std::vector<double> bal9((size_t)n_cam * 9), pts((size_t)n_pts * 3), uv((size_t)n_obs * 2);
-    std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs);
+    const double split = a.f("split-landmarks", 0.0);
+    // room for the landmarks split_landmarks appends
+    const size_t pts_cap = (size_t)n_pts + (split > 0.0 ? (size_t)(std::min(split, 1.0) * (double)n_pts) + 1 : 0);
+    std::vector<double> bal9((size_t)n_cam * 9 + 1), pts(pts_cap * 3 + 1), uv((size_t)n_obs * 2 + 1);
+    std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs + 1);
     ck(c2b_bal_copy(f, bal9.data(), pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
     c2b_bal_close(f);
 
@@ -223,6 +223,32 @@ int run_noise(int argc, char **argv) {
     ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
     ck(c2b_problem_total_reprojection_error(p, 2.0, &l2));
     std::printf("Initial error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
+
+    // index-corruption passes on the host arrays, each followed by cull() (src/bin/city2ba.rs:288-303); camera rows
+    // stay 9-vectors (cull treats them as opaque)
+    bool reshaped = false;
+    auto cull = [&]() {
+        ck(c2b_cull(&n_cam, bal9.data(), 9, &n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data(), 1));
+        n_obs = (int64_t)row_ptr[(size_t)n_cam];
+        reshaped = true;
+    };
+    if (a.f("drop-features", 1.0) < 1.0) {
+        ck(c2b_drop_features(n_cam, row_ptr.data(), pt_idx.data(), uv.data(), a.f("drop-features", 1.0), seed + 2));
+        cull();
+    }
+    if (a.f("join-landmarks", 0.0) > 0.0) {
+        // the reference passes opt.split_landmarks as the fraction here (src/bin/city2ba.rs:296)
+        ck(c2b_join_landmarks(n_pts, pts.data(), (int64_t)row_ptr[(size_t)n_cam], pt_idx.data(), split, seed + 3));
+        cull();
+    }
+    if (split > 0.0) {
+        ck(c2b_split_landmarks(&n_pts, pts.data(), (int64_t)pts_cap, (int64_t)row_ptr[(size_t)n_cam], pt_idx.data(), split, seed + 4));
+        cull();
+    }
+    if (reshaped) {
+        if (n_cam == 0 || n_pts == 0) die("EmptyProblem: nothing remains after culling");
+        ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    }
 
     // src/bin/city2ba.rs:305-316: drift is ALWAYS applied, even with zero strength
     if (a.has("fixed-drift")) {
@@ -239,13 +265,19 @@ int run_noise(int argc, char **argv) {
     }
     ck(c2b_problem_add_noise(p, a.f("translation-std", 0), a.f("rotation-std", 0), a.f("point-std", 0),
                              a.f("observation-std", 0), seed + 1));      // :334-340, always
+    ck(c2b_problem_download(p, nullptr, pts.data(), uv.data()));
+    if (a.f("mismatch-chance", 0.0) > 0.0) {                             // :341, on the noised image positions
+        std::vector<double> cams15((size_t)n_cam * 15 + 1);
+        ck(c2b_problem_download(p, cams15.data(), nullptr, nullptr));
+        ck(c2b_add_incorrect_correspondences(n_cam, row_ptr.data(), pt_idx.data(), uv.data(), a.f("mismatch-chance", 0.0), seed + 5));
+        ck(c2b_problem_upload(p, n_cam, cams15.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    }
     std::printf("BA Problem with %lld cameras, %lld points, %lld correspondences\n", (long long)n_cam, (long long)n_pts,
                 (long long)n_obs);
     ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
     ck(c2b_problem_total_reprojection_error(p, 2.0, &l2));
     std::printf("Final error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
     ck(c2b_problem_download_bal(p, bal9.data()));
-    ck(c2b_problem_download(p, nullptr, pts.data(), uv.data()));
     ck(c2b_bal_write(a.positional[1].c_str(), n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
     c2b_problem_destroy(p);
     return 0;

@@ -15,6 +15,7 @@
 
 #include "host_baproblem.hpp"
 #include "host_generate.hpp"
+#include "host_noise.hpp"
 #include "host_synthetic.hpp"
 #include "kernels.hpp"
 
@@ -797,6 +798,76 @@ int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, doubl
         *n_pts = c.n_pts;
     } catch (const std::bad_alloc &) {
         return fail(C2B_ERR_OOM, "cull: out of host memory");
+    }
+    return C2B_OK;
+}
+
+/* ---- index-corruption noise, host side ---- */
+static int check_csr(const char *who, int64_t n_cam, const uint64_t *row_ptr) {
+    if (n_cam < 0 || !row_ptr) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: bad arguments", who);
+    if (row_ptr[0] != 0) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: row_ptr[0] != 0", who);
+    for (int64_t c = 0; c < n_cam; ++c)
+        if (row_ptr[c + 1] < row_ptr[c]) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: row_ptr not monotone at camera %lld", who, (long long)c);
+    return C2B_OK;
+}
+
+int c2b_add_incorrect_correspondences(int64_t n_cam, const uint64_t *row_ptr, uint64_t *pt_idx, const double *uv,
+                                      double mismatch_chance, uint64_t seed) {
+    int rc = check_csr("add_incorrect_correspondences", n_cam, row_ptr);
+    if (rc) return rc;
+    if (row_ptr[n_cam] && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_incorrect_correspondences: NULL observations");
+    std::string err;
+    try {
+        if (!c2b_host::add_incorrect_correspondences(n_cam, row_ptr, pt_idx, uv, mismatch_chance, seed, &err))
+            return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    } catch (const std::bad_alloc &) {
+        return fail(C2B_ERR_OOM, "add_incorrect_correspondences: out of host memory");
+    }
+    return C2B_OK;
+}
+
+int c2b_drop_features(int64_t n_cam, uint64_t *row_ptr, uint64_t *pt_idx, double *uv, double keep_fraction, uint64_t seed) {
+    int rc = check_csr("drop_features", n_cam, row_ptr);
+    if (rc) return rc;
+    if (row_ptr[n_cam] && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "drop_features: NULL observations");
+    if (keep_fraction != keep_fraction) return fail(C2B_ERR_INVALID_ARGUMENT, "drop_features: keep_fraction is NaN");
+    try {
+        c2b_host::drop_features(n_cam, row_ptr, pt_idx, uv, keep_fraction, seed);
+    } catch (const std::bad_alloc &) {
+        return fail(C2B_ERR_OOM, "drop_features: out of host memory");
+    }
+    return C2B_OK;
+}
+
+int c2b_split_landmarks(int64_t *n_pts, double *pts3, int64_t pts_capacity, int64_t n_obs, uint64_t *pt_idx,
+                        double split_fraction, uint64_t seed) {
+    if (!n_pts || *n_pts < 0 || n_obs < 0 || (*n_pts && !pts3) || (n_obs && !pt_idx) || split_fraction != split_fraction)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "split_landmarks: bad arguments");
+    const uint64_t n = std::min<uint64_t>(c2b_host::fraction_of(split_fraction, (uint64_t)*n_pts), (uint64_t)*n_pts);
+    if (pts_capacity < *n_pts + (int64_t)n)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "split_landmarks: pts3 holds %lld rows, %lld needed", (long long)pts_capacity,
+                    (long long)(*n_pts + (int64_t)n));
+    for (int64_t o = 0; o < n_obs; ++o)
+        if (pt_idx[o] >= (uint64_t)*n_pts) return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "split_landmarks: point index out of range");
+    try {
+        *n_pts = c2b_host::split_landmarks(*n_pts, pts3, n_obs, pt_idx, split_fraction, seed);
+    } catch (const std::bad_alloc &) {
+        return fail(C2B_ERR_OOM, "split_landmarks: out of host memory");
+    }
+    return C2B_OK;
+}
+
+int c2b_join_landmarks(int64_t n_pts, const double *pts3, int64_t n_obs, uint64_t *pt_idx, double join_fraction, uint64_t seed) {
+    if (n_pts < 0 || n_obs < 0 || (n_pts && !pts3) || (n_obs && !pt_idx) || join_fraction != join_fraction)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "join_landmarks: bad arguments");
+    for (int64_t o = 0; o < n_obs; ++o)
+        if (pt_idx[o] >= (uint64_t)n_pts) return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "join_landmarks: point index out of range");
+    std::string err;
+    try {
+        if (!c2b_host::join_landmarks(n_pts, pts3, n_obs, pt_idx, join_fraction, seed, &err))
+            return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
+    } catch (const std::bad_alloc &) {
+        return fail(C2B_ERR_OOM, "join_landmarks: out of host memory");
     }
     return C2B_OK;
 }

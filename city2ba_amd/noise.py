@@ -33,6 +33,58 @@ def add_noise(bal, translation_std, rotation_std, point_std, observations_std, s
     return bal
 
 
+# ---- index-corruption functions (src/noise.rs:179-378): host-side reshuffles of the visibility graph ------------
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _graph(bal):
+    return (bal.cameras(), bal.points(), bal.row_ptr.astype(np.uint64).copy(), bal.pt_idx.astype(np.uint64).copy(),
+            np.ascontiguousarray(bal.observations(), dtype=np.float64).copy())
+
+
+def _rebuild(bal, cams, pts, row_ptr, pt_idx, uv):
+    from .baproblem import BAProblem
+    return BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv, bal._device)
+
+
+def add_incorrect_correspondences(bal, mismatch_chance, seed=0):
+    """add_incorrect_correspondences (src/noise.rs:180-226); returns a new problem"""
+    cams, pts, row_ptr, pt_idx, uv = _graph(bal)
+    L.check(L.lib().c2b_add_incorrect_correspondences(len(cams), _ptr(row_ptr), _ptr(pt_idx), _ptr(uv),
+                                                      float(mismatch_chance), int(seed)))
+    return _rebuild(bal, cams, pts, row_ptr, pt_idx, uv)
+
+
+def drop_features(bal, drop_percent, seed=0):
+    """drop_features (src/noise.rs:229-251): `drop_percent` is the fraction of each camera's observations KEPT
+    (`l = len * drop_percent`, :238), as in the reference"""
+    cams, pts, row_ptr, pt_idx, uv = _graph(bal)
+    L.check(L.lib().c2b_drop_features(len(cams), _ptr(row_ptr), _ptr(pt_idx), _ptr(uv), float(drop_percent), int(seed)))
+    n = int(row_ptr[-1])
+    return _rebuild(bal, cams, pts, row_ptr, pt_idx[:n].copy(), uv[:n].copy())
+
+
+def split_landmarks(bal, split_percent, seed=0):
+    """split_landmarks (src/noise.rs:255-291)"""
+    cams, pts, row_ptr, pt_idx, uv = _graph(bal)
+    n_pts = len(pts)
+    buf = np.zeros((n_pts + int(max(0.0, split_percent) * n_pts) + 1, 3))
+    buf[:n_pts] = pts
+    n = C.c_int64(n_pts)
+    L.check(L.lib().c2b_split_landmarks(C.byref(n), _ptr(buf), len(buf), len(pt_idx), _ptr(pt_idx), float(split_percent),
+                                        int(seed)))
+    return _rebuild(bal, cams, buf[:n.value].copy(), row_ptr, pt_idx, uv)
+
+
+def join_landmarks(bal, join_percent, seed=0):
+    """join_landmarks (src/noise.rs:326-378)"""
+    cams, pts, row_ptr, pt_idx, uv = _graph(bal)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    L.check(L.lib().c2b_join_landmarks(len(pts), _ptr(pts), len(pt_idx), _ptr(pt_idx), float(join_percent), int(seed)))
+    return _rebuild(bal, cams, pts, row_ptr, pt_idx, uv)
+
+
 def add_sin_noise(ba, dir, noise_dir, strength, frequency):               # noqa: A002
     d, dp = _v3(dir)
     n, np_ = _v3(noise_dir)

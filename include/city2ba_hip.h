@@ -269,6 +269,25 @@ int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *ce
 int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
              uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful);
 
+/* noise.rs' index-corruption functions: sequential random reshuffles of the visibility graph, on the host over
+ * the flat CSR arrays, IN PLACE, seeded (the reference: thread_rng()).
+ * add_incorrect_correspondences (src/noise.rs:180-226): per observation, with probability mismatch_chance, swap
+ *   its point index with a distance-weighted partner of the same camera (weights as at :198-206). */
+int c2b_add_incorrect_correspondences(int64_t n_cam, const uint64_t *row_ptr, uint64_t *pt_idx, const double *uv,
+                                      double mismatch_chance, uint64_t seed);
+/* drop_features (:229-251): per camera keep floor(len * keep_fraction) observations of a random shuffle;
+ *   rewrites row_ptr and compacts pt_idx / uv. */
+int c2b_drop_features(int64_t n_cam, uint64_t *row_ptr, uint64_t *pt_idx, double *uv, double keep_fraction,
+                      uint64_t seed);
+/* split_landmarks (:255-291): floor(split_fraction * *n_pts) landmarks are duplicated at the end of pts3 (which must
+ *   hold pts_capacity >= *n_pts + that many rows) and their observations move to the copy with probability 1/2. */
+int c2b_split_landmarks(int64_t *n_pts, double *pts3, int64_t pts_capacity, int64_t n_obs, uint64_t *pt_idx,
+                        double split_fraction, uint64_t seed);
+/* join_landmarks (:326-378): floor(join_fraction * n_pts) random observations are re-pointed at one of the 10
+ *   nearest other landmarks of their landmark. */
+int c2b_join_landmarks(int64_t n_pts, const double *pts3, int64_t n_obs, uint64_t *pt_idx, double join_fraction,
+                       uint64_t seed);
+
 /* BAProblem::from_file (src/baproblem.rs:697-706): ".bal" text / ".bbal" big-endian binary by extension.
  * Cameras come back as 9-vectors (upload them with c2b_problem_upload_bal = from_vec). */
 typedef struct c2b_balfile c2b_balfile;

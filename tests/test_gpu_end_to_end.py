@@ -71,6 +71,41 @@ def test_noise(c2b):                                 # tests/main.rs:143-150
     assert ba.total_reprojection_error(2.0) > err_start
 
 
+def test_incorrect_correspondences(c2b):             # tests/main.rs:152-159
+    ba = make_test_grid(c2b)
+    err_start = ba.total_reprojection_error(2.0)
+    out = c2b.noise.add_incorrect_correspondences(ba, 0.01, seed=3)
+    assert out.total_reprojection_error(2.0) > err_start
+    assert out.num_observations() == ba.num_observations() and np.array_equal(out.observations(), ba.observations())
+
+
+def test_drop_features(c2b):                         # tests/main.rs:161-168
+    ba = make_test_grid(c2b)
+    err_start = ba.total_reprojection_error(2.0)
+    out = c2b.noise.drop_features(ba, 0.1, seed=3)
+    assert out.total_reprojection_error(2.0) >= err_start
+    want = np.floor(np.diff(ba.row_ptr.astype(np.int64)) * 0.1).astype(np.int64)
+    assert np.array_equal(np.diff(out.row_ptr.astype(np.int64)), want)
+    assert out.total_reprojection_error(2.0) == 0.0      # kept observations are still exact projections
+
+
+def test_split_landmarks(c2b):                       # tests/main.rs:170-177
+    ba = make_test_grid(c2b)
+    err_start = ba.total_reprojection_error(2.0)
+    out = c2b.noise.split_landmarks(ba, 0.1, seed=3)
+    assert out.total_reprojection_error(2.0) >= err_start
+    assert out.num_points() == ba.num_points() + int(0.1 * ba.num_points())
+    assert out.total_reprojection_error(2.0) == 0.0      # copies sit on their sources
+
+
+def test_join_landmarks(c2b):                        # tests/main.rs:179-186
+    ba = make_test_grid(c2b)
+    err_start = ba.total_reprojection_error(2.0)
+    out = c2b.noise.join_landmarks(ba, 0.01, seed=3)
+    assert out.total_reprojection_error(2.0) > err_start
+    assert int((out.pt_idx != ba.pt_idx).sum()) == int(0.01 * ba.num_points())
+
+
 def test_sin_noise(c2b):                             # tests/main.rs:188-195
     ba = make_test_grid(c2b)
     err_start = ba.total_reprojection_error(2.0)
@@ -133,14 +168,43 @@ def test_cli_noise_blocks(cli, tmp_path):            # noise_blocks, :37-63
     bbal = tmp_path / "blocks.bbal"
     r = _run(cli, "synthetic", bbal)
     assert r.returncode == 0 and "Bundle Adjustment Problem" in r.stdout
-    # the reference test also passes --mismatch-chance 0.00001 (index-shuffling noise: out of scope here)
-    r = _run(cli, "noise", bbal, tmp_path / "blocks_noised.bbal", "--drift-strength", "0.00001", "--seed", "3")
+    r = _run(cli, "noise", bbal, tmp_path / "blocks_noised.bbal", "--drift-strength", "0.00001",
+             "--mismatch-chance", "0.00001", "--seed", "3")
     assert r.returncode == 0, r.stderr
     assert "Initial error" in r.stdout and "Final error" in r.stdout
     assert "Initial error: 0.00e0 (L1) 0.00e0 (L2)" in r.stdout
     assert os.path.getsize(tmp_path / "blocks_noised.bbal") == os.path.getsize(bbal)
-    r2 = _run(cli, "noise", bbal, tmp_path / "x.bbal", "--mismatch-chance", "0.00001")
-    assert r2.returncode != 0 and "outside this build's scope" in r2.stderr
+
+
+def test_cli_noise_index_corruption_flags(c2b, cli, tmp_path):
+    """run_noise's optional passes (src/bin/city2ba.rs:288-303, :341): drop -> cull, join -> cull, split -> cull
+    before the arithmetic noise, mismatches after it"""
+    src = tmp_path / "g.bbal"
+    assert _run(cli, "synthetic", src, "--blocks", "3", "--points-per-block", "20").returncode == 0
+    ba = c2b.BAProblem.from_file(src)
+    out = tmp_path / "n.bbal"
+    r = _run(cli, "noise", src, out, "--drop-features", "0.8", "--split-landmarks", "0.1", "--join-landmarks", "0.05",
+             "--mismatch-chance", "0.05", "--seed", "11")
+    assert r.returncode == 0, r.stderr
+    got = c2b.BAProblem.from_file(out)
+    assert ("BA Problem with %d cameras, %d points, %d correspondences" % (got.num_cameras(), got.num_points(), got.num_observations())) in r.stdout
+    assert got.num_observations() < ba.num_observations()                    # 20 % dropped, then culled
+    assert got.num_points() != ba.num_points()                               # split adds, cull removes
+    assert np.all(np.diff(got.row_ptr.astype(np.int64)) > 3)                 # cull post-conditions hold
+    assert np.all(np.bincount(got.pt_idx.astype(np.int64), minlength=got.num_points()) > 1)
+    l2 = got.total_reprojection_error(2.0)
+    assert l2 > 0 and ("Final error: " in r.stdout)                          # joins / mismatches break projections
+    # the same pipeline from the Python host mirror with the CLI's seed assignment gives the same problem
+    from city2ba_amd import noise as N
+    b = N.drop_features(ba, 0.8, seed=11 + 2).cull()
+    b = N.join_landmarks(b, 0.1, seed=11 + 3).cull()                         # the reference passes split_landmarks here (:296)
+    b = N.split_landmarks(b, 0.1, seed=11 + 4).cull()
+    b = N.add_drift_normalized(b, 0.0, 0.0, 0.0, seed=11)
+    b = N.add_noise(b, 0.0, 0.0, 0.0, 0.0, seed=12)
+    b = N.add_incorrect_correspondences(b, 0.05, seed=11 + 5)
+    assert str(b) == str(got)
+    assert np.array_equal(b.row_ptr, got.row_ptr) and np.array_equal(b.pt_idx, got.pt_idx)
+    assert np.array_equal(b.points(), got.points()) and np.array_equal(b.observations(), got.observations())
 
 
 def test_cli_synthetic_line_and_errors(cli, tmp_path):
