@@ -13,6 +13,9 @@
 //
 //   city2ba generate FILE OUT [--cameras N --intrinsics-start x,y,z --intrinsics-end x,y,z --points N --max-dist X
 //                              --ground X --height X --no-lcc --move-to-origin --path NAME --step-size X] [--seed N]
+//                             [--exact-lcc]   (extension: cull without the reference's observation-filter quirk at
+//                                              src/baproblem.rs:523, which discards most observations whenever the
+//                                              graph holds unseen points)
 //   city2ba ply IN OUT
 //
 // `generate` casts its rays by brute force over the triangles instead of through Embree.  Every random draw is
@@ -312,7 +315,7 @@ std::string display_f64(double v) {
 // run_generate, src/bin/city2ba.rs:480-573.  Ray casts: brute force over the mesh's triangles (host for camera
 // placement, the device occlusion kernel for the visibility graph) in place of Embree.
 int run_generate(int argc, char **argv) {
-    const Args a = parse(argc, argv, 2, {"no-lcc", "move-to-origin"},
+    const Args a = parse(argc, argv, 2, {"no-lcc", "move-to-origin", "exact-lcc"},
                          {"cameras", "intrinsics-start", "intrinsics-end", "points", "max-dist", "ground", "height", "path",
                           "step-size", "seed", "device"});
     if (a.positional.size() != 2) die("The following required arguments were not provided:\n    <FILE> <OUT>");
@@ -390,7 +393,8 @@ int run_generate(int argc, char **argv) {
     std::printf("Computed visibility graph with %zu edges\n", n_edges);
 
     if (!a.has("no-lcc"))
-        ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(), 1));
+        ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(),
+                    a.has("exact-lcc") ? 0 : 1));
     if (hp.n_cam == 0 || hp.n_pts == 0) die("EmptyProblem(\"No cameras remain\")");
     hp.cams15.resize((size_t)hp.n_cam * 15);
     hp.pts.resize((size_t)hp.n_pts * 3);

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "host_baproblem.hpp"
+#include "host_bvh.hpp"
 #include "host_generate.hpp"
 #include "host_noise.hpp"
 #include "host_synthetic.hpp"
@@ -396,6 +397,66 @@ int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_
     if (!keep || n_tri < 0 || (n_tri && !tri9)) return fail(C2B_ERR_INVALID_ARGUMENT, "occlusion_filter: bad arguments");
     hipLaunchKernelGGL(k_occlusion, dim3(blocks_for(n_obs)), dim3(kBlock), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, n_obs, tri9, n_tri, keep);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+struct c2b_bvh {
+    c2b_host::Bvh b;
+};
+
+int c2b_bvh_build(const float *tri9, int64_t n_tri, c2b_bvh **out) {
+    if (!out || n_tri < 0 || (n_tri && !tri9)) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_build: bad arguments");
+    *out = nullptr;
+    if (n_tri >= ((int64_t)1 << 28)) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_build: more than 2^28 triangles");
+    for (int64_t k = 0; k < 9 * n_tri; ++k)
+        if (!std::isfinite(tri9[k])) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_build: triangle %lld is not finite", (long long)(k / 9));
+    c2b_bvh *h = new (std::nothrow) c2b_bvh();
+    if (!h) return fail(C2B_ERR_OOM, "bvh_build: host allocation failed");
+    try {
+        c2b_host::bvh_build(tri9, n_tri, h->b);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return fail(C2B_ERR_OOM, "bvh_build: out of host memory");
+    }
+    if (h->b.depth >= kBvhStack) {
+        const int d = h->b.depth;
+        delete h;
+        return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_build: hierarchy depth %d exceeds the traversal stack", d);
+    }
+    *out = h;
+    return C2B_OK;
+}
+
+int c2b_bvh_sizes(const c2b_bvh *b, int64_t *n_nodes, int64_t *n_slots, int *depth) {
+    if (!b) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_sizes: bvh is NULL");
+    if (n_nodes) *n_nodes = (int64_t)b->b.nodes.size();
+    if (n_slots) *n_slots = (int64_t)b->b.order.size();
+    if (depth) *depth = b->b.depth;
+    return C2B_OK;
+}
+
+int c2b_bvh_copy(const c2b_bvh *b, void *nodes, void *tris, uint32_t *order) {
+    if (!b) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_copy: bvh is NULL");
+    if (nodes) std::memcpy(nodes, b->b.nodes.data(), b->b.nodes.size() * sizeof(c2b_host::BvhNode));
+    if (tris && !b->b.tris.empty()) std::memcpy(tris, b->b.tris.data(), b->b.tris.size() * sizeof(float));
+    if (order && !b->b.order.empty()) std::memcpy(order, b->b.order.data(), b->b.order.size() * sizeof(uint32_t));
+    return C2B_OK;
+}
+
+void c2b_bvh_free(c2b_bvh *b) { delete b; }
+
+int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                             int64_t n_obs, const void *nodes, int64_t n_nodes, const void *tris, int64_t n_slots,
+                             uint8_t *keep, void *stream) {
+    int rc = check_obs_args("occlusion_filter_bvh", camblk, pts4, cam_idx, pt_idx, n_obs);
+    if (rc) return rc;
+    if (!n_obs) return C2B_OK;
+    if (!keep || !nodes || n_nodes < 1 || n_slots < 0 || (n_slots && !tris) || !aligned16(nodes) || (tris && !aligned16(tris)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "occlusion_filter_bvh: NULL/misaligned buffer");
+    hipLaunchKernelGGL(k_occlusion_bvh, dim3(blocks_for(n_obs)), dim3(kBlock), 0, S(stream), camblk,
+                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, n_obs, reinterpret_cast<const float4 *>(nodes),
+                       reinterpret_cast<const float4 *>(tris), keep);
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -1372,13 +1433,30 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
     std::vector<uint32_t> pt((size_t)n);
     std::vector<double> uv((size_t)n * 2);
     int rc = C2B_OK;
-    hipError_t e = hipMalloc((void **)&d_tri, sizeof(float) * 9 * (size_t)n_tri);
+    // small meshes: every ray against every triangle; larger ones through a hierarchy built here on the host
+    const bool use_bvh = n_tri >= kBvhMinTriangles;
+    c2b_bvh *bvh = nullptr;
+    void *d_nodes = nullptr;
+    int64_t n_nodes = 0;
+    if (use_bvh) {
+        rc = c2b_bvh_build(tri9, n_tri, &bvh);
+        if (rc) return rc;
+        n_nodes = (int64_t)bvh->b.nodes.size();
+    }
+    const size_t tri_bytes = use_bvh ? (size_t)C2B_BVH_TRI_BYTES * (size_t)n_tri : sizeof(float) * 9 * (size_t)n_tri;
+    const void *tri_src = use_bvh ? (const void *)bvh->b.tris.data() : (const void *)tri9;
+    hipError_t e = hipMalloc((void **)&d_tri, tri_bytes);
+    if (e == hipSuccess && use_bvh) e = hipMalloc(&d_nodes, (size_t)C2B_BVH_NODE_BYTES * (size_t)n_nodes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_cam, sizeof(uint32_t) * (size_t)n);
     if (e == hipSuccess) e = hipMalloc((void **)&d_keep, (size_t)n);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tri, tri9, sizeof(float) * 9 * (size_t)n_tri, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tri, tri_src, tri_bytes, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess && use_bvh)
+        e = hipMemcpyAsync(d_nodes, bvh->b.nodes.data(), (size_t)C2B_BVH_NODE_BYTES * (size_t)n_nodes, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) {
         rc = c2b_expand_rows(p->dense_row, n_cam, 0, n, d_cam, p->stream);
-        if (!rc) rc = c2b_occlusion_filter(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_tri, n_tri, d_keep, p->stream);
+        if (!rc)
+            rc = use_bvh ? c2b_occlusion_filter_bvh(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_nodes, n_nodes, d_tri, n_tri, d_keep, p->stream)
+                         : c2b_occlusion_filter(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_tri, n_tri, d_keep, p->stream);
         if (!rc) {
             e = hipMemcpyAsync(keep.data(), d_keep, (size_t)n, hipMemcpyDeviceToHost, p->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(pt.data(), p->dense_pt, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, p->stream);
@@ -1410,8 +1488,10 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
         if (e == hipSuccess) { p->dense_n = w; std::copy(nrow.begin(), nrow.end(), row_ptr); }
     }
     if (d_tri) (void)hipFree(d_tri);
+    if (d_nodes) (void)hipFree(d_nodes);
     if (d_cam) (void)hipFree(d_cam);
     if (d_keep) (void)hipFree(d_keep);
+    c2b_bvh_free(bvh);
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense_occlude: %s", hipGetErrorString(e));
     return C2B_OK;

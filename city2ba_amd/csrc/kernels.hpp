@@ -1148,4 +1148,100 @@ __global__ __launch_bounds__(kBlock) void k_occlusion(const double *__restrict__
     if (valid) keep[i] = occluded ? 0 : 1;
 }
 
+// The same rays through the host-built hierarchy (csrc/host_bvh.hpp): one 64-byte node (both children's boxes) per
+// step, per-lane traversal stack, first hit ends the ray.  Leaves run the triangle test of k_occlusion on
+// (v0, e1, e2) rows whose edges were subtracted in float32 on the host, i.e. the same values; boxes are inflated
+// and compared with slack, so the hierarchy prunes without changing the answer.
+constexpr int kBvhStack = 64;
+constexpr int kBvhMinTriangles = 64;     // Level 1 switches from the all-triangles loop to the hierarchy here
+constexpr int kBvhEmptyChild = INT32_MIN;
+
+__device__ __forceinline__ bool bvh_box_hit(const float lo[3], const float hi[3], float ox, float oy, float oz, float ix,
+                                            float iy, float iz, float tfar, float &tnear) {
+    // fminf / fmaxf drop a NaN operand ((lo - o) * inf with lo == o): that slab then does not constrain
+    const float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
+    const float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
+    const float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    tnear = tn;
+    return tn <= tf * 1.00001f + 1e-30f && tf >= 0.0f && tn <= tfar;
+}
+
+__global__ __launch_bounds__(kBlock) void k_occlusion_bvh(const double *__restrict__ camblk, const double4 *__restrict__ pts4,
+                                                         const uint32_t *__restrict__ cam_idx,
+                                                         const uint32_t *__restrict__ pt_idx, int64_t n,
+                                                         const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
+                                                         uint8_t *__restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double *c = camblk + (int64_t)cam_idx[i] * kCamBlk + kCenter;
+    const double4 p = pts4[pt_idx[i]];
+    const double ex = p.x - c[0], ey = p.y - c[1], ez = p.z - c[2];
+    const double mag = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+    const double inv = 1.0 / mag;
+    const float ox = (float)c[0], oy = (float)c[1], oz = (float)c[2];
+    const float dx = (float)(ex * inv), dy = (float)(ey * inv), dz = (float)(ez * inv);
+    const float tfar = (float)mag - 1e-6f;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    int stack[kBvhStack];
+    int sp = 0;
+    int node = 0;
+    bool occluded = false;
+    while (true) {
+        const float4 n0 = nodes[4 * (int64_t)node], n1 = nodes[4 * (int64_t)node + 1], n2 = nodes[4 * (int64_t)node + 2],
+                     n3 = nodes[4 * (int64_t)node + 3];
+        const float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
+        const float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
+        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+        float t0, t1;
+        const bool h0 = c0 != kBvhEmptyChild && bvh_box_hit(lo0, hi0, ox, oy, oz, ix, iy, iz, tfar, t0);
+        const bool h1 = c1 != kBvhEmptyChild && bvh_box_hit(lo1, hi1, ox, oy, oz, ix, iy, iz, tfar, t1);
+        int next = -1;                                   // inner node to descend into
+        int other = -1;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool h = side ? h1 : h0;
+            const int ch = side ? c1 : c0;
+            if (!h) continue;
+            if (ch >= 0) {
+                if (next < 0) next = ch; else other = ch;
+                continue;
+            }
+            const unsigned code = (unsigned)~ch;
+            const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+            for (int s = first; s < first + cnt && !occluded; ++s) {
+                const float4 q0 = tris[3 * (int64_t)s], q1 = tris[3 * (int64_t)s + 1], q2 = tris[3 * (int64_t)s + 2];
+                const float v0x = q0.x, v0y = q0.y, v0z = q0.z, e1x = q0.w, e1y = q1.x, e1z = q1.y, e2x = q1.z, e2y = q1.w,
+                            e2z = q2.x;
+                const float px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+                const float det = e1x * px + e1y * py + e1z * pz;
+                if (det == 0.0f) continue;
+                const float idet = 1.0f / det;
+                const float tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+                const float u = (tx * px + ty * py + tz * pz) * idet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+                const float w = (dx * qx + dy * qy + dz * qz) * idet;
+                if (w < 0.0f || u + w > 1.0f) continue;
+                const float th = (e2x * qx + e2y * qy + e2z * qz) * idet;
+                if (th > 0.0f && th <= tfar) occluded = true;
+            }
+        }
+        if (occluded) break;
+        if (next >= 0) {
+            if (other >= 0) {
+                // both children are inner nodes: nearer first
+                if (t1 < t0) { const int tmp = next; next = other; other = tmp; }
+                if (sp < kBvhStack) stack[sp++] = other;
+            }
+            node = next;
+        } else {
+            if (!sp) break;
+            node = stack[--sp];
+        }
+    }
+    keep[i] = occluded ? 0 : 1;
+}
+
 }  // namespace c2b

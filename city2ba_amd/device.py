@@ -112,6 +112,42 @@ def visibility_pairs(camblk, pts4, cam_idx, pt_idx, max_dist, uv_out, keep):
                                          float(max_dist), _p(uv_out), _p(keep), _stream()))
 
 
+def occlusion_filter(camblk, pts4, cam_idx, pt_idx, tri9, keep):
+    """occlusion rays of visibility_graph (src/generate.rs:455-476) against f32 triangles [n,9], brute force"""
+    _chk(tri9, torch.float32, "tri9")
+    L.check(L.lib().c2b_occlusion_filter(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), cam_idx.shape[0], _p(tri9),
+                                         tri9.shape[0], _p(keep), _stream()))
+
+
+class OcclusionBVH:
+    """host-built hierarchy over f32 triangles [n,9] placed in device memory; filter() = occlusion_filter through it"""
+
+    def __init__(self, tri9, device):
+        import numpy as np
+        tri = np.ascontiguousarray(tri9, dtype=np.float32).reshape(-1, 9)
+        h = C.c_void_p()
+        L.check(L.lib().c2b_bvh_build(tri.ctypes.data_as(C.c_void_p), len(tri), C.byref(h)))
+        try:
+            nn, ns, depth = C.c_int64(), C.c_int64(), C.c_int()
+            L.check(L.lib().c2b_bvh_sizes(h, C.byref(nn), C.byref(ns), C.byref(depth)))
+            self.n_nodes, self.n_slots, self.depth = nn.value, ns.value, depth.value
+            nodes = np.empty((self.n_nodes, 16), dtype=np.float32)
+            tris = np.empty((max(self.n_slots, 1), 12), dtype=np.float32)
+            self.order = np.empty(self.n_slots, dtype=np.uint32)
+            L.check(L.lib().c2b_bvh_copy(h, nodes.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p),
+                                         self.order.ctypes.data_as(C.c_void_p)))
+        finally:
+            L.lib().c2b_bvh_free(h)
+        self.nodes_host = nodes
+        self.nodes = torch.from_numpy(nodes).to(device)
+        self.tris = torch.from_numpy(tris).to(device)
+
+    def filter(self, camblk, pts4, cam_idx, pt_idx, keep):
+        L.check(L.lib().c2b_occlusion_filter_bvh(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), cam_idx.shape[0],
+                                                 _p(self.nodes), self.n_nodes, _p(self.tris), self.n_slots, _p(keep),
+                                                 _stream()))
+
+
 def stats(camblk, pts4, ws, out=None):
     out = out if out is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=camblk.device)
     L.check(L.lib().c2b_stats(_p(camblk), camblk.shape[0], _p(pts4), pts4.shape[0], _p(ws), _p(out), _stream()))

@@ -112,9 +112,10 @@ def generate_world_points_uniform(triangles, centers, num_points, max_dist, seed
 
 def generate(path, num_cameras=100, num_world_points=1000, max_dist=100.0, intrinsics_start=(1.0, 0.0, 0.0),
              intrinsics_end=(1.0, 0.0, 0.0), ground=0.0, height=1.0, no_lcc=False, move_to_origin=False, path_name=None,
-             step_size=0.0, seed=0, device=0):
+             step_size=0.0, seed=0, device=0, faithful=True):
     """run_generate (src/bin/city2ba.rs:480-573) as a library call; returns the BAProblem.  Seeds: cameras `seed`,
-    intrinsics `seed + 1`, points `seed + 2` (the C++ CLI uses the same assignment)."""
+    intrinsics `seed + 1`, points `seed + 2` (the C++ CLI uses the same assignment).  faithful=False culls without
+    the reference's observation-filter quirk (src/baproblem.rs:523; the CLI's --exact-lcc)."""
     from .baproblem import BAProblem
     obj = ObjFile(path)
     pm = -1
@@ -143,7 +144,7 @@ def generate(path, num_cameras=100, num_world_points=1000, max_dist=100.0, intri
     row_ptr, pt_idx, uv = ba.visibility_graph(max_dist, triangles=tri)
     ba = BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv, device)
     if not no_lcc:
-        ba = ba.cull()
+        ba = ba.cull(faithful)
     if ba.num_cameras() == 0 or ba.num_points() == 0:
         raise L.City2baError(L.ERR_INVALID_ARGUMENT, "EmptyProblem: No cameras remain")
     return ba

@@ -139,6 +139,22 @@ int c2b_visibility_dense_fill(const double *camblk, int64_t n_cam, const double 
 int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                          const uint32_t *pt_idx, int64_t n_obs, const float *tri9, int64_t n_tri,
                          uint8_t *keep, void *stream);
+/* The same filter through a bounding-volume hierarchy, for meshes too large for the all-triangles loop (the
+ * reference commits its meshes to an Embree scene, src/bin/city2ba.rs:515-521).  c2b_bvh_build runs on the HOST
+ * over host triangles; c2b_bvh_copy fills host buffers of n_nodes * C2B_BVH_NODE_BYTES and n_slots *
+ * C2B_BVH_TRI_BYTES bytes (and, optionally, order[n_slots] = input triangle of each slot) for the caller to place
+ * in device memory (16-byte aligned); c2b_occlusion_filter_bvh traverses them.  Leaves run the triangle test of
+ * c2b_occlusion_filter, so both filters return the same mask. */
+#define C2B_BVH_NODE_BYTES 64
+#define C2B_BVH_TRI_BYTES 48
+typedef struct c2b_bvh c2b_bvh;
+int c2b_bvh_build(const float *tri9, int64_t n_tri, c2b_bvh **out);
+int c2b_bvh_sizes(const c2b_bvh *b, int64_t *n_nodes, int64_t *n_slots, int *depth);
+int c2b_bvh_copy(const c2b_bvh *b, void *nodes, void *tris, uint32_t *order);
+void c2b_bvh_free(c2b_bvh *b);
+int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                             const uint32_t *pt_idx, int64_t n_obs, const void *nodes, int64_t n_nodes,
+                             const void *tris, int64_t n_slots, uint8_t *keep, void *stream);
 
 /* BAProblem::mean/std/extent/dimensions (src/baproblem.rs:282-337) + add_drift's origin
  * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES]. */

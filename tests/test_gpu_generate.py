@@ -112,6 +112,58 @@ def test_visibility_graph_with_occlusion(c2b, seed, n_tri):
     assert np.array_equal(row2, row0) and np.array_equal(pi2, pi0)
 
 
+def test_bvh_filter_equals_all_triangles_filter(c2b):
+    """Level 0: the hierarchy only prunes -- the mask equals the all-triangles kernel's on random soups of mixed
+    scale (incl. axis-aligned triangles and rays) and on a city-block mesh with the synthetic grid's own rays"""
+    import torch
+    from city2ba_amd import device as D
+    from city2ba_amd import synthetic as S
+    dev = torch.device("cuda", 0)
+    for seed, n_tri in ((4, 65), (5, 5000), (6, 60000)):
+        cams, pts, _ = scene(seed, n_cam=64, n_pts=3000, n_tri=1)
+        rng = np.random.default_rng(seed)
+        a = rng.uniform(-5, 5, (n_tri, 3))
+        size = rng.choice([0.05, 0.4, 3.0], n_tri, p=[0.6, 0.3, 0.1])[:, None] * min(1.0, (300.0 / n_tri) ** 0.5)
+        tri = np.concatenate([a, a + rng.normal(0, 1, (n_tri, 3)) * size, a + rng.normal(0, 1, (n_tri, 3)) * size], axis=1).astype(f32)
+        tri[: n_tri // 10, [1, 4, 7]] = f32(0.5)                              # horizontal triangles: zero-height boxes
+        pts[:200, 1] = O.centers(cams)[np.arange(200) % len(cams), 1]          # rays with dy == 0 exactly
+        camblk = D.cameras_prepare_state(torch.from_numpy(cams).to(dev))
+        pts4 = D.points_pad(torch.from_numpy(pts).to(dev))
+        ci = torch.from_numpy(np.repeat(np.arange(len(cams)), len(pts)).astype(np.int32)).to(dev)
+        pi = torch.from_numpy(np.tile(np.arange(len(pts)), len(cams)).astype(np.int32)).to(dev)
+        brute = torch.empty(len(ci), dtype=torch.uint8, device=dev)
+        D.occlusion_filter(camblk, pts4, ci, pi, torch.from_numpy(tri).to(dev), brute)
+        bvh = D.OcclusionBVH(tri, dev)
+        got = torch.full((len(ci),), 7, dtype=torch.uint8, device=dev)
+        bvh.filter(camblk, pts4, ci, pi, got)
+        assert bvh.depth < 64 and sorted(bvh.order.tolist()) == list(range(n_tri))
+        assert torch.equal(got, brute)
+        frac = float(brute.float().mean())
+        assert 0.0 < frac < 1.0
+    # city blocks (one box per block) against the grid generator's own cameras and points
+    B, L, inset = 6, 20.0, 1.0
+    pos, dirs, gpts = S.grid_layout(B, 10, 10, L, inset, 1.0, 1.0)
+    cam15 = D.cameras_from_position_direction(torch.from_numpy(pos).to(dev), torch.from_numpy(dirs).to(dev))
+    camblk = D.cameras_prepare_state(cam15)
+    pts4 = D.points_pad(torch.from_numpy(gpts).to(dev))
+    ci, pi = S.candidate_pairs(camblk[:, 24:27].cpu().numpy(), gpts, 10.0)
+    ci_d, pi_d = torch.from_numpy(ci.astype(np.int32)).to(dev), torch.from_numpy(pi.astype(np.int32)).to(dev)
+    boxes = []
+    for bx in range(B):
+        for bz in range(B):
+            x0, x1, z0, z1 = L * bx + inset, L * (bx + 1) - inset, L * bz + inset, L * (bz + 1) - inset   # facades ON the points
+            c = [(x0, -1, z0), (x1, -1, z0), (x1, -1, z1), (x0, -1, z1), (x0, 9, z0), (x1, 9, z0), (x1, 9, z1), (x0, 9, z1)]
+            for q in ((0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7), (4, 5, 6, 7), (0, 3, 2, 1)):
+                boxes.append(c[q[0]] + c[q[1]] + c[q[2]])
+                boxes.append(c[q[0]] + c[q[2]] + c[q[3]])
+    tri = np.array(boxes, dtype=f32)
+    brute = torch.empty(len(ci), dtype=torch.uint8, device=dev)
+    D.occlusion_filter(camblk, pts4, ci_d, pi_d, torch.from_numpy(tri).to(dev), brute)
+    got = torch.empty_like(brute)
+    D.OcclusionBVH(tri, dev).filter(camblk, pts4, ci_d, pi_d, got)
+    assert torch.equal(got, brute) and 0.2 < float(brute.float().mean()) < 0.95
+
+
 def test_occlusion_wall(c2b):
     """one camera at the origin looking down -z, a wall at z = -2 covering x < 0: points behind the wall on that
     side are dropped, points in front of it or on the open side are kept; a point ON the wall is its own occluder
