@@ -344,7 +344,7 @@ def main():
                 "total_L2_error": total_err,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_residual_jacobian_w<true,8,2,true,0,2>", "achieved": round(achieved, 1),
+                "bound": "hbm", "kernel": "k_residual_jacobian_w<true,8,2,true,0,2,true>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic() if (world == 1 and args.blocks == 128) else None,
                 "algorithmic_bytes_per_launch": alg, "observations_per_launch": n,

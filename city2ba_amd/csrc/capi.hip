@@ -59,7 +59,41 @@ constexpr int64_t kWsStatsDoubles = (int64_t)kRedBlocks * kStatRec;
 constexpr int64_t kWsPartials = kWsStatsDoubles + kSumBlocks;
 
 // residual+Jacobian kernel variant (tuning knob of tools/tune_jac.py, not part of the ABI): see launch_jacobian
-int g_jac_variant = 13;
+int g_jac_variant = 14;
+// light per-observation kernels: observations per lane * 100 + waves per workgroup, + 1000 = camera reads through
+// LDS-only pointers (tools/tune_obs.py)
+int g_obs_variant = 1208;
+
+template <int MODE, int OPL, int WPB, bool LDSCAM = false>
+void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                  const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
+                  double *partials, hipStream_t st) {
+    const int64_t tiles = ((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL);
+    hipLaunchKernelGGL((k_observations<MODE, OPL, WPB, LDSCAM>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st, camblk,
+                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, reinterpret_cast<const double2 *>(uv_obs), n,
+                       tiles, norm, max_dist, reinterpret_cast<double2 *>(uv_out), keep, partials);
+}
+
+template <int MODE>
+void launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
+                double *partials, hipStream_t st) {
+#define C2B_OBS_CASE(O, W)                                                                                           \
+    case O * 100 + W:                                                                                                \
+        return launch_obs_v<MODE, O, W>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st)
+    switch (g_obs_variant) {
+        C2B_OBS_CASE(1, 8);
+        C2B_OBS_CASE(2, 16);
+        C2B_OBS_CASE(4, 8);
+        case 1108: return launch_obs_v<MODE, 1, 8, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);
+        C2B_OBS_CASE(2, 8);
+        case 1216: return launch_obs_v<MODE, 2, 16, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);
+        case 1408: return launch_obs_v<MODE, 4, 8, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);
+        default:
+        case 1208: return launch_obs_v<MODE, 2, 8, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);   // shipped
+    }
+#undef C2B_OBS_CASE
+}
 
 int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) {
     double *ws = reinterpret_cast<double *>(workspace);
@@ -75,13 +109,13 @@ int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) 
     return C2B_OK;
 }
 
-template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1>
+template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1, bool LDSCAM = false>
 void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                          const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                          double *partials, hipStream_t st) {
     const int64_t wave_tiles = (n_obs + 63) / 64;
     const int64_t btiles = (wave_tiles + WPB * OPL - 1) / (WPB * OPL);
-    hipLaunchKernelGGL((k_residual_jacobian_w<WITH_ERR, WPB, SPLIT, NT, ABL, OPL>), dim3((unsigned)btiles), dim3(WPB * 64), 0, st,
+    hipLaunchKernelGGL((k_residual_jacobian_w<WITH_ERR, WPB, SPLIT, NT, ABL, OPL, LDSCAM>), dim3((unsigned)btiles), dim3(WPB * 64), 0, st,
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
                        reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r),
                        Jc, Jp, partials);
@@ -97,8 +131,11 @@ void launch_jacobian(int variant, const double *camblk, const double *pts4, cons
         case 9: C2B_W(8, 2, true); break;                    // 512-thread
         case 10: C2B_W(16, 2, true); break;                  // 1024-thread
         case 11: launch_jac_w<WITH_ERR, 16, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+        case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // r01d: FLAT camera reads
         default:
-        case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // shipped
+        case 14: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // shipped: + LDS-only camera reads
+        case 15: launch_jac_w<WITH_ERR, 16, 2, true, 0, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+        case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
         case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no Jacobian stores
         case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no arithmetic
         case 30: case 31: case 32: {      // store-pattern-only timing builds
@@ -198,6 +235,7 @@ int64_t c2b_workspace_bytes(int64_t n_obs) {
 
 // hidden tuning hook (tools/tune_jac.py); not declared in the public header
 int c2b_tune_set_jacobian_variant(int v) { g_jac_variant = v; return C2B_OK; }
+int c2b_tune_set_observation_variant(int v) { g_obs_variant = v; return C2B_OK; }
 
 /* ------------------------------- level 0 --------------------------------------------- */
 
@@ -317,10 +355,7 @@ int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_id
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
     if (!uv_out || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "project: uv_out NULL or misaligned");
-    const int64_t tiles = ((n_obs + 63) / 64 + kObsWPB * kObsOPL - 1) / (kObsWPB * kObsOPL);
-    hipLaunchKernelGGL(k_observations<MODE_PROJECT>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
-                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_obs,
-                       tiles, 0.0, 0.0, reinterpret_cast<double2 *>(uv_out), (uint8_t *)nullptr, (double *)nullptr);
+    launch_obs<MODE_PROJECT>(camblk, pts4, cam_idx, pt_idx, nullptr, n_obs, 0.0, 0.0, uv_out, nullptr, nullptr, S(stream));
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -336,11 +371,7 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
         return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: uv_obs/workspace NULL or misaligned");
     double *partials = reinterpret_cast<double *>(workspace) + kWsPartials;
     const int64_t wave_tiles = (n_obs + 63) / 64;
-    const int64_t tiles = (wave_tiles + kObsWPB * kObsOPL - 1) / (kObsWPB * kObsOPL);
-    hipLaunchKernelGGL(k_observations<MODE_ERROR>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
-                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
-                       reinterpret_cast<const double2 *>(uv_obs), n_obs, tiles, norm, 0.0, (double2 *)nullptr,
-                       (uint8_t *)nullptr, partials);
+    launch_obs<MODE_ERROR>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, norm, 0.0, nullptr, nullptr, partials, S(stream));
     LAUNCH_CHECK();
     return launch_sum(workspace, wave_tiles, out_sum, S(stream));
 }
@@ -381,10 +412,7 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
     if (rc) return rc;
     if (!n_pairs) return C2B_OK;
     if (!uv_out || !keep || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_pairs: NULL/misaligned output");
-    const int64_t tiles = ((n_pairs + 63) / 64 + kObsWPB * kObsOPL - 1) / (kObsWPB * kObsOPL);
-    hipLaunchKernelGGL(k_observations<MODE_VISIBILITY>, dim3((unsigned)tiles), dim3(kObsWPB * 64), 0, S(stream), camblk,
-                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, (const double2 *)nullptr, n_pairs,
-                       tiles, 0.0, max_dist, reinterpret_cast<double2 *>(uv_out), keep, (double *)nullptr);
+    launch_obs<MODE_VISIBILITY>(camblk, pts4, cam_idx, pt_idx, nullptr, n_pairs, 0.0, max_dist, uv_out, keep, nullptr, S(stream));
     LAUNCH_CHECK();
     return C2B_OK;
 }

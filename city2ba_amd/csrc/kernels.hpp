@@ -173,16 +173,15 @@ constexpr int kCamLight = 16;
 
 constexpr int kObsOPL = 2;                     // observations per lane (both tiles' loads issued up front)
 
-template <int MODE>
-__global__ __launch_bounds__(kObsWPB * 64) void k_observations(
+template <int MODE, int OPL = kObsOPL, int WPB = kObsWPB, bool LDSCAM = true>
+__global__ __launch_bounds__(WPB * 64) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ partials) {
-    constexpr int OPL = kObsOPL;
-    __shared__ __attribute__((aligned(16))) double sCamAll[kObsWPB * kCamW * kCamLight];
+    __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kCamW * kCamLight];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * kObsWPB + wave) * OPL;
+    const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * WPB + wave) * OPL;
     const int64_t base = wt0 * 64;
     if (base >= n) return;                                               // wave-uniform
 
@@ -229,10 +228,17 @@ __global__ __launch_bounds__(kObsWPB * 64) void k_observations(
         if (wave0 >= n) break;                                           // wave-uniform
         const int64_t o = wave0 + lane;
         double e = 0.0;
+        const uint32_t local = ci[t] - c_first;
+        const bool in_tile = valid[t] && local < n_staged;
+        // wave-uniform fast path reads the camera with ds_read; only the mixed LDS / global fallback needs FLAT loads
+        Proj p;
+        if (LDSCAM && __builtin_amdgcn_ballot_w64(valid[t] && !in_tile) == 0ull) {
+            p = project_obs(sCam + (in_tile ? local : 0u) * kCamLight, X[t].x, X[t].y, X[t].z);
+        } else {
+            const double *cam = in_tile ? (sCam + local * kCamLight) : (camblk + (int64_t)ci[t] * kCamBlk);
+            p = project_obs(cam, X[t].x, X[t].y, X[t].z);
+        }
         if (valid[t]) {
-            const uint32_t local = ci[t] - c_first;
-            const double *cam = local < n_staged ? (sCam + local * kCamLight) : (camblk + (int64_t)ci[t] * kCamBlk);
-            const Proj p = project_obs(cam, X[t].x, X[t].y, X[t].z);
             if (MODE == MODE_VISIBILITY) {
                 // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1
                 const double *g = camblk + (int64_t)ci[t] * kCamBlk + kCenter;
@@ -325,7 +331,7 @@ C2B_DEV void jacobian_obs(const double *cam, const double4 X, const double2 ob, 
     }
 }
 
-template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1>   // ABL: timing-only ablations (tools/)
+template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1, bool LDSCAM = true>   // ABL: timing-only ablations (tools/)
 __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -387,10 +393,17 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
         const int64_t o = wave0 + lane;
         const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
         const uint32_t local = ci[t] - c_first;
-        const double *cam = (valid[t] && local < n_staged) ? (sCam + local * kCamHot)
-                                                           : (camblk + (int64_t)ci[t] * kCamBlk);
+        const bool in_tile = valid[t] && local < n_staged;
         double r0, r1, jc[18], jp[6];
-        jacobian_obs<ABL>(cam, X[t], ob[t], r0, r1, jc, jp);
+        // The usual case is wave-uniform: every lane's camera is in the LDS tile, and a pointer that can only be LDS
+        // compiles to ds_read (lgkmcnt).  A pointer that may be LDS or global compiles to FLAT loads, which count in
+        // vmcnt behind the previous tile's stores (vmcnt retires in order) -- keep those for the rare fallback only.
+        if (LDSCAM && __builtin_amdgcn_ballot_w64(valid[t] && !in_tile) == 0ull) {
+            jacobian_obs<ABL>(sCam + (in_tile ? local : 0u) * kCamHot, X[t], ob[t], r0, r1, jc, jp);
+        } else {
+            const double *cam = in_tile ? (sCam + local * kCamHot) : (camblk + (int64_t)ci[t] * kCamBlk);
+            jacobian_obs<ABL>(cam, X[t], ob[t], r0, r1, jc, jp);
+        }
 
         // residual: 16 B per lane, already coalesced
         if (valid[t]) store16<NT>(reinterpret_cast<char *>(r_out + o), make_double2(r0, r1));

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""A/B the light per-observation kernels (project / error / visibility) over (observations per lane, waves per
+workgroup) in ONE process, interleaved rounds, on the bench workload; outputs checked bit-for-bit against the first
+variant.   python tools/tune_obs.py [--blocks 128] [--variants 208,108,204,216,308,408,404]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from city2ba_amd import _lib as L  # noqa: E402
+from city2ba_amd import device as D  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--blocks", type=int, default=128)
+ap.add_argument("--variants", default="208,108,104,204,216,308,408,404")
+ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--reps", type=int, default=20)
+a = ap.parse_args()
+variants = [int(v) for v in a.variants.split(",")]
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+sh = bench.build_shard(argparse.Namespace(blocks=a.blocks), 0, 1, dev)
+n = sh["n_obs"]
+raw = C.CDLL(L.LIB_PATH)
+raw.c2b_tune_set_observation_variant.argtypes = [C.c_int]
+ws = D.workspace(n, dev)
+err = torch.zeros(1, dtype=torch.float64, device=dev)
+camblk, pts4, ci, pi, uv = sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"]
+uv_out = torch.empty_like(uv)
+keep = torch.empty(n, dtype=torch.uint8, device=dev)
+
+modes = {
+    "project": lambda: D.project(camblk, pts4, ci, pi, uv_out),
+    "error_L2": lambda: D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, err),
+    "visibility": lambda: D.visibility_pairs(camblk, pts4, ci, pi, 10.0, uv_out, keep),
+}
+
+ref = {}
+for v in variants:
+    raw.c2b_tune_set_observation_variant(v)
+    uv_out.fill_(float("nan"))
+    modes["project"]()
+    torch.cuda.synchronize()
+    p = uv_out.clone()
+    modes["error_L2"]()
+    torch.cuda.synchronize()
+    e = err.item()
+    modes["visibility"]()
+    torch.cuda.synchronize()
+    k = keep.clone()
+    if not ref:
+        ref = {"p": p, "e": e, "k": k}
+    else:
+        print("variant %d: project bit-equal %s, keep equal %s, error rel diff %.1e" %
+              (v, torch.equal(p, ref["p"]), torch.equal(k, ref["k"]), abs(e - ref["e"]) / max(ref["e"], 1e-300)))
+
+times = {(m, v): [] for m in modes for v in variants}
+for _ in range(a.rounds):
+    for m, fn in modes.items():
+        for v in variants:
+            raw.c2b_tune_set_observation_variant(v)
+            fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(a.reps):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            times[(m, v)].append(s.elapsed_time(e) / a.reps * 1e3)
+print("n_obs=%d" % n)
+for m in modes:
+    for v in variants:
+        t = sorted(times[(m, v)])
+        print("%-10s OPL=%d WPB=%-2d: median %.1f us  min %.1f us  %.1f Gobs/s" % (m, v // 100, v % 100, t[len(t) // 2], t[0], n / t[len(t) // 2] / 1e3))
