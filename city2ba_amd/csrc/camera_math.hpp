@@ -273,4 +273,26 @@ C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32
     z1 = rad * s;
 }
 
+// The direction of normal_pair's pair, (z0, z1) / |(z0, z1)| = (cos, sin)(2 pi u2), without its radius.
+C2B_DEV void unit_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot, double &c, double &s) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), slot, stream, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), o);
+    const uint64_t b = ((uint64_t)o[3] << 32) | o[2];
+    const double u2 = (double)(b >> 11) * 0x1.0p-53;
+    sincospi(2.0 * u2, &s, &c);
+}
+
+// z0 of normal_pair alone.
+C2B_DEV double normal_first(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), slot, stream, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), o);
+    const uint64_t a = ((uint64_t)o[1] << 32) | o[0];
+    const uint64_t b = ((uint64_t)o[3] << 32) | o[2];
+    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   // (0,1]
+    const double u2 = (double)(b >> 11) * 0x1.0p-53;         // [0,1)
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
 }  // namespace c2b

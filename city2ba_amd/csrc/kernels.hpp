@@ -800,14 +800,17 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_observations(double2 *__re
                                                                   uint64_t seed) {
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (o >= n) return;
-    double nx, ny, z, unused;
-    normal_pair(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 0, nx, ny);
-    normal_pair(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 1, z, unused);
-    const double m = sqrt(nx * nx + ny * ny);
+    // Same draws as the CPU path: slot 0 = the Box-Muller pair (nx, ny), slot 1 = z.  The pair is only used as
+    // (nx, ny) / |(nx, ny)| = (cos, sin)(2 pi u2): its radius cancels, so the log / sqrt of slot 0 and the
+    // normalisation (sqrt + two divides) are not evaluated; slot 1 needs the cosine branch only.  The kernel is
+    // VALU-bound (two Philox blocks + transcendentals per 32 bytes), so the instructions are what it costs.
+    double c, s, z;
+    unit_pair(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 0, c, s);
+    z = normal_first(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 1);
     const double r = 0.0 + observations_std * z;
     double2 v = uv[o];
-    v.x = v.x + nx / m * r;
-    v.y = v.y + ny / m * r;
+    v.x = v.x + c * r;
+    v.y = v.y + s * r;
     uv[o] = v;
 }
 
