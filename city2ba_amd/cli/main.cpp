@@ -21,6 +21,7 @@
 // `generate` casts its rays by brute force over the triangles instead of through Embree.  Every random draw is
 // seeded (--seed; default: std::random_device) where the reference uses thread_rng().
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -105,6 +106,18 @@ Args parse(int argc, char **argv, int first, const std::vector<std::string> &fla
     }
     return a;
 }
+
+// C2B_TIMING=1: wall time of each phase on stderr
+struct PhaseTimer {
+    bool on = std::getenv("C2B_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[timing] %-50s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
 
 struct HostProblem {
     int64_t n_cam = 0, n_pts = 0;
@@ -330,8 +343,10 @@ int run_generate(int argc, char **argv) {
     if (a.has("seed")) seed = (uint64_t)a.i("seed", 0);
     else { std::random_device rd; seed = ((uint64_t)rd() << 32) ^ rd(); }   // the reference: unseeded thread_rng()
 
+    PhaseTimer timer;
     c2b_obj *obj = nullptr;
     ck(c2b_obj_load(a.positional[0].c_str(), &obj));
+    timer.mark("load .obj");
     int64_t path_model = -1;
     if (a.has("path")) {
         const std::string want = a.opt.at("path");
@@ -356,11 +371,18 @@ int run_generate(int argc, char **argv) {
         pos.resize((size_t)n_cam * 3 + 1); dir.resize((size_t)n_cam * 9 + 1);
         ck(c2b_generate_cameras_path(obj, path_model, num_cameras, step_size, seed, pos.data(), dir.data()));
     } else {
-        ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, 0, nullptr, nullptr, &n_cam));
-        pos.resize((size_t)n_cam * 3 + 1); dir.resize((size_t)n_cam * 9 + 1);
-        ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, n_cam, pos.data(), dir.data(), &n_cam));
+        // 2 * num_cameras disks at the densest packing bound the sample count (plus a rim for the open boundary)
+        int64_t cap = 2 * num_cameras + 8 * (int64_t)std::sqrt((double)(2 * num_cameras)) + 64;
+        pos.resize((size_t)cap * 3 + 1); dir.resize((size_t)cap * 9 + 1);
+        ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, cap, pos.data(), dir.data(), &n_cam));
+        if (n_cam > cap) {                                  // same seed => same cameras
+            cap = n_cam;
+            pos.resize((size_t)cap * 3 + 1); dir.resize((size_t)cap * 9 + 1);
+            ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, cap, pos.data(), dir.data(), &n_cam));
+        }
     }
     c2b_obj_free(obj);
+    timer.mark("triangles + camera placement");
     std::printf("Generated %lld cameras\n", (long long)n_cam);
 
     c2b_problem *p = nullptr;
@@ -370,6 +392,7 @@ int run_generate(int argc, char **argv) {
     hp.cams15.resize((size_t)n_cam * 15 + 1);
     if (n_cam) ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), hp.cams15.data()));
     ck(c2b_modify_intrinsics(hp.cams15.data(), n_cam, istart, iend, seed + 1));
+    timer.mark("device init + from_position_direction + intrinsics");
     std::printf("Modified intrinsics\n");
 
     std::vector<double> centers((size_t)n_cam * 3 + 1);
@@ -380,16 +403,20 @@ int run_generate(int argc, char **argv) {
     }
     hp.pts.resize((size_t)num_points * 3 + 1);
     ck(c2b_generate_world_points(tri.data(), n_tri, centers.data(), n_cam, num_points, max_dist, seed + 2, hp.pts.data(), &hp.n_pts));
+    timer.mark("centres + world points");
     std::printf("Generated %lld world points\n", (long long)hp.n_pts);
 
     // visibility_graph, src/generate.rs:424-481: dense (camera, point) sweep, then the occlusion rays
     ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), rows.data(), nullptr, nullptr));
     hp.row_ptr.assign((size_t)n_cam + 1, 0);
     ck(c2b_problem_visibility_dense(p, max_dist, hp.row_ptr.data()));
+    timer.mark("upload + dense sweep");
     ck(c2b_problem_visibility_dense_occlude(p, tri.data(), n_tri, hp.row_ptr.data()));
+    timer.mark("hierarchy build + occlusion rays + compaction");
     const size_t n_edges = (size_t)hp.row_ptr[(size_t)n_cam];
     hp.pt_idx.resize(n_edges + 1); hp.uv.resize(2 * n_edges + 2);
     ck(c2b_problem_visibility_dense_fetch(p, hp.pt_idx.data(), hp.uv.data()));
+    timer.mark("fetch");
     std::printf("Computed visibility graph with %zu edges\n", n_edges);
 
     if (!a.has("no-lcc"))
@@ -401,6 +428,7 @@ int run_generate(int argc, char **argv) {
     hp.row_ptr.resize((size_t)hp.n_cam + 1);
     const size_t n_obs = (size_t)hp.row_ptr[(size_t)hp.n_cam];
     hp.pt_idx.resize(n_obs); hp.uv.resize(2 * n_obs);
+    timer.mark("cull");
     std::printf("Computed LCC with %lld cameras, %lld points, %zu edges\n", (long long)hp.n_cam, (long long)hp.n_pts, n_obs);
 
     ck(c2b_problem_upload(p, hp.n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
@@ -409,7 +437,9 @@ int run_generate(int argc, char **argv) {
     std::printf("Total reprojection error: %s\n", display_f64(l1).c_str());
     std::vector<double> bal9((size_t)hp.n_cam * 9);
     ck(c2b_problem_download_bal(p, bal9.data()));
+    timer.mark("upload + error + to_vec");
     ck(c2b_bal_write(a.positional[1].c_str(), hp.n_cam, bal9.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+    timer.mark("write");
     c2b_problem_destroy(p);
     return 0;
 }

@@ -20,6 +20,8 @@
 #include <tuple>
 #include <vector>
 
+#include "host_bvh.hpp"
+
 namespace c2b_host {
 
 // ---- .obj (tobj 0.1.12 conventions) ---------------------------------------------------------------
@@ -322,9 +324,11 @@ inline bool cameras_path_step(const ObjModel &path, int64_t num_cameras, double 
 inline void poisson_unit_square(int64_t n_target, std::mt19937_64 &rng, std::vector<double> &xy) {
     xy.clear();
     if (n_target <= 0) return;
-    // minimum distance r such that a maximal Poisson-disk set holds ~n_target samples: the random-sequential
-    // jamming density of disks of radius r/2 is ~0.547, i.e. N ~ 0.697 / r^2
-    const double r = std::sqrt(0.697 / (double)n_target);
+    // The poisson crate's with_samples(n, 1.0, ..) picks the minimum distance r at which n disks of radius r/2 would
+    // tile the unit square at the densest (hexagonal) packing, pi / sqrt(12): r^2 = 2 / (sqrt(3) n) = 1.1547 / n.
+    // A maximal random set at that distance reaches the jamming density 0.547, i.e. ~0.6 n samples -- which is why
+    // the reference asks for 2x the cameras it wants (src/generate.rs:231).
+    const double r = std::sqrt(1.1547005383792515 / (double)n_target);
     const double cell = r / std::sqrt(2.0);
     const int64_t g = std::max<int64_t>(1, (int64_t)std::ceil(1.0 / cell));
     std::vector<int64_t> grid((size_t)(g * g), -1);
@@ -358,12 +362,16 @@ inline void cameras_poisson(const std::vector<float> &tri9, int64_t num_points, 
     const double start[3] = {(double)hi[0], (double)hi[1] + 0.1, (double)hi[2]};
     const double delta[3] = {(double)(hi[0] - lo[0]), 0.0, (double)(hi[2] - lo[2])};
     std::vector<double> positions;
+    // meshes beyond a few dozen triangles are searched through the hierarchy (same nearest hit, see host_bvh.hpp)
+    const bool use_bvh = tri9.size() / 9 >= 64;
+    Bvh bvh;
+    if (use_bvh) bvh_build(tri9.data(), (int64_t)(tri9.size() / 9), bvh);
     for (size_t s = 0; s + 1 < samples.size(); s += 2) {
         const double origin[3] = {start[0] - delta[0] * samples[s], start[1] - delta[1] * 0.0, start[2] - delta[2] * samples[s + 1]};
         const float of[3] = {(float)origin[0], (float)origin[1], (float)origin[2]};
         const float df[3] = {0.0f, -1.0f, 0.0f};
         float t;
-        if (cast_ray(tri9, of, df, &t)) {
+        if (use_bvh ? bvh_cast_ray(bvh, of, df, &t) : cast_ray(tri9, of, df, &t)) {
             const double pt[3] = {origin[0] + 0.0 * (double)t + 0.0, origin[1] + -1.0 * (double)t + height, origin[2] + 0.0 * (double)t + 0.0};
             if (pt[2] < (double)lo[1] + ground) positions.insert(positions.end(), pt, pt + 3);
         }
@@ -406,18 +414,49 @@ inline bool world_points_uniform(const std::vector<float> &tri9, const double *c
         areas[t] = std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) / 2.0;
     }
     // cameras binned on a grid of cell max_dist for the "within max_dist of any camera" test (rstar in the reference)
+    // (an open-addressing table from cell coordinates to a run of the cell-sorted camera list)
     const double cs = max_dist > 0 ? max_dist : 1.0;
-    std::map<std::tuple<int64_t, int64_t, int64_t>, std::vector<int64_t>> bins;
-    auto cell = [&](const double *p) { return std::make_tuple((int64_t)std::floor(p[0] / cs), (int64_t)std::floor(p[1] / cs), (int64_t)std::floor(p[2] / cs)); };
-    for (int64_t c = 0; c < n_cam; ++c) bins[cell(centers + 3 * c)].push_back(c);
+    struct Cell { int64_t x, y, z; };
+    auto cell = [&](const double *p) { return Cell{(int64_t)std::floor(p[0] / cs), (int64_t)std::floor(p[1] / cs), (int64_t)std::floor(p[2] / cs)}; };
+    auto hash = [](int64_t x, int64_t y, int64_t z) {
+        uint64_t h = (uint64_t)x * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)y + 0x7F4A7C159E3779B9ull) * 0xC2B2AE3D27D4EB4Full;
+        h ^= ((uint64_t)z + 0x165667B19E3779F9ull) * 0xFF51AFD7ED558CCDull;
+        return h ^ (h >> 29);
+    };
+    std::vector<Cell> ccell((size_t)n_cam);
+    std::vector<int64_t> order((size_t)n_cam);
+    for (int64_t c = 0; c < n_cam; ++c) { ccell[(size_t)c] = cell(centers + 3 * c); order[(size_t)c] = c; }
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        const Cell &p = ccell[(size_t)a], &q = ccell[(size_t)b];
+        return std::tie(p.x, p.y, p.z, a) < std::tie(q.x, q.y, q.z, b);
+    });
+    struct Slot { Cell c; int64_t begin, end; };
+    size_t cap = 16;
+    while (cap < 2 * (size_t)n_cam) cap <<= 1;
+    std::vector<Slot> table(cap, Slot{{0, 0, 0}, 0, -1});                      // end < 0: empty
+    for (int64_t i = 0; i < n_cam;) {
+        const Cell k = ccell[(size_t)order[(size_t)i]];
+        int64_t j = i;
+        while (j < n_cam && ccell[(size_t)order[(size_t)j]].x == k.x && ccell[(size_t)order[(size_t)j]].y == k.y &&
+               ccell[(size_t)order[(size_t)j]].z == k.z)
+            ++j;
+        size_t s = (size_t)hash(k.x, k.y, k.z) & (cap - 1);
+        while (table[s].end >= 0) s = (s + 1) & (cap - 1);
+        table[s] = Slot{k, i, j};
+        i = j;
+    }
     auto near_camera = [&](const double *p) {
-        const auto k = cell(p);
+        const Cell k = cell(p);
         for (int64_t dx = -1; dx <= 1; ++dx)
             for (int64_t dy = -1; dy <= 1; ++dy)
                 for (int64_t dz = -1; dz <= 1; ++dz) {
-                    auto it = bins.find(std::make_tuple(std::get<0>(k) + dx, std::get<1>(k) + dy, std::get<2>(k) + dz));
-                    if (it == bins.end()) continue;
-                    for (int64_t c : it->second) {
+                    const int64_t x = k.x + dx, y = k.y + dy, z = k.z + dz;
+                    size_t s = (size_t)hash(x, y, z) & (cap - 1);
+                    while (table[s].end >= 0 && !(table[s].c.x == x && table[s].c.y == y && table[s].c.z == z)) s = (s + 1) & (cap - 1);
+                    if (table[s].end < 0) continue;
+                    for (int64_t i = table[s].begin; i < table[s].end; ++i) {
+                        const int64_t c = order[(size_t)i];
                         const double e[3] = {centers[3 * c] - p[0], centers[3 * c + 1] - p[1], centers[3 * c + 2] - p[2]};
                         if ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2] <= max_dist * max_dist) return true;
                     }

@@ -84,10 +84,13 @@ def generate_cameras_poisson(triangles, num_points, height, ground, seed=0):
     tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
     n = C.c_int64()
     args = (_ptr(tri), len(tri), int(num_points), float(height), float(ground), int(seed))
-    L.check(L.lib().c2b_generate_cameras_poisson(*args, 0, None, None, C.byref(n)))
-    pos, dirs = np.empty((n.value, 3)), np.empty((n.value, 9))
-    L.check(L.lib().c2b_generate_cameras_poisson(*args, n.value, _ptr(pos), _ptr(dirs), C.byref(n)))
-    return pos, dirs
+    cap = 2 * int(num_points) + 8 * int((2 * int(num_points)) ** 0.5) + 64      # densest packing bounds the count
+    pos, dirs = np.empty((cap, 3)), np.empty((cap, 9))
+    L.check(L.lib().c2b_generate_cameras_poisson(*args, cap, _ptr(pos), _ptr(dirs), C.byref(n)))
+    if n.value > cap:                                                          # same seed => same cameras
+        pos, dirs = np.empty((n.value, 3)), np.empty((n.value, 9))
+        L.check(L.lib().c2b_generate_cameras_poisson(*args, n.value, _ptr(pos), _ptr(dirs), C.byref(n)))
+    return pos[:n.value].copy(), dirs[:n.value].copy()
 
 
 def modify_intrinsics(cams15, intrinsic_start, intrinsic_end, seed=0):

@@ -1,6 +1,6 @@
 """Host-side mirror of synthetic.rs over the C ABI: layout and candidate search run in the native
 host code (csrc/host_synthetic.hpp), from_position_direction and the visibility predicate
-(src/synthetic.rs:285-291) on the GPU.  cull() is not applied yet."""
+(src/synthetic.rs:285-291) on the GPU, cull() (src/synthetic.rs:299) in the native host code again."""
 import ctypes as C
 import os
 

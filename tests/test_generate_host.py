@@ -152,7 +152,7 @@ def test_cameras_poisson(G):
     lo, hi = tri.reshape(-1, 3).min(0), tri.reshape(-1, 3).max(0)
     height = 1.0
     pos, dirs = G.generate_cameras_poisson(tri, 100, height, 5.0, seed=11)
-    assert 60 <= len(pos) <= 400                             # about 2 x num_points darts hit the 8 x 8 plane
+    assert 80 <= len(pos) <= 140                             # ~0.6 x (2 x num_points): with_samples' radius rule
     # straight down from (x, top + 0.1, z): first surface is the cube top (y = 1) over [-1,1]^2, else the plane
     on_cube = (np.abs(pos[:, 0]) < 1) & (np.abs(pos[:, 2]) < 1)
     surf = np.where(on_cube, 1.0, float(np.float32(-0.876138)))
@@ -164,7 +164,7 @@ def test_cameras_poisson(G):
     dx = (pos[:, None, 0] - pos[None, :, 0]) / (hi[0] - lo[0])
     dz = (pos[:, None, 2] - pos[None, :, 2]) / (hi[2] - lo[2])
     dist = np.sqrt(dx * dx + dz * dz) + np.eye(len(pos))
-    assert dist.min() >= np.sqrt(0.697 / 200) - 1e-12
+    assert dist.min() >= np.sqrt(2 / np.sqrt(3) / 200) - 1e-12
     # the filter of src/generate.rs:264 compares pt[2] (the z coordinate) with lower_y + ground
     assert np.all(pos[:, 2] < lo[1] + 5.0)
     few, _ = G.generate_cameras_poisson(tri, 100, height, -1.0, seed=11)
@@ -173,6 +173,32 @@ def test_cameras_poisson(G):
     for m in dirs:
         R = m.reshape(3, 3).T
         assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and R[1, 1] == 1.0 and R[0, 1] == 0.0 and R[2, 1] == 0.0
+
+
+def test_cameras_poisson_through_hierarchy(G):
+    """test_scene.obj has 200 triangles, so the downward rays go through the host hierarchy: every camera must sit
+    `height` above the FIRST surface under it (independent float64 vertical ray against all triangles)"""
+    o = G.ObjFile(os.path.join(os.path.dirname(BOX), "test_scene.obj"))
+    tri = o.triangles(o.index("path")).astype(np.float64).reshape(-1, 3, 3)
+    height = 0.75
+    pos, _ = G.generate_cameras_poisson(tri.reshape(-1, 9), 300, height, 1e9, seed=4)
+    assert len(pos) > 100
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    checked = 0
+    for p in pos:
+        # barycentric coordinates of (x, z) in each triangle's x-z footprint
+        d = (b[:, 0] - a[:, 0]) * (c[:, 2] - a[:, 2]) - (c[:, 0] - a[:, 0]) * (b[:, 2] - a[:, 2])
+        with np.errstate(all="ignore"):
+            u = ((p[0] - a[:, 0]) * (c[:, 2] - a[:, 2]) - (c[:, 0] - a[:, 0]) * (p[2] - a[:, 2])) / d
+            w = ((b[:, 0] - a[:, 0]) * (p[2] - a[:, 2]) - (p[0] - a[:, 0]) * (b[:, 2] - a[:, 2])) / d
+        inside = (np.abs(d) > 1e-12) & (u >= 0) & (w >= 0) & (u + w <= 1)
+        margin = np.minimum(np.minimum(u, w), 1 - u - w)
+        if not inside.any() or np.any(inside & (margin < 1e-4)):
+            continue                                              # on an edge: either neighbour may win
+        y = a[inside, 1] + u[inside] * (b[inside, 1] - a[inside, 1]) + w[inside] * (c[inside, 1] - a[inside, 1])
+        assert abs(p[1] - (y.max() + height)) < 1e-4
+        checked += 1
+    assert checked > 0.8 * len(pos)
 
 
 def test_modify_intrinsics(G):
