@@ -130,6 +130,7 @@ HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, 
                                 const std::vector<double> &pts, double max_dist, bool occlusion, double L, double inset) {
     const int64_t n_cam = (int64_t)pos.size() / 3, n_pts = (int64_t)pts.size() / 3;
     HostProblem hp;
+    PhaseTimer timer;
     hp.n_cam = n_cam; hp.n_pts = n_pts; hp.pts = pts;
     hp.cams15.resize((size_t)n_cam * 15);
     ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), hp.cams15.data()));
@@ -137,13 +138,16 @@ HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, 
     ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), n_pts, pts.data(), empty_rows.data(), nullptr, nullptr));
     std::vector<double> centers((size_t)n_cam * 3);
     ck(c2b_problem_centers(p, centers.data()));
+    timer.mark("from_position_direction + upload + centres");
     c2b_pairs *pairs = nullptr;
     const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
     ck(c2b_candidate_pairs(centers.data(), n_cam, pts.data(), n_pts, max_dist, 0, n_cam, occlusion ? 1 : 0, L, inset, threads, &pairs));
+    timer.mark("candidate pairs (host, threaded)");
     const int64_t n_pairs = c2b_pairs_count(pairs);
     std::vector<double> uv((size_t)n_pairs * 2);
     std::vector<uint8_t> keep((size_t)n_pairs);
     ck(c2b_problem_visibility_pairs(p, n_pairs, c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, uv.data(), keep.data()));
+    timer.mark("visibility predicate (device, host buffers in/out)");
     const uint32_t *ci = c2b_pairs_cam_idx(pairs), *pi = c2b_pairs_pt_idx(pairs);
     hp.row_ptr.assign((size_t)n_cam + 1, 0);
     for (int64_t k = 0; k < n_pairs; ++k)
@@ -155,8 +159,10 @@ HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, 
         }
     for (int64_t c = 0; c < n_cam; ++c) hp.row_ptr[(size_t)c + 1] += hp.row_ptr[(size_t)c];
     c2b_pairs_free(pairs);
+    timer.mark("compaction");
     // .cull(), src/synthetic.rs:299
     ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(), 1));
+    timer.mark("cull");
     hp.cams15.resize((size_t)hp.n_cam * 15);
     hp.pts.resize((size_t)hp.n_pts * 3);
     hp.row_ptr.resize((size_t)hp.n_cam + 1);

@@ -28,49 +28,6 @@ struct Graph {
     int64_t n_obs() const { return (int64_t)pt_idx.size(); }
 };
 
-// BAProblem::subset, src/baproblem.rs:394-423
-inline Graph subset(const Graph &g, const std::vector<int64_t> &ci, const std::vector<int64_t> &pi) {
-    Graph o;
-    o.stride = g.stride;
-    o.n_cam = (int64_t)ci.size();
-    o.n_pts = (int64_t)pi.size();
-    o.cams.resize((size_t)o.n_cam * g.stride);
-    o.pts.resize((size_t)o.n_pts * 3);
-    for (size_t k = 0; k < ci.size(); ++k)
-        std::copy(&g.cams[(size_t)ci[k] * g.stride], &g.cams[(size_t)(ci[k] + 1) * g.stride], &o.cams[k * g.stride]);
-    std::vector<int64_t> point_indices((size_t)g.n_pts, -1);
-    for (size_t k = 0; k < pi.size(); ++k) {
-        std::copy(&g.pts[(size_t)pi[k] * 3], &g.pts[(size_t)pi[k] * 3 + 3], &o.pts[k * 3]);
-        point_indices[(size_t)pi[k]] = (int64_t)k;
-    }
-    o.row_ptr.assign(1, 0);
-    for (int64_t c : ci) {
-        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) {
-            const int64_t ni = point_indices[(size_t)g.pt_idx[(size_t)e]];
-            if (ni >= 0) {
-                o.pt_idx.push_back((uint64_t)ni);
-                o.uv.push_back(g.uv[2 * (size_t)e]);
-                o.uv.push_back(g.uv[2 * (size_t)e + 1]);
-            }
-        }
-        o.row_ptr.push_back((uint64_t)o.pt_idx.size());
-    }
-    return o;
-}
-
-// remove_singletons, src/baproblem.rs:426-453: cameras need > 3 observations, points > 1; the point
-// counts are taken over ALL cameras, including the ones being removed (reference TODO at :437).
-inline Graph remove_singletons(const Graph &g) {
-    std::vector<int64_t> ci, pi;
-    for (int64_t c = 0; c < g.n_cam; ++c)
-        if (g.row_ptr[(size_t)c + 1] - g.row_ptr[(size_t)c] > 3) ci.push_back(c);
-    std::vector<int64_t> count((size_t)g.n_pts, 0);
-    for (uint64_t p : g.pt_idx) ++count[(size_t)p];
-    for (int64_t p = 0; p < g.n_pts; ++p)
-        if (count[(size_t)p] > 1) pi.push_back(p);
-    return subset(g, ci, pi);
-}
-
 struct UnionFind {
     std::vector<int64_t> parent, rank_;
     explicit UnionFind(int64_t n) : parent((size_t)n), rank_((size_t)n, 0) { std::iota(parent.begin(), parent.end(), 0); }
@@ -90,26 +47,68 @@ struct UnionFind {
     }
 };
 
-// largest_connected_component, src/baproblem.rs:456-534.
+// ---- cull on indices only -----------------------------------------------------------------------------------
+// The fixed-point loop of cull() renumbers cameras, points and observations on every pass (and, in faithful mode,
+// the observation filter depends on that numbering), but the payloads (camera rows, points, uv) only matter at the
+// end.  IndexGraph carries the current numbering plus, for every camera / point / observation, where it came
+// from; lcc_pass and singleton_pass are largest_connected_component (src/baproblem.rs:456-534) and
+// remove_singletons (:426-453, through subset :394-423) on those indices, and the payloads are gathered once.
+struct IndexGraph {
+    int64_t n_cam = 0, n_pts = 0;
+    std::vector<uint64_t> row_ptr, pt_idx;        // current numbering
+    std::vector<int64_t> cam_orig, pt_orig;       // current -> input
+    std::vector<uint64_t> edge_orig;              // current observation -> input observation
+};
+
+// keep cameras / points by mask; an observation of a kept camera survives iff edge_keep(current edge) and its point
+// is kept
+template <typename EdgeKeep>
+inline void compact(IndexGraph &g, const std::vector<uint8_t> &keep_cam, const std::vector<uint8_t> &keep_pt, EdgeKeep edge_keep) {
+    std::vector<int64_t> pt_new((size_t)g.n_pts, -1);
+    int64_t np = 0;
+    for (int64_t p = 0; p < g.n_pts; ++p)
+        if (keep_pt[(size_t)p]) { pt_new[(size_t)p] = np; g.pt_orig[(size_t)np] = g.pt_orig[(size_t)p]; ++np; }
+    g.pt_orig.resize((size_t)np);
+    int64_t nc = 0;
+    uint64_t w = 0, b = 0;
+    for (int64_t c = 0; c < g.n_cam; ++c) {
+        const uint64_t e_end = g.row_ptr[(size_t)c + 1];
+        if (keep_cam[(size_t)c]) {
+            g.cam_orig[(size_t)nc] = g.cam_orig[(size_t)c];
+            g.row_ptr[(size_t)nc] = w;
+            for (uint64_t e = b; e < e_end; ++e) {
+                const int64_t p = pt_new[(size_t)g.pt_idx[(size_t)e]];
+                if (p >= 0 && edge_keep(e)) { g.pt_idx[(size_t)w] = (uint64_t)p; g.edge_orig[(size_t)w] = g.edge_orig[(size_t)e]; ++w; }
+            }
+            ++nc;
+        }
+        b = e_end;
+    }
+    g.row_ptr[(size_t)nc] = w;
+    g.row_ptr.resize((size_t)nc + 1);
+    g.cam_orig.resize((size_t)nc);
+    g.pt_idx.resize((size_t)w);
+    g.edge_orig.resize((size_t)w);
+    g.n_cam = nc;
+    g.n_pts = np;
+}
+
+// largest_connected_component, src/baproblem.rs:456-534:
 //   * Tie between equally large components: the reference takes HashMap iteration order
 //     (nondeterministic, :483-488); here the component with the smallest member index wins.
 //   * `faithful` keeps the reference's observation filter `sets[x.0] == lcc_id` (:523), which indexes the
 //     camera-first union-find array with a POINT index: an observation of point j is dropped when element j of
 //     that array (camera j, or point j - n_cam) lies outside the largest component.  With faithful = false the
 //     filter tests the observed point itself.
-inline Graph largest_connected_component(const Graph &g, bool faithful) {
-    if (g.n_cam == 0) return g;
+inline void lcc_pass(IndexGraph &g, bool faithful) {
+    if (g.n_cam == 0) return;
     const int64_t nc = g.n_cam, np = g.n_pts;
     UnionFind uf(nc + np);
     for (int64_t c = 0; c < nc; ++c)
-        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e)
-            uf.unite(c, nc + (int64_t)g.pt_idx[(size_t)e]);
-    std::vector<int64_t> sets((size_t)(nc + np));
-    for (int64_t i = 0; i < nc + np; ++i) sets[(size_t)i] = uf.find(i);
-    // canonical id of a set = its smallest member
-    std::vector<int64_t> canon((size_t)(nc + np), -1), size((size_t)(nc + np), 0);
+        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) uf.unite(c, nc + (int64_t)g.pt_idx[(size_t)e]);
+    std::vector<int64_t> sets((size_t)(nc + np)), canon((size_t)(nc + np), -1), size((size_t)(nc + np), 0);
     for (int64_t i = 0; i < nc + np; ++i) {
-        const int64_t r = sets[(size_t)i];
+        const int64_t r = sets[(size_t)i] = uf.find(i);
         if (canon[(size_t)r] < 0) canon[(size_t)r] = i;
         ++size[(size_t)r];
     }
@@ -118,41 +117,64 @@ inline Graph largest_connected_component(const Graph &g, bool faithful) {
         if (size[(size_t)r] > 0 && (size[(size_t)r] > best || (size[(size_t)r] == best && canon[(size_t)r] < best_canon))) {
             best = size[(size_t)r]; lcc = r; best_canon = canon[(size_t)r];
         }
-    Graph o;
-    o.stride = g.stride;
-    std::vector<int64_t> point_map((size_t)np, -1);
-    for (int64_t p = 0; p < np; ++p)
-        if (sets[(size_t)(nc + p)] == lcc) {
-            point_map[(size_t)p] = o.n_pts++;
-            o.pts.insert(o.pts.end(), &g.pts[(size_t)p * 3], &g.pts[(size_t)p * 3 + 3]);
-        }
-    o.row_ptr.assign(1, 0);
-    for (int64_t c = 0; c < nc; ++c) {
-        if (sets[(size_t)c] != lcc) continue;
-        ++o.n_cam;
-        o.cams.insert(o.cams.end(), &g.cams[(size_t)c * g.stride], &g.cams[(size_t)(c + 1) * g.stride]);
-        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) {
-            const int64_t p = (int64_t)g.pt_idx[(size_t)e];
-            const bool keep = faithful ? sets[(size_t)p] == lcc : sets[(size_t)(nc + p)] == lcc;
-            if (!keep) continue;
-            o.pt_idx.push_back((uint64_t)point_map[(size_t)p]);   // p is in the component (camera c observes it)
-            o.uv.push_back(g.uv[2 * (size_t)e]);
-            o.uv.push_back(g.uv[2 * (size_t)e + 1]);
-        }
-        o.row_ptr.push_back((uint64_t)o.pt_idx.size());
+    std::vector<uint8_t> keep_cam((size_t)nc), keep_pt((size_t)np);
+    for (int64_t c = 0; c < nc; ++c) keep_cam[(size_t)c] = sets[(size_t)c] == lcc;
+    for (int64_t p = 0; p < np; ++p) keep_pt[(size_t)p] = sets[(size_t)(nc + p)] == lcc;
+    if (faithful) {
+        // the reference's filter (:523) looks up element `point index` of the camera-first array
+        const std::vector<uint64_t> old_pt(g.pt_idx);               // compact() overwrites pt_idx in place
+        compact(g, keep_cam, keep_pt, [&](uint64_t e) { return sets[(size_t)old_pt[(size_t)e]] == lcc; });
+    } else {
+        compact(g, keep_cam, keep_pt, [](uint64_t) { return true; });
     }
-    return o;
+}
+
+// remove_singletons, src/baproblem.rs:426-453: cameras need > 3 observations, points > 1; the point counts are taken
+// over ALL cameras, including the ones being removed (reference TODO at :437).
+inline void singleton_pass(IndexGraph &g) {
+    std::vector<uint8_t> keep_cam((size_t)g.n_cam), keep_pt((size_t)g.n_pts);
+    for (int64_t c = 0; c < g.n_cam; ++c) keep_cam[(size_t)c] = g.row_ptr[(size_t)c + 1] - g.row_ptr[(size_t)c] > 3;
+    std::vector<int64_t> count((size_t)g.n_pts, 0);
+    for (uint64_t p : g.pt_idx) ++count[(size_t)p];
+    for (int64_t p = 0; p < g.n_pts; ++p) keep_pt[(size_t)p] = count[(size_t)p] > 1;
+    compact(g, keep_cam, keep_pt, [](uint64_t) { return true; });
 }
 
 // cull, src/baproblem.rs:538-549
 inline Graph cull(const Graph &g, bool faithful) {
+    IndexGraph ig;
+    ig.n_cam = g.n_cam; ig.n_pts = g.n_pts;
+    ig.row_ptr = g.row_ptr; ig.pt_idx = g.pt_idx;
+    ig.cam_orig.resize((size_t)g.n_cam); std::iota(ig.cam_orig.begin(), ig.cam_orig.end(), (int64_t)0);
+    ig.pt_orig.resize((size_t)g.n_pts); std::iota(ig.pt_orig.begin(), ig.pt_orig.end(), (int64_t)0);
+    ig.edge_orig.resize(g.pt_idx.size()); std::iota(ig.edge_orig.begin(), ig.edge_orig.end(), (uint64_t)0);
     int64_t nc = g.n_cam, np = g.n_pts;
-    Graph c = remove_singletons(largest_connected_component(g, faithful));
-    while (c.n_cam != nc || c.n_pts != np) {
-        nc = c.n_cam; np = c.n_pts;
-        c = remove_singletons(largest_connected_component(c, faithful));
+    lcc_pass(ig, faithful);
+    singleton_pass(ig);
+    while (ig.n_cam != nc || ig.n_pts != np) {
+        nc = ig.n_cam; np = ig.n_pts;
+        lcc_pass(ig, faithful);
+        singleton_pass(ig);
     }
-    return c;
+    Graph o;
+    o.stride = g.stride;
+    o.n_cam = ig.n_cam; o.n_pts = ig.n_pts;
+    o.cams.resize((size_t)o.n_cam * g.stride);
+    for (int64_t c = 0; c < o.n_cam; ++c)
+        std::copy(&g.cams[(size_t)ig.cam_orig[(size_t)c] * g.stride], &g.cams[(size_t)(ig.cam_orig[(size_t)c] + 1) * g.stride],
+                  &o.cams[(size_t)c * g.stride]);
+    o.pts.resize((size_t)o.n_pts * 3);
+    for (int64_t p = 0; p < o.n_pts; ++p)
+        std::copy(&g.pts[(size_t)ig.pt_orig[(size_t)p] * 3], &g.pts[(size_t)ig.pt_orig[(size_t)p] * 3 + 3], &o.pts[(size_t)p * 3]);
+    o.row_ptr = ig.row_ptr;
+    if (o.row_ptr.empty()) o.row_ptr.assign(1, 0);
+    o.pt_idx = ig.pt_idx;
+    o.uv.resize(2 * ig.edge_orig.size());
+    for (size_t e = 0; e < ig.edge_orig.size(); ++e) {
+        o.uv[2 * e] = g.uv[2 * (size_t)ig.edge_orig[e]];
+        o.uv[2 * e + 1] = g.uv[2 * (size_t)ig.edge_orig[e] + 1];
+    }
+    return o;
 }
 
 // ---- .bal / .bbal -----------------------------------------------------------------------------------
