@@ -16,6 +16,7 @@ _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i64 = C.c_int64
 _u64 = C.c_uint64
 _d = C.c_double
@@ -64,6 +65,7 @@ def lib():
     sig("orc_extent", None, _dp, _i64, _dp, _i64, _dp, _dp)
     sig("orc_dimensions", None, _dp, _i64, _dp, _i64, _dp)
     sig("orc_visibility_pairs", None, _dp, _dp, _u32p, _u32p, _i64, _d, _dp, _u8p)
+    sig("orc_occlusion_filter", None, _dp, _dp, _u32p, _u32p, _i64, _f32p, _i64, _u8p)
     sig("orc_residual_jacobian_one", None, _dp, _dp, _dp, _dp, _dp, _dp, _dp)
     sig("orc_residual_jacobian_bal", None, _dp, _i64, _dp, _u64p, _u64p, _dp, _dp, _dp, _dp)
     sig("orc_residual_jacobian", None, _dp, _i64, _dp, _u64p, _u64p, _dp, _dp, _dp, _dp)
@@ -272,6 +274,17 @@ def visibility_pairs(cams15, pts, cam_idx, pt_idx, max_dist):
     uv = np.empty((n, 2)); keep = np.empty(n, dtype=np.uint8)
     lib().orc_visibility_pairs(cams15, _f(pts), cam_idx, pt_idx, n, float(max_dist), uv, keep)
     return uv, keep
+
+
+def occlusion_filter(cams15, pts, cam_idx, pt_idx, tri9):
+    """keep mask of the occlusion rays of generate::visibility_graph (src/generate.rs:455-476), all triangles"""
+    cams15 = _f(cams15).reshape(-1, 15)
+    cam_idx = np.ascontiguousarray(cam_idx, dtype=np.uint32)
+    pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint32)
+    tri = np.ascontiguousarray(tri9, dtype=np.float32).reshape(-1, 9)
+    keep = np.empty(len(cam_idx), dtype=np.uint8)
+    lib().orc_occlusion_filter(cams15, _f(pts), cam_idx, pt_idx, len(cam_idx), tri, len(tri), keep)
+    return keep
 
 
 # ---- noise --------------------------------------------------------------------

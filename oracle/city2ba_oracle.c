@@ -422,6 +422,46 @@ void orc_visibility_pairs(const double *cams15, const double *pts, const uint32_
     }
 }
 
+/* Occlusion rays of generate::visibility_graph, src/generate.rs:455-476:        */
+/* ray = (center as f32, normalize(point - center) as f32), tfar = |dir| as f32   */
+/* - 1e-6; the pair is kept iff the scene does not occlude the ray.  The scene    */
+/* query itself is Embree's (embree-rs 0.3 / libembree3, neither vendored nor     */
+/* installed here: parity unpinned); restated as the textbook Moeller-Trumbore    */
+/* test in float32 against every triangle, occluded iff some 0 < t <= tfar.       */
+void orc_occlusion_filter(const double *cams15, const double *pts, const uint32_t *cam_idx,
+                          const uint32_t *pt_idx, int64_t n_pairs, const float *tri9, int64_t n_tri,
+                          uint8_t *keep) {
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const double *p = &pts[3 * (int64_t)pt_idx[i]];
+        double c[3], e[3];
+        orc_center(&cams15[15 * (int64_t)cam_idx[i]], c);
+        e[0] = p[0] - c[0]; e[1] = p[1] - c[1]; e[2] = p[2] - c[2];
+        const double mag = mag3(e), inv = 1.0 / mag;
+        const float o[3] = { (float)c[0], (float)c[1], (float)c[2] };
+        const float d[3] = { (float)(e[0] * inv), (float)(e[1] * inv), (float)(e[2] * inv) };
+        const float tfar = (float)mag - 1e-6f;
+        uint8_t occluded = 0;
+        for (int64_t t = 0; t < n_tri && !occluded; ++t) {
+            const float *q = &tri9[9 * t];
+            const float e1[3] = { q[3] - q[0], q[4] - q[1], q[5] - q[2] };
+            const float e2[3] = { q[6] - q[0], q[7] - q[1], q[8] - q[2] };
+            const float pv[3] = { d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0] };
+            const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+            if (det == 0.0f) continue;
+            const float idet = 1.0f / det;
+            const float tv[3] = { o[0] - q[0], o[1] - q[1], o[2] - q[2] };
+            const float u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * idet;
+            if (u < 0.0f || u > 1.0f) continue;
+            const float qv[3] = { tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0] };
+            const float w = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * idet;
+            if (w < 0.0f || u + w > 1.0f) continue;
+            const float th = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * idet;
+            if (th > 0.0f && th <= tfar) occluded = 1;
+        }
+        keep[i] = occluded ? 0 : 1;
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* Residual + 2x(9+3) Jacobian.  NOT IN THE REFERENCE (parity unpinned */
 /* by it).  r = project(project_world(X)) - uv_obs, matching the sign  */

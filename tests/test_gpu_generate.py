@@ -102,6 +102,7 @@ def test_visibility_graph_with_occlusion(c2b, seed, n_tri):
     ci_k, pi_k, uv_k = ci_all[k], pi_all[k], uv_all[k]
     assert np.array_equal(pi0, pi_k.astype(np.uint64)) and int(row0[-1]) == int(k.sum())
     occ = occluded_numpy(O.centers(cams)[ci_k], pts[pi_k], tri)
+    assert np.array_equal(O.occlusion_filter(cams, pts, ci_k, pi_k, tri) == 0, occ)      # C oracle == numpy statement
     assert 0.05 * len(occ) < occ.sum() < 0.98 * len(occ) or n_tri == 1
     want_row = np.concatenate([[0], np.cumsum(np.bincount(ci_k[~occ], minlength=n_cam))]).astype(np.uint64)
     assert np.array_equal(row, want_row)

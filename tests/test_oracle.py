@@ -201,3 +201,49 @@ def test_stats_against_numpy():
     mn, mx = O.extent(P["cams15"], P["pts"])
     assert np.allclose(mn, allp.min(axis=0), rtol=1e-13) and np.allclose(mx, allp.max(axis=0), rtol=1e-13)
     assert np.allclose(O.dimensions(P["cams15"], P["pts"]), mx - mn)
+
+
+def test_occlusion_filter_wall_and_float64_agreement():
+    """occlusion rays of generate::visibility_graph (src/generate.rs:455-476) in the oracle: a hand-checkable wall,
+    then random rays against random triangles compared with a float64 ray / triangle test away from the edges"""
+    cams = np.zeros((1, 15))
+    cams[0, :9] = np.eye(3).reshape(9)
+    cams[0, 12] = 1.0
+    wall = np.array([[-50, -50, -2, 0, -50, -2, 0, 50, -2], [-50, -50, -2, 0, 50, -2, -50, 50, -2]], dtype=np.float32)
+    pts = np.array([[-1.0, 0.2, -4.0], [1.0, 0.2, -4.0], [-0.4, 0.1, -1.0], [-0.5, -0.3, -3.0], [0.3, 0.3, -1.5]])
+    ci, pi = np.zeros(5, np.uint32), np.arange(5, dtype=np.uint32)
+    assert list(O.occlusion_filter(cams, pts, ci, pi, wall)) == [0, 1, 1, 0, 1]
+    assert list(O.occlusion_filter(cams, pts, ci, pi, np.zeros((0, 9), np.float32))) == [1] * 5
+    rng = np.random.default_rng(12)
+    pts = rng.uniform(-5, 5, (400, 3))
+    a = rng.uniform(-4, 4, (60, 3))
+    tri = np.concatenate([a, a + rng.normal(0, 1.5, (60, 3)), a + rng.normal(0, 1.5, (60, 3))], axis=1).astype(np.float32)
+    ci, pi = np.zeros(400, np.uint32), np.arange(400, dtype=np.uint32)
+    keep = O.occlusion_filter(cams, pts, ci, pi, tri)
+    T = tri.astype(np.float64).reshape(-1, 3, 3)
+    checked = 0
+    for k, p in enumerate(pts):
+        mag = np.linalg.norm(p)
+        d = p / mag
+        hit, marginal = False, False
+        for v0, v1, v2 in T:
+            e1, e2 = v1 - v0, v2 - v0
+            pv = np.cross(d, e2)
+            det = e1 @ pv
+            if abs(det) < 1e-9:
+                marginal = True
+                continue
+            tv = -v0
+            u = (tv @ pv) / det
+            qv = np.cross(tv, e1)
+            w = (d @ qv) / det
+            t = (e2 @ qv) / det
+            inside = min(u, w, 1 - u - w)
+            if abs(inside) < 1e-4 or abs(t - mag) < 1e-4 or abs(t) < 1e-4:
+                marginal = True
+            if inside > 0 and 0 < t <= mag:
+                hit = True
+        if not marginal:
+            assert keep[k] == (0 if hit else 1)
+            checked += 1
+    assert checked > 300 and 0 < keep.sum() < 400

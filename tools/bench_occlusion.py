@@ -107,6 +107,18 @@ def main():
         else:
             brute = keep3.clone()
     out["kept_after_mesh"] = int(brute.sum().item())
+    # CPU side: the oracle's all-triangles loop (1 thread) on a bounded sample of the same rays, checked against the device
+    import time
+    import oracle as O
+    n_s = int(min(n_rays, max(1000, 2e8 // max(len(tri), 1))))
+    cams_h = cam15.cpu().numpy()
+    ci_s, pi_s = rays_c[:n_s].cpu().numpy().astype(np.uint32), rays_p[:n_s].cpu().numpy().astype(np.uint32)
+    t0 = time.perf_counter()
+    keep_cpu = O.occlusion_filter(cams_h, pts, ci_s, pi_s, tri)
+    dt = time.perf_counter() - t0
+    out["cpu_all_triangles"] = {"rays": n_s, "seconds": round(dt, 3), "Mrays_per_s": round(n_s / dt / 1e6, 4),
+                                "Gtests_per_s_upper": round(n_s * len(tri) / dt / 1e9, 3), "threads": 1,
+                                "mismatch_vs_device": int((keep_cpu != brute[:n_s].cpu().numpy()).sum())}
     # 3-D mesh occlusion against the generator's 2-D segment test on the same pairs
     out["kept_2d_hits_building"] = n_2d
     if kept_2d is not None and n_rays <= 8_000_000:
