@@ -191,8 +191,8 @@ def test_cameras_poisson_through_hierarchy(G):
         with np.errstate(all="ignore"):
             u = ((p[0] - a[:, 0]) * (c[:, 2] - a[:, 2]) - (c[:, 0] - a[:, 0]) * (p[2] - a[:, 2])) / d
             w = ((b[:, 0] - a[:, 0]) * (p[2] - a[:, 2]) - (p[0] - a[:, 0]) * (b[:, 2] - a[:, 2])) / d
-        inside = (np.abs(d) > 1e-12) & (u >= 0) & (w >= 0) & (u + w <= 1)
-        margin = np.minimum(np.minimum(u, w), 1 - u - w)
+            inside = (np.abs(d) > 1e-12) & (u >= 0) & (w >= 0) & (u + w <= 1)
+            margin = np.minimum(np.minimum(u, w), 1 - u - w)
         if not inside.any() or np.any(inside & (margin < 1e-4)):
             continue                                              # on an edge: either neighbour may win
         y = a[inside, 1] + u[inside] * (b[inside, 1] - a[inside, 1]) + w[inside] * (c[inside, 1] - a[inside, 1])
