@@ -644,6 +644,8 @@ int c2b_visibility_dense_count(const double *camblk, int64_t n_cam, const double
     dim3 grid;
     int64_t per;
     dense_grid(n_cam, n_tiles, &grid, &per);
+    // the count pass writes non-empty (camera, tile) cells only
+    HIP_TRY(hipMemsetAsync(tile_counts, 0, sizeof(uint32_t) * (size_t)n_cam * (size_t)n_tiles, S(stream)));
     hipLaunchKernelGGL(k_visibility_dense<false>, grid, dim3(kDenseWPB * 64), 0, S(stream), camblk, n_cam, per,
                        reinterpret_cast<const double4 *>(pts4), n_pts, n_tiles, max_dist, tile_counts,
                        (const uint64_t *)nullptr, (uint32_t *)nullptr, (double2 *)nullptr);

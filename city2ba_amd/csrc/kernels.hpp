@@ -870,18 +870,18 @@ __global__ void k_f32_to_f64(const float *__restrict__ a, int64_t n, double *__r
 // points.iter().enumerate()` push order.
 //
 // Mapping: a wave owns a tile of 256 consecutive points (4 per lane, in registers for the whole kernel)
-// and walks a chunk of cameras staged 64 at a time in LDS (18 doubles each, read by broadcast).  The
-// common case -- the point is farther than max_dist -- costs 8 f64 operations per pair; only survivors
-// run project_world / project.  Pass 1 counts survivors per (camera, tile); a row scan turns counts into
-// offsets; pass 2 repeats the predicate and writes (point index, uv) at offset + wave-prefix rank.
+// and walks a chunk of cameras whose centres come in through scalar loads (the camera index is
+// wave-uniform).  The common case -- all four points farther than max_dist -- costs 8 f64 operations per
+// pair and one wave-uniform branch; only survivors run project_world / project.  Pass 1 counts survivors
+// per (camera, tile) into a zeroed table; a row scan turns counts into offsets; pass 2 repeats the
+// predicate and writes (point index, uv) at offset + wave-prefix rank.
 // =====================================================================================================
 namespace c2b {
 
 constexpr int kDensePPL = 4;                       // points per lane
 constexpr int kDenseTile = 64 * kDensePPL;         // points per wave tile
 constexpr int kDenseWPB = 4;                       // waves per workgroup
-constexpr int kDenseCamTile = 64;                  // cameras staged per LDS round
-constexpr int kDenseRec = 18;                      // center3 | R9 (row-major) | t3 | f,k1,k2
+constexpr int kDenseCamTile = 64;                  // granularity of the camera chunks of blockIdx.y
 
 C2B_DEV int wave_excl_scan(int v, int lane, int &total) {
     int inc = v;
@@ -899,18 +899,18 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
     const double *__restrict__ camblk, int64_t n_cam, int64_t cams_per_chunk, const double4 *__restrict__ pts4,
     int64_t n_pts, int64_t n_tiles, double max_dist, uint32_t *__restrict__ tile_counts,
     const uint64_t *__restrict__ row_ptr, uint32_t *__restrict__ pt_out, double2 *__restrict__ uv_out) {
-    __shared__ double sCam[kDenseCamTile * kDenseRec];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * kDenseWPB + wave;
     const int64_t p0 = tile * kDenseTile + (int64_t)lane * kDensePPL;      // this lane's first point
-    const bool wave_live = tile < n_tiles;
+    if (tile >= n_tiles) return;                                           // wave-uniform; no workgroup barriers below
 
+    // points past the end sit at 1e300: their squared distance is +inf and never passes the test
     double X[kDensePPL], Y[kDensePPL], Z[kDensePPL];
     bool pv[kDensePPL];
 #pragma unroll
     for (int j = 0; j < kDensePPL; ++j) {
-        pv[j] = wave_live && p0 + j < n_pts;
-        const double4 p = pv[j] ? pts4[p0 + j] : make_double4(0, 0, 0, 0);
+        pv[j] = p0 + j < n_pts;
+        const double4 p = pv[j] ? pts4[p0 + j] : make_double4(1e300, 1e300, 1e300, 0);
         X[j] = p.x; Y[j] = p.y; Z[j] = p.z;
     }
     const double m2 = max_dist * max_dist;
@@ -918,58 +918,55 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
 
     const int64_t c_begin = (int64_t)blockIdx.y * cams_per_chunk;
     const int64_t c_end = c_begin + cams_per_chunk < n_cam ? c_begin + cams_per_chunk : n_cam;
-    for (int64_t cb = c_begin; cb < c_end; cb += kDenseCamTile) {
-        const int nc = c_end - cb < kDenseCamTile ? (int)(c_end - cb) : kDenseCamTile;
-        __syncthreads();
-        for (int e = threadIdx.x; e < nc * kDenseRec; e += kDenseWPB * 64) {
-            const int k = e / kDenseRec, f = e % kDenseRec;
-            const double *src = camblk + (cb + k) * kCamBlk;
-            sCam[e] = f < 3 ? src[kCenter + f] : src[f - 3];         // center | R, t, intrinsics (camblk[0..14])
-        }
-        __syncthreads();
-        if (!wave_live) continue;
-        for (int k = 0; k < nc; ++k) {
-            const double *cam = sCam + k * kDenseRec;
-            const double cx = cam[0], cy = cam[1], cz = cam[2];
-            unsigned keep_bits = 0;
-            double u[kDensePPL], v[kDensePPL];
+    // The camera index is wave-uniform, so its centre arrives by scalar loads (SGPR operands of the vector
+    // arithmetic): no LDS staging, no barriers.  The far-reject of all four points is one wave-uniform branch; a wave
+    // that has a candidate falls into the per-point path below.  tile_counts is zeroed by the launcher, so only
+    // non-empty (camera, tile) cells are written.
+    for (int64_t c = c_begin; c < c_end; ++c) {
+        const double *cam = camblk + c * kCamBlk;
+        const double cx = cam[kCenter], cy = cam[kCenter + 1], cz = cam[kCenter + 2];
+        double d2[kDensePPL];
+        bool cand = false;
 #pragma unroll
-            for (int j = 0; j < kDensePPL; ++j) {
-                // (camera.center() - point).magnitude() < max_dist, src/generate.rs:450
-                const double dx = cx - X[j], dy = cy - Y[j], dz = cz - Z[j];
-                const double d2 = (dx * dx + dy * dy) + dz * dz;
-                u[j] = 0.0; v[j] = 0.0;
-                if (pv[j] && d2 < m2_hi) {
-                    bool near = d2 < m2_lo;
-                    if (!near) near = sqrt(d2) < max_dist;               // exact decision on the boundary band
-                    if (near) {
-                        const Proj p = project_obs(cam + 3, X[j], Y[j], Z[j]);
-                        if (p.qz <= 0.0 && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0) {
-                            keep_bits |= 1u << j;
-                            u[j] = p.u; v[j] = p.v;
-                        }
+        for (int j = 0; j < kDensePPL; ++j) {
+            // (camera.center() - point).magnitude() < max_dist, src/generate.rs:450
+            const double dx = cx - X[j], dy = cy - Y[j], dz = cz - Z[j];
+            d2[j] = (dx * dx + dy * dy) + dz * dz;
+            cand |= d2[j] < m2_hi;
+        }
+        if (!__any(cand)) continue;
+        unsigned keep_bits = 0;
+        double u[kDensePPL], v[kDensePPL];
+#pragma unroll
+        for (int j = 0; j < kDensePPL; ++j) {
+            u[j] = 0.0; v[j] = 0.0;
+            if (pv[j] && d2[j] < m2_hi) {
+                bool near = d2[j] < m2_lo;
+                if (!near) near = sqrt(d2[j]) < max_dist;                // exact decision on the boundary band
+                if (near) {
+                    const Proj p = project_obs(cam, X[j], Y[j], Z[j]);
+                    if (p.qz <= 0.0 && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0) {
+                        keep_bits |= 1u << j;
+                        u[j] = p.u; v[j] = p.v;
                     }
                 }
             }
-            const int mine = __popc(keep_bits);
-            if (!__any(mine != 0)) {
-                if (!FILL && lane == 0) tile_counts[(cb + k) * n_tiles + tile] = 0;
-                continue;
-            }
-            int total;
-            const int before = wave_excl_scan(mine, lane, total);
-            if (!FILL) {
-                if (lane == 0) tile_counts[(cb + k) * n_tiles + tile] = (uint32_t)total;
-            } else {
-                int64_t dst = (int64_t)row_ptr[cb + k] + tile_counts[(cb + k) * n_tiles + tile] + before;
+        }
+        const int mine = __popc(keep_bits);
+        if (!__any(mine != 0)) continue;
+        int total;
+        const int before = wave_excl_scan(mine, lane, total);
+        if (!FILL) {
+            if (lane == 0) tile_counts[c * n_tiles + tile] = (uint32_t)total;
+        } else {
+            int64_t dst = (int64_t)row_ptr[c] + tile_counts[c * n_tiles + tile] + before;
 #pragma unroll
-                for (int j = 0; j < kDensePPL; ++j)
-                    if (keep_bits & (1u << j)) {
-                        pt_out[dst] = (uint32_t)(p0 + j);
-                        uv_out[dst] = make_double2(u[j], v[j]);
-                        ++dst;
-                    }
-            }
+            for (int j = 0; j < kDensePPL; ++j)
+                if (keep_bits & (1u << j)) {
+                    pt_out[dst] = (uint32_t)(p0 + j);
+                    uv_out[dst] = make_double2(u[j], v[j]);
+                    ++dst;
+                }
         }
     }
 }
