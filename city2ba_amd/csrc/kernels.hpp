@@ -943,7 +943,8 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
             if (pv[j] && d2[j] < m2_hi) {
                 bool near = d2[j] < m2_lo;
                 if (!near) near = sqrt(d2[j]) < max_dist;                // exact decision on the boundary band
-                if (near) {
+                // behind the camera (q.z > 0, about half of the candidates): skip the divides of the projection
+                if (near && dot3(cam[6], cam[7], cam[8], X[j], Y[j], Z[j]) + cam[11] <= 0.0) {
                     const Proj p = project_obs(cam, X[j], Y[j], Z[j]);
                     if (p.qz <= 0.0 && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0) {
                         keep_bits |= 1u << j;
