@@ -922,7 +922,7 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
     // arithmetic): no LDS staging, no barriers.  The far-reject of all four points is one wave-uniform branch; a wave
     // that has a candidate falls into the per-point path below.  tile_counts is zeroed by the launcher, so only
     // non-empty (camera, tile) cells are written.
-    for (int64_t c = c_begin; c < c_end; ++c) {
+    auto camera_step = [&](const int64_t c) {
         const double *cam = camblk + c * kCamBlk;
         const double cx = cam[kCenter], cy = cam[kCenter + 1], cz = cam[kCenter + 2];
         double d2[kDensePPL];
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
             d2[j] = (dx * dx + dy * dy) + dz * dz;
             cand |= d2[j] < m2_hi;
         }
-        if (!__any(cand)) continue;
+        if (!__any(cand)) return;
         unsigned keep_bits = 0;
         double u[kDensePPL], v[kDensePPL];
 #pragma unroll
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
             }
         }
         const int mine = __popc(keep_bits);
-        if (!__any(mine != 0)) continue;
+        if (!__any(mine != 0)) return;
         int total;
         const int before = wave_excl_scan(mine, lane, total);
         if (!FILL) {
@@ -968,6 +968,29 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
                     uv_out[dst] = make_double2(u[j], v[j]);
                     ++dst;
                 }
+        }
+    };
+    if (!FILL) {
+        for (int64_t c = c_begin; c < c_end; ++c) camera_step(c);
+    } else {
+        // Pass 1 left the survivors of every (camera, tile) cell; only ~15 % of the cells hold any.  Sixty-four
+        // cameras at a time, each lane reads one camera's offset and its successor (= the cell's count), and the
+        // wave revisits the non-empty cells only.
+        for (int64_t c0 = c_begin; c0 < c_end; c0 += 64) {
+            const int64_t ci = c0 + lane;
+            bool nonempty = false;
+            if (ci < c_end) {
+                const uint32_t o0 = tile_counts[ci * n_tiles + tile];
+                const uint32_t o1 = tile + 1 < n_tiles ? tile_counts[ci * n_tiles + tile + 1]
+                                                       : (uint32_t)(row_ptr[ci + 1] - row_ptr[ci]);
+                nonempty = o1 != o0;
+            }
+            unsigned long long m = __ballot(nonempty);
+            while (m) {
+                const int k = __builtin_ctzll(m);
+                m &= m - 1;
+                camera_step(c0 + k);
+            }
         }
     }
 }
