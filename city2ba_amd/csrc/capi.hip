@@ -1452,16 +1452,16 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: no sweep result");
     if (!row_ptr || n_tri < 0 || (n_tri && !tri9)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: bad arguments");
     const int64_t n = p->dense_n, n_cam = p->n_cam;
-    std::vector<uint64_t> row((size_t)n_cam + 1);
-    HIP_TRY(hipMemcpyAsync(row.data(), p->dense_row, sizeof(uint64_t) * row.size(), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    if (!n || !n_tri) { std::copy(row.begin(), row.end(), row_ptr); return C2B_OK; }
+    if (!n || !n_tri) {
+        HIP_TRY(hipMemcpyAsync(row_ptr, p->dense_row, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return C2B_OK;
+    }
     float *d_tri = nullptr;
-    uint32_t *d_cam = nullptr;
+    uint32_t *d_cam = nullptr, *d_pt_new = nullptr;
     uint8_t *d_keep = nullptr;
-    std::vector<uint8_t> keep((size_t)n);
-    std::vector<uint32_t> pt((size_t)n);
-    std::vector<double> uv((size_t)n * 2);
+    uint64_t *d_tot = nullptr, *d_row_new = nullptr;
+    double *d_uv_new = nullptr;
     int rc = C2B_OK;
     // small meshes: every ray against every triangle; larger ones through a hierarchy built here on the host
     const bool use_bvh = n_tri >= kBvhMinTriangles;
@@ -1487,40 +1487,47 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
         if (!rc)
             rc = use_bvh ? c2b_occlusion_filter_bvh(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_nodes, n_nodes, d_tri, n_tri, d_keep, p->stream)
                          : c2b_occlusion_filter(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_tri, n_tri, d_keep, p->stream);
-        if (!rc) {
-            e = hipMemcpyAsync(keep.data(), d_keep, (size_t)n, hipMemcpyDeviceToHost, p->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(pt.data(), p->dense_pt, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, p->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(uv.data(), p->dense_uv, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, p->stream);
-        }
-        hipError_t e2 = hipStreamSynchronize(p->stream);
-        if (e == hipSuccess) e = e2;
-    }
-    if (!rc && e == hipSuccess) {
-        // stable compaction of the survivor lists (per-camera order of the sweep is kept) and the new row pointer
-        int64_t w = 0;
-        std::vector<uint64_t> nrow((size_t)n_cam + 1, 0);
-        for (int64_t c = 0; c < n_cam; ++c) {
-            nrow[(size_t)c] = (uint64_t)w;
-            for (uint64_t i = row[(size_t)c]; i < row[(size_t)c + 1]; ++i)
-                if (keep[(size_t)i]) {
-                    pt[(size_t)w] = pt[(size_t)i];
-                    uv[2 * (size_t)w] = uv[2 * (size_t)i];
-                    uv[2 * (size_t)w + 1] = uv[2 * (size_t)i + 1];
-                    ++w;
+        // Stable compaction of the survivor lists on the device (per-camera order of the sweep is kept): kept count per
+        // row, row scan, scatter.  Only the new row pointer travels to the host.
+        if (!rc && e == hipSuccess) e = hipMalloc((void **)&d_tot, sizeof(uint64_t) * (size_t)(n_cam + 1));
+        if (!rc && e == hipSuccess) e = hipMalloc((void **)&d_row_new, sizeof(uint64_t) * (size_t)(n_cam + 1));
+        if (!rc && e == hipSuccess) {
+            const unsigned row_blocks = (unsigned)((n_cam + 3) / 4);
+            hipLaunchKernelGGL(k_keep_row_counts, dim3(row_blocks), dim3(256), 0, p->stream, (const uint64_t *)p->dense_row,
+                               (const uint8_t *)d_keep, n_cam, d_tot);
+            hipLaunchKernelGGL(k_dense_cam_scan, dim3(1), dim3(256), 0, p->stream, (const uint64_t *)d_tot, n_cam, d_row_new);
+            e = hipMemcpyAsync(row_ptr, d_row_new, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+            if (e == hipSuccess) {
+                const int64_t w = (int64_t)row_ptr[n_cam];
+                e = hipMalloc((void **)&d_pt_new, sizeof(uint32_t) * (size_t)(w ? w : 4));
+                if (e == hipSuccess) e = hipMalloc((void **)&d_uv_new, sizeof(double) * 2 * (size_t)(w ? w : 1));
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(k_keep_row_scatter, dim3(row_blocks), dim3(256), 0, p->stream, (const uint64_t *)p->dense_row,
+                                       (const uint64_t *)d_row_new, (const uint8_t *)d_keep, (const uint32_t *)p->dense_pt,
+                                       reinterpret_cast<const double2 *>(p->dense_uv), n_cam, d_pt_new,
+                                       reinterpret_cast<double2 *>(d_uv_new));
+                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
                 }
+                if (e == hipSuccess) {                       // the filtered lists replace the sweep's
+                    std::swap(p->dense_pt, d_pt_new);
+                    std::swap(p->dense_uv, d_uv_new);
+                    std::swap(p->dense_row, d_row_new);
+                    p->dense_n = w;
+                }
+            }
         }
-        nrow[(size_t)n_cam] = (uint64_t)w;
-        e = hipMemcpyAsync(p->dense_row, nrow.data(), sizeof(uint64_t) * nrow.size(), hipMemcpyHostToDevice, p->stream);
-        if (e == hipSuccess && w) e = hipMemcpyAsync(p->dense_pt, pt.data(), sizeof(uint32_t) * (size_t)w, hipMemcpyHostToDevice, p->stream);
-        if (e == hipSuccess && w) e = hipMemcpyAsync(p->dense_uv, uv.data(), sizeof(double) * 2 * (size_t)w, hipMemcpyHostToDevice, p->stream);
-        hipError_t e2 = hipStreamSynchronize(p->stream);
-        if (e == hipSuccess) e = e2;
-        if (e == hipSuccess) { p->dense_n = w; std::copy(nrow.begin(), nrow.end(), row_ptr); }
     }
+    if (rc || e != hipSuccess) (void)hipStreamSynchronize(p->stream);   // nothing below may free what a copy still reads
     if (d_tri) (void)hipFree(d_tri);
     if (d_nodes) (void)hipFree(d_nodes);
     if (d_cam) (void)hipFree(d_cam);
     if (d_keep) (void)hipFree(d_keep);
+    if (d_tot) (void)hipFree(d_tot);
+    if (d_row_new) (void)hipFree(d_row_new);
+    if (d_pt_new) (void)hipFree(d_pt_new);
+    if (d_uv_new) (void)hipFree(d_uv_new);
     c2b_bvh_free(bvh);
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense_occlude: %s", hipGetErrorString(e));

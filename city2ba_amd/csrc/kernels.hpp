@@ -1021,6 +1021,43 @@ __global__ __launch_bounds__(256) void k_dense_row_scan(uint32_t *__restrict__ t
     if (threadIdx.x == 0) cam_total[blockIdx.x] = (uint64_t)sCarry;
 }
 
+// ---- stable compaction of a CSR observation list by a keep mask (the occlusion filter's output), on the device ----
+// one wave per camera: kept observations per row ...
+__global__ __launch_bounds__(256) void k_keep_row_counts(const uint64_t *__restrict__ row_ptr, const uint8_t *__restrict__ keep,
+                                                        int64_t n_cam, uint64_t *__restrict__ cam_total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_cam) return;
+    const uint64_t b = row_ptr[c], e = row_ptr[c + 1];
+    int count = 0;
+    for (uint64_t i = b + lane; i < e; i += 64) count += keep[i] ? 1 : 0;
+    const double s = wave_sum((double)count);                 // exact: counts are far below 2^53
+    if (lane == 0) cam_total[c] = (uint64_t)s;
+}
+
+// ... and, after the row scan, the kept (point index, uv) pairs moved to their new rows in their old order
+__global__ __launch_bounds__(256) void k_keep_row_scatter(const uint64_t *__restrict__ row_old, const uint64_t *__restrict__ row_new,
+                                                         const uint8_t *__restrict__ keep, const uint32_t *__restrict__ pt_in,
+                                                         const double2 *__restrict__ uv_in, int64_t n_cam,
+                                                         uint32_t *__restrict__ pt_out, double2 *__restrict__ uv_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_cam) return;
+    const uint64_t b = row_old[c], e = row_old[c + 1];
+    uint64_t dst = row_new[c];
+    for (uint64_t base = b; base < e; base += 64) {           // wave-uniform trip count
+        const uint64_t i = base + lane;
+        const bool k = i < e && keep[i] != 0;
+        const unsigned long long m = __ballot(k);
+        if (k) {
+            const uint64_t at = dst + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+            pt_out[at] = pt_in[i];
+            uv_out[at] = uv_in[i];
+        }
+        dst += (uint64_t)__popcll(m);
+    }
+}
+
 // row_ptr[0..n_cam] = exclusive scan of cam_total (one workgroup; n_cam is small next to n_cam * n_tiles)
 __global__ __launch_bounds__(256) void k_dense_cam_scan(const uint64_t *__restrict__ cam_total, int64_t n_cam,
                                                        uint64_t *__restrict__ row_ptr) {
