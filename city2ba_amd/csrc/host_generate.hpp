@@ -222,11 +222,26 @@ struct WeightedIndex {
         double acc = 0;
         for (double x : w) { acc += x; cum.push_back(acc); }
     }
-    size_t sample(std::mt19937_64 &rng) const {
-        const double u = uniform01(rng) * cum.back();
+    size_t at(double u01) const {
+        const double u = u01 * cum.back();
         size_t i = (size_t)(std::upper_bound(cum.begin(), cum.end(), u) - cum.begin());
         return std::min(i, cum.size() - 1);
     }
+    size_t sample(std::mt19937_64 &rng) const { return at(uniform01(rng)); }
+};
+
+// Counter-based draws for loops that run on several threads: candidate k of a seeded loop owns its own splitmix64
+// stream, so the outcome does not depend on how candidates are spread over threads.
+struct CounterRng {
+    uint64_t s;
+    CounterRng(uint64_t seed, uint64_t k) : s(seed * 0xD6E8FEB86659FD93ull + k * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform01() { return (double)(next() >> 11) * 0x1.0p-53; }
 };
 
 struct CameraSamples {
@@ -463,20 +478,41 @@ inline bool world_points_uniform(const std::vector<float> &tri9, const double *c
                 }
         return false;
     };
-    std::mt19937_64 rng(seed);
+    // The reference's loop (draw a triangle by area, a point in it, keep it if a camera is near, stop at num_points
+    // successes or 10 * num_points failures) with candidate k drawing from its own counter-based stream: candidates
+    // are evaluated a chunk at a time on all threads, then accepted in candidate order exactly as a sequential
+    // loop would.
     const WeightedIndex dist(areas);
     int64_t fail = 0;
     const int64_t fail_threshold = 10 * num_points;
-    while ((int64_t)(pts.size() / 3) < num_points && fail < fail_threshold) {
-        const size_t t = dist.sample(rng);
-        const float *q = &tri9[9 * t];
-        double rx = uniform01(rng), ry = uniform01(rng);
-        if (rx + ry > 1.0) { rx = 1.0 - rx; ry = 1.0 - ry; }
-        double p[3];
-        for (int k = 0; k < 3; ++k)
-            p[k] = (double)q[k] + rx * ((double)q[3 + k] - (double)q[k]) + ry * ((double)q[6 + k] - (double)q[k]);
-        if (near_camera(p)) pts.insert(pts.end(), p, p + 3);
-        else ++fail;
+    const unsigned n_threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const int64_t chunk = std::max<int64_t>(4096, std::min<int64_t>(num_points, 1 << 20));
+    std::vector<double> cand((size_t)chunk * 3);
+    std::vector<uint8_t> ok((size_t)chunk);
+    for (int64_t k0 = 0; (int64_t)(pts.size() / 3) < num_points && fail < fail_threshold; k0 += chunk) {
+        auto work = [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                CounterRng rng(seed, (uint64_t)(k0 + i));
+                const size_t t = dist.at(rng.uniform01());
+                const float *q = &tri9[9 * t];
+                double rx = rng.uniform01(), ry = rng.uniform01();
+                if (rx + ry > 1.0) { rx = 1.0 - rx; ry = 1.0 - ry; }
+                double *p = &cand[3 * (size_t)i];
+                for (int c = 0; c < 3; ++c)
+                    p[c] = (double)q[c] + rx * ((double)q[3 + c] - (double)q[c]) + ry * ((double)q[6 + c] - (double)q[c]);
+                ok[(size_t)i] = near_camera(p) ? 1 : 0;
+            }
+        };
+        std::vector<std::thread> pool;
+        const int64_t per = (chunk + n_threads - 1) / n_threads;
+        for (unsigned t = 1; t < n_threads; ++t)
+            if ((int64_t)t * per < chunk) pool.emplace_back(work, (int64_t)t * per, std::min(chunk, (int64_t)(t + 1) * per));
+        work(0, std::min(chunk, per));
+        for (auto &th : pool) th.join();
+        for (int64_t i = 0; i < chunk && (int64_t)(pts.size() / 3) < num_points && fail < fail_threshold; ++i) {
+            if (ok[(size_t)i]) pts.insert(pts.end(), &cand[3 * (size_t)i], &cand[3 * (size_t)i] + 3);
+            else ++fail;
+        }
     }
     if (fail >= fail_threshold && num_points > 0) {
         char buf[200];

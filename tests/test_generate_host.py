@@ -219,6 +219,9 @@ def test_world_points_on_mesh_near_cameras(G):
     max_dist = 2.5
     pts = G.generate_world_points_uniform(tri, centers, 300, max_dist, seed=3)
     assert len(pts) == 300
+    # candidates draw from counter-based streams and are accepted in candidate order: a shorter request is a prefix
+    assert np.array_equal(G.generate_world_points_uniform(tri, centers, 120, max_dist, seed=3), pts[:120])
+    assert not np.array_equal(G.generate_world_points_uniform(tri, centers, 120, max_dist, seed=4), pts[:120])
     d = np.linalg.norm(pts[:, None, :] - centers[None], axis=2).min(1)
     assert np.all(d <= max_dist)
     # every point lies on a triangle of the mesh: barycentric coordinates in [0,1] and zero plane distance
