@@ -114,6 +114,7 @@ SIGNATURES = {
     "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_stats": (_int, [_vp, _vp]),
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),
+    "c2b_problem_visibility_pairs_compact": (_int, [_vp, _i64, _vp, _vp, _d, _vp]),
     "c2b_problem_visibility_dense": (_int, [_vp, _d, _vp]),
     "c2b_problem_visibility_dense_fetch": (_int, [_vp, _vp, _vp]),
     "c2b_problem_visibility_dense_occlude": (_int, [_vp, _vp, _i64, _vp]),

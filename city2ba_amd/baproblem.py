@@ -252,6 +252,22 @@ class BAProblem:
                                                      _ptr(uv), _ptr(keep)))
         return uv, keep
 
+    def visibility_pairs_compact(self, cam_idx, pt_idx, max_dist):
+        """the same predicate with the kept pairs compacted on the device (cam_idx non-decreasing): returns the CSR
+        graph (row_ptr u64, pt_idx u64, uv) of the survivors in candidate order"""
+        cam_idx = np.ascontiguousarray(cam_idx, dtype=np.uint32)
+        pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint32)
+        if len(pt_idx) != len(cam_idx):
+            raise L.City2baError(L.ERR_INVALID_ARGUMENT, "cam_idx and pt_idx differ in length")
+        row_ptr = np.zeros(self.num_cameras() + 1, dtype=np.uint64)
+        L.check(L.lib().c2b_problem_visibility_pairs_compact(self._h, len(cam_idx), _ptr(cam_idx), _ptr(pt_idx),
+                                                             float(max_dist), _ptr(row_ptr)))
+        n = int(row_ptr[-1])
+        kept = np.empty(n, dtype=np.uint64)
+        uv = np.empty((n, 2))
+        L.check(L.lib().c2b_problem_visibility_dense_fetch(self._h, _ptr(kept), _ptr(uv)))
+        return row_ptr, kept, uv
+
 
 # ---- host-array helpers over the C ABI (no GPU involved) ------------------------------------------------
 def cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful=True):

@@ -144,22 +144,15 @@ HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, 
     ck(c2b_candidate_pairs(centers.data(), n_cam, pts.data(), n_pts, max_dist, 0, n_cam, occlusion ? 1 : 0, L, inset, threads, &pairs));
     timer.mark("candidate pairs (host, threaded)");
     const int64_t n_pairs = c2b_pairs_count(pairs);
-    std::vector<double> uv((size_t)n_pairs * 2);
-    std::vector<uint8_t> keep((size_t)n_pairs);
-    ck(c2b_problem_visibility_pairs(p, n_pairs, c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, uv.data(), keep.data()));
-    timer.mark("visibility predicate (device, host buffers in/out)");
-    const uint32_t *ci = c2b_pairs_cam_idx(pairs), *pi = c2b_pairs_pt_idx(pairs);
+    // predicate + stable compaction on the device: only the kept pairs come back
     hp.row_ptr.assign((size_t)n_cam + 1, 0);
-    for (int64_t k = 0; k < n_pairs; ++k)
-        if (keep[(size_t)k]) {
-            ++hp.row_ptr[(size_t)ci[k] + 1];
-            hp.pt_idx.push_back(pi[k]);
-            hp.uv.push_back(uv[2 * (size_t)k]);
-            hp.uv.push_back(uv[2 * (size_t)k + 1]);
-        }
-    for (int64_t c = 0; c < n_cam; ++c) hp.row_ptr[(size_t)c + 1] += hp.row_ptr[(size_t)c];
+    ck(c2b_problem_visibility_pairs_compact(p, n_pairs, c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, hp.row_ptr.data()));
     c2b_pairs_free(pairs);
-    timer.mark("compaction");
+    const size_t n_kept = (size_t)hp.row_ptr[(size_t)n_cam];
+    hp.pt_idx.resize(n_kept + 1); hp.uv.resize(2 * n_kept + 2);
+    ck(c2b_problem_visibility_dense_fetch(p, hp.pt_idx.data(), hp.uv.data()));
+    hp.pt_idx.resize(n_kept); hp.uv.resize(2 * n_kept);
+    timer.mark("visibility predicate + compaction (device), fetch");
     // .cull(), src/synthetic.rs:299
     ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(), 1));
     timer.mark("cull");

@@ -1403,6 +1403,97 @@ int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t
     return C2B_OK;
 }
 
+// Stable compaction of CSR lists (point index, uv) by a keep mask, on the device: kept count per row -> row scan ->
+// one wave per camera scatters in order.  The new row pointer goes to row_ptr_host; on success the three new device
+// buffers are handed to the caller (who owns them), *w = kept count.  Synchronises the problem's stream.
+static hipError_t compact_rows_on_device(c2b_problem *p, const uint64_t *d_row_old, const uint8_t *d_keep, const uint32_t *d_pt,
+                                         const double *d_uv, int64_t n_cam, uint64_t *row_ptr_host, uint64_t **d_row_new,
+                                         uint32_t **d_pt_new, double **d_uv_new, int64_t *w) {
+    uint64_t *d_tot = nullptr;
+    *d_row_new = nullptr; *d_pt_new = nullptr; *d_uv_new = nullptr; *w = 0;
+    hipError_t e = hipMalloc((void **)&d_tot, sizeof(uint64_t) * (size_t)(n_cam + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)d_row_new, sizeof(uint64_t) * (size_t)(n_cam + 1));
+    if (e == hipSuccess) {
+        const unsigned row_blocks = (unsigned)((n_cam + 3) / 4);
+        if (n_cam) hipLaunchKernelGGL(k_keep_row_counts, dim3(row_blocks), dim3(256), 0, p->stream, d_row_old, d_keep, n_cam, d_tot);
+        hipLaunchKernelGGL(k_dense_cam_scan, dim3(1), dim3(256), 0, p->stream, (const uint64_t *)d_tot, n_cam, *d_row_new);
+        e = hipMemcpyAsync(row_ptr_host, *d_row_new, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (e == hipSuccess) {
+            *w = (int64_t)row_ptr_host[n_cam];
+            e = hipMalloc((void **)d_pt_new, sizeof(uint32_t) * (size_t)(*w ? *w : 4));
+            if (e == hipSuccess) e = hipMalloc((void **)d_uv_new, sizeof(double) * 2 * (size_t)(*w ? *w : 1));
+            if (e == hipSuccess && n_cam) {
+                hipLaunchKernelGGL(k_keep_row_scatter, dim3(row_blocks), dim3(256), 0, p->stream, d_row_old,
+                                   (const uint64_t *)*d_row_new, d_keep, d_pt, reinterpret_cast<const double2 *>(d_uv), n_cam,
+                                   *d_pt_new, reinterpret_cast<double2 *>(*d_uv_new));
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        }
+    }
+    if (d_tot) (void)hipFree(d_tot);
+    if (e != hipSuccess) {
+        if (*d_row_new) (void)hipFree(*d_row_new);
+        if (*d_pt_new) (void)hipFree(*d_pt_new);
+        if (*d_uv_new) (void)hipFree(*d_uv_new);
+        *d_row_new = nullptr; *d_pt_new = nullptr; *d_uv_new = nullptr;
+    }
+    return e;
+}
+
+int c2b_problem_visibility_pairs_compact(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                                         double max_dist, uint64_t *row_ptr) {
+    NEED_UPLOADED(p, "problem_visibility_pairs_compact");
+    if (n_pairs < 0 || !row_ptr || (n_pairs && (!cam_idx || !pt_idx)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_pairs_compact: bad arguments");
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        if (cam_idx[i] >= (uint64_t)p->n_cam || pt_idx[i] >= (uint64_t)p->n_pts)
+            return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "problem_visibility_pairs_compact: pair %lld out of range", (long long)i);
+        if (i && cam_idx[i] < cam_idx[i - 1])
+            return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_pairs_compact: cam_idx must be non-decreasing (pair %lld)", (long long)i);
+    }
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    free_dense(p);
+    const int64_t n_cam = p->n_cam;
+    const size_t n = (size_t)(n_pairs ? n_pairs : 1);
+    uint32_t *d_c = nullptr, *d_p = nullptr, *d_pt_new = nullptr;
+    double *d_uv = nullptr, *d_uv_new = nullptr;
+    uint8_t *d_k = nullptr;
+    uint64_t *d_row = nullptr, *d_row_new = nullptr;
+    int64_t w = 0;
+    hipError_t e = hipMalloc((void **)&d_c, sizeof(uint32_t) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_p, sizeof(uint32_t) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_uv, sizeof(double) * 2 * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_k, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_row, sizeof(uint64_t) * (size_t)(n_cam + 1));
+    if (e == hipSuccess && n_pairs) e = hipMemcpyAsync(d_c, cam_idx, sizeof(uint32_t) * n, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess && n_pairs) e = hipMemcpyAsync(d_p, pt_idx, sizeof(uint32_t) * n, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) {
+        if (n_pairs) rc = c2b_visibility_pairs(p->camblk, p->pts4, d_c, d_p, n_pairs, max_dist, d_uv, d_k, p->stream);
+        if (!rc) {
+            hipLaunchKernelGGL(k_rows_from_sorted, dim3(blocks_for(n_pairs + 1)), dim3(kBlock), 0, p->stream, (const uint32_t *)d_c,
+                               n_pairs, n_cam, d_row);
+            e = hipGetLastError();
+            if (e == hipSuccess)
+                e = compact_rows_on_device(p, d_row, d_k, d_p, d_uv, n_cam, row_ptr, &d_row_new, &d_pt_new, &d_uv_new, &w);
+        }
+    }
+    if (rc || e != hipSuccess) (void)hipStreamSynchronize(p->stream);
+    if (!rc && e == hipSuccess) {                 // becomes the pending visibility result (fetch with _dense_fetch)
+        p->dense_row = d_row_new; p->dense_pt = d_pt_new; p->dense_uv = d_uv_new; p->dense_n = w;
+    }
+    if (d_c) (void)hipFree(d_c);
+    if (d_p) (void)hipFree(d_p);
+    if (d_uv) (void)hipFree(d_uv);
+    if (d_k) (void)hipFree(d_k);
+    if (d_row) (void)hipFree(d_row);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_pairs_compact: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr) {
     NEED_UPLOADED(p, "problem_visibility_dense");
     if (!row_ptr) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense: row_ptr is NULL");
@@ -1489,33 +1580,15 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
                          : c2b_occlusion_filter(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_tri, n_tri, d_keep, p->stream);
         // Stable compaction of the survivor lists on the device (per-camera order of the sweep is kept): kept count per
         // row, row scan, scatter.  Only the new row pointer travels to the host.
-        if (!rc && e == hipSuccess) e = hipMalloc((void **)&d_tot, sizeof(uint64_t) * (size_t)(n_cam + 1));
-        if (!rc && e == hipSuccess) e = hipMalloc((void **)&d_row_new, sizeof(uint64_t) * (size_t)(n_cam + 1));
-        if (!rc && e == hipSuccess) {
-            const unsigned row_blocks = (unsigned)((n_cam + 3) / 4);
-            hipLaunchKernelGGL(k_keep_row_counts, dim3(row_blocks), dim3(256), 0, p->stream, (const uint64_t *)p->dense_row,
-                               (const uint8_t *)d_keep, n_cam, d_tot);
-            hipLaunchKernelGGL(k_dense_cam_scan, dim3(1), dim3(256), 0, p->stream, (const uint64_t *)d_tot, n_cam, d_row_new);
-            e = hipMemcpyAsync(row_ptr, d_row_new, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, p->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-            if (e == hipSuccess) {
-                const int64_t w = (int64_t)row_ptr[n_cam];
-                e = hipMalloc((void **)&d_pt_new, sizeof(uint32_t) * (size_t)(w ? w : 4));
-                if (e == hipSuccess) e = hipMalloc((void **)&d_uv_new, sizeof(double) * 2 * (size_t)(w ? w : 1));
-                if (e == hipSuccess) {
-                    hipLaunchKernelGGL(k_keep_row_scatter, dim3(row_blocks), dim3(256), 0, p->stream, (const uint64_t *)p->dense_row,
-                                       (const uint64_t *)d_row_new, (const uint8_t *)d_keep, (const uint32_t *)p->dense_pt,
-                                       reinterpret_cast<const double2 *>(p->dense_uv), n_cam, d_pt_new,
-                                       reinterpret_cast<double2 *>(d_uv_new));
-                    e = hipGetLastError();
-                    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-                }
-                if (e == hipSuccess) {                       // the filtered lists replace the sweep's
-                    std::swap(p->dense_pt, d_pt_new);
-                    std::swap(p->dense_uv, d_uv_new);
-                    std::swap(p->dense_row, d_row_new);
-                    p->dense_n = w;
-                }
+        if (!rc) {
+            int64_t w = 0;
+            e = compact_rows_on_device(p, p->dense_row, d_keep, p->dense_pt, p->dense_uv, n_cam, row_ptr, &d_row_new, &d_pt_new,
+                                       &d_uv_new, &w);
+            if (e == hipSuccess) {                           // the filtered lists replace the sweep's
+                std::swap(p->dense_pt, d_pt_new);
+                std::swap(p->dense_uv, d_uv_new);
+                std::swap(p->dense_row, d_row_new);
+                p->dense_n = w;
             }
         }
     }

@@ -1021,6 +1021,16 @@ __global__ __launch_bounds__(256) void k_dense_row_scan(uint32_t *__restrict__ t
     if (threadIdx.x == 0) cam_total[blockIdx.x] = (uint64_t)sCarry;
 }
 
+// row_ptr[0..n_cam] of a non-decreasing camera index list: row_ptr[c] = first position whose camera is >= c
+__global__ __launch_bounds__(kBlock) void k_rows_from_sorted(const uint32_t *__restrict__ cam_idx, int64_t n, int64_t n_cam,
+                                                            uint64_t *__restrict__ row_ptr) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i > n) return;
+    const int64_t prev = i == 0 ? -1 : (int64_t)cam_idx[i - 1];
+    const int64_t cur = i == n ? n_cam : (int64_t)cam_idx[i];
+    for (int64_t c = prev + 1; c <= cur && c <= n_cam; ++c) row_ptr[c] = (uint64_t)i;
+}
+
 // ---- stable compaction of a CSR observation list by a keep mask (the occlusion filter's output), on the device ----
 // one wave per camera: kept observations per row ...
 __global__ __launch_bounds__(256) void k_keep_row_counts(const uint64_t *__restrict__ row_ptr, const uint8_t *__restrict__ keep,

@@ -74,12 +74,8 @@ def _visibility_problem(pos, dirs, pts, max_dist, occlusion, block_length, block
     s = ba._camera_centers()
     ci, pi = candidate_pairs(s, pts, max_dist, occlusion=occlusion, block_length=block_length,
                              block_inset=block_inset)
-    uv, keep = ba.visibility_pairs(ci, pi, max_dist)
-    k = keep == 1
-    ci, pi, uv = ci[k], pi[k], uv[k]
-    row_ptr = np.zeros(n_cam + 1, dtype=np.uint64)
-    row_ptr[1:] = np.cumsum(np.bincount(ci.astype(np.int64), minlength=n_cam))
-    out = BAProblem.from_visibility(cam15, pts, row_ptr, pi.astype(np.uint64), uv, device)
+    row_ptr, kept, uv = ba.visibility_pairs_compact(ci, pi, max_dist)      # survivors compacted on the device
+    out = BAProblem.from_visibility(cam15, pts, row_ptr, kept, uv, device)
     return out.cull() if cull else out
 
 

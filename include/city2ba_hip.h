@@ -358,6 +358,12 @@ int c2b_problem_stats(c2b_problem *p, double *stats /* C2B_STATS_DOUBLES */);
 int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx,
                                  const uint32_t *pt_idx, double max_dist, double *uv_out,
                                  uint8_t *keep);
+/* The same predicate over candidate pairs whose cam_idx is non-decreasing (the generators' loops,
+ * src/synthetic.rs:275-296, :360-378), with the kept pairs compacted on the device in their order: writes
+ * row_ptr[n_cam + 1]; the kept (point index, uv) lists come back through c2b_problem_visibility_dense_fetch, so only
+ * survivors cross PCIe. */
+int c2b_problem_visibility_pairs_compact(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx,
+                                         const uint32_t *pt_idx, double max_dist, uint64_t *row_ptr);
 /* dense sweep (src/generate.rs:446-469, no occlusion) over the problem's cameras and points: writes
  * row_ptr[n_cam + 1] and keeps the survivors on the device; _fetch copies pt_idx[row_ptr[n_cam]] and
  * uv[row_ptr[n_cam]][2] out (either may be NULL). */

@@ -57,6 +57,28 @@ def test_synthetic_grid_against_oracle_pipeline(c2b):
     assert np.all(np.bincount(ba.pt_idx.astype(np.int64), minlength=ba.num_points()) > 1)
 
 
+def test_visibility_pairs_compact_equals_mask_then_host_compaction(c2b):
+    from city2ba_amd import synthetic as S
+    cams, pts = grid_cameras_points(3, cpb=10, ppb=20, L=5.0)
+    empty = np.zeros(len(cams) + 1, dtype=np.uint64)
+    ba = c2b.BAProblem.from_visibility(cams, pts, empty, [], np.zeros((0, 2)))
+    ci, pi = S.candidate_pairs(O.centers(cams), pts, 10.0)
+    # leave some cameras without candidates (first, last and a run in the middle)
+    sel = (ci > 2) & ((ci < 40) | (ci > 55)) & (ci < len(cams) - 3)
+    ci, pi = ci[sel], pi[sel]
+    uv, keep = ba.visibility_pairs(ci, pi, 10.0)
+    k = keep == 1
+    want_row = np.concatenate([[0], np.cumsum(np.bincount(ci[k], minlength=len(cams)))]).astype(np.uint64)
+    row, kept, uv_c = ba.visibility_pairs_compact(ci, pi, 10.0)
+    assert np.array_equal(row, want_row) and np.array_equal(kept, pi[k].astype(np.uint64)) and np.array_equal(uv_c, uv[k])
+    assert 0 < k.sum() < len(k)
+    # degenerate inputs: no pairs; unsorted cameras are refused
+    row0, kept0, _ = ba.visibility_pairs_compact(ci[:0], pi[:0], 10.0)
+    assert np.all(row0 == 0) and len(kept0) == 0
+    with pytest.raises(c2b.City2baError, match="non-decreasing"):
+        ba.visibility_pairs_compact(ci[::-1].copy(), pi[::-1].copy(), 10.0)
+
+
 def test_normalized_drift(c2b):                      # tests/main.rs:134-141
     ba = make_test_grid(c2b)
     err_start = ba.total_reprojection_error(2.0)
