@@ -114,6 +114,9 @@ SIGNATURES = {
     "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_stats": (_int, [_vp, _vp]),
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),
+    "c2b_problem_cull": (_int, [_vp, _int]),
+    "c2b_problem_adopt_visibility": (_int, [_vp]),
+    "c2b_problem_download_graph": (_int, [_vp, _vp, _vp]),
     "c2b_problem_visibility_pairs_compact": (_int, [_vp, _i64, _vp, _vp, _d, _vp]),
     "c2b_problem_visibility_dense": (_int, [_vp, _d, _vp]),
     "c2b_problem_visibility_dense_fetch": (_int, [_vp, _vp, _vp]),

@@ -187,7 +187,7 @@ class BAProblem:
         s = self._stats()
         return s[15:18].copy(), int(s[18])
 
-    def visibility_graph(self, max_dist, triangles=None):
+    def visibility_graph(self, max_dist, triangles=None, fetch=True):
         """The camera x point sweep of generate::visibility_graph (src/generate.rs:424-481): every camera of
         the problem against every point; with `triangles` ([n,9] f32 mesh) the survivors also pass the occlusion
         rays of :455-476 (brute force over the triangles on the device in place of Embree).  Returns the CSR graph
@@ -198,6 +198,8 @@ class BAProblem:
         if triangles is not None:
             tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
             L.check(L.lib().c2b_problem_visibility_dense_occlude(self._h, _ptr(tri), len(tri), _ptr(row_ptr)))
+        if not fetch:                     # lists stay on the device for adopt_visibility()
+            return row_ptr
         n = int(row_ptr[-1])
         pt_idx = np.empty(n, dtype=np.uint64)
         uv = np.empty((n, 2))
@@ -220,7 +222,28 @@ class BAProblem:
     # ---- host-side rows: cull and file IO (C++ host code behind the same ABI) -----------------------
     def cull(self, faithful=True):
         """BAProblem::cull (src/baproblem.rs:538-549): largest connected component + cameras with > 3
-        observations / points with > 1, to a fixed point.  Returns a NEW device problem."""
+        observations / points with > 1, to a fixed point -- on the device, in place (the reference consumes self and
+        returns the culled problem; this returns self)."""
+        L.check(L.lib().c2b_problem_cull(self._h, int(bool(faithful))))
+        return self._refresh_graph()
+
+    def _refresh_graph(self):
+        """host mirrors of the graph (row_ptr, pt_idx) after a device-side change"""
+        n_cam, _, n_obs = self._sizes()
+        row_ptr = np.zeros(n_cam + 1, dtype=np.uint64)
+        pt_idx = np.zeros(n_obs, dtype=np.uint64)
+        L.check(L.lib().c2b_problem_download_graph(self._h, _ptr(row_ptr), _ptr(pt_idx)))
+        self._row_ptr, self._pt_idx = row_ptr, pt_idx
+        return self
+
+    def adopt_visibility(self):
+        """BAProblem::from_visibility (src/baproblem.rs:360-376) on the device: the pending result of
+        visibility_pairs_compact(fetch=False) / visibility_graph(fetch=False) becomes this problem's vis_graph"""
+        L.check(L.lib().c2b_problem_adopt_visibility(self._h))
+        return self._refresh_graph()
+
+    def cull_host(self, faithful=True):
+        """the same through the host implementation (c2b_cull on downloaded arrays); returns a NEW device problem"""
         cams = self.cameras()
         pts = self.points()
         uv = self.observations()
@@ -252,9 +275,10 @@ class BAProblem:
                                                      _ptr(uv), _ptr(keep)))
         return uv, keep
 
-    def visibility_pairs_compact(self, cam_idx, pt_idx, max_dist):
+    def visibility_pairs_compact(self, cam_idx, pt_idx, max_dist, fetch=True):
         """the same predicate with the kept pairs compacted on the device (cam_idx non-decreasing): returns the CSR
-        graph (row_ptr u64, pt_idx u64, uv) of the survivors in candidate order"""
+        graph (row_ptr u64, pt_idx u64, uv) of the survivors in candidate order; fetch=False leaves the lists on the
+        device (for adopt_visibility) and returns the row pointer only"""
         cam_idx = np.ascontiguousarray(cam_idx, dtype=np.uint32)
         pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint32)
         if len(pt_idx) != len(cam_idx):
@@ -262,6 +286,8 @@ class BAProblem:
         row_ptr = np.zeros(self.num_cameras() + 1, dtype=np.uint64)
         L.check(L.lib().c2b_problem_visibility_pairs_compact(self._h, len(cam_idx), _ptr(cam_idx), _ptr(pt_idx),
                                                              float(max_dist), _ptr(row_ptr)))
+        if not fetch:
+            return row_ptr
         n = int(row_ptr[-1])
         kept = np.empty(n, dtype=np.uint64)
         uv = np.empty((n, 2))

@@ -125,7 +125,24 @@ struct HostProblem {
     std::vector<uint64_t> row_ptr, pt_idx;
 };
 
-// shared tail of synthetic_grid / synthetic_line: visibility (device predicate) then cull (host)
+// the resident problem (cameras as in-memory records, points, graph, observations) on the host
+void download_problem(c2b_problem *p, HostProblem &hp) {
+    int64_t n_obs = 0;
+    ck(c2b_problem_sizes(p, &hp.n_cam, &hp.n_pts, &n_obs));
+    hp.cams15.assign((size_t)hp.n_cam * 15 + 1, 0.0);
+    hp.pts.assign((size_t)hp.n_pts * 3 + 1, 0.0);
+    hp.uv.assign((size_t)n_obs * 2 + 1, 0.0);
+    hp.row_ptr.assign((size_t)hp.n_cam + 1, 0);
+    hp.pt_idx.assign((size_t)n_obs + 1, 0);
+    ck(c2b_problem_download(p, hp.cams15.data(), hp.pts.data(), hp.uv.data()));
+    ck(c2b_problem_download_graph(p, hp.row_ptr.data(), hp.pt_idx.data()));
+    hp.cams15.resize((size_t)hp.n_cam * 15);
+    hp.pts.resize((size_t)hp.n_pts * 3);
+    hp.uv.resize((size_t)n_obs * 2);
+    hp.pt_idx.resize((size_t)n_obs);
+}
+
+// shared tail of synthetic_grid / synthetic_line: visibility predicate, then cull, both on the device
 HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, const std::vector<double> &dir,
                                 const std::vector<double> &pts, double max_dist, bool occlusion, double L, double inset) {
     const int64_t n_cam = (int64_t)pos.size() / 3, n_pts = (int64_t)pts.size() / 3;
@@ -144,29 +161,21 @@ HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, 
     ck(c2b_candidate_pairs(centers.data(), n_cam, pts.data(), n_pts, max_dist, 0, n_cam, occlusion ? 1 : 0, L, inset, threads, &pairs));
     timer.mark("candidate pairs (host, threaded)");
     const int64_t n_pairs = c2b_pairs_count(pairs);
-    // predicate + stable compaction on the device: only the kept pairs come back
-    hp.row_ptr.assign((size_t)n_cam + 1, 0);
-    ck(c2b_problem_visibility_pairs_compact(p, n_pairs, c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, hp.row_ptr.data()));
+    // predicate + stable compaction on the device; the kept pairs become the problem's vis_graph there
+    std::vector<uint64_t> rows((size_t)n_cam + 1, 0);
+    ck(c2b_problem_visibility_pairs_compact(p, n_pairs, c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, rows.data()));
     c2b_pairs_free(pairs);
-    const size_t n_kept = (size_t)hp.row_ptr[(size_t)n_cam];
-    hp.pt_idx.resize(n_kept + 1); hp.uv.resize(2 * n_kept + 2);
-    ck(c2b_problem_visibility_dense_fetch(p, hp.pt_idx.data(), hp.uv.data()));
-    hp.pt_idx.resize(n_kept); hp.uv.resize(2 * n_kept);
-    timer.mark("visibility predicate + compaction (device), fetch");
-    // .cull(), src/synthetic.rs:299
-    ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(), 1));
-    timer.mark("cull");
-    hp.cams15.resize((size_t)hp.n_cam * 15);
-    hp.pts.resize((size_t)hp.n_pts * 3);
-    hp.row_ptr.resize((size_t)hp.n_cam + 1);
-    const size_t n_obs = (size_t)hp.row_ptr[(size_t)hp.n_cam];
-    hp.pt_idx.resize(n_obs);
-    hp.uv.resize(2 * n_obs);
+    ck(c2b_problem_adopt_visibility(p));
+    timer.mark("visibility predicate + compaction (device)");
+    // .cull(), src/synthetic.rs:299 -- on the device
+    ck(c2b_problem_cull(p, 1));
+    timer.mark("cull (device)");
+    download_problem(p, hp);
+    timer.mark("download");
     return hp;
 }
 
 void display_and_write(c2b_problem *p, const HostProblem &hp, const std::string &out) {
-    ck(c2b_problem_upload(p, hp.n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
     std::printf("Bundle Adjustment Problem with %lld cameras, %lld points, and %lld observations\n", (long long)hp.n_cam,
                 (long long)hp.n_pts, (long long)hp.pt_idx.size());
     std::vector<double> bal9((size_t)hp.n_cam * 9);
@@ -413,24 +422,18 @@ int run_generate(int argc, char **argv) {
     ck(c2b_problem_visibility_dense_occlude(p, tri.data(), n_tri, hp.row_ptr.data()));
     timer.mark("hierarchy build + occlusion rays + compaction");
     const size_t n_edges = (size_t)hp.row_ptr[(size_t)n_cam];
-    hp.pt_idx.resize(n_edges + 1); hp.uv.resize(2 * n_edges + 2);
-    ck(c2b_problem_visibility_dense_fetch(p, hp.pt_idx.data(), hp.uv.data()));
-    timer.mark("fetch");
     std::printf("Computed visibility graph with %zu edges\n", n_edges);
 
-    if (!a.has("no-lcc"))
-        ck(c2b_cull(&hp.n_cam, hp.cams15.data(), 15, &hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data(),
-                    a.has("exact-lcc") ? 0 : 1));
+    // from_visibility and cull stay on the device; one download at the end
+    ck(c2b_problem_adopt_visibility(p));
+    if (!a.has("no-lcc")) ck(c2b_problem_cull(p, a.has("exact-lcc") ? 0 : 1));
+    timer.mark("from_visibility + cull (device)");
+    download_problem(p, hp);
     if (hp.n_cam == 0 || hp.n_pts == 0) die("EmptyProblem(\"No cameras remain\")");
-    hp.cams15.resize((size_t)hp.n_cam * 15);
-    hp.pts.resize((size_t)hp.n_pts * 3);
-    hp.row_ptr.resize((size_t)hp.n_cam + 1);
-    const size_t n_obs = (size_t)hp.row_ptr[(size_t)hp.n_cam];
-    hp.pt_idx.resize(n_obs); hp.uv.resize(2 * n_obs);
-    timer.mark("cull");
+    const size_t n_obs = hp.pt_idx.size();
+    timer.mark("download");
     std::printf("Computed LCC with %lld cameras, %lld points, %zu edges\n", (long long)hp.n_cam, (long long)hp.n_pts, n_obs);
 
-    ck(c2b_problem_upload(p, hp.n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
     double l1 = 0;
     ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
     std::printf("Total reprojection error: %s\n", display_f64(l1).c_str());

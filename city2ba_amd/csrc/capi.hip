@@ -19,6 +19,7 @@
 #include "host_noise.hpp"
 #include "host_synthetic.hpp"
 #include "kernels.hpp"
+#include "cull_kernels.hpp"
 
 using namespace c2b;
 
@@ -1400,6 +1401,217 @@ int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t
     if (d_k) (void)hipFree(d_k);
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_pairs: %s", hipGetErrorString(e));
+    return C2B_OK;
+}
+
+/* ---- BAProblem::cull on the device (src/baproblem.rs:538-549) ---- */
+extern "C++" {
+namespace {
+
+// device allocation that frees itself (the cull pipeline holds ~20 scratch arrays)
+struct DevBuf {
+    void *ptr = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (ptr) (void)hipFree(ptr); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes ? bytes : 16); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
+    void *release() { void *q = ptr; ptr = nullptr; return q; }
+};
+
+unsigned blocks_of(int64_t n, int per) { return (unsigned)((n + per - 1) / per > 0 ? (n + per - 1) / per : 1); }
+
+// exclusive scan of n 0/1 flags into pos; *total_host = number of set flags.  Synchronises.
+hipError_t scan_flags(hipStream_t st, const uint32_t *flags, int64_t n, uint32_t *pos, uint32_t *tile_scratch, uint32_t *d_total,
+                      uint32_t *total_host) {
+    const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    if (n > 0) hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, flags, n, pos, tile_scratch);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, st, tile_scratch, tiles, d_total);
+    if (n > 0) hipLaunchKernelGGL(k_scan_add, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, pos, n, (const uint32_t *)tile_scratch);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(total_host, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int c2b_problem_cull(c2b_problem *p, int faithful) {
+    NEED_UPLOADED(p, "problem_cull");
+    if (p->n_obs >= ((int64_t)1 << 32) || p->n_cam + p->n_pts >= ((int64_t)1 << 32))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_cull: more than 2^32 observations or entities");
+    free_dense(p);
+    hipStream_t st = p->stream;
+    const int64_t nc0 = p->n_cam, np0 = p->n_pts, no0 = p->n_obs;
+    const int64_t nodes0 = nc0 + np0, big0 = std::max(std::max(nc0, np0), no0);
+    // current graph (ping-pong pairs) + where everything came from
+    DevBuf cam[2], pt[2], eorig[2], corig[2], porig[2];
+    DevBuf parent, sets, size, keep_c, keep_p, keep_o, pos_c, pos_p, pos_o, tiles, best, total, deg, cnt;
+    hipError_t e = hipSuccess;
+    auto A = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
+    for (int k = 0; k < 2; ++k) {
+        A(cam[k], 4 * (size_t)no0); A(pt[k], 4 * (size_t)no0); A(eorig[k], 4 * (size_t)no0);
+        A(corig[k], 4 * (size_t)nc0); A(porig[k], 4 * (size_t)np0);
+    }
+    A(parent, 4 * (size_t)nodes0); A(sets, 4 * (size_t)nodes0); A(size, 4 * (size_t)nodes0);
+    A(keep_c, 4 * (size_t)nc0); A(keep_p, 4 * (size_t)np0); A(keep_o, 4 * (size_t)no0);
+    A(pos_c, 4 * (size_t)nc0); A(pos_p, 4 * (size_t)np0); A(pos_o, 4 * (size_t)no0);
+    A(tiles, 4 * (size_t)(big0 / kScanTile + 2)); A(best, 8); A(total, 4);
+    A(deg, 4 * (size_t)nc0); A(cnt, 4 * (size_t)np0);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_cull: %s", hipGetErrorString(e));
+
+    int cur = 0;
+    int64_t nc = nc0, np = np0, no = no0;
+    if (no) {
+        e = hipMemcpyAsync(cam[0].ptr, p->cam_idx, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(pt[0].ptr, p->pt_idx, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_uf_init, dim3(blocks_of(no, kBlock)), dim3(kBlock), 0, st, eorig[0].as<uint32_t>(), no);   // iota
+        hipLaunchKernelGGL(k_uf_init, dim3(blocks_of(nc, kBlock)), dim3(kBlock), 0, st, corig[0].as<uint32_t>(), nc);
+        hipLaunchKernelGGL(k_uf_init, dim3(blocks_of(np, kBlock)), dim3(kBlock), 0, st, porig[0].as<uint32_t>(), np);
+        e = hipGetLastError();
+    }
+
+    // renumber by the keep flags currently in keep_c / keep_p / keep_o
+    auto compact = [&]() -> hipError_t {
+        uint32_t nc_new = 0, np_new = 0, no_new = 0;
+        hipError_t s = scan_flags(st, keep_c.as<uint32_t>(), nc, pos_c.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &nc_new);
+        if (s == hipSuccess) s = scan_flags(st, keep_p.as<uint32_t>(), np, pos_p.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &np_new);
+        if (s == hipSuccess) s = scan_flags(st, keep_o.as<uint32_t>(), no, pos_o.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &no_new);
+        if (s != hipSuccess) return s;
+        const int nxt = cur ^ 1;
+        hipLaunchKernelGGL(k_cull_move_nodes, dim3(blocks_of(nc, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)keep_c.as<uint32_t>(),
+                           (const uint32_t *)pos_c.as<uint32_t>(), nc, (const uint32_t *)corig[cur].as<uint32_t>(), corig[nxt].as<uint32_t>());
+        hipLaunchKernelGGL(k_cull_move_nodes, dim3(blocks_of(np, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)keep_p.as<uint32_t>(),
+                           (const uint32_t *)pos_p.as<uint32_t>(), np, (const uint32_t *)porig[cur].as<uint32_t>(), porig[nxt].as<uint32_t>());
+        hipLaunchKernelGGL(k_cull_move_edges, dim3(blocks_of(no, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)keep_o.as<uint32_t>(),
+                           (const uint32_t *)pos_o.as<uint32_t>(), no, (const uint32_t *)cam[cur].as<uint32_t>(),
+                           (const uint32_t *)pt[cur].as<uint32_t>(), (const uint32_t *)eorig[cur].as<uint32_t>(),
+                           (const uint32_t *)pos_c.as<uint32_t>(), (const uint32_t *)pos_p.as<uint32_t>(), cam[nxt].as<uint32_t>(),
+                           pt[nxt].as<uint32_t>(), eorig[nxt].as<uint32_t>());
+        cur = nxt;
+        nc = nc_new; np = np_new; no = no_new;
+        return hipGetLastError();
+    };
+    auto lcc_pass = [&]() -> hipError_t {
+        if (nc == 0) return hipSuccess;                      // largest_connected_component returns self (:457-459)
+        const int64_t nodes = nc + np, big = std::max(std::max(nc, np), no);
+        hipError_t s = hipMemsetAsync(size.ptr, 0, 4 * (size_t)nodes, st);
+        if (s == hipSuccess) s = hipMemsetAsync(best.ptr, 0, 8, st);
+        if (s != hipSuccess) return s;
+        hipLaunchKernelGGL(k_uf_init, dim3(blocks_of(nodes, kBlock)), dim3(kBlock), 0, st, parent.as<uint32_t>(), nodes);
+        if (no) hipLaunchKernelGGL(k_uf_union, dim3(blocks_of(no, kBlock)), dim3(kBlock), 0, st, parent.as<uint32_t>(),
+                                   (const uint32_t *)cam[cur].as<uint32_t>(), (const uint32_t *)pt[cur].as<uint32_t>(), no, (uint32_t)nc);
+        hipLaunchKernelGGL(k_uf_flatten, dim3(blocks_of(nodes, kBlock)), dim3(kBlock), 0, st, parent.as<uint32_t>(), nodes,
+                           sets.as<uint32_t>(), size.as<uint32_t>());
+        hipLaunchKernelGGL(k_uf_largest, dim3(blocks_of(nodes, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)sets.as<uint32_t>(),
+                           (const uint32_t *)size.as<uint32_t>(), nodes, best.as<unsigned long long>());
+        hipLaunchKernelGGL(k_lcc_flags, dim3(blocks_of(big, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)sets.as<uint32_t>(),
+                           (const unsigned long long *)best.as<unsigned long long>(), (uint32_t)nc, (uint32_t)np,
+                           (const uint32_t *)cam[cur].as<uint32_t>(), (const uint32_t *)pt[cur].as<uint32_t>(), no, faithful ? 1 : 0,
+                           keep_c.as<uint32_t>(), keep_p.as<uint32_t>(), keep_o.as<uint32_t>());
+        s = hipGetLastError();
+        return s == hipSuccess ? compact() : s;
+    };
+    auto singleton_pass = [&]() -> hipError_t {
+        const int64_t big = std::max(std::max(nc, np), no);
+        hipError_t s = hipMemsetAsync(deg.ptr, 0, 4 * (size_t)(nc ? nc : 1), st);
+        if (s == hipSuccess) s = hipMemsetAsync(cnt.ptr, 0, 4 * (size_t)(np ? np : 1), st);
+        if (s != hipSuccess) return s;
+        if (no) hipLaunchKernelGGL(k_degree, dim3(blocks_of(no, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)cam[cur].as<uint32_t>(),
+                                   (const uint32_t *)pt[cur].as<uint32_t>(), no, deg.as<uint32_t>(), cnt.as<uint32_t>());
+        hipLaunchKernelGGL(k_singleton_flags, dim3(blocks_of(big, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)deg.as<uint32_t>(),
+                           (const uint32_t *)cnt.as<uint32_t>(), (uint32_t)nc, (uint32_t)np, (const uint32_t *)cam[cur].as<uint32_t>(),
+                           (const uint32_t *)pt[cur].as<uint32_t>(), no, keep_c.as<uint32_t>(), keep_p.as<uint32_t>(), keep_o.as<uint32_t>());
+        s = hipGetLastError();
+        return s == hipSuccess ? compact() : s;
+    };
+    // culled = lcc().remove_singletons(); while the counts change: again (src/baproblem.rs:541-547)
+    int64_t pnc = nc, pnp = np;
+    if (e == hipSuccess) e = lcc_pass();
+    if (e == hipSuccess) e = singleton_pass();
+    while (e == hipSuccess && (nc != pnc || np != pnp)) {
+        pnc = nc; pnp = np;
+        e = lcc_pass();
+        if (e == hipSuccess) e = singleton_pass();
+    }
+
+    // gather the payloads once and swap them in
+    DevBuf n_cam15, n_bal9, n_camblk, n_pts4, n_uv, n_ws;
+    if (e == hipSuccess) {
+        A(n_cam15, sizeof(double) * 15 * (size_t)nc); A(n_bal9, sizeof(double) * 9 * (size_t)nc);
+        A(n_camblk, sizeof(double) * kCamBlk * (size_t)nc); A(n_pts4, sizeof(double) * 4 * (size_t)np);
+        A(n_uv, sizeof(double) * 2 * (size_t)no); A(n_ws, (size_t)c2b_workspace_bytes(no));
+    }
+    if (e == hipSuccess) {
+        auto gather = [&](const double *in, const DevBuf &orig, int64_t n, int width, DevBuf &out) {
+            if (n) hipLaunchKernelGGL(k_gather_rows, dim3(blocks_of(n * width, kBlock)), dim3(kBlock), 0, st, in,
+                                      (const uint32_t *)orig.as<uint32_t>(), n, width, out.as<double>());
+        };
+        gather(p->cam15, corig[cur], nc, 15, n_cam15);
+        if (p->bal_valid) gather(p->bal9, corig[cur], nc, 9, n_bal9);
+        gather(p->pts4, porig[cur], np, 4, n_pts4);
+        gather(p->uv, eorig[cur], no, 2, n_uv);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_cull: %s", hipGetErrorString(e));
+    }
+    void *old[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws};
+    for (void *q : old) if (q) (void)hipFree(q);
+    p->cam15 = (double *)n_cam15.release(); p->bal9 = (double *)n_bal9.release(); p->camblk = (double *)n_camblk.release();
+    p->pts4 = (double *)n_pts4.release(); p->uv = (double *)n_uv.release(); p->ws = n_ws.release();
+    p->cam_idx = (uint32_t *)cam[cur].release(); p->pt_idx = (uint32_t *)pt[cur].release();
+    p->n_cam = nc; p->n_pts = np; p->n_obs = no;
+    p->blk_valid = false;                                     // camblk is rebuilt on demand from the gathered cameras
+    return C2B_OK;
+}
+
+int c2b_problem_adopt_visibility(c2b_problem *p) {
+    NEED_UPLOADED(p, "problem_adopt_visibility");
+    if (!p->dense_pt || !p->dense_uv || !p->dense_row)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_adopt_visibility: no pending visibility result");
+    const int64_t n = p->dense_n;
+    if (n >= ((int64_t)1 << 32)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_adopt_visibility: more than 2^32 observations");
+    DevBuf cam_idx, ws;
+    hipError_t e = cam_idx.alloc(sizeof(uint32_t) * (size_t)n);
+    if (e == hipSuccess) e = ws.alloc((size_t)c2b_workspace_bytes(n));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_adopt_visibility: %s", hipGetErrorString(e));
+    int rc = c2b_expand_rows(p->dense_row, p->n_cam, 0, n, cam_idx.as<uint32_t>(), p->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    void *old[] = {p->uv, p->cam_idx, p->pt_idx, p->ws, p->dense_row};
+    for (void *q : old) if (q) (void)hipFree(q);
+    p->cam_idx = (uint32_t *)cam_idx.release();
+    p->ws = ws.release();
+    p->pt_idx = p->dense_pt; p->uv = p->dense_uv; p->n_obs = n;
+    p->dense_pt = nullptr; p->dense_uv = nullptr; p->dense_row = nullptr; p->dense_n = 0;
+    return C2B_OK;
+}
+
+int c2b_problem_download_graph(c2b_problem *p, uint64_t *row_ptr, uint64_t *pt_idx) {
+    NEED_UPLOADED(p, "problem_download_graph");
+    if (!row_ptr || (p->n_obs && !pt_idx)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_download_graph: bad arguments");
+    const int64_t n_cam = p->n_cam, n_obs = p->n_obs;
+    DevBuf d_row;
+    hipError_t e = d_row.alloc(sizeof(uint64_t) * (size_t)(n_cam + 1));
+    std::vector<uint32_t> tmp((size_t)n_obs);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rows_from_sorted, dim3(blocks_for(n_obs + 1)), dim3(kBlock), 0, p->stream, (const uint32_t *)p->cam_idx, n_obs,
+                           n_cam, d_row.as<uint64_t>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(row_ptr, d_row.ptr, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess && n_obs) e = hipMemcpyAsync(tmp.data(), p->pt_idx, sizeof(uint32_t) * (size_t)n_obs, hipMemcpyDeviceToHost, p->stream);
+    hipError_t e2 = hipStreamSynchronize(p->stream);
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_download_graph: %s", hipGetErrorString(e));
+    for (int64_t i = 0; i < n_obs; ++i) pt_idx[i] = tmp[(size_t)i];
     return C2B_OK;
 }
 

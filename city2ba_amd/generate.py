@@ -144,8 +144,8 @@ def generate(path, num_cameras=100, num_world_points=1000, max_dist=100.0, intri
     centers = BAProblem.from_visibility(cams, np.zeros((0, 3)), empty, [], np.zeros((0, 2)), device)._camera_centers()
     pts = generate_world_points_uniform(tri, centers, num_world_points, max_dist, seed + 2)
     ba = BAProblem.from_visibility(cams, pts, empty, [], np.zeros((0, 2)), device)
-    row_ptr, pt_idx, uv = ba.visibility_graph(max_dist, triangles=tri)
-    ba = BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv, device)
+    ba.visibility_graph(max_dist, triangles=tri, fetch=False)             # sweep + occlusion rays, lists stay on the device
+    ba.adopt_visibility()
     if not no_lcc:
         ba = ba.cull(faithful)
     if ba.num_cameras() == 0 or ba.num_points() == 0:

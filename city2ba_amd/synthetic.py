@@ -74,9 +74,9 @@ def _visibility_problem(pos, dirs, pts, max_dist, occlusion, block_length, block
     s = ba._camera_centers()
     ci, pi = candidate_pairs(s, pts, max_dist, occlusion=occlusion, block_length=block_length,
                              block_inset=block_inset)
-    row_ptr, kept, uv = ba.visibility_pairs_compact(ci, pi, max_dist)      # survivors compacted on the device
-    out = BAProblem.from_visibility(cam15, pts, row_ptr, kept, uv, device)
-    return out.cull() if cull else out
+    ba.visibility_pairs_compact(ci, pi, max_dist, fetch=False)             # survivors compacted on the device ...
+    ba.adopt_visibility()                                                  # ... where they become the vis_graph
+    return ba.cull() if cull else ba
 
 
 def synthetic_grid(num_cameras_per_block, num_points_per_block, num_blocks, block_length, block_inset,

@@ -355,6 +355,15 @@ int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *ou
  * c2b_problem_upload_bal, otherwise to w = to_rodrigues(R) (what to_vec would write). */
 int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double *Jp);
 int c2b_problem_stats(c2b_problem *p, double *stats /* C2B_STATS_DOUBLES */);
+/* BAProblem::cull (src/baproblem.rs:538-549) of the resident problem, on the device and in place: union-find
+ * components, singleton counts and order-preserving renumbering by scans; same result as c2b_cull (same `faithful`
+ * switch, same tie-break).  Sizes change: read them with c2b_problem_sizes, the new graph with
+ * c2b_problem_download_graph (row_ptr[n_cam + 1], pt_idx[n_obs]) and the payloads with c2b_problem_download. */
+int c2b_problem_cull(c2b_problem *p, int faithful);
+/* BAProblem::from_visibility (src/baproblem.rs:360-376) without leaving the device: the pending result of
+ * c2b_problem_visibility_pairs_compact / _dense (+ _dense_occlude) becomes the problem's vis_graph. */
+int c2b_problem_adopt_visibility(c2b_problem *p);
+int c2b_problem_download_graph(c2b_problem *p, uint64_t *row_ptr, uint64_t *pt_idx);
 int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx,
                                  const uint32_t *pt_idx, double max_dist, double *uv_out,
                                  uint8_t *keep);

@@ -1,0 +1,93 @@
+"""BAProblem::cull on the device (c2b_problem_cull: union-find components, singleton counts, scan renumbering) against
+the host implementation (c2b_cull, itself checked against a pure-Python restatement of src/baproblem.rs:392-550 in
+tests/test_host_rows.py): identical cameras, points, graph and observations, for both settings of the reference's
+observation-filter quirk."""
+import numpy as np
+import pytest
+
+from _problems import grid_cameras_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2b():
+    import __graft_entry__ as entry
+    entry.build()
+    import city2ba_amd
+    assert city2ba_amd.device_count() > 0
+    return city2ba_amd
+
+
+def random_graph(seed, n_cam, n_pts, lo, hi, clusters, spread):
+    """cameras see points near their own cluster: several components, isolated points, weak cameras"""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(lo, hi, n_cam)
+    deg[rng.random(n_cam) < 0.1] = 0                                        # cameras without observations
+    home = rng.integers(0, clusters, n_cam)
+    rows, cols = [], []
+    per = n_pts // clusters
+    for c in range(n_cam):
+        lo_p = home[c] * per
+        span = min(per, spread)
+        start = lo_p + rng.integers(0, max(1, per - span))
+        cols.append(np.sort(rng.choice(np.arange(start, start + span), size=min(deg[c], span), replace=False)))
+        rows.append(len(cols[-1]))
+    row_ptr = np.concatenate([[0], np.cumsum(rows)]).astype(np.uint64)
+    pt_idx = np.concatenate(cols).astype(np.uint64) if len(cols) else np.zeros(0, np.uint64)
+    uv = rng.uniform(-1, 1, (len(pt_idx), 2))
+    cams = rng.uniform(-1, 1, (n_cam, 15))
+    cams[:, :9] = np.eye(3).reshape(9)
+    pts = rng.uniform(-5, 5, (n_pts, 3))
+    return cams, pts, row_ptr, pt_idx, uv
+
+
+def check(c2b, cams, pts, row_ptr, pt_idx, uv, faithful):
+    from city2ba_amd.baproblem import cull_arrays
+    want = cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful)
+    ba = c2b.BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv)
+    out = ba.cull(faithful)
+    assert out is ba
+    assert (ba.num_cameras(), ba.num_points(), ba.num_observations()) == (len(want[0]), len(want[1]), len(want[3]))
+    assert np.array_equal(ba.row_ptr, want[2]) and np.array_equal(ba.pt_idx, want[3])
+    assert np.array_equal(ba.cameras(), want[0]) and np.array_equal(ba.points(), want[1])
+    assert np.array_equal(ba.observations(), want[4])
+    return ba
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+@pytest.mark.parametrize("seed,n_cam,n_pts,lo,hi,clusters,spread", [
+    (1, 300, 2000, 0, 12, 1, 400),          # one loose component, many isolated points
+    (2, 500, 3000, 2, 10, 5, 300),          # five components of similar size: the tie-break and the quirk matter
+    (3, 2000, 20000, 0, 30, 3, 2000),
+    (4, 50, 100, 0, 4, 2, 20),              # almost everything is a singleton: may cull to nothing
+])
+def test_device_cull_equals_host_cull(c2b, seed, n_cam, n_pts, lo, hi, clusters, spread, faithful):
+    g = random_graph(seed, n_cam, n_pts, lo, hi, clusters, spread)
+    check(c2b, *g, faithful)
+
+
+def test_device_cull_on_the_grid_and_degenerate_graphs(c2b):
+    from city2ba_amd import synthetic as S
+    ba = S.synthetic_grid(10, 20, 3, 5.0, 1.0, 1.0, 1.0, 10.0, False, cull=False)
+    g = (ba.cameras(), ba.points(), ba.row_ptr.copy(), ba.pt_idx.copy(), ba.observations())
+    for faithful in (True, False):
+        out = check(c2b, *g, faithful)
+        assert out.num_cameras() > 100 and out.total_reprojection_error(2.0) == 0.0
+        # a culled problem is a fixed point
+        n = (out.num_cameras(), out.num_points(), out.num_observations())
+        out.cull(faithful)
+        assert (out.num_cameras(), out.num_points(), out.num_observations()) == n
+    # no observations at all; no cameras at all
+    cams, pts = grid_cameras_points(1, cpb=2, ppb=2, L=5.0)
+    empty = c2b.BAProblem.from_visibility(cams, pts, np.zeros(len(cams) + 1, np.uint64), [], np.zeros((0, 2)))
+    empty.cull()
+    assert (empty.num_cameras(), empty.num_points(), empty.num_observations()) == (0, 0, 0)
+    none = c2b.BAProblem.from_visibility(np.zeros((0, 15)), pts, np.zeros(1, np.uint64), [], np.zeros((0, 2)))
+    none.cull()
+    assert none.num_cameras() == 0
+    # the 9-vector form survives the cull (columns of the Jacobian keep referring to the file's own w)
+    bal = c2b.BAProblem.from_bal(np.tile([0.1, 0.2, -0.1, 0, 0, 0, 1.0, 0, 0], (len(g[0]), 1)), g[1], g[2], g[3], g[4])
+    before = bal.cameras_bal()
+    bal.cull()
+    assert np.all(bal.cameras_bal() == before[0])
