@@ -91,3 +91,34 @@ def test_device_cull_on_the_grid_and_degenerate_graphs(c2b):
     before = bal.cameras_bal()
     bal.cull()
     assert np.all(bal.cameras_bal() == before[0])
+
+
+def test_device_cull_property_small_graphs(c2b):
+    """hypothesis over small graphs (components, ties and the faithful filter's index aliasing are frequent there):
+    device == host, element for element"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from city2ba_amd.baproblem import cull_arrays
+
+    graphs = st.integers(1, 9).flatmap(lambda nc: st.integers(1, 12).flatmap(lambda npt: st.tuples(
+        st.just(nc), st.just(npt),
+        st.lists(st.lists(st.integers(0, npt - 1), max_size=7, unique=True), min_size=nc, max_size=nc), st.booleans())))
+
+    @settings(max_examples=150, deadline=None)
+    @given(graphs)
+    def run(g):
+        n_cam, n_pts, obs, faithful = g
+        row_ptr = np.concatenate([[0], np.cumsum([len(r) for r in obs])]).astype(np.uint64)
+        pt_idx = np.array([p for r in obs for p in r], dtype=np.uint64)
+        uv = (np.arange(2 * len(pt_idx), dtype=np.float64).reshape(-1, 2) + 0.25)
+        cams = np.arange(n_cam * 15, dtype=np.float64).reshape(n_cam, 15)
+        pts = np.arange(n_pts * 3, dtype=np.float64).reshape(n_pts, 3) + 0.5
+        want = cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful)
+        ba = c2b.BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv)
+        ba.cull(faithful)
+        assert np.array_equal(ba.row_ptr, want[2]) and np.array_equal(ba.pt_idx, want[3])
+        assert np.array_equal(ba.cameras(), want[0].reshape(-1, 15)) and np.array_equal(ba.points(), want[1].reshape(-1, 3))
+        assert np.array_equal(ba.observations(), want[4].reshape(-1, 2))
+        ba.close()
+
+    run()

@@ -188,6 +188,38 @@ def test_cull_matches_python_restatement(seed, faithful):
         assert np.all(np.bincount(pi2.astype(np.int64), minlength=len(p2)) > 1)
 
 
+def test_cull_property_small_graphs():
+    """hypothesis over small graphs (where components, ties and the faithful filter's index aliasing all occur
+    often): c2b_cull == the Python restatement, and the result is a fixed point"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    graphs = st.integers(1, 9).flatmap(lambda nc: st.integers(1, 12).flatmap(lambda npt: st.tuples(
+        st.just(nc), st.just(npt),
+        st.lists(st.lists(st.integers(0, npt - 1), max_size=7, unique=True), min_size=nc, max_size=nc), st.booleans())))
+
+    @settings(max_examples=300, deadline=None)
+    @given(graphs)
+    def run(g):
+        n_cam, n_pts, obs, faithful = g
+        rows = [[(p, 100 * c + j) for j, p in enumerate(r)] for c, r in enumerate(obs)]
+        row_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.uint64)
+        pt_idx = np.array([p for r in rows for (p, _) in r], dtype=np.uint64)
+        tags = np.array([t for r in rows for (_, t) in r], dtype=np.float64)
+        uv = np.stack([tags, -tags], axis=1).reshape(-1, 2)
+        cams = np.arange(n_cam * 15, dtype=np.float64).reshape(n_cam, 15)
+        pts = np.arange(n_pts * 3, dtype=np.float64).reshape(n_pts, 3) + 0.5
+        out = cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful)
+        kc, kp, krows = _py_cull(n_cam, n_pts, rows, faithful)
+        assert np.array_equal(out[0], cams[kc].reshape(-1, 15)) and np.array_equal(out[1], pts[kp].reshape(-1, 3))
+        assert list(out[3]) == [p for r in krows for (p, _) in r]
+        assert list(out[4][:, 0]) == [t for r in krows for (_, t) in r]
+        again = cull_arrays(*out, faithful)
+        assert all(np.array_equal(a, b) for a, b in zip(out, again))
+
+    run()
+
+
 def test_cull_fixed_point_and_empty():
     P = random_problem(30, 300, 9, seed=4)                 # every point seen once => everything is culled
     out = cull_arrays(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
