@@ -479,6 +479,37 @@ void usage() {
                 c2b_version());
 }
 
+// flags of each subcommand with the reference's defaults (src/bin/city2ba.rs:33-260)
+const char *subcommand_help(const std::string &sub) {
+    if (sub == "synthetic")
+        return "city2ba synthetic <OUTPUT>\n"
+               "    --blocks <N>              city blocks per side [5]\n"
+               "    --cameras-per-block <N>   [10]        --points-per-block <N>   [10]\n"
+               "    --block-length <X>        [20]        --block-inset <X>        [1]\n"
+               "    --camera-height <X>       [1]         --point-height <X>       [1]\n"
+               "    --max-dist <X>            maximum camera-point distance [10]\n";
+    if (sub == "synthetic-line")
+        return "city2ba synthetic-line <OUTPUT>\n"
+               "    --cameras <N> [10]   --points <N> [10]   --length <X> [20]   --point-offset <X> [1]\n"
+               "    --camera-height <X> [1]   --point-height <X> [1]   --max-dist <X> [10]\n";
+    if (sub == "noise")
+        return "city2ba noise <FILE> <OUT>\n"
+               "    --rotation-std <X> --translation-std <X> --point-std <X> --observation-std <X>   Gaussian noise [0]\n"
+               "    --drift-strength <X> --drift-angle <X> --drift-std <X> [--fixed-drift]            drift [0]\n"
+               "    --sin-strength <X> [0]  --sin-frequency <X> [1]                                  sine displacement\n"
+               "    --mismatch-chance <X> [0]  --drop-features <X> [1]  --split-landmarks <X> [0]  --join-landmarks <X> [0]\n"
+               "    --seed <N>                every random draw is seeded (default: std::random_device)\n";
+    if (sub == "generate")
+        return "city2ba generate <FILE.obj> <OUT>\n"
+               "    --cameras <N> [100]   --points <N> [1000]   --max-dist <X> [100]\n"
+               "    --intrinsics-start <f,k1,k2> [1,0,0]   --intrinsics-end <f,k1,k2> [1,0,0]\n"
+               "    --path <NAME> [--step-size <X> [0]]    cameras along the polyline model NAME\n"
+               "    --ground <X> [0]  --height <X> [1]     Poisson placement (without --path)\n"
+               "    --move-to-origin   --no-lcc   --exact-lcc (extension)   --seed <N>\n";
+    if (sub == "ply") return "city2ba ply <FILE> <OUT.ply>\n";
+    return nullptr;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -487,6 +518,11 @@ int main(int argc, char **argv) {
         return argc < 2 ? 1 : 0;
     }
     const std::string sub = argv[1];
+    for (int k = 2; k < argc; ++k)
+        if (!std::strcmp(argv[k], "--help") || !std::strcmp(argv[k], "-h")) {
+            const char *h = subcommand_help(sub);
+            if (h) { std::printf("%s    --device <N>              GPU index [0]; C2B_TIMING=1 prints phase times\n", h); return 0; }
+        }
     if (sub == "synthetic") return run_synthetic(argc, argv);
     if (sub == "synthetic-line") return run_synthetic_line(argc, argv);
     if (sub == "noise") return run_noise(argc, argv);
