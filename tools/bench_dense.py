@@ -88,6 +88,13 @@ for name, fn in (("stats", lambda: D.stats(camblk, pts4, ws, stt)),
                  ("add_drift_normalized", lambda: D.add_drift_normalized(c2, p2, stt, 1e-9, 1e-9, 0.1, 3)),
                  ("add_noise_entities", lambda: D.add_noise_entities(c2, p2, stt, 1e-9, 1e-9, 1e-9, 4))):
     out[name + "_us"] = round(timed(fn) * 1e6, 1)
+# the f32 path of the same entity kernels (configs[4]): cameras / points stored as float, draws and statistics in f64
+c32, p32 = D.to_f32(cam15), D.to_f32(pts4)
+st32 = D.stats_f32(c32, p32, ws)
+for name, fn in (("stats_f32", lambda: D.stats_f32(c32, p32, ws, st32)),
+                 ("add_drift_normalized_f32", lambda: D.add_drift_normalized_f32(c32, p32, st32, 1e-9, 1e-9, 0.1, 3)),
+                 ("add_noise_entities_f32", lambda: D.add_noise_entities_f32(c32, p32, st32, 1e-9, 1e-9, 1e-9, 4))):
+    out[name + "_us"] = round(timed(fn) * 1e6, 1)
 # CPU oracle on a sample of the same pairs (1 thread)
 if a.cpu_pairs > 0:
     sys.path.insert(0, ROOT)
