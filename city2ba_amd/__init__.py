@@ -4,6 +4,6 @@ The compute lives in csrc/ (hand-written HIP for gfx950) behind the C ABI of inc
 this package is the thin host-side mirror.  No CPU fallback exists."""
 from ._lib import City2baError, device_count, lib  # noqa: F401
 from .baproblem import BAProblem  # noqa: F401
-from . import generate, noise, synthetic  # noqa: F401   (device / dist import torch: import them explicitly)
+from . import camera, generate, noise, synthetic  # noqa: F401   (device / dist import torch: import them explicitly)
 
-__all__ = ["BAProblem", "City2baError", "device_count", "lib", "generate", "noise", "synthetic"]
+__all__ = ["BAProblem", "City2baError", "device_count", "lib", "camera", "generate", "noise", "synthetic"]

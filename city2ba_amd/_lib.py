@@ -115,6 +115,10 @@ SIGNATURES = {
     "c2b_problem_stats": (_int, [_vp, _vp]),
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),
     "c2b_problem_cull": (_int, [_vp, _int]),
+    "c2b_problem_largest_connected_component": (_int, [_vp, _int]),
+    "c2b_problem_remove_singletons": (_int, [_vp]),
+    "c2b_largest_connected_component": (_int, [C.POINTER(_i64), _vp, _int, C.POINTER(_i64), _vp, _vp, _vp, _vp, _int]),
+    "c2b_remove_singletons": (_int, [C.POINTER(_i64), _vp, _int, C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "c2b_problem_adopt_visibility": (_int, [_vp]),
     "c2b_problem_download_graph": (_int, [_vp, _vp, _vp]),
     "c2b_problem_visibility_pairs_compact": (_int, [_vp, _i64, _vp, _vp, _d, _vp]),

@@ -227,6 +227,40 @@ class BAProblem:
         L.check(L.lib().c2b_problem_cull(self._h, int(bool(faithful))))
         return self._refresh_graph()
 
+    def largest_connected_component(self, faithful=True):
+        """BAProblem::largest_connected_component (src/baproblem.rs:456-534), one application, on the device"""
+        L.check(L.lib().c2b_problem_largest_connected_component(self._h, int(bool(faithful))))
+        return self._refresh_graph()
+
+    def remove_singletons(self):
+        """BAProblem::remove_singletons (src/baproblem.rs:426-453), one application, on the device"""
+        L.check(L.lib().c2b_problem_remove_singletons(self._h))
+        return self._refresh_graph()
+
+    def subset(self, ci, pi):
+        """BAProblem::subset (src/baproblem.rs:394-423): cameras ci and points pi in the given order; observations of
+        dropped points disappear.  Host-side index shuffling; returns a NEW device problem."""
+        ci = np.asarray(ci, dtype=np.int64).reshape(-1)
+        pi = np.asarray(pi, dtype=np.int64).reshape(-1)
+        n_cam, n_pts = self.num_cameras(), self.num_points()
+        if (len(ci) and (ci.min() < 0 or ci.max() >= n_cam)) or (len(pi) and (pi.min() < 0 or pi.max() >= n_pts)):
+            raise L.City2baError(L.ERR_INDEX_OUT_OF_RANGE, "subset: index out of range")
+        cams, pts, uv = self.cameras(), self.points(), self.observations()
+        new_of = np.full(n_pts, -1, dtype=np.int64)
+        new_of[pi] = np.arange(len(pi))                       # HashMap::from_iter: a repeated point keeps its last slot
+        rows, cols, vals = [0], [], []
+        for c in ci:
+            a, b = int(self._row_ptr[c]), int(self._row_ptr[c + 1])
+            p_new = new_of[self._pt_idx[a:b].astype(np.int64)]
+            k = p_new >= 0
+            cols.append(p_new[k])
+            vals.append(uv[a:b][k])
+            rows.append(rows[-1] + int(k.sum()))
+        cols = np.concatenate(cols).astype(np.uint64) if cols else np.zeros(0, np.uint64)
+        vals = np.concatenate(vals) if vals else np.zeros((0, 2))
+        return BAProblem.from_visibility(cams[ci], pts[pi], np.array(rows, dtype=np.uint64), cols, vals.reshape(-1, 2),
+                                         self._device)
+
     def _refresh_graph(self):
         """host mirrors of the graph (row_ptr, pt_idx) after a device-side change"""
         n_cam, _, n_obs = self._sizes()
@@ -296,8 +330,9 @@ class BAProblem:
 
 
 # ---- host-array helpers over the C ABI (no GPU involved) ------------------------------------------------
-def cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful=True):
-    """c2b_cull on numpy arrays; cams is [n, stride] (cam15 or bal9 rows).  Returns the culled copies."""
+def cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful=True, step="cull"):
+    """c2b_cull on numpy arrays; cams is [n, stride] (cam15 or bal9 rows).  Returns the culled copies.
+    step = "cull" | "lcc" (largest_connected_component once) | "singletons" (remove_singletons once)"""
     cams = np.array(cams, dtype=np.float64, order="C", copy=True)
     cams = cams.reshape(len(cams), -1) if cams.size else cams.reshape(0, cams.shape[-1] if cams.ndim == 2 else 15)
     pts = np.array(pts, dtype=np.float64, order="C", copy=True).reshape(-1, 3)
@@ -308,8 +343,15 @@ def cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful=True):
         raise L.City2baError(L.ERR_INVALID_ARGUMENT, "row_ptr must have n_cameras + 1 entries")
     stride = cams.shape[1] if cams.ndim == 2 and len(cams) else 0
     nc, npts = C.c_int64(len(cams)), C.c_int64(len(pts))
-    L.check(L.lib().c2b_cull(C.byref(nc), _ptr(cams), int(stride), C.byref(npts), _ptr(pts), _ptr(row_ptr),
-                             _ptr(pt_idx), _ptr(uv), int(bool(faithful))))
+    args = (C.byref(nc), _ptr(cams), int(stride), C.byref(npts), _ptr(pts), _ptr(row_ptr), _ptr(pt_idx), _ptr(uv))
+    if step == "cull":
+        L.check(L.lib().c2b_cull(*args, int(bool(faithful))))
+    elif step == "lcc":
+        L.check(L.lib().c2b_largest_connected_component(*args, int(bool(faithful))))
+    elif step == "singletons":
+        L.check(L.lib().c2b_remove_singletons(*args))
+    else:
+        raise L.City2baError(L.ERR_INVALID_ARGUMENT, "step must be 'cull', 'lcc' or 'singletons'")
     n_obs = int(row_ptr[nc.value])
     return (cams[:nc.value].copy(), pts[:npts.value].copy(), row_ptr[:nc.value + 1].copy(), pt_idx[:n_obs].copy(),
             uv[:n_obs].copy())

@@ -863,8 +863,8 @@ int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *ce
     return C2B_OK;
 }
 
-int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
-             uint64_t *pt_idx, double *uv, int faithful) {
+static int cull_host(int mode, int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
+                     uint64_t *pt_idx, double *uv, int faithful) {
     if (!n_cam || !n_pts || !row_ptr || *n_cam < 0 || *n_pts < 0 || cam_stride < 0 || (*n_cam && cam_stride && !cams) ||
         (*n_pts && !pts3))
         return fail(C2B_ERR_INVALID_ARGUMENT, "cull: bad arguments");
@@ -880,7 +880,7 @@ int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, doubl
         g.row_ptr.assign(row_ptr, row_ptr + *n_cam + 1);
         g.pt_idx.assign(pt_idx, pt_idx + n_obs);
         g.uv.assign(uv, uv + 2 * n_obs);
-        const c2b_host::Graph c = c2b_host::cull(g, faithful != 0);
+        const c2b_host::Graph c = c2b_host::cull(g, faithful != 0, mode);
         std::copy(c.cams.begin(), c.cams.end(), cams);
         std::copy(c.pts.begin(), c.pts.end(), pts3);
         std::copy(c.row_ptr.begin(), c.row_ptr.end(), row_ptr);
@@ -892,6 +892,19 @@ int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, doubl
         return fail(C2B_ERR_OOM, "cull: out of host memory");
     }
     return C2B_OK;
+}
+
+int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
+             uint64_t *pt_idx, double *uv, int faithful) {
+    return cull_host(0, n_cam, cams, cam_stride, n_pts, pts3, row_ptr, pt_idx, uv, faithful);
+}
+int c2b_largest_connected_component(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
+                                    uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful) {
+    return cull_host(1, n_cam, cams, cam_stride, n_pts, pts3, row_ptr, pt_idx, uv, faithful);
+}
+int c2b_remove_singletons(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
+                          uint64_t *pt_idx, double *uv) {
+    return cull_host(2, n_cam, cams, cam_stride, n_pts, pts3, row_ptr, pt_idx, uv, 1);
 }
 
 /* ---- index-corruption noise, host side ---- */
@@ -1438,7 +1451,8 @@ hipError_t scan_flags(hipStream_t st, const uint32_t *flags, int64_t n, uint32_t
 }  // namespace
 }  // extern "C++"
 
-int c2b_problem_cull(c2b_problem *p, int faithful) {
+// mode 0: cull() = both passes to a fixed point; 1: largest_connected_component() once; 2: remove_singletons() once
+static int cull_impl(c2b_problem *p, int faithful, int mode) {
     NEED_UPLOADED(p, "problem_cull");
     if (p->n_obs >= ((int64_t)1 << 32) || p->n_cam + p->n_pts >= ((int64_t)1 << 32))
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_cull: more than 2^32 observations or entities");
@@ -1531,9 +1545,9 @@ int c2b_problem_cull(c2b_problem *p, int faithful) {
     };
     // culled = lcc().remove_singletons(); while the counts change: again (src/baproblem.rs:541-547)
     int64_t pnc = nc, pnp = np;
-    if (e == hipSuccess) e = lcc_pass();
-    if (e == hipSuccess) e = singleton_pass();
-    while (e == hipSuccess && (nc != pnc || np != pnp)) {
+    if (e == hipSuccess && mode != 2) e = lcc_pass();
+    if (e == hipSuccess && mode != 1) e = singleton_pass();
+    while (mode == 0 && e == hipSuccess && (nc != pnc || np != pnp)) {
         pnc = nc; pnp = np;
         e = lcc_pass();
         if (e == hipSuccess) e = singleton_pass();
@@ -1571,6 +1585,10 @@ int c2b_problem_cull(c2b_problem *p, int faithful) {
     p->blk_valid = false;                                     // camblk is rebuilt on demand from the gathered cameras
     return C2B_OK;
 }
+
+int c2b_problem_cull(c2b_problem *p, int faithful) { return cull_impl(p, faithful, 0); }
+int c2b_problem_largest_connected_component(c2b_problem *p, int faithful) { return cull_impl(p, faithful, 1); }
+int c2b_problem_remove_singletons(c2b_problem *p) { return cull_impl(p, 1, 2); }
 
 int c2b_problem_adopt_visibility(c2b_problem *p) {
     NEED_UPLOADED(p, "problem_adopt_visibility");

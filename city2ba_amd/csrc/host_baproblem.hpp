@@ -140,8 +140,8 @@ inline void singleton_pass(IndexGraph &g) {
     compact(g, keep_cam, keep_pt, [](uint64_t) { return true; });
 }
 
-// cull, src/baproblem.rs:538-549
-inline Graph cull(const Graph &g, bool faithful) {
+// cull, src/baproblem.rs:538-549 (mode 0); mode 1: largest_connected_component once; mode 2: remove_singletons once
+inline Graph cull(const Graph &g, bool faithful, int mode = 0) {
     IndexGraph ig;
     ig.n_cam = g.n_cam; ig.n_pts = g.n_pts;
     ig.row_ptr = g.row_ptr; ig.pt_idx = g.pt_idx;
@@ -149,9 +149,9 @@ inline Graph cull(const Graph &g, bool faithful) {
     ig.pt_orig.resize((size_t)g.n_pts); std::iota(ig.pt_orig.begin(), ig.pt_orig.end(), (int64_t)0);
     ig.edge_orig.resize(g.pt_idx.size()); std::iota(ig.edge_orig.begin(), ig.edge_orig.end(), (uint64_t)0);
     int64_t nc = g.n_cam, np = g.n_pts;
-    lcc_pass(ig, faithful);
-    singleton_pass(ig);
-    while (ig.n_cam != nc || ig.n_pts != np) {
+    if (mode != 2) lcc_pass(ig, faithful);
+    if (mode != 1) singleton_pass(ig);
+    while (mode == 0 && (ig.n_cam != nc || ig.n_pts != np)) {
         nc = ig.n_cam; np = ig.n_pts;
         lcc_pass(ig, faithful);
         singleton_pass(ig);

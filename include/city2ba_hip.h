@@ -284,6 +284,12 @@ int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *ce
  * with the smallest member (the reference: HashMap order). */
 int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
              uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful);
+/* its two halves as the reference also exposes them: BAProblem::largest_connected_component (:456-534) and
+ * BAProblem::remove_singletons (:426-453), one application each, same calling convention */
+int c2b_largest_connected_component(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
+                                    uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful);
+int c2b_remove_singletons(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
+                          uint64_t *row_ptr, uint64_t *pt_idx, double *uv);
 
 /* noise.rs' index-corruption functions: sequential random reshuffles of the visibility graph, on the host over
  * the flat CSR arrays, IN PLACE, seeded (the reference: thread_rng()).
@@ -360,6 +366,8 @@ int c2b_problem_stats(c2b_problem *p, double *stats /* C2B_STATS_DOUBLES */);
  * switch, same tie-break).  Sizes change: read them with c2b_problem_sizes, the new graph with
  * c2b_problem_download_graph (row_ptr[n_cam + 1], pt_idx[n_obs]) and the payloads with c2b_problem_download. */
 int c2b_problem_cull(c2b_problem *p, int faithful);
+int c2b_problem_largest_connected_component(c2b_problem *p, int faithful);   /* one application, on the device */
+int c2b_problem_remove_singletons(c2b_problem *p);                            /* one application, on the device */
 /* BAProblem::from_visibility (src/baproblem.rs:360-376) without leaving the device: the pending result of
  * c2b_problem_visibility_pairs_compact / _dense (+ _dense_occlude) becomes the problem's vis_graph. */
 int c2b_problem_adopt_visibility(c2b_problem *p);

@@ -122,3 +122,50 @@ def test_device_cull_property_small_graphs(c2b):
         ba.close()
 
     run()
+
+
+def test_single_steps_subset_and_camera_accessors(c2b):
+    """the reference's separate public methods: largest_connected_component, remove_singletons, subset
+    (src/baproblem.rs:394-534) and SnavelyCamera's accessors (:178-225)"""
+    from city2ba_amd.baproblem import cull_arrays
+    from city2ba_amd import camera as K
+    g = random_graph(7, 400, 2500, 0, 12, 4, 300)
+    for faithful in (True, False):
+        want = cull_arrays(*g, faithful, step="lcc")
+        ba = c2b.BAProblem.from_visibility(*g).largest_connected_component(faithful)
+        assert np.array_equal(ba.row_ptr, want[2]) and np.array_equal(ba.pt_idx, want[3])
+        assert np.array_equal(ba.cameras(), want[0]) and np.array_equal(ba.points(), want[1])
+        assert np.array_equal(ba.observations(), want[4])
+    want = cull_arrays(*g, step="singletons")
+    ba = c2b.BAProblem.from_visibility(*g).remove_singletons()
+    assert np.array_equal(ba.row_ptr, want[2]) and np.array_equal(ba.pt_idx, want[3]) and np.array_equal(ba.cameras(), want[0])
+    # subset: cameras / points in the GIVEN order, observations of dropped points disappear
+    cams, pts, row_ptr, pt_idx, uv = g
+    full = c2b.BAProblem.from_visibility(*g)
+    ci, pi = np.array([5, 2, 300, 17]), np.array([9, 3, 4, 2000, 1999, 8])
+    sub = full.subset(ci, pi)
+    assert np.array_equal(sub.cameras(), cams[ci]) and np.array_equal(sub.points(), pts[pi])
+    new_of = {int(p): k for k, p in enumerate(pi)}
+    rows = []
+    for c in ci:
+        a, b = int(row_ptr[c]), int(row_ptr[c + 1])
+        rows.append([(new_of[int(p)], tuple(v)) for p, v in zip(pt_idx[a:b], uv[a:b]) if int(p) in new_of])
+    assert list(sub.row_ptr) == list(np.concatenate([[0], np.cumsum([len(r) for r in rows])]))
+    assert list(sub.pt_idx) == [p for r in rows for (p, _) in r]
+    assert [tuple(v) for v in sub.observations()] == [v for r in rows for (_, v) in r]
+    with pytest.raises(c2b.City2baError):
+        full.subset([len(cams)], [0])
+    # camera records: from_vec / to_vec round trip and the accessors
+    bal = np.array([[0.1, -0.2, 0.3, 1.0, 2.0, 3.0, 1.5, 0.01, -0.002], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0]])
+    rec = K.from_vec(bal)
+    assert rec.shape == (2, 15) and np.allclose(K.to_vec(rec), bal, atol=1e-12)
+    R = K.rotation(rec)
+    assert np.allclose(R @ np.swapaxes(R, -1, -2), np.eye(3), atol=1e-12) and np.allclose(R[1], np.eye(3))
+    w = bal[0, :3]
+    th = np.linalg.norm(w)
+    k = w / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    assert np.allclose(R[0], np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx, atol=1e-12)     # Rodrigues
+    assert np.array_equal(K.focal_length(rec), [1.5, 1.0]) and np.array_equal(K.distortion(rec)[0], [0.01, 0.0])
+    mod = K.modify_intrin(rec, [0.5, 0.1, 0.2])
+    assert np.array_equal(mod[:, :12], rec[:, :12]) and np.allclose(mod[:, 12:], rec[:, 12:] + [0.5, 0.1, 0.2])

@@ -188,6 +188,35 @@ def test_cull_matches_python_restatement(seed, faithful):
         assert np.all(np.bincount(pi2.astype(np.int64), minlength=len(p2)) > 1)
 
 
+def test_cull_halves_compose_to_cull():
+    """largest_connected_component and remove_singletons as separate calls (the reference exposes both,
+    src/baproblem.rs:426, :456): applying them alternately until the sizes stop changing is cull()"""
+    rng = np.random.default_rng(11)
+    n_cam, n_pts = 60, 90
+    rows = [np.sort(rng.choice(np.arange((c % 3) * 30, (c % 3) * 30 + 30), size=int(rng.integers(0, 9)), replace=False)) for c in range(n_cam)]
+    row_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.uint64)
+    pt_idx = np.concatenate(rows).astype(np.uint64)
+    uv = rng.uniform(-1, 1, (len(pt_idx), 2))
+    cams = rng.uniform(-1, 1, (n_cam, 9))                       # 9-vector camera rows are opaque payload too
+    pts = rng.uniform(-1, 1, (n_pts, 3))
+    for faithful in (True, False):
+        want = cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful)
+        g = (cams, pts, row_ptr, pt_idx, uv)
+        while True:
+            n = (len(g[0]), len(g[1]))
+            g = cull_arrays(*cull_arrays(*g, faithful, step="lcc"), faithful, step="singletons")
+            if (len(g[0]), len(g[1])) == n:
+                break
+        assert all(np.array_equal(a, b) for a, b in zip(g, want))
+    one = cull_arrays(cams, pts, row_ptr, pt_idx, uv, step="singletons")
+    deg = np.diff(row_ptr.astype(np.int64))
+    cnt = np.bincount(pt_idx.astype(np.int64), minlength=n_pts)
+    assert len(one[0]) == int((deg > 3).sum()) and len(one[1]) == int((cnt > 1).sum())
+    assert np.array_equal(one[0], cams[deg > 3]) and np.array_equal(one[1], pts[cnt > 1])
+    with pytest.raises(L.City2baError):
+        cull_arrays(cams, pts, row_ptr, pt_idx, uv, step="nope")
+
+
 def test_cull_property_small_graphs():
     """hypothesis over small graphs (where components, ties and the faithful filter's index aliasing all occur
     often): c2b_cull == the Python restatement, and the result is a fixed point"""
