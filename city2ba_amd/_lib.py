@@ -99,6 +99,8 @@ SIGNATURES = {
     "c2b_bal_copy": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "c2b_bal_close": (None, [_vp]),
     "c2b_bal_write": (_int, [C.c_char_p, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_bal_read_as": (_int, [C.c_char_p, _int, C.POINTER(_vp)]),
+    "c2b_bal_write_as": (_int, [C.c_char_p, _int, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "c2b_ply_write": (_int, [C.c_char_p, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_problem_create": (_int, [_int, C.POINTER(_vp)]),
     "c2b_problem_destroy": (None, [_vp]),

@@ -287,14 +287,28 @@ class BAProblem:
         return BAProblem.from_visibility(cams, pts, row_ptr, pt_idx, uv, self._device)
 
     @classmethod
-    def from_file(cls, path, device=0):
+    def from_file(cls, path, device=0, fmt=None):
         """BAProblem::from_file (src/baproblem.rs:697-706): .bal text or .bbal binary by extension."""
-        bal9, pts, row_ptr, pt_idx, uv = read_bal(path)
+        bal9, pts, row_ptr, pt_idx, uv = read_bal(path, fmt)
         return cls.from_bal(bal9, pts, row_ptr, pt_idx, uv, device)
 
-    def write(self, path):
+    @classmethod
+    def from_file_text(cls, path, device=0):        # src/baproblem.rs:580-630
+        return cls.from_file(path, device, "text")
+
+    @classmethod
+    def from_file_binary(cls, path, device=0):      # src/baproblem.rs:632-695
+        return cls.from_file(path, device, "binary")
+
+    def write(self, path, fmt=None):
         """BAProblem::write (src/baproblem.rs:768-785)"""
-        write_bal(path, self.cameras_bal(), self.points(), self._row_ptr, self._pt_idx, self.observations())
+        write_bal(path, self.cameras_bal(), self.points(), self._row_ptr, self._pt_idx, self.observations(), fmt)
+
+    def write_text(self, path):                     # src/baproblem.rs:709-733
+        self.write(path, "text")
+
+    def write_binary(self, path):                   # src/baproblem.rs:736-764
+        self.write(path, "binary")
 
     def visibility_pairs(self, cam_idx, pt_idx, max_dist):
         """predicate of the generator loops (src/synthetic.rs:285-291; src/generate.rs:448-454)"""
@@ -357,10 +371,14 @@ def cull_arrays(cams, pts, row_ptr, pt_idx, uv, faithful=True, step="cull"):
             uv[:n_obs].copy())
 
 
-def read_bal(path):
-    """(bal9 [n,9], pts [m,3], row_ptr, pt_idx, uv) from a .bal / .bbal file."""
+_FORMATS = {None: -1, "text": 0, "binary": 1}
+
+
+def read_bal(path, fmt=None):
+    """(bal9 [n,9], pts [m,3], row_ptr, pt_idx, uv) from a .bal / .bbal file; fmt None = by extension (from_file),
+    "text" = from_file_text, "binary" = from_file_binary (src/baproblem.rs:580, :632, :697)."""
     h = C.c_void_p()
-    L.check(L.lib().c2b_bal_read(str(path).encode(), C.byref(h)))
+    L.check(L.lib().c2b_bal_read_as(str(path).encode(), _FORMATS[fmt], C.byref(h)))
     try:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.lib().c2b_bal_sizes(h, C.byref(a), C.byref(b), C.byref(c)))
@@ -374,11 +392,12 @@ def read_bal(path):
     return bal9, pts, row_ptr, pt_idx, uv
 
 
-def write_bal(path, bal9, pts, row_ptr, pt_idx, uv):
+def write_bal(path, bal9, pts, row_ptr, pt_idx, uv, fmt=None):
+    """write (by extension), write_text or write_binary (src/baproblem.rs:709, :736, :768)"""
     bal9 = _f64(bal9, (-1, 9))
     pts = _f64(pts, (-1, 3))
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
     pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint64)
     uv = _f64(uv, (-1, 2))
-    L.check(L.lib().c2b_bal_write(str(path).encode(), len(bal9), _ptr(bal9), len(pts), _ptr(pts), _ptr(row_ptr),
-                                  _ptr(pt_idx), _ptr(uv)))
+    L.check(L.lib().c2b_bal_write_as(str(path).encode(), _FORMATS[fmt], len(bal9), _ptr(bal9), len(pts), _ptr(pts),
+                                     _ptr(row_ptr), _ptr(pt_idx), _ptr(uv)))

@@ -981,11 +981,23 @@ struct c2b_balfile {
     c2b_host::Graph g;
 };
 
-int c2b_bal_read(const char *path, c2b_balfile **out) {
+// format: 0 text (from_file_text), 1 binary (from_file_binary), -1 by extension (from_file)
+static int bal_format(const char *path, int format, bool *binary) {
+    if (format == 0 || format == 1) { *binary = format == 1; return C2B_OK; }
+    const std::string ext = c2b_host::extension(path);
+    if (ext.empty()) return fail(C2B_ERR_INVALID_ARGUMENT, "file does not have an extension");
+    if (ext != "bal" && ext != "bbal") return fail(C2B_ERR_INVALID_ARGUMENT, "unknown file extension %s", ext.c_str());
+    *binary = ext == "bbal";
+    return C2B_OK;
+}
+
+int c2b_bal_read_as(const char *path, int format, c2b_balfile **out) {
     if (!path || !out) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_read: bad arguments");
     *out = nullptr;
-    const std::string ext = c2b_host::extension(path);
-    if (ext != "bal" && ext != "bbal") return fail(C2B_ERR_INVALID_ARGUMENT, "unknown file extension %s", ext.c_str());
+    bool binary = false;
+    int rc = bal_format(path, format, &binary);
+    if (rc) return rc;
+    const std::string ext = binary ? "bbal" : "bal";
     c2b_balfile *f = new (std::nothrow) c2b_balfile();
     if (!f) return fail(C2B_ERR_OOM, "bal_read: host allocation failed");
     std::string err;
@@ -1003,6 +1015,8 @@ int c2b_bal_read(const char *path, c2b_balfile **out) {
     *out = f;
     return C2B_OK;
 }
+
+int c2b_bal_read(const char *path, c2b_balfile **out) { return c2b_bal_read_as(path, -1, out); }
 
 int c2b_bal_sizes(const c2b_balfile *f, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs) {
     if (!f) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_sizes: file is NULL");
@@ -1024,13 +1038,14 @@ int c2b_bal_copy(const c2b_balfile *f, double *bal9, double *pts3, uint64_t *row
 
 void c2b_bal_close(c2b_balfile *f) { delete f; }
 
-int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
-                  const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+int c2b_bal_write_as(const char *path, int format, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
+                     const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
     if (!path || n_cam < 0 || n_pts < 0 || !row_ptr || (n_cam && !bal9) || (n_pts && !pts3))
         return fail(C2B_ERR_INVALID_ARGUMENT, "bal_write: bad arguments");
-    const std::string ext = c2b_host::extension(path);
-    if (ext.empty()) return fail(C2B_ERR_INVALID_ARGUMENT, "file does not have an extension");
-    if (ext != "bal" && ext != "bbal") return fail(C2B_ERR_INVALID_ARGUMENT, "unknown file extension %s", ext.c_str());
+    bool binary = false;
+    int rc = bal_format(path, format, &binary);
+    if (rc) return rc;
+    const std::string ext = binary ? "bbal" : "bal";
     const int64_t n_obs = (int64_t)row_ptr[n_cam];
     if (n_obs && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_write: NULL observations");
     std::string err;
@@ -1049,6 +1064,11 @@ int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n
     }
     if (!ok) return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
     return C2B_OK;
+}
+
+int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
+                  const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    return c2b_bal_write_as(path, -1, n_cam, bal9, n_pts, pts3, row_ptr, pt_idx, uv);
 }
 
 int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,

@@ -321,6 +321,11 @@ void c2b_bal_close(c2b_balfile *f);
 /* BAProblem::write (src/baproblem.rs:768-785); bal9 = to_vec of every camera (c2b_problem_download_bal) */
 int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
                   const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv);
+/* the format chosen by the caller instead of by the extension: format 0 = text (from_file_text :580, write_text
+ * :709), 1 = binary (from_file_binary :632, write_binary :736), -1 = by extension */
+int c2b_bal_read_as(const char *path, int format, c2b_balfile **out);
+int c2b_bal_write_as(const char *path, int format, int64_t n_cam, const double *bal9, int64_t n_pts,
+                     const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv);
 /* write_cameras of the `ply` subcommand (src/bin/city2ba.rs:359-439): ASCII PLY with one red vertex per camera
  * centre, one green vertex per point (f32) and one edge per observation (camera, n_cam + point) */
 int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,

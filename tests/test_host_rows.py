@@ -355,3 +355,14 @@ def test_file_errors(tmp_path):
         read_bal(trunc)
     with pytest.raises(L.City2baError):
         read_bal(tmp_path / "missing.bbal")
+    # write_text / write_binary / from_file_text / from_file_binary ignore the extension (src/baproblem.rs:580-764)
+    for fmt in ("text", "binary"):
+        path = tmp_path / ("explicit_" + fmt)
+        write_bal(path, bal9, pts, row_ptr, pt_idx, uv, fmt)
+        back = read_bal(path, fmt)
+        assert all(np.array_equal(a, b) for a, b in zip(back, (bal9, pts, row_ptr, pt_idx, uv)))
+        with pytest.raises(L.City2baError) as ei:
+            read_bal(path)
+        assert "does not have an extension" in str(ei.value)
+    assert (tmp_path / "explicit_binary").read_bytes()[:8] == struct.pack(">Q", len(bal9))
+    assert (tmp_path / "explicit_text").read_text().split("\n")[0] == "%d %d %d" % (len(bal9), len(pts), len(pt_idx))
