@@ -6,12 +6,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian (residual, Jc, Jp,
-per-tile error partials) + c2b_error_sum_finish on every rank's shard, then ONE 1-element RCCL
-all-reduce (N > 1; fold + all-reduce run on a side stream and overlap the next pass, all of it
-completed inside the timed region).  Inputs are resident in HBM before the timed region.  Strong scaling: the same
-`--blocks 128` problem is sharded over the ranks by contiguous camera ranges (BASELINE.json
-configs[3]); at N = 1 one GPU holds all of it.
+One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian_sum (residual, Jc, Jp and
+the folded sum of squared residuals, ONE launch) on every rank's shard, then ONE 1-element RCCL all-reduce
+(N > 1; it runs on a side stream and overlaps the next pass, all of it completed inside the timed region).
+Inputs are resident in HBM before the timed region.  Strong scaling: the same `--blocks 128` problem is sharded
+over the ranks by contiguous camera ranges cut on the observation prefix sum (BASELINE.json configs[3]); at
+N = 1 one GPU holds all of it.
 
 Only the `cpu_baseline` leg touches oracle/ (rank 0, N = 1, bounded sample).
 """
@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+KERNEL_NAME = "k_residual_jacobian_p<NORM_2, true, 4, 1, true>"     # the launch the roofline object describes
 
 
 def parse():
@@ -39,8 +40,10 @@ def parse():
     return ap.parse_args()
 
 
-def build_shard(args, rank, world, dev):
-    """This rank's shard of `synthetic --blocks B` (defaults of src/bin/city2ba.rs:113-152), on device."""
+def build_shard(args, rank, world, dev, bounds=None):
+    """This rank's shard of `synthetic --blocks B` (defaults of src/bin/city2ba.rs:113-152), on device.
+    bounds = camera range boundaries per rank; None = equal camera counts (the first pass of
+    balanced_bounds, which then re-splits on the observation prefix sum)."""
     import numpy as np
     import torch
     from city2ba_amd import device as D
@@ -50,8 +53,9 @@ def build_shard(args, rank, world, dev):
     B, max_dist, L, inset = args.blocks, 10.0, 20.0, 1.0
     pos, dirs, pts = S.grid_layout(B)
     n_cam, n_pts = len(pos), len(pts)
-    bounds = Dist.camera_count_bounds(n_cam, world)
-    lo, hi = bounds[rank], bounds[rank + 1]
+    if bounds is None:
+        bounds = Dist.camera_count_bounds(n_cam, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
 
     pts4 = D.points_pad(torch.from_numpy(pts).to(dev))
     cam15 = D.cameras_from_position_direction(torch.from_numpy(pos[lo:hi]).to(dev),
@@ -80,7 +84,26 @@ def build_shard(args, rank, world, dev):
     torch.cuda.synchronize()
     return dict(camblk=camblk, cam15=cam15, pts4=pts4, cam_idx=cam_idx, pt_idx=pt_idx, uv=uv, n_obs=n_obs,
                 n_obs_total=n_obs_total, n_cam=n_cam, n_pts=n_pts, n_cam_local=hi - lo, n_candidates=n_cand,
-                pts_host=pts)
+                pts_host=pts, cam_lo=lo, cam_hi=hi, obs_base=obs_base)
+
+
+def balanced_bounds(sh, rank, world):
+    """contiguous camera ranges split on the observation prefix sum.  Every rank counts the
+    observations of its equal-camera-count slice, the per-camera counts are all-gathered, and
+    c2b_partition_cameras (Dist.partition_by_observations) cuts the global row_ptr into `world` ranges of ~equal
+    observation counts."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from city2ba_amd import dist as Dist
+    counts = torch.bincount(sh["cam_idx"].long(), minlength=sh["n_cam_local"]).cpu().numpy().astype(np.int64)
+    parts = [None] * world
+    dist.all_gather_object(parts, (sh["cam_lo"], counts))
+    allc = np.zeros(sh["n_cam"], dtype=np.int64)
+    for lo, c in parts:
+        allc[lo:lo + len(c)] = c
+    row_ptr = np.concatenate([[0], np.cumsum(allc)]).astype(np.uint64)
+    return Dist.partition_by_observations(row_ptr, world)
 
 
 def algorithmic_bytes(n_obs, n_cam, n_pts):
@@ -215,14 +238,48 @@ def adversarial_gather(sh, r, Jc, Jp, ws):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
-    (profiles/, produced by tools/profile_bench.sh with the guide's gfx950 FETCH_SIZE correction)."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (profiles/, produced
+    by tools/profile_bench.sh with the guide's gfx950 FETCH_SIZE correction).  PMC counters cannot be collected
+    from inside the timed run, so this is a figure from a SEPARATE run of the same command; it is only reported when
+    the summary names the kernel this build launches, and it carries its tag."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get("traffic_bytes_per_launch")
+            j = json.load(fh)
+        if KERNEL_NAME.split("<")[0] not in str(j.get("kernel", "")):
+            return None, None
+        return j.get("traffic_bytes_per_launch"), j.get("tag")
     except Exception:
-        return None
+        return None, None
+
+
+def same_run_calibration(n, r, Jc, Jp, dev, alg):
+    """What THIS device does for pure streams, measured in this process right after the timed region: the Jacobian
+    kernel's store geometry alone (208 B/observation of non-temporal 1-KiB stores, no loads, no arithmetic) and a
+    16-B-per-lane copy moving the launch's algorithmic byte count.  Lets a slow box be told from a slow kernel."""
+    import torch
+    from city2ba_amd import device as D
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps * 1e-3
+    t_store = timed(lambda: D.calib_store_pattern(r, Jc, Jp))
+    numel = int(alg) // 16 // 2 * 2
+    src = torch.empty(numel, dtype=torch.float64, device=dev).normal_()
+    dst = torch.empty_like(src)
+    t_copy = timed(lambda: D.calib_copy(src, dst))
+    return {"same_run_store_floor_us": round(t_store * 1e6, 2),
+            "same_run_store_GBs": round(n * 208 / t_store / 1e9, 1),
+            "same_run_copy_us": round(t_copy * 1e6, 2),
+            "same_run_copy_GBs": round(numel * 16 / t_copy / 1e9, 1)}
 
 
 def main():
@@ -255,50 +312,52 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     sh = build_shard(args, rank, world, dev)
+    bounds = None
+    if world > 1:
+        # re-split on the observation prefix sum and rebuild the shard for the balanced range
+        bounds = balanced_bounds(sh, rank, world)
+        if (int(bounds[rank]), int(bounds[rank + 1])) != (sh["cam_lo"], sh["cam_hi"]):
+            del sh
+            torch.cuda.empty_cache()
+            sh = build_shard(args, rank, world, dev, bounds=bounds)
     n = sh["n_obs"]
     r = torch.empty((n, 2), dtype=torch.float64, device=dev)
     Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
     Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
-    # The reduced scalar of step k is not an input of step k+1, so the fixed-order fold and the 8-byte all-reduce run
-    # on a side stream and overlap the next pass of the Jacobian kernel (collectives overlapped with compute on
-    # separate HIP streams).  The error partials are double-buffered so pass k+1 never overwrites what fold k reads.
-    ws2 = [D.workspace(n, dev), D.workspace(n, dev)]
-    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    ws = D.workspace(n, dev)
+    # One launch per step: residual + Jacobian + the folded L2 error sum (in-kernel ticket fold) -> err[k].  For
+    # N > 1 the 8-byte all-reduce of step k runs on a side stream and overlaps step k+1's kernel (the reduced
+    # scalar is not an input of the next step); err is double-buffered so that kernel k+1 never writes what
+    # all-reduce k is reading, and kernel k+2 waits for all-reduce k.
+    err2 = [torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)]
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream(device=dev)
-    fold_done = [None, None]
+    reduced = [None, None]
     produced_ev = [torch.cuda.Event(), torch.cuda.Event()]
-    fold_ev = [torch.cuda.Event(), torch.cuda.Event()]
+    reduced_ev = [torch.cuda.Event(), torch.cuda.Event()]
     counter = [0]
 
     def step(ev=None):
-        if world == 1:                             # nothing to overlap: plain in-order step on one stream
-            if ev is not None:
-                ev[0].record()
-            D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws2[0])
-            if ev is not None:
-                ev[1].record()
-            D.error_sum_finish(ws2[0], n, err)
-            return
         k = counter[0] & 1
         counter[0] += 1
-        if fold_done[k] is not None:
-            main.wait_event(fold_done[k])          # workspace k is free again (its fold ran a whole pass ago)
+        if world > 1 and reduced[k] is not None:
+            main.wait_event(reduced[k])            # err2[k] is free again (its all-reduce ran a whole step ago)
         if ev is not None:
             ev[0].record()
-        D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws2[k])
+        D.residual_jacobian_sum(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws,
+                                err2[k])
         if ev is not None:
             ev[1].record()
-            produced = ev[1]                       # the kernel-end timing event doubles as the hand-off event
-        else:
-            produced = produced_ev[k]
+        if world == 1:
+            return
+        produced = ev[1] if ev is not None else produced_ev[k]      # the kernel-end timing event doubles as hand-off
+        if ev is None:
             produced.record(main)
         with torch.cuda.stream(side):
             side.wait_event(produced)
-            D.error_sum_finish(ws2[k], n, err)
-            Dist.all_reduce_sum_(err)
-            fold_ev[k].record(side)
-            fold_done[k] = fold_ev[k]
+            Dist.all_reduce_sum_(err2[k])
+            reduced_ev[k].record(side)
+            reduced[k] = reduced_ev[k]
 
     for _ in range(args.warmup):
         step()
@@ -306,10 +365,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = None
+    if rank == 0:                                   # per-kernel HIP events only where the roofline is reported
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k] if rank == 0 else None)      # per-kernel HIP events only where the roofline is reported
+        step(events[k] if events is not None else None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -319,15 +380,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_err = Dist.finish_error(err.item(), 2.0)
+    last = (counter[0] - 1) & 1
+    total_err = Dist.finish_error(err2[last].item(), 2.0)
+    per_rank_obs = [n]
+    if world > 1:
+        per_rank_obs = [None] * world
+        dist.all_gather_object(per_rank_obs, n)
 
-    kern_ms = sorted(a.elapsed_time(b) for a, b in events)
-    kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
     if rank == 0:
+        kern_ms = sorted(a.elapsed_time(b) for a, b in events)
+        kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
         n_total = sh["n_obs_total"]
         value = n_total * args.steps / elapsed / 1e6
         alg = algorithmic_bytes(n, sh["n_cam_local"], sh["n_pts"])
         achieved = alg / kern_avg_s / 1e9
+        traffic, traffic_tag = pmc_traffic() if (world == 1 and args.blocks == 128) else (None, None)
         out = {
             "metric": "million observations/sec (project+Jacobian)",
             "value": round(value, 3), "unit": "Mobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -335,30 +402,36 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "city2ba synthetic --blocks %d (cpb=10 ppb=10 block-length=20 inset=1 max-dist=10): "
-                            "residual + 2x(9+3) Jacobian + fused L2 error reduce, f64; 1-scalar all-reduce when N>1"
-                            % args.blocks,
+                            "residual + 2x(9+3) Jacobian + fused L2 error reduce in ONE launch, f64; 1-scalar all-reduce "
+                            "when N>1" % args.blocks,
                 "blocks": args.blocks, "n_cameras": sh["n_cam"], "n_points": sh["n_pts"],
                 "n_observations": n_total, "n_candidates_rank0": sh["n_candidates"],
                 "occlusion": True, "cull": False,
-                "sharding": "contiguous camera ranges (n_cam/N each), points replicated, outputs sharded",
+                "sharding": "contiguous camera ranges balanced on the observation prefix sum (c2b_partition_cameras), "
+                            "points replicated, outputs sharded",
+                "observations_per_rank": [int(x) for x in per_rank_obs],
+                "camera_bounds": [int(x) for x in bounds] if bounds is not None else [0, sh["n_cam"]],
                 "total_L2_error": total_err,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_residual_jacobian_w<true,8,2,true,0,2,true>", "achieved": round(achieved, 1),
+                "bound": "hbm", "kernel": KERNEL_NAME, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic() if (world == 1 and args.blocks == 128) else None,
+                "traffic": traffic, "traffic_source": ("separate rocprofv3 --pmc run, profiles/ tag %s" % traffic_tag)
+                if traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg, "observations_per_launch": n,
                 "bytes_per_observation": round(alg / max(n, 1), 2),
                 "kernel_avg_us": round(kern_avg_s * 1e6, 2), "kernel_min_us": round(kern_ms[0] * 1e3, 2),
             },
         }
+        if world == 1 and not args.no_extras:
+            out["roofline"].update(same_run_calibration(n, r, Jc, Jp, dev, alg))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sh, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         if world == 1 and args.blocks == 128 and not args.no_extras:
             out["other_configs"] = other_configs(dev)
-            out["other_configs"]["blocks128_uniform_random_point_gather"] = adversarial_gather(sh, r, Jc, Jp, ws2[0])
+            out["other_configs"]["blocks128_uniform_random_point_gather"] = adversarial_gather(sh, r, Jc, Jp, ws)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -45,6 +45,9 @@ SIGNATURES = {
     "c2b_reprojection_error_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp]),
     "c2b_error_sum_finish": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_residual_jacobian_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "c2b_calib_store_pattern": (_int, [_i64, _vp, _vp, _vp, _vp]),
+    "c2b_calib_copy": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_visibility_dense_tiles": (_i64, [_i64]),
     "c2b_visibility_dense_count": (_int, [_vp, _i64, _vp, _i64, _d, _vp, _vp, _vp, _vp]),

@@ -214,7 +214,13 @@ struct Proj {
 // cam points at a camblk-shaped record (LDS or global).  |p|^4 is evaluated as n*n; the
 // reference writes magnitude().powf(4.0) (= pow(sqrt(n),4)), a <= 2.5 ulp different rounding
 // of the same value (libm pow is not reproducible across platforms anyway).
-C2B_DEV Proj project_obs(const double *cam, double X, double Y, double Z) {
+// P is a pointer to double in any address space: a generic pointer, or one typed LDS-only / global-only (lds_cptr /
+// glb_cptr) so that the loads compile to ds_read / global_load and two call sites can never be merged into FLAT loads.
+typedef const __attribute__((address_space(3))) double *lds_cptr;
+typedef const __attribute__((address_space(1))) double *glb_cptr;
+
+template <typename P>
+C2B_DEV Proj project_obs(P cam, double X, double Y, double Z) {
     Proj p;
     p.qx = dot3(cam[0], cam[1], cam[2], X, Y, Z) + cam[9];
     p.qy = dot3(cam[3], cam[4], cam[5], X, Y, Z) + cam[10];
@@ -234,6 +240,16 @@ C2B_DEV double abs_pow(double x, double norm) {
     const double a = fabs(x);
     if (norm == 2.0) return a * a;
     if (norm == 1.0) return a;
+    return pow(a, norm);
+}
+// The same with the norm fixed at compile time (the launchers dispatch on the host-side value): kernels for the
+// reference's two norms carry no pow() code at all.  NORM_ANY = any other exponent.
+enum { NORM_ANY = 0, NORM_1 = 1, NORM_2 = 2 };
+template <int NK>
+C2B_DEV double abs_pow_k(double x, double norm) {
+    const double a = fabs(x);
+    if (NK == NORM_2) return a * a;
+    if (NK == NORM_1) return a;
     return pow(a, norm);
 }
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "host_noise.hpp"
 #include "host_synthetic.hpp"
 #include "kernels.hpp"
+#include "obs_pipeline.hpp"
 #include "cull_kernels.hpp"
 
 using namespace c2b;
@@ -54,17 +56,75 @@ inline hipStream_t S(void *s) {
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)((n + b - 1) / b); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// workspace layout (doubles): [stats records: kRedBlocks*kStatRec] [stage-1 sums: kSumBlocks]
-//                            [error partials: one per 64-observation wave tile]
+// workspace layout (doubles): [stats records: kRedBlocks*kStatRec] [final sum, ticket word: 16]
+//                            [workgroup partials of the ticket fold: kMaxBlockPart]
+//                            [tuning builds only: stage-1 sums kSumBlocks + one partial per 64-observation tile]
 constexpr int64_t kWsStatsDoubles = (int64_t)kRedBlocks * kStatRec;
-constexpr int64_t kWsPartials = kWsStatsDoubles + kSumBlocks;
+constexpr int64_t kWsFinal = kWsStatsDoubles;            // [0] = the folded sum, [2] = ticket word (u64)
+constexpr int64_t kWsBlockPart = kWsFinal + 16;
+constexpr int64_t kWsStage = kWsBlockPart + kMaxBlockPart;
+constexpr int64_t kWsPartials = kWsStage + kSumBlocks;
 
-// residual+Jacobian kernel variant (tuning knob of tools/tune_jac.py, not part of the ABI): see launch_jacobian
-int g_jac_variant = 14;
-// light per-observation kernels: observations per lane * 100 + waves per workgroup, + 1000 = camera reads through
-// LDS-only pointers (tools/tune_obs.py)
-int g_obs_variant = 1208;
+// launch epoch of the ticket fold (obs_pipeline.hpp: ticket_arrive); 44 bits, never 0
+std::atomic<unsigned long long> g_epoch{1};
+inline unsigned long long next_epoch() {
+    unsigned long long e;
+    do { e = g_epoch.fetch_add(1, std::memory_order_relaxed) & ((1ull << 44) - 1); } while (e == 0);
+    return e;
+}
 
+// Persistent grid: (resident workgroups per CU) x (CUs), a multiple of 8 (one slice per XCD), never more
+// workgroups than there is work for.  Occupancy and CU count are queried once per kernel and device.
+template <typename K>
+int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cached[dev]) {
+        int occ = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, 0) != hipSuccess || occ < 1) occ = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached[dev] = occ * cus;
+    }
+    int64_t g = cached[dev];
+    if (g > work_blocks) g = work_blocks;
+    g = (g + 7) & ~(int64_t)7;
+    if (g < 8) g = 8;
+    if (g > kMaxBlockPart) g = kMaxBlockPart;
+    return (int)g;
+}
+
+#ifdef C2B_TUNE
+// Tuning build only (libcity2ba_hip_tune.so, tools/tune_*.py): kernel variants, including timing-only ablations
+// whose outputs are wrong by construction.  None of this exists in the product library.
+int g_jac_variant = 100;
+int g_obs_variant = 2008;
+#endif
+
+template <int MODE, int WPB>
+int launch_obs_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                 const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
+                 void *workspace, double *out_sum, hipStream_t st) {
+    double *ws = reinterpret_cast<double *>(workspace);
+    const int64_t work = ((n >> 6) + WPB - 1) / WPB + 1;
+#define C2B_GO(NK)                                                                                                      \
+    do {                                                                                                                \
+        const int grid = persistent_grid(k_observations_p<MODE, NK, WPB>, WPB * 64, work);                              \
+        hipLaunchKernelGGL((k_observations_p<MODE, NK, WPB>), dim3(grid), dim3(WPB * 64), 0, st, camblk,                \
+                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                                   \
+                           reinterpret_cast<const double2 *>(uv_obs), (int)n, norm, max_dist,                          \
+                           reinterpret_cast<double2 *>(uv_out), keep, ws ? ws + kWsBlockPart : nullptr,                 \
+                           ws ? reinterpret_cast<unsigned long long *>(ws + kWsFinal + 2) : nullptr, next_epoch(),     \
+                           out_sum);                                                                                    \
+    } while (0)
+    if (MODE != MODE_ERROR || norm == 2.0) C2B_GO(NORM_2);
+    else if (norm == 1.0) C2B_GO(NORM_1);
+    else C2B_GO(NORM_ANY);
+#undef C2B_GO
+    return C2B_OK;
+}
+
+#ifdef C2B_TUNE
 template <int MODE, int OPL, int WPB, bool LDSCAM = false>
 void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
@@ -75,31 +135,10 @@ void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_
                        tiles, norm, max_dist, reinterpret_cast<double2 *>(uv_out), keep, partials);
 }
 
-template <int MODE>
-void launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-                double *partials, hipStream_t st) {
-#define C2B_OBS_CASE(O, W)                                                                                           \
-    case O * 100 + W:                                                                                                \
-        return launch_obs_v<MODE, O, W>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st)
-    switch (g_obs_variant) {
-        C2B_OBS_CASE(1, 8);
-        C2B_OBS_CASE(2, 16);
-        C2B_OBS_CASE(4, 8);
-        case 1108: return launch_obs_v<MODE, 1, 8, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);
-        C2B_OBS_CASE(2, 8);
-        case 1216: return launch_obs_v<MODE, 2, 16, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);
-        case 1408: return launch_obs_v<MODE, 4, 8, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);
-        default:
-        case 1208: return launch_obs_v<MODE, 2, 8, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st);   // shipped
-    }
-#undef C2B_OBS_CASE
-}
-
 int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) {
     double *ws = reinterpret_cast<double *>(workspace);
     const double *partials = ws + kWsPartials;
-    double *stage = ws + kWsStatsDoubles;
+    double *stage = ws + kWsStage;
     int64_t chunk = (count + kSumBlocks - 1) / kSumBlocks;
     if (chunk < 256) chunk = 256;
     const int blocks = (int)((count + chunk - 1) / chunk);
@@ -109,7 +148,63 @@ int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) 
     LAUNCH_CHECK();
     return C2B_OK;
 }
+#endif
 
+// project / error sum / visibility predicate over an observation list.  MODE_ERROR leaves the folded sum in
+// out_sum (device pointer).
+template <int MODE>
+int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+               const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
+               void *workspace, double *out_sum, hipStream_t st) {
+#ifdef C2B_TUNE
+    if (g_obs_variant < 2000) {
+        double *partials = workspace ? reinterpret_cast<double *>(workspace) + kWsPartials : nullptr;
+#define C2B_OBS_CASE(V, O, W, L)                                                                                        \
+    case V: launch_obs_v<MODE, O, W, L>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st); break
+        switch (g_obs_variant) {
+            C2B_OBS_CASE(108, 1, 8, false);
+            C2B_OBS_CASE(208, 2, 8, false);
+            C2B_OBS_CASE(1108, 1, 8, true);
+            C2B_OBS_CASE(1216, 2, 16, true);
+            C2B_OBS_CASE(1408, 4, 8, true);
+            default:
+            C2B_OBS_CASE(1208, 2, 8, true);          // round-1 shipped
+        }
+#undef C2B_OBS_CASE
+        if (MODE == MODE_ERROR) { LAUNCH_CHECK(); return launch_sum(workspace, (n + 63) / 64, out_sum, st); }
+        return C2B_OK;
+    }
+    if (g_obs_variant == 2004)
+        return launch_obs_p<MODE, 4>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, workspace, out_sum, st);
+    if (g_obs_variant == 2016)
+        return launch_obs_p<MODE, 16>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, workspace, out_sum, st);
+#endif
+    return launch_obs_p<MODE, 8>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, workspace, out_sum, st);
+}
+
+template <bool WITH_ERR, int WPB, int MINW>
+void launch_jac_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                  const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
+                  double *out_sum, hipStream_t st) {
+    double *ws = reinterpret_cast<double *>(workspace);
+    const int64_t work = ((n_obs >> 6) + WPB - 1) / WPB + 1;
+#define C2B_GO(NK)                                                                                                      \
+    do {                                                                                                                \
+        const int grid = persistent_grid(k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>, WPB * 64, work);               \
+        hipLaunchKernelGGL((k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>), dim3(grid), dim3(WPB * 64), 0, st, camblk, \
+                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                                   \
+                           reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, norm, reinterpret_cast<double2 *>(r), Jc, \
+                           Jp, ws ? ws + kWsBlockPart : nullptr,                                                        \
+                           ws ? reinterpret_cast<unsigned long long *>(ws + kWsFinal + 2) : nullptr, next_epoch(),     \
+                           out_sum);                                                                                    \
+    } while (0)
+    if (!WITH_ERR || norm == 2.0) C2B_GO(NORM_2);
+    else if (norm == 1.0) C2B_GO(NORM_1);
+    else C2B_GO(NORM_ANY);
+#undef C2B_GO
+}
+
+#ifdef C2B_TUNE
 template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1, bool LDSCAM = false>
 void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                          const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
@@ -121,33 +216,38 @@ void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_
                        reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r),
                        Jc, Jp, partials);
 }
+#endif
 
+// residual + Jacobian; WITH_ERR also folds sum |r|^norm into out_sum (device pointer) in the same launch
 template <bool WITH_ERR>
-void launch_jacobian(int variant, const double *camblk, const double *pts4, const uint32_t *cam_idx,
-                            const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
-                            double *Jp, double norm, double *partials, hipStream_t st) {
-#define C2B_W(WPB, SPLIT, NT) launch_jac_w<WITH_ERR, WPB, SPLIT, NT>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st)
-    switch (variant) {
-        case 2: C2B_W(4, 2, true); break;                    // 256-thread workgroups, one tile per wave
-        case 9: C2B_W(8, 2, true); break;                    // 512-thread
-        case 10: C2B_W(16, 2, true); break;                  // 1024-thread
-        case 11: launch_jac_w<WITH_ERR, 16, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
-        case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // r01d: FLAT camera reads
-        default:
-        case 14: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // shipped: + LDS-only camera reads
-        case 15: launch_jac_w<WITH_ERR, 16, 2, true, 0, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
-        case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
-        case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no Jacobian stores
-        case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no arithmetic
-        case 30: case 31: case 32: {      // store-pattern-only timing builds
-            const int64_t wt = (n_obs + 63) / 64;
-            if (variant == 30) { const int64_t bt = (wt + 7) / 8; hipLaunchKernelGGL((k_store_pattern<true, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
-            if (variant == 31) { const int64_t bt = (wt + 7) / 8; hipLaunchKernelGGL((k_store_pattern<false, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
-            if (variant == 32) { const int64_t bt = (wt + 3) / 4; hipLaunchKernelGGL((k_store_pattern<true, 4>), dim3((unsigned)bt), dim3(256), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); }
-            break;
+int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                    const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
+                    double *out_sum, hipStream_t st) {
+#ifdef C2B_TUNE
+    const int variant = g_jac_variant;
+    if (variant < 100) {
+        double *partials = workspace ? reinterpret_cast<double *>(workspace) + kWsPartials : nullptr;
+        switch (variant) {
+            case 9: launch_jac_w<WITH_ERR, 8, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+            case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+            default:
+            case 14: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // round-1 shipped
+            case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
+            case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no Jacobian stores
+            case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no arithmetic
         }
+        if (WITH_ERR && out_sum) { LAUNCH_CHECK(); return launch_sum(workspace, (n_obs + 63) / 64, out_sum, st); }
+        return C2B_OK;
     }
-#undef C2B_W
+#define C2B_JP(V, W, M) if (variant == V) { launch_jac_p<WITH_ERR, W, M>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, out_sum, st); return C2B_OK; }
+    C2B_JP(104, 4, 1)      // 12 waves per CU at the natural register count
+    C2B_JP(105, 4, 4)      // 16 waves per CU
+    C2B_JP(108, 8, 1)      //  8 waves per CU
+    C2B_JP(116, 16, 4)     // 16 waves per CU, one workgroup
+#undef C2B_JP
+#endif
+    launch_jac_p<WITH_ERR, 8, 4>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, out_sum, st);
+    return C2B_OK;
 }
 
 template <typename Src>
@@ -230,13 +330,19 @@ int c2b_device_count(int *count) {
 
 int64_t c2b_workspace_bytes(int64_t n_obs) {
     if (n_obs < 0) n_obs = 0;
-    const int64_t wave_tiles = (n_obs + 63) / 64;
+#ifdef C2B_TUNE
+    const int64_t wave_tiles = (n_obs + 63) / 64;       // round-1 kernels: one partial per 64-observation tile
     return (kWsPartials + wave_tiles + 16) * (int64_t)sizeof(double);
+#else
+    return kWsStage * (int64_t)sizeof(double);          // independent of n_obs (kept as a parameter of the ABI)
+#endif
 }
 
-// hidden tuning hook (tools/tune_jac.py); not declared in the public header
+#ifdef C2B_TUNE
+// tuning hooks of libcity2ba_hip_tune.so (tools/tune_jac.py, tools/tune_obs.py); absent from the product library
 int c2b_tune_set_jacobian_variant(int v) { g_jac_variant = v; return C2B_OK; }
 int c2b_tune_set_observation_variant(int v) { g_obs_variant = v; return C2B_OK; }
+#endif
 
 /* ------------------------------- level 0 --------------------------------------------- */
 
@@ -344,6 +450,8 @@ int c2b_expand_rows(const uint64_t *row_ptr, int64_t n_cam, int64_t obs_base, in
 static int check_obs_args(const char *who, const void *camblk, const void *pts4, const void *cam_idx,
                           const void *pt_idx, int64_t n) {
     if (n < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: negative count", who);
+    if (n > (int64_t)0x7fffffff - 4096 * 64)       // 32-bit observation indices on the device; 2^31 observations are 34 GB of indices and uv alone
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s: more than 2^31 observations in one launch", who);
     if (n && (!camblk || !pts4 || !cam_idx || !pt_idx)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: NULL input", who);
     if (n && (!aligned16(camblk) || !aligned16(pts4)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "%s: camblk/pts4 must be 16-byte aligned", who);
@@ -356,7 +464,8 @@ int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_id
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
     if (!uv_out || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "project: uv_out NULL or misaligned");
-    launch_obs<MODE_PROJECT>(camblk, pts4, cam_idx, pt_idx, nullptr, n_obs, 0.0, 0.0, uv_out, nullptr, nullptr, S(stream));
+    rc = launch_obs<MODE_PROJECT>(camblk, pts4, cam_idx, pt_idx, nullptr, n_obs, 0.0, 0.0, uv_out, nullptr, nullptr, nullptr, S(stream));
+    if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -370,11 +479,10 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
     if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
     if (!uv_obs || !aligned16(uv_obs) || !workspace)
         return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: uv_obs/workspace NULL or misaligned");
-    double *partials = reinterpret_cast<double *>(workspace) + kWsPartials;
-    const int64_t wave_tiles = (n_obs + 63) / 64;
-    launch_obs<MODE_ERROR>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, norm, 0.0, nullptr, nullptr, partials, S(stream));
+    rc = launch_obs<MODE_ERROR>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, norm, 0.0, nullptr, nullptr, workspace, out_sum, S(stream));
+    if (rc) return rc;
     LAUNCH_CHECK();
-    return launch_sum(workspace, wave_tiles, out_sum, S(stream));
+    return C2B_OK;
 }
 
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
@@ -386,14 +494,51 @@ int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32
     if (!uv_obs || !r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: NULL buffer");
     if (!aligned16(uv_obs) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
         return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: uv/r/Jc/Jp must be 16-byte aligned");
-    if (workspace) {
-        double *partials = reinterpret_cast<double *>(workspace) + kWsPartials;
-        launch_jacobian<true>(g_jac_variant, camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials,
-                              S(stream));
-    } else {
-        launch_jacobian<false>(g_jac_variant, camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr,
-                               S(stream));
-    }
+    // with a workspace the fused error sum lands in the workspace's result slot (c2b_error_sum_finish copies it out)
+    double *slot = workspace ? reinterpret_cast<double *>(workspace) + kWsFinal : nullptr;
+#ifdef C2B_TUNE
+    if (g_jac_variant < 100) slot = nullptr;        // round-1 kernels: per-tile partials, folded by c2b_error_sum_finish
+#endif
+    if (workspace) rc = launch_jacobian<true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, slot, S(stream));
+    else rc = launch_jacobian<false>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr, nullptr, S(stream));
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                              const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
+                              double *Jp, double norm, void *workspace, double *out_sum, void *stream) {
+    int rc = check_obs_args("residual_jacobian_sum", camblk, pts4, cam_idx, pt_idx, n_obs);
+    if (rc) return rc;
+    if (!out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_sum: out_sum is NULL");
+    if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
+    if (!uv_obs || !r || !Jc || !Jp || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_sum: NULL buffer");
+    if (!aligned16(uv_obs) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_sum: uv/r/Jc/Jp must be 16-byte aligned");
+    rc = launch_jacobian<true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, out_sum, S(stream));
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, void *stream) {
+    if (n_obs < 0 || (n_obs && (!r || !Jc || !Jp)) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "calib_store_pattern: bad arguments");
+    if (n_obs < 64) return C2B_OK;
+    const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
+    hipLaunchKernelGGL((k_store_pattern<true, 8>), dim3((unsigned)bt), dim3(512), 0, S(stream), n_obs, bt,
+                       reinterpret_cast<double2 *>(r), Jc, Jp);
+    LAUNCH_CHECK();
+    return C2B_OK;
+}
+
+int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
+    if (bytes < 0 || (bytes && (!src || !dst)) || !aligned16(src) || !aligned16(dst) || (bytes & 15))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "calib_copy: NULL, misaligned or not a multiple of 16 bytes");
+    if (!bytes) return C2B_OK;
+    hipLaunchKernelGGL(k_copy16, dim3(256 * 32), dim3(256), 0, S(stream), reinterpret_cast<const double2 *>(src),
+                       reinterpret_cast<double2 *>(dst), bytes / 16);
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -402,8 +547,12 @@ int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, 
     if (n_obs < 0 || !out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: bad arguments");
     if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
     if (!workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: workspace is NULL");
-    const int64_t count = (n_obs + 63) / 64;       // one partial per 64-observation tile
-    return launch_sum(const_cast<void *>(workspace), count, out_sum, S(stream));
+#ifdef C2B_TUNE
+    if (g_jac_variant < 100) return launch_sum(const_cast<void *>(workspace), (n_obs + 63) / 64, out_sum, S(stream));
+#endif
+    HIP_TRY(hipMemcpyAsync(out_sum, reinterpret_cast<const double *>(workspace) + kWsFinal, sizeof(double),
+                           hipMemcpyDeviceToDevice, S(stream)));
+    return C2B_OK;
 }
 
 int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_t *cam_idx,
@@ -413,7 +562,8 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
     if (rc) return rc;
     if (!n_pairs) return C2B_OK;
     if (!uv_out || !keep || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_pairs: NULL/misaligned output");
-    launch_obs<MODE_VISIBILITY>(camblk, pts4, cam_idx, pt_idx, nullptr, n_pairs, 0.0, max_dist, uv_out, keep, nullptr, S(stream));
+    rc = launch_obs<MODE_VISIBILITY>(camblk, pts4, cam_idx, pt_idx, nullptr, n_pairs, 0.0, max_dist, uv_out, keep, nullptr, nullptr, S(stream));
+    if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
 }

@@ -282,8 +282,8 @@ C2B_DEV void store16(char *dst, const double2 v) {
 }
 
 // one observation: projection (reference order) + the 2x9 / 2x3 blocks (explicit FMAs)
-template <int ABL>
-C2B_DEV void jacobian_obs(const double *cam, const double4 X, const double2 ob, double &r0, double &r1,
+template <int ABL, typename P>
+C2B_DEV void jacobian_obs(P cam, const double4 X, const double2 ob, double &r0, double &r1,
                           double jc[18], double jp[6]) {
     Proj p;
     if (ABL == 2) {        // memory-only build: keep every load live, skip the arithmetic
@@ -309,7 +309,7 @@ C2B_DEV void jacobian_obs(const double *cam, const double4 X, const double2 ob, 
     const double yx = p.qx - cam[9], yy = p.qy - cam[10], yz = p.qz - cam[11];
     const double v0x = fma(yy, a02, -yz * a01), v0y = fma(yz, a00, -yx * a02), v0z = fma(yx, a01, -yy * a00);
     const double v1x = fma(yy, a12, -yz * a11), v1y = fma(yz, a10, -yx * a12), v1z = fma(yx, a11, -yy * a10);
-    const double *Jl = cam + kJl;
+    const P Jl = cam + kJl;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         jc[j] = fma(v0z, Jl[6 + j], fma(v0y, Jl[3 + j], v0x * Jl[j]));
@@ -1099,8 +1099,12 @@ __global__ __launch_bounds__(256) void k_dense_cam_scan(const uint64_t *__restri
 
 }  // namespace c2b
 
-// ---- timing-only: the Jacobian kernel's store pattern with no loads, no LDS, no arithmetic (tools/tune_jac.py) ----
+// ---- calibration kernels (c2b_calib_*): what this device does for pure streams, measured in the same process as ----
+// ---- the bench so that a slow box can be told from a slow kernel.  They read / write only the buffers handed to ----
+// ---- them and are not part of any compute path.                                                                 ----
 namespace c2b {
+// the residual + Jacobian kernel's 208 B/observation store geometry (1-KiB non-temporal stores of whole lines) with no
+// loads, no LDS and no arithmetic: the floor its stores alone would take
 template <bool NT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n_btiles, double2 *__restrict__ r_out,
                                                            double *__restrict__ Jc, double *__restrict__ Jp) {
@@ -1116,6 +1120,17 @@ __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n
     char *dp = reinterpret_cast<char *>(Jp) + wave0 * 48;
 #pragma unroll
     for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
+}
+
+// 16 bytes per lane streaming copy (the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for), 4 per thread in flight
+__global__ __launch_bounds__(256) void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 }  // namespace c2b
 

@@ -88,9 +88,28 @@ def reprojection_error_sum(camblk, pts4, cam_idx, pt_idx, uv, norm, ws, out_sum)
 
 
 def residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None):
-    """ws != None -> the kernel also leaves per-tile error partials in ws (see error_sum_finish)."""
+    """ws != None -> the same launch also folds sum |r|^norm into ws (see error_sum_finish)."""
     L.check(L.lib().c2b_residual_jacobian(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv), cam_idx.shape[0],
                                           _p(r), _p(Jc), _p(Jp), float(norm), _p(ws), _stream()))
+
+
+def residual_jacobian_sum(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm, ws, out_sum):
+    """residual + Jacobian + sum |r|^norm -> out_sum[0], ONE launch."""
+    L.check(L.lib().c2b_residual_jacobian_sum(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv), cam_idx.shape[0],
+                                              _p(r), _p(Jc), _p(Jp), float(norm), _p(ws), _p(out_sum), _stream()))
+    return out_sum
+
+
+def calib_store_pattern(r, Jc, Jp):
+    """Calibration: the residual+Jacobian kernel's store geometry alone (fills r, Jc, Jp with a pattern)."""
+    L.check(L.lib().c2b_calib_store_pattern(r.shape[0], _p(r), _p(Jc), _p(Jp), _stream()))
+
+
+def calib_copy(src, dst):
+    """Calibration: 16-bytes-per-lane streaming copy of src into dst (same byte size, multiple of 16)."""
+    nbytes = src.numel() * src.element_size()
+    assert nbytes == dst.numel() * dst.element_size()
+    L.check(L.lib().c2b_calib_copy(_p(src), _p(dst), nbytes, _stream()))
 
 
 def error_sum_finish(ws, n_obs, out_sum):

@@ -60,7 +60,10 @@ int c2b_device_count(int *count);
  * Observations may come in any order; camera-major (CSR) order is the fast path.
  * ===================================================================================== */
 
-/* bytes of scratch the reductions below need for a problem with n_obs observations */
+/* Bytes of scratch the reductions below need for a problem with n_obs observations.  The workspace needs no
+ * initialisation (the in-kernel arrival ticket is tagged with a per-launch epoch, so stale or garbage contents
+ * count as "no arrivals").  One workspace serves one stream at a time: two launches that may run concurrently
+ * must not share it. */
 int64_t c2b_workspace_bytes(int64_t n_obs);
 
 /* SnavelyCamera::from_vec / from_rodrigues (src/baproblem.rs:78-90, 180-186) */
@@ -97,20 +100,34 @@ int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_id
 
 /* Sum over observations of |du|^norm + |dv|^norm, i.e. BAProblem::total_reprojection_error
  * (src/baproblem.rs:265-279) WITHOUT the final powf(1/norm): the quantity that is
- * all-reduced across GPUs.  Deterministic two-pass tree (no float atomics). */
+ * all-reduced across GPUs.  ONE launch: every workgroup leaves a partial, the last one to arrive folds them
+ * in index order (no float atomics; the same problem on the same device gives the same bits every run). */
 int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                                const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
                                double norm, void *workspace, double *out_sum, void *stream);
 
 /* residual + 2x9 camera block + 2x3 point block per observation (no reference equivalent).
- * With workspace != NULL the kernel also leaves one partial of sum |du|^norm + |dv|^norm per
- * 64-observation tile in the workspace (fused error reduce); c2b_error_sum_finish folds them. */
+ * With workspace != NULL the same launch also folds sum |du|^norm + |dv|^norm (fused error reduce, same fold
+ * as c2b_reprojection_error_sum) into the workspace; c2b_error_sum_finish copies it out. */
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                           const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
                           double *r, double *Jc, double *Jp,
                           double norm, void *workspace, void *stream);
-/* fixed-order fold of the per-tile partials left by c2b_residual_jacobian -> out_sum[0] */
+/* the sum left in the workspace by the last c2b_residual_jacobian on this stream -> out_sum[0] (8-byte copy) */
 int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, void *stream);
+/* c2b_residual_jacobian + the folded error sum straight into out_sum[0] (device pointer): the whole
+ * total_reprojection_error numerator and the Jacobian in ONE launch.  workspace must not be NULL. */
+int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
+                              const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                              double *r, double *Jc, double *Jp,
+                              double norm, void *workspace, double *out_sum, void *stream);
+
+/* Calibration (measurement aids, no reference counterpart; used by bench.py in the same process as the timed run so
+ * that a slow device can be told from a slow kernel).  _store_pattern writes a fill pattern over r [n][2], Jc [n][18],
+ * Jp [n][6] in exactly the residual+Jacobian kernel's store geometry with no loads and no arithmetic -- the time its
+ * stores alone take; _copy is a 16-bytes-per-lane streaming copy (bytes % 16 == 0). */
+int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, void *stream);
+int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream);
 
 /* visibility predicate of the generators (src/synthetic.rs:285-291, 368-375;
  * src/generate.rs:448-454): keep = |center - p| < max_dist && q.z <= 0 && |u|,|v| <= 1.

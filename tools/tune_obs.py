@@ -11,13 +11,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-import bench  # noqa: E402
+import __graft_entry__ as entry  # noqa: E402
 from city2ba_amd import _lib as L  # noqa: E402
+
+L.LIB_PATH = entry.build_tune()        # the tuning library (kernel variants + selectors), never the product one
+import bench  # noqa: E402
 from city2ba_amd import device as D  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--blocks", type=int, default=128)
-ap.add_argument("--variants", default="208,108,104,204,216,308,408,404")
+ap.add_argument("--variants", default="1208,2008,2004,2016")
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=20)
 a = ap.parse_args()
