@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -20,7 +21,9 @@
 #include "host_noise.hpp"
 #include "host_synthetic.hpp"
 #include "kernels.hpp"
-#include "obs_pipeline.hpp"
+#ifdef C2B_TUNE
+#include "obs_pipeline.hpp"      // persistent pipelined variants: measured slower, tuning library only
+#endif
 #include "cull_kernels.hpp"
 
 using namespace c2b;
@@ -56,25 +59,45 @@ inline hipStream_t S(void *s) {
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)((n + b - 1) / b); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// workspace layout (doubles): [stats records: kRedBlocks*kStatRec] [final sum, ticket word: 16]
-//                            [workgroup partials of the ticket fold: kMaxBlockPart]
-//                            [tuning builds only: stage-1 sums kSumBlocks + one partial per 64-observation tile]
+// workspace layout (doubles): [stats records: kRedBlocks*kStatRec] [result slot of the fused error sum: 16]
+//                            [workgroup partials of the ticket fold: one per workgroup of the launch]
 constexpr int64_t kWsStatsDoubles = (int64_t)kRedBlocks * kStatRec;
-constexpr int64_t kWsFinal = kWsStatsDoubles;            // [0] = the folded sum, [2] = ticket word (u64)
+constexpr int64_t kWsFinal = kWsStatsDoubles;
 constexpr int64_t kWsBlockPart = kWsFinal + 16;
-constexpr int64_t kWsStage = kWsBlockPart + kMaxBlockPart;
-constexpr int64_t kWsPartials = kWsStage + kSumBlocks;
-
-// launch epoch of the ticket fold (obs_pipeline.hpp: ticket_arrive); 44 bits, never 0
-std::atomic<unsigned long long> g_epoch{1};
-inline unsigned long long next_epoch() {
-    unsigned long long e;
-    do { e = g_epoch.fetch_add(1, std::memory_order_relaxed) & ((1ull << 44) - 1); } while (e == 0);
-    return e;
+// workgroups never hold fewer than 4 tiles of 64 observations (WPB * OPL >= 4 in every instantiation)
+inline int64_t block_part_slots(int64_t n_obs) {
+    const int64_t one_shot = ((n_obs + 63) / 64 + 3) / 4 + 8;
+    return one_shot > 4096 + 8 ? one_shot : 4096 + 8;        // 4096: the persistent grids of the tuning library
 }
 
-// Persistent grid: (resident workgroups per CU) x (CUs), a multiple of 8 (one slice per XCD), never more
-// workgroups than there is work for.  Occupancy and CU count are queried once per kernel and device.
+// Arrival tickets of the in-kernel folds (kernels.hpp: ticket_fold): a pool of zero-initialised words owned by the
+// library, one pool per device, allocated on first use.  A launch takes the next word of the pool; its last
+// workgroup resets it.  Launches that could run concurrently take different slots (128 before a slot repeats).
+constexpr unsigned kTicketSlots = 128;
+unsigned *ticket_slot() {
+    static std::mutex mu;
+    static unsigned *pool[64] = {nullptr};
+    static std::atomic<unsigned> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pool[dev]) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!pool[dev]) {
+            unsigned *p = nullptr;
+            if (hipMalloc((void **)&p, kTicketSlots * kTicketWords * sizeof(unsigned)) != hipSuccess) return nullptr;
+            if (hipMemset(p, 0, kTicketSlots * kTicketWords * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+            pool[dev] = p;
+        }
+    }
+    return pool[dev] + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketWords;
+}
+
+#ifdef C2B_TUNE
+// Tuning build only (libcity2ba_hip_tune.so, tools/tune_*.py): kernel variants, including timing-only ablations
+// whose outputs are wrong by construction.  None of this exists in the product library.
+int g_jac_variant = 14;
+int g_obs_variant = 1208;
+
 template <typename K>
 int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
     static int cached[64] = {0};
@@ -90,22 +113,14 @@ int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
     if (g > work_blocks) g = work_blocks;
     g = (g + 7) & ~(int64_t)7;
     if (g < 8) g = 8;
-    if (g > kMaxBlockPart) g = kMaxBlockPart;
+    if (g > 4096) g = 4096;
     return (int)g;
 }
 
-#ifdef C2B_TUNE
-// Tuning build only (libcity2ba_hip_tune.so, tools/tune_*.py): kernel variants, including timing-only ablations
-// whose outputs are wrong by construction.  None of this exists in the product library.
-int g_jac_variant = 100;
-int g_obs_variant = 2008;
-#endif
-
 template <int MODE, int WPB>
-int launch_obs_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                 const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-                 void *workspace, double *out_sum, hipStream_t st) {
-    double *ws = reinterpret_cast<double *>(workspace);
+void launch_obs_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                  const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
+                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
     const int64_t work = ((n >> 6) + WPB - 1) / WPB + 1;
 #define C2B_GO(NK)                                                                                                      \
     do {                                                                                                                \
@@ -113,140 +128,126 @@ int launch_obs_p(const double *camblk, const double *pts4, const uint32_t *cam_i
         hipLaunchKernelGGL((k_observations_p<MODE, NK, WPB>), dim3(grid), dim3(WPB * 64), 0, st, camblk,                \
                            reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                                   \
                            reinterpret_cast<const double2 *>(uv_obs), (int)n, norm, max_dist,                          \
-                           reinterpret_cast<double2 *>(uv_out), keep, ws ? ws + kWsBlockPart : nullptr,                 \
-                           ws ? reinterpret_cast<unsigned long long *>(ws + kWsFinal + 2) : nullptr, next_epoch(),     \
-                           out_sum);                                                                                    \
+                           reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum);                     \
     } while (0)
-    if (MODE != MODE_ERROR || norm == 2.0) C2B_GO(NORM_2);
+    if constexpr (MODE != MODE_ERROR) { C2B_GO(NORM_2); }
+    else if (norm == 2.0) C2B_GO(NORM_2);
     else if (norm == 1.0) C2B_GO(NORM_1);
     else C2B_GO(NORM_ANY);
 #undef C2B_GO
-    return C2B_OK;
-}
-
-#ifdef C2B_TUNE
-template <int MODE, int OPL, int WPB, bool LDSCAM = false>
-void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                  const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-                  double *partials, hipStream_t st) {
-    const int64_t tiles = ((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL);
-    hipLaunchKernelGGL((k_observations<MODE, OPL, WPB, LDSCAM>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st, camblk,
-                       reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, reinterpret_cast<const double2 *>(uv_obs), n,
-                       tiles, norm, max_dist, reinterpret_cast<double2 *>(uv_out), keep, partials);
-}
-
-int launch_sum(void *workspace, int64_t count, double *out_sum, hipStream_t st) {
-    double *ws = reinterpret_cast<double *>(workspace);
-    const double *partials = ws + kWsPartials;
-    double *stage = ws + kWsStage;
-    int64_t chunk = (count + kSumBlocks - 1) / kSumBlocks;
-    if (chunk < 256) chunk = 256;
-    const int blocks = (int)((count + chunk - 1) / chunk);
-    hipLaunchKernelGGL(k_sum_stage1, dim3(blocks), dim3(256), 0, st, partials, count, chunk, stage);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(kSumBlocks), 0, st, (const double *)stage, blocks, out_sum);
-    LAUNCH_CHECK();
-    return C2B_OK;
-}
-#endif
-
-// project / error sum / visibility predicate over an observation list.  MODE_ERROR leaves the folded sum in
-// out_sum (device pointer).
-template <int MODE>
-int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-               const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-               void *workspace, double *out_sum, hipStream_t st) {
-#ifdef C2B_TUNE
-    if (g_obs_variant < 2000) {
-        double *partials = workspace ? reinterpret_cast<double *>(workspace) + kWsPartials : nullptr;
-#define C2B_OBS_CASE(V, O, W, L)                                                                                        \
-    case V: launch_obs_v<MODE, O, W, L>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, partials, st); break
-        switch (g_obs_variant) {
-            C2B_OBS_CASE(108, 1, 8, false);
-            C2B_OBS_CASE(208, 2, 8, false);
-            C2B_OBS_CASE(1108, 1, 8, true);
-            C2B_OBS_CASE(1216, 2, 16, true);
-            C2B_OBS_CASE(1408, 4, 8, true);
-            default:
-            C2B_OBS_CASE(1208, 2, 8, true);          // round-1 shipped
-        }
-#undef C2B_OBS_CASE
-        if (MODE == MODE_ERROR) { LAUNCH_CHECK(); return launch_sum(workspace, (n + 63) / 64, out_sum, st); }
-        return C2B_OK;
-    }
-    if (g_obs_variant == 2004)
-        return launch_obs_p<MODE, 4>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, workspace, out_sum, st);
-    if (g_obs_variant == 2016)
-        return launch_obs_p<MODE, 16>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, workspace, out_sum, st);
-#endif
-    return launch_obs_p<MODE, 8>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, workspace, out_sum, st);
 }
 
 template <bool WITH_ERR, int WPB, int MINW>
 void launch_jac_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                  const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
-                  double *out_sum, hipStream_t st) {
-    double *ws = reinterpret_cast<double *>(workspace);
+                  const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
+                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
     const int64_t work = ((n_obs >> 6) + WPB - 1) / WPB + 1;
 #define C2B_GO(NK)                                                                                                      \
     do {                                                                                                                \
-        const int grid = persistent_grid(k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>, WPB * 64, work);               \
-        hipLaunchKernelGGL((k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>), dim3(grid), dim3(WPB * 64), 0, st, camblk, \
-                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                                   \
-                           reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, norm, reinterpret_cast<double2 *>(r), Jc, \
-                           Jp, ws ? ws + kWsBlockPart : nullptr,                                                        \
-                           ws ? reinterpret_cast<unsigned long long *>(ws + kWsFinal + 2) : nullptr, next_epoch(),     \
-                           out_sum);                                                                                    \
+        const int grid = persistent_grid(k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>, WPB * 64, work);         \
+        hipLaunchKernelGGL((k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>), dim3(grid), dim3(WPB * 64), 0, st,  \
+                           camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                           \
+                           reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, norm, reinterpret_cast<double2 *>(r), \
+                           Jc, Jp, block_part, ticket, out_sum);                                                        \
     } while (0)
-    if (!WITH_ERR || norm == 2.0) C2B_GO(NORM_2);
+    if constexpr (!WITH_ERR) { C2B_GO(NORM_2); }
+    else if (norm == 2.0) C2B_GO(NORM_2);
+    else if (norm == 1.0) C2B_GO(NORM_1);
+    else C2B_GO(NORM_ANY);
+#undef C2B_GO
+}
+#endif
+
+// one-shot launch of k_observations<MODE, NK, OPL, WPB, LDSCAM>: one workgroup per WPB * OPL tiles of 64 observations
+template <int MODE, int OPL, int WPB, bool LDSCAM>
+void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                  const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
+                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
+    const int64_t tiles = ((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL);
+#define C2B_GO(NK)                                                                                                      \
+    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, LDSCAM>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,       \
+                       camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                               \
+                       reinterpret_cast<const double2 *>(uv_obs), n, tiles, norm, max_dist,                            \
+                       reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum)
+    if constexpr (MODE != MODE_ERROR) { C2B_GO(NORM_2); }
+    else if (norm == 2.0) C2B_GO(NORM_2);
     else if (norm == 1.0) C2B_GO(NORM_1);
     else C2B_GO(NORM_ANY);
 #undef C2B_GO
 }
 
+// project / error sum / visibility predicate over an observation list.  MODE_ERROR folds the sum into out_sum
+// (device pointer) in the same launch; it needs the workspace for its workgroup partials.
+template <int MODE>
+int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+               const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
+               void *workspace, double *out_sum, hipStream_t st) {
+    double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
+    unsigned *ticket = nullptr;
+    if (MODE == MODE_ERROR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool");
+#define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st
 #ifdef C2B_TUNE
-template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1, bool LDSCAM = false>
+    switch (g_obs_variant) {
+        case 108: launch_obs_v<MODE, 1, 8, false>(C2B_ARGS); return C2B_OK;
+        case 208: launch_obs_v<MODE, 2, 8, false>(C2B_ARGS); return C2B_OK;
+        case 1108: launch_obs_v<MODE, 1, 8, true>(C2B_ARGS); return C2B_OK;
+        case 1216: launch_obs_v<MODE, 2, 16, true>(C2B_ARGS); return C2B_OK;
+        case 1408: launch_obs_v<MODE, 4, 8, true>(C2B_ARGS); return C2B_OK;
+        case 2004: launch_obs_p<MODE, 4>(C2B_ARGS); return C2B_OK;       // persistent pipelined forms (obs_pipeline.hpp)
+        case 2008: launch_obs_p<MODE, 8>(C2B_ARGS); return C2B_OK;
+        case 2016: launch_obs_p<MODE, 16>(C2B_ARGS); return C2B_OK;
+        default: break;
+    }
+#endif
+    launch_obs_v<MODE, 2, 8, true>(C2B_ARGS);                           // shipped
+#undef C2B_ARGS
+    return C2B_OK;
+}
+
+template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL, int OPL, bool LDSCAM>
 void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                         const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
-                         double *partials, hipStream_t st) {
+                  const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
+                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
     const int64_t wave_tiles = (n_obs + 63) / 64;
     const int64_t btiles = (wave_tiles + WPB * OPL - 1) / (WPB * OPL);
-    hipLaunchKernelGGL((k_residual_jacobian_w<WITH_ERR, WPB, SPLIT, NT, ABL, OPL, LDSCAM>), dim3((unsigned)btiles), dim3(WPB * 64), 0, st,
-                       camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,
-                       reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r),
-                       Jc, Jp, partials);
+#define C2B_GO(NK)                                                                                                      \
+    hipLaunchKernelGGL((k_residual_jacobian_w<NK, WITH_ERR, WPB, SPLIT, NT, ABL, OPL, LDSCAM>), dim3((unsigned)btiles), \
+                       dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
+                       reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r), \
+                       Jc, Jp, block_part, ticket, out_sum)
+    if constexpr (!WITH_ERR) { C2B_GO(NORM_2); }
+    else if (norm == 2.0) C2B_GO(NORM_2);
+    else if (norm == 1.0) C2B_GO(NORM_1);
+    else C2B_GO(NORM_ANY);
+#undef C2B_GO
 }
-#endif
 
 // residual + Jacobian; WITH_ERR also folds sum |r|^norm into out_sum (device pointer) in the same launch
 template <bool WITH_ERR>
 int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                     const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
                     double *out_sum, hipStream_t st) {
+    double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
+    unsigned *ticket = nullptr;
+    if (WITH_ERR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool");
+#define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st
 #ifdef C2B_TUNE
-    const int variant = g_jac_variant;
-    if (variant < 100) {
-        double *partials = workspace ? reinterpret_cast<double *>(workspace) + kWsPartials : nullptr;
-        switch (variant) {
-            case 9: launch_jac_w<WITH_ERR, 8, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
-            case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
-            default:
-            case 14: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // round-1 shipped
-            case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;
-            case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no Jacobian stores
-            case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, partials, st); break;   // no arithmetic
-        }
-        if (WITH_ERR && out_sum) { LAUNCH_CHECK(); return launch_sum(workspace, (n_obs + 63) / 64, out_sum, st); }
-        return C2B_OK;
+    switch (g_jac_variant) {
+        case 9: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, false>(C2B_ARGS); return C2B_OK;
+        case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, false>(C2B_ARGS); return C2B_OK;     // FLAT camera reads
+        case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(C2B_ARGS); return C2B_OK;
+        case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2, false>(C2B_ARGS); return C2B_OK;     // no Jacobian stores
+        case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2, false>(C2B_ARGS); return C2B_OK;     // no arithmetic
+        case 100: launch_jac_p<WITH_ERR, 8, 4>(C2B_ARGS); return C2B_OK;     // persistent pipelined forms (obs_pipeline.hpp)
+        case 104: launch_jac_p<WITH_ERR, 4, 1>(C2B_ARGS); return C2B_OK;     // 12 waves per CU at the natural register count
+        case 105: launch_jac_p<WITH_ERR, 4, 4>(C2B_ARGS); return C2B_OK;     // 16 waves per CU (spills)
+        case 108: launch_jac_p<WITH_ERR, 8, 1>(C2B_ARGS); return C2B_OK;     //  8 waves per CU
+        case 116: launch_jac_p<WITH_ERR, 16, 4>(C2B_ARGS); return C2B_OK;    // 16 waves per CU, one workgroup
+        default: break;
     }
-#define C2B_JP(V, W, M) if (variant == V) { launch_jac_p<WITH_ERR, W, M>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, out_sum, st); return C2B_OK; }
-    C2B_JP(104, 4, 1)      // 12 waves per CU at the natural register count
-    C2B_JP(105, 4, 4)      // 16 waves per CU
-    C2B_JP(108, 8, 1)      //  8 waves per CU
-    C2B_JP(116, 16, 4)     // 16 waves per CU, one workgroup
-#undef C2B_JP
 #endif
-    launch_jac_p<WITH_ERR, 8, 4>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, out_sum, st);
+    launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(C2B_ARGS);             // shipped: two tiles per wave, LDS-only camera reads
+#undef C2B_ARGS
     return C2B_OK;
 }
 
@@ -330,12 +331,7 @@ int c2b_device_count(int *count) {
 
 int64_t c2b_workspace_bytes(int64_t n_obs) {
     if (n_obs < 0) n_obs = 0;
-#ifdef C2B_TUNE
-    const int64_t wave_tiles = (n_obs + 63) / 64;       // round-1 kernels: one partial per 64-observation tile
-    return (kWsPartials + wave_tiles + 16) * (int64_t)sizeof(double);
-#else
-    return kWsStage * (int64_t)sizeof(double);          // independent of n_obs (kept as a parameter of the ABI)
-#endif
+    return (kWsBlockPart + block_part_slots(n_obs)) * (int64_t)sizeof(double);
 }
 
 #ifdef C2B_TUNE
@@ -496,9 +492,6 @@ int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32
         return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian: uv/r/Jc/Jp must be 16-byte aligned");
     // with a workspace the fused error sum lands in the workspace's result slot (c2b_error_sum_finish copies it out)
     double *slot = workspace ? reinterpret_cast<double *>(workspace) + kWsFinal : nullptr;
-#ifdef C2B_TUNE
-    if (g_jac_variant < 100) slot = nullptr;        // round-1 kernels: per-tile partials, folded by c2b_error_sum_finish
-#endif
     if (workspace) rc = launch_jacobian<true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, slot, S(stream));
     else rc = launch_jacobian<false>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr, nullptr, S(stream));
     if (rc) return rc;
@@ -537,7 +530,7 @@ int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
     if (bytes < 0 || (bytes && (!src || !dst)) || !aligned16(src) || !aligned16(dst) || (bytes & 15))
         return fail(C2B_ERR_INVALID_ARGUMENT, "calib_copy: NULL, misaligned or not a multiple of 16 bytes");
     if (!bytes) return C2B_OK;
-    hipLaunchKernelGGL(k_copy16, dim3(256 * 32), dim3(256), 0, S(stream), reinterpret_cast<const double2 *>(src),
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)((bytes / 16 + 255) / 256)), dim3(256), 0, S(stream), reinterpret_cast<const double2 *>(src),
                        reinterpret_cast<double2 *>(dst), bytes / 16);
     LAUNCH_CHECK();
     return C2B_OK;
@@ -547,9 +540,6 @@ int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, 
     if (n_obs < 0 || !out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: bad arguments");
     if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
     if (!workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: workspace is NULL");
-#ifdef C2B_TUNE
-    if (g_jac_variant < 100) return launch_sum(const_cast<void *>(workspace), (n_obs + 63) / 64, out_sum, S(stream));
-#endif
     HIP_TRY(hipMemcpyAsync(out_sum, reinterpret_cast<const double *>(workspace) + kWsFinal, sizeof(double),
                            hipMemcpyDeviceToDevice, S(stream)));
     return C2B_OK;

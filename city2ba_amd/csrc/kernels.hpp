@@ -49,6 +49,70 @@ C2B_DEV double wave_max(double v) {
     return v;
 }
 
+// ---- one-launch deterministic sum: workgroup partials + last-arriver fold ---------------------------------------
+// Every wave hands in one value (valid on lane 0).  LDS -> one partial per workgroup, written through to memory
+// (agent-scope store, drained) -> fetch_add on the launch's ticket words -> the workgroup that arrives last
+// reads all gridDim.x partials (plain loads behind ONE agent-scope acquire) and sums them in a fixed order:
+// thread t takes partials t, t + blockDim, ...; wave shuffle tree; waves in order.  Same grid => the same bits,
+// run to run; no float atomics; no second launch.  The ticket word comes from a zero-initialised pool owned by
+// the library (capi.hip: ticket_slot) and is reset by the last arriver, so caller memory needs no initialisation
+// and a replayed launch (hipGraph) starts clean.  Deliberately NO release fence per workgroup: its L2 write-back
+// costs microseconds and serialises chip-wide (measured +2 ms over 768 workgroups); a CAS loop on the ticket
+// serialises the same way -- one fetch_add does not.
+// sRed: >= blockDim.x/64 + 1 doubles of LDS.  Every thread of every workgroup must call this.
+constexpr unsigned kTicketLine = 32;                 // words per 128-B line
+constexpr unsigned kTicketWords = 65 * kTicketLine;  // one launch's ticket: top word + 64 leaf words, a line each
+C2B_DEV void ticket_fold(double wave_value, double *sRed, double *__restrict__ block_part,
+                         unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    __syncthreads();                                   // sRed may alias LDS other waves were still using
+    if (lane == 0) sRed[wave] = wave_value;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = 0.0;
+        for (int w = 0; w < n_waves; ++w) b += sRed[w];
+        __hip_atomic_store(block_part + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);                 // (a builtin, not inline asm: asm would halve the VGPR budget)
+        // Two-level arrival count: workgroup b arrives at leaf word b % 64 (each leaf in its own 128-B line), the
+        // workgroup that completes a leaf arrives at the top word.  18 849 workgroups adding to ONE word cost the
+        // light kernels +115 us (one same-address atomic per ~13 ns); 64 leaves spread them over 64 lines.
+        const unsigned leaf = blockIdx.x & 63u, leaf_n = (gridDim.x - leaf + 63u) >> 6;
+        unsigned *lw = ticket + kTicketLine * (1u + leaf);
+        bool last = false;
+        if (__hip_atomic_fetch_add(lw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaf_n - 1) {
+            __hip_atomic_store(lw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned top_n = gridDim.x < 64u ? gridDim.x : 64u;
+            if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == top_n - 1) {
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = true;
+            }
+        }
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        sRed[n_waves] = last ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (sRed[n_waves] == 0.0) return;                  // workgroup-uniform
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // four independent chains keep the loads in flight
+    const unsigned n = gridDim.x, step = blockDim.x;
+    unsigned k = threadIdx.x;
+    for (; k + 3 * step < n; k += 4 * step) {
+        a0 += block_part[k]; a1 += block_part[k + step]; a2 += block_part[k + 2 * step]; a3 += block_part[k + 3 * step];
+    }
+    for (; k < n; k += step) a0 += block_part[k];
+    const double w = wave_sum((a0 + a1) + (a2 + a3));
+    __syncthreads();
+    if (lane == 0) sRed[wave] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < n_waves; ++i) t += sRed[i];
+        out_sum[0] = t;
+    }
+}
+
 // ---- per-camera kernels ---------------------------------------------------------------------
 __global__ void k_cameras_from_bal(const double *__restrict__ bal9, int64_t n, double *__restrict__ cam15) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,17 +237,21 @@ constexpr int kCamLight = 16;
 
 constexpr int kObsOPL = 2;                     // observations per lane (both tiles' loads issued up front)
 
-template <int MODE, int OPL = kObsOPL, int WPB = kObsWPB, bool LDSCAM = true>
+// NK (camera_math.hpp: NORM_1 / NORM_2 / NORM_ANY) fixes the error norm at compile time; MODE_ERROR folds
+// sum |du|^norm + |dv|^norm over ALL observations into out_sum[0] in this one launch (ticket_fold).
+template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, bool LDSCAM = true>
 __global__ __launch_bounds__(WPB * 64) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm, double max_dist,
-    double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ partials) {
+    double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ block_part,
+    unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
     __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kCamW * kCamLight];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * WPB + wave) * OPL;
     const int64_t base = wt0 * 64;
-    if (base >= n) return;                                               // wave-uniform
+    double eacc = 0.0;
+    if (base < n) {                                                      // wave-uniform; waves past the end only fold
 
     uint32_t ci[OPL], pi[OPL];
     double2 ob[OPL];
@@ -252,14 +320,13 @@ __global__ __launch_bounds__(WPB * 64) void k_observations(
             } else if (MODE == MODE_PROJECT) {
                 uv_out[o] = make_double2(p.u, p.v);
             } else {
-                e = abs_pow(p.u - ob[t].x, norm) + abs_pow(p.v - ob[t].y, norm);
+                e = abs_pow_k<NK>(p.u - ob[t].x, norm) + abs_pow_k<NK>(p.v - ob[t].y, norm);
             }
         }
-        if (MODE == MODE_ERROR) {
-            const double w = wave_sum(e);
-            if (lane == 0) partials[wt0 + t] = w;
-        }
+        if (MODE == MODE_ERROR) eacc += e;
     }
+    }
+    if (MODE == MODE_ERROR) ticket_fold(wave_sum(eacc), sCamAll, block_part, ticket, out_sum);
 }
 
 // ---- residual + Jacobian, wave-centric form -------------------------------------------------------
@@ -331,13 +398,15 @@ C2B_DEV void jacobian_obs(P cam, const double4 X, const double2 ob, double &r0, 
     }
 }
 
-template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1, bool LDSCAM = true>   // ABL: timing-only ablations (tools/)
+// ABL != 0: timing-only ablations, instantiated by the tuning library only (their outputs are wrong by construction).
+// WITH_ERR folds sum |r|^norm over all observations into out_sum[0] in the same launch (ticket_fold).
+template <int NK, bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1, bool LDSCAM = true>
 __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm,
     double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
-    double *__restrict__ partials) {
+    double *__restrict__ block_part, unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
     constexpr int kSlab = 64 * 144 / SPLIT;
     constexpr int kCamBytes = kCamW * kCamHot * 8;
     __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
@@ -345,7 +414,8 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * WPB + wave) * OPL;   // this wave's first 64-observation tile
     const int64_t base = wt0 * 64;
-    if (base >= n) return;                                                     // wave-uniform
+    double eacc = 0.0;
+    if (base < n) {                                                            // wave-uniform; waves past the end only fold
 
     // ---- all loads of all OPL tiles up front: indices + uv, then the dependent point gathers ----
     uint32_t ci[OPL], pi[OPL];
@@ -457,44 +527,10 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
             __builtin_amdgcn_wave_barrier();
         }
 
-        if (WITH_ERR) {
-            const double e = valid[t] ? abs_pow(r0, norm) + abs_pow(r1, norm) : 0.0;
-            const double w = wave_sum(e);
-            if (lane == 0) partials[wt0 + t] = w;
-        }
+        if (WITH_ERR) eacc += valid[t] ? abs_pow_k<NK>(r0, norm) + abs_pow_k<NK>(r1, norm) : 0.0;
     }
-}
-
-// Fixed-order two-stage sum of n partials: stage 1 = up to kSumBlocks workgroups, each summing one
-// contiguous chunk; stage 2 = one workgroup summing the stage-1 results.  Deterministic.
-constexpr int kSumBlocks = 512;
-
-__global__ __launch_bounds__(256) void k_sum_stage1(const double *__restrict__ partials, int64_t n, int64_t chunk,
-                                                   double *__restrict__ out) {
-    __shared__ double sRed[4];
-    const int64_t lo = (int64_t)blockIdx.x * chunk;
-    const int64_t hi = lo + chunk < n ? lo + chunk : n;
-    double acc = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += partials[i];
-    const double w = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
-}
-
-__global__ __launch_bounds__(kSumBlocks) void k_sum_stage2(const double *__restrict__ partials, int n,
-                                                          double *__restrict__ out) {
-    __shared__ double sRed[kSumBlocks / 64];
-    const double v = (int)threadIdx.x < n ? partials[threadIdx.x] : 0.0;
-    const double w = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < kSumBlocks / 64; ++i) t += sRed[i];
-        out[0] = t;
     }
+    if (WITH_ERR) ticket_fold(wave_sum(eacc), reinterpret_cast<double *>(smem), block_part, ticket, out_sum);
 }
 
 // ---- stats over camera centers ++ points ------------------------------------------------------------
@@ -1122,15 +1158,10 @@ __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n
     for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
 }
 
-// 16 bytes per lane streaming copy (the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for), 4 per thread in flight
+// 16 bytes per lane streaming copy, one element per thread (the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for)
 __global__ __launch_bounds__(256) void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n16) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 }  // namespace c2b
 

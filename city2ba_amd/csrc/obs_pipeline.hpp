@@ -20,9 +20,15 @@
 // (occupancy x CUs workgroups); XCD x streams the x-th eighth of the tile list, its waves walk it with a stride of
 // (waves per XCD), so at any time an XCD writes one moving window of the output.
 //
-// Error reduce: every lane accumulates its |r|^norm over its tiles, wave shuffle -> LDS -> one partial per
-// workgroup -> the last workgroup to arrive (epoch-tagged ticket, see ticket_arrive) folds the partials in index
-// order.  Same launch geometry => bitwise the same sum, run to run; no float atomics, no extra launches.
+// Error reduce: every lane accumulates its |r|^norm over its tiles, then ticket_fold (kernels.hpp).
+//
+// MEASURED (round 2, tools/tune_jac.py / tune_obs.py, --blocks 128): this form LOSES to the one-shot kernels of
+// kernels.hpp -- 780 us against 718 us for the Jacobian (no error reduce), 145 us against 127 us for project -- and is
+// therefore compiled into the tuning library only (-DC2B_TUNE).  Why: vmcnt retires in order, so the data of a
+// gather issued after tile i-1's stores is only *visible* once those stores are acknowledged; a one-shot wave never
+// waits for a store acknowledgement at all (it ends), a persistent one does every iteration.  And with one tile of
+// look-ahead per dependent level a wave completes one tile per memory latency, which 12-24 resident waves per CU
+// do not turn into more bytes in flight than 32 short-lived ones.
 #pragma once
 #include "kernels.hpp"
 
@@ -33,7 +39,6 @@ namespace c2b {
 // On the synthetic grid (~29 observations per camera) a tile spans 3-5 cameras; a tile that spans more takes the
 // slower global-read path (still correct).
 constexpr int pipe_cam_w(int hot) { return 64 / (hot / 2); }
-constexpr int kMaxBlockPart = 4096;                                   // workgroup partials the ticket fold can hold
 
 struct PipeSet {
     uint32_t ci, pi;
@@ -42,65 +47,6 @@ struct PipeSet {
     d2_t cs;                           // this lane's 16-byte chunk of the tile's camera rows
     uint32_t c_first, n_staged;        // wave-uniform
 };
-
-// ---- epoch-tagged arrival ticket ---------------------------------------------------------------------------------
-// word = (epoch << 20) | arrivals.  A word whose tag is not this launch's epoch (first use of a workspace, garbage,
-// an older launch) counts as zero arrivals, so the workspace needs no initialisation; the last arriver leaves
-// (epoch << 20) | 0, so a replay of the same launch (hipGraph: frozen arguments) starts clean as well.
-// Returns true on the last of `expected` arrivals.  One lane per workgroup calls this, after its payload is
-// written through (agent-scope atomic store) and drained.
-C2B_DEV bool ticket_arrive(unsigned long long *ticket, unsigned long long epoch, unsigned expected) {
-    const unsigned long long tag = epoch << 20;
-    unsigned long long old = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        const unsigned long long cur = ((old >> 20) == epoch) ? (old & 0xFFFFFull) : 0ull;
-        const bool last = cur + 1 == expected;
-        const unsigned long long neu = tag | (last ? 0ull : cur + 1);
-        if (__hip_atomic_compare_exchange_strong(ticket, &old, neu, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT))
-            return last;
-    }
-}
-
-// Fold one value per wave (valid on lane 0) into out_sum[0]: LDS -> workgroup partial -> ticket -> the last
-// workgroup sums the partials of all gridDim.x workgroups in index order.  sRed: >= blockDim.x/64 + 1 doubles of
-// LDS that no wave still uses.  Every thread of every workgroup must call this.
-// (waits are __builtin_amdgcn_s_waitcnt(0) = vmcnt(0) expcnt(0) lgkmcnt(0), not inline asm: a kernel that contains
-// an asm statement is assumed to need AGPRs and loses half of its VGPR budget.)
-C2B_DEV void ticket_fold(double wave_value, double *sRed, double *__restrict__ block_part,
-                         unsigned long long *__restrict__ ticket, unsigned long long epoch,
-                         double *__restrict__ out_sum) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    __syncthreads();                                   // sRed may alias LDS other waves were still using
-    if (lane == 0) sRed[wave] = wave_value;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double b = 0.0;
-        for (int w = 0; w < n_waves; ++w) b += sRed[w];
-        __hip_atomic_store(block_part + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_s_waitcnt(0);
-        const bool last = ticket_arrive(ticket, epoch, gridDim.x);
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __builtin_amdgcn_s_waitcnt(0);
-        sRed[n_waves] = last ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    if (sRed[n_waves] == 0.0) return;                  // workgroup-uniform
-    double acc = 0.0;
-    for (unsigned k = threadIdx.x; k < gridDim.x; k += blockDim.x)
-        acc += __hip_atomic_load(block_part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double w = wave_sum(acc);
-    __syncthreads();
-    if (lane == 0) sRed[wave] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < n_waves; ++k) t += sRed[k];
-        out_sum[0] = t;
-    }
-}
 
 // ---- pipeline stages ----------------------------------------------------------------------------------------------
 template <bool WITH_UV>
@@ -275,7 +221,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_p(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4, const uint32_t *__restrict__ cam_idx,
     const uint32_t *__restrict__ pt_idx, const double2 *__restrict__ uv_obs, int n, double norm,
     double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp, double *__restrict__ block_part,
-    unsigned long long *__restrict__ ticket, unsigned long long epoch, double *__restrict__ out_sum) {
+    unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
     constexpr int kSlab = 64 * 144;                       // the whole tile's 2x9 blocks
     constexpr int kCamBytes = 64 * 16;                    // one 16-byte chunk per lane
     __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
@@ -336,7 +282,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_p(
 
     if (WITH_ERR) {
         const double w = wave_sum(eacc);
-        ticket_fold(w, reinterpret_cast<double *>(smem), block_part, ticket, epoch, out_sum);
+        ticket_fold(w, reinterpret_cast<double *>(smem), block_part, ticket, out_sum);
     }
 }
 
@@ -398,7 +344,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observations_p(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4, const uint32_t *__restrict__ cam_idx,
     const uint32_t *__restrict__ pt_idx, const double2 *__restrict__ uv_obs, int n, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ block_part,
-    unsigned long long *__restrict__ ticket, unsigned long long epoch, double *__restrict__ out_sum) {
+    unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
     constexpr int HOT = MODE == MODE_VISIBILITY ? kCamBlk : kCamLight;
     constexpr bool UV = MODE == MODE_ERROR;
     __shared__ __attribute__((aligned(16))) double sCamAll[WPB * 128];   // 64 x 16-byte chunks per wave
@@ -455,7 +401,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observations_p(
 
     if (MODE == MODE_ERROR) {
         const double w = wave_sum(eacc);
-        ticket_fold(w, sCamAll, block_part, ticket, epoch, out_sum);
+        ticket_fold(w, sCamAll, block_part, ticket, out_sum);
     }
 }
 

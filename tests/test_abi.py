@@ -89,9 +89,8 @@ def test_product_never_imports_oracle():
 def test_workspace_and_partition_host_helpers(c2b):
     L = c2b.lib()
     assert L.c2b_workspace_bytes(0) > 0
-    # the in-kernel ticket fold needs one partial per workgroup of a persistent grid, not one per tile
-    assert L.c2b_workspace_bytes(10_000_000) >= 4096 * 8
-    assert L.c2b_workspace_bytes(10_000_000) == L.c2b_workspace_bytes(0)
+    # the in-kernel ticket fold needs one partial per workgroup (>= 4 tiles of 64 observations each)
+    assert L.c2b_workspace_bytes(10_000_000) >= 10_000_000 // 256 * 8
     counts = np.array([5, 0, 0, 7, 1, 1, 30, 2, 2, 0, 12], dtype=np.uint64)
     row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
     for parts in (1, 2, 3, 4, 8, 16):

@@ -23,6 +23,7 @@ ap.add_argument("--blocks", type=int, default=128)
 ap.add_argument("--variants", default="14,100,104,105,108,116,-1,-2")   # -1 = store pattern only, -2 = 16-B copy of the same bytes
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--no-err", action="store_true", help="launch without the fused error reduce")
 a = ap.parse_args()
 variants = [int(v) for v in a.variants.split(",")]
 
@@ -47,7 +48,7 @@ def run(v, r, Jc, Jp):
     if v == -2:
         return D.calib_copy(copy_src, copy_dst)
     raw.c2b_tune_set_jacobian_variant(v)
-    D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws)
+    D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, None if a.no_err else ws)
 
 
 bufs = [torch.empty((n, 2), dtype=torch.float64, device=dev), torch.empty((n, 18), dtype=torch.float64, device=dev),
