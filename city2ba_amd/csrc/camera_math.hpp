@@ -211,9 +211,26 @@ struct Proj {
     double u, v;           // pixel             (project, src/baproblem.rs:145-151)
 };
 
-// cam points at a camblk-shaped record (LDS or global).  |p|^4 is evaluated as n*n; the
-// reference writes magnitude().powf(4.0) (= pow(sqrt(n),4)), a <= 2.5 ulp different rounding
-// of the same value (libm pow is not reproducible across platforms anyway).
+// x^4 correctly rounded: x^2 = h + l exactly (one FMA), h^2 = hh + hl exactly, x^4 = hh + (hl + 2 h l + l^2) with
+// the bracket accurate to ~2^-104 of the result, one final rounding.  Overflow / NaN / underflow-to-zero keep the
+// class pow() would return.
+C2B_DEV double pow4_cr(double x) {
+    const double h = x * x;
+    const double hh = h * h;
+    if (!(hh < __longlong_as_double(0x7ff0000000000000LL)) || hh == 0.0) return hh;
+    const double l = fma(x, x, -h);
+    const double hl = fma(h, h, -hh);
+    double t = fma(2.0 * h, l, hl);
+    t = fma(l, l, t);
+    return hh + t;
+}
+
+// cam points at a camblk-shaped record (LDS or global).  The reference writes |p|^4 as p.magnitude().powf(4.0)
+// (src/baproblem.rs:147-149) = libm pow(sqrt(n), 4): here the CORRECTLY ROUNDED value of fl(sqrt(n))^4, which is what
+// glibc's pow returns in 99.9 % of cases (it is accurate to 0.52 ulp, not correctly rounded; the rest differ by
+// one ulp and cannot be reproduced without being glibc -- oracle/city2ba_oracle.c, tests/test_pow4.py).  With
+// k2 = 0 the term is k2 * n^4 = 0 whatever the rounding of n^4, so that (wave-uniform on the generators' cameras)
+// case skips the square root.
 // P is a pointer to double in any address space: a generic pointer, or one typed LDS-only / global-only (lds_cptr /
 // glb_cptr) so that the loads compile to ds_read / global_load and two call sites can never be merged into FLAT loads.
 typedef const __attribute__((address_space(3))) double *lds_cptr;
@@ -228,7 +245,10 @@ C2B_DEV Proj project_obs(P cam, double X, double Y, double Z) {
     p.px = -p.qx / p.qz;
     p.py = -p.qy / p.qz;
     p.n = p.px * p.px + p.py * p.py;
-    p.rad = 1.0 + cam[13] * p.n + cam[14] * (p.n * p.n);
+    const double k2 = cam[14];
+    double n4 = p.n * p.n;
+    if (k2 != 0.0) n4 = pow4_cr(sqrt(p.n));
+    p.rad = 1.0 + cam[13] * p.n + k2 * n4;
     const double fr = cam[12] * p.rad;
     p.u = fr * p.px;
     p.v = fr * p.py;

@@ -235,11 +235,44 @@ void orc_project_world(const double cam[15], const double p[3], double q[3]) {
     q[0] = rp[0] + cam[9]; q[1] = rp[1] + cam[10]; q[2] = rp[2] + cam[11];
 }
 
+/* p.magnitude().powf(4.0), :149.  Rust's f64::powf is the platform libm's pow (glibc here, as on the machine the
+ * reference would run on).  glibc's pow is accurate to ~0.52 ulp, NOT correctly rounded: on this image
+ * pow(sqrt(n), 4.0) differs from the correctly rounded value of fl(sqrt(n))^4 in 0.085 % of draws (always by one ulp;
+ * tests/test_pow4.py measures it).  No implementation other than glibc itself reproduces those draws, so the device
+ * evaluates the CORRECTLY ROUNDED value and the oracle offers both: mode 0 = libm pow (the reference restated; default),
+ * mode 1 = correctly rounded (what the device is compared with bit for bit). */
+static int g_pow4_mode = 0;
+void orc_set_pow4_mode(int mode) { g_pow4_mode = mode; }
+int orc_get_pow4_mode(void) { return g_pow4_mode; }
+
+/* x^4 correctly rounded for finite x of ordinary magnitude: x^2 = h + l exactly (one FMA), h^2 = hh + hl exactly,
+ * x^4 = hh + (hl + 2 h l + l^2) with the bracket accurate to ~2^-104 of the result, one final rounding. */
+double orc_pow4_cr(double x) {
+    const double h = x * x;
+    const double hh = h * h;
+    if (!(hh < INFINITY) || hh == 0.0) return hh;  /* overflow, NaN, or underflow to zero: same class as pow() */
+    const double l = fma(x, x, -h);
+    const double hl = fma(h, h, -hh);
+    double t = fma(2.0 * h, l, hl);
+    t = fma(l, l, t);
+    return hh + t;
+}
+
+/* both evaluations of x[i]^4 for an array (tests measure how often libm's pow is not correctly rounded) */
+void orc_pow4_both(const double *x, int64_t n, double *out_libm, double *out_cr) {
+    for (int64_t i = 0; i < n; ++i) { out_libm[i] = pow(x[i], 4.0); out_cr[i] = orc_pow4_cr(x[i]); }
+}
+
+static double magnitude_pow4(double mag2) {
+    const double x = sqrt(mag2);
+    return g_pow4_mode ? orc_pow4_cr(x) : pow(x, 4.0);
+}
+
 /* project, :145-151 */
 void orc_project(const double cam[15], const double q[3], double uv[2]) {
     double px = -q[0] / q[2], py = -q[1] / q[2];
     double mag2 = px * px + py * py;               /* Vector2::magnitude2 */
-    double r = 1.0 + cam[13] * mag2 + cam[14] * pow(sqrt(mag2), 4.0);
+    double r = 1.0 + cam[13] * mag2 + cam[14] * magnitude_pow4(mag2);
     double fr = cam[12] * r;                       /* focal_length() * r */
     uv[0] = fr * px; uv[1] = fr * py;
 }
