@@ -228,7 +228,7 @@ C2B_DEV double pow4_cr(double x) {
 // cam points at a camblk-shaped record (LDS or global).  The reference writes |p|^4 as p.magnitude().powf(4.0)
 // (src/baproblem.rs:147-149) = libm pow(sqrt(n), 4): here the CORRECTLY ROUNDED value of fl(sqrt(n))^4, which is what
 // glibc's pow returns in 99.9 % of cases (it is accurate to 0.52 ulp, not correctly rounded; the rest differ by
-// one ulp and cannot be reproduced without being glibc -- oracle/city2ba_oracle.c, tests/test_pow4.py).  With
+// one ulp and cannot be reproduced without being glibc -- measured in tests/test_pow4.py).  With
 // k2 = 0 the term is k2 * n^4 = 0 whatever the rounding of n^4, so that (wave-uniform on the generators' cameras)
 // case skips the square root.
 // P is a pointer to double in any address space: a generic pointer, or one typed LDS-only / global-only (lds_cptr /
