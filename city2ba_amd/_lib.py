@@ -57,7 +57,7 @@ SIGNATURES = {
     "c2b_bvh_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
     "c2b_bvh_copy": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_bvh_free": (None, [_vp]),
-    "c2b_occlusion_filter_bvh": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "c2b_occlusion_filter_bvh": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
     "c2b_add_drift_normalized": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),

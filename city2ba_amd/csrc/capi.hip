@@ -48,13 +48,44 @@ int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                           \
     } while (0)
 
-#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+// A launch is checked by what it ADDS to the thread's error state: S() notes the error (if any) that was already
+// pending before the launch -- left there by torch, RCCL or anyone else sharing the HIP runtime -- and LAUNCH_CHECK
+// reports only an error that differs from it, consuming that one alone.  A pending foreign error is neither cleared
+// nor blamed on this library.
+thread_local hipError_t g_pending = hipSuccess;
+#define LAUNCH_CHECK()                                                                                    \
+    do {                                                                                                  \
+        const hipError_t e_ = hipPeekAtLastError();                                                       \
+        if (e_ != hipSuccess && e_ != g_pending) {                                                        \
+            (void)hipGetLastError();                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "kernel launch: %s (%s:%d)",   \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                       \
+        }                                                                                                 \
+    } while (0)
 
-// Every launch passes its stream through S(): clearing the thread's sticky error there means the
-// hipGetLastError() after the launch reports THIS launch, not a stale error left by another library.
+// No C++ exception may cross the extern "C" boundary (std::vector / std::string allocate in the host-side rows): every
+// int-returning entry point runs inside this pair and maps what it catches to a status code.
+#define C2B_API_BEGIN try {
+#define C2B_API_END(who)                                                                                  \
+    } catch (const std::bad_alloc &) {                                                                    \
+        return fail(C2B_ERR_OOM, who ": out of host memory");                                             \
+    } catch (const std::exception &e_) {                                                                  \
+        return fail(C2B_ERR_INVALID_ARGUMENT, who ": %s", e_.what());                                     \
+    } catch (...) {                                                                                       \
+        return fail(C2B_ERR_INVALID_ARGUMENT, who ": unknown C++ exception");                             \
+    }
+
+// Every launch passes its stream through S() (see LAUNCH_CHECK).
 inline hipStream_t S(void *s) {
-    (void)hipGetLastError();
+    g_pending = hipPeekAtLastError();
     return reinterpret_cast<hipStream_t>(s);
+}
+// the same rule for code that launches several kernels and checks once: the error those launches added, if any
+inline hipError_t launch_error() {
+    const hipError_t e = hipPeekAtLastError();
+    if (e == hipSuccess || e == g_pending) return hipSuccess;
+    (void)hipGetLastError();
+    return e;
 }
 inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)((n + b - 1) / b); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -321,12 +352,14 @@ const char *c2b_version(void) { return "city2ba_hip 0.1.0 (gfx950)"; }
 const char *c2b_last_error(void) { return g_err; }
 
 int c2b_device_count(int *count) {
+    C2B_API_BEGIN
     if (!count) return fail(C2B_ERR_INVALID_ARGUMENT, "count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *count = 0; return fail(C2B_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *count = n;
     return C2B_OK;
+    C2B_API_END("device_count")
 }
 
 int64_t c2b_workspace_bytes(int64_t n_obs) {
@@ -343,41 +376,50 @@ int c2b_tune_set_observation_variant(int v) { g_obs_variant = v; return C2B_OK; 
 /* ------------------------------- level 0 --------------------------------------------- */
 
 int c2b_cameras_from_bal(const double *bal9, int64_t n, double *cam15, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!bal9 || !cam15))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_from_bal: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_cameras_from_bal, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), bal9, n, cam15);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("cameras_from_bal")
 }
 
 int c2b_cameras_to_bal(const double *cam15, int64_t n, double *bal9, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!bal9 || !cam15))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_to_bal: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_cameras_to_bal, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n, bal9);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("cameras_to_bal")
 }
 
 int c2b_cameras_prepare_state(const double *cam15, int64_t n, double *camblk, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!cam15 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_state: bad arguments");
     if (!n) return C2B_OK;
     if (!aligned16(camblk)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk must be 16-byte aligned");
     hipLaunchKernelGGL(k_cameras_prepare<false>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n, camblk);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("cameras_prepare_state")
 }
 
 int c2b_cameras_prepare_bal(const double *bal9, int64_t n, double *camblk, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!bal9 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_bal: bad arguments");
     if (!n) return C2B_OK;
     if (!aligned16(camblk)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk must be 16-byte aligned");
     hipLaunchKernelGGL(k_cameras_prepare<true>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), bal9, n, camblk);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("cameras_prepare_bal")
 }
 
 int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, int64_t n, double *cam15,
                                         void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!pos3 || !dir9 || !cam15)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_from_position_direction: bad arguments");
     if (!n) return C2B_OK;
@@ -385,34 +427,42 @@ int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, 
                        n, cam15);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("cameras_from_position_direction")
 }
 
 int c2b_project_world(const double *cam15, const uint32_t *cam_idx, const double *p3, int64_t n, double *out3,
                       void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!cam15 || !cam_idx || !p3 || !out3))) return fail(C2B_ERR_INVALID_ARGUMENT, "project_world: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_camera_point_map<false>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, cam_idx, p3, n, out3);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("project_world")
 }
 
 int c2b_to_world(const double *cam15, const uint32_t *cam_idx, const double *p3, int64_t n, double *out3, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!cam15 || !cam_idx || !p3 || !out3))) return fail(C2B_ERR_INVALID_ARGUMENT, "to_world: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_camera_point_map<true>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, cam_idx, p3, n, out3);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("to_world")
 }
 
 int c2b_cameras_transform(double *cam15, const double *delta_dir9, const double *delta_loc3, int64_t n, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!cam15 || !delta_dir9 || !delta_loc3))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_transform: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_cameras_transform, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, delta_dir9, delta_loc3, n);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("cameras_transform")
 }
 
 int c2b_points_pad(const double *pts3, int64_t n, double *pts4, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!pts3 || !pts4))) return fail(C2B_ERR_INVALID_ARGUMENT, "points_pad: bad arguments");
     if (!n) return C2B_OK;
     if (!aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "pts4 must be 16-byte aligned");
@@ -420,19 +470,23 @@ int c2b_points_pad(const double *pts3, int64_t n, double *pts4, void *stream) {
                        reinterpret_cast<double4 *>(pts4));
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("points_pad")
 }
 
 int c2b_points_unpad(const double *pts4, int64_t n, double *pts3, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!pts3 || !pts4))) return fail(C2B_ERR_INVALID_ARGUMENT, "points_unpad: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_points_unpad, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream),
                        reinterpret_cast<const double4 *>(pts4), n, pts3);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("points_unpad")
 }
 
 int c2b_expand_rows(const uint64_t *row_ptr, int64_t n_cam, int64_t obs_base, int64_t n_obs,
                     uint32_t *cam_idx, void *stream) {
+    C2B_API_BEGIN
     if (n_cam < 0 || n_obs < 0 || obs_base < 0 || (n_obs && (!row_ptr || !cam_idx)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "expand_rows: bad arguments");
     if (n_cam >= (int64_t)1 << 32) return fail(C2B_ERR_INVALID_ARGUMENT, "expand_rows: n_cam exceeds u32");
@@ -441,6 +495,7 @@ int c2b_expand_rows(const uint64_t *row_ptr, int64_t n_cam, int64_t obs_base, in
                        obs_base, n_obs, cam_idx);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("expand_rows")
 }
 
 static int check_obs_args(const char *who, const void *camblk, const void *pts4, const void *cam_idx,
@@ -456,6 +511,7 @@ static int check_obs_args(const char *who, const void *camblk, const void *pts4,
 
 int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                 int64_t n_obs, double *uv_out, void *stream) {
+    C2B_API_BEGIN
     int rc = check_obs_args("project", camblk, pts4, cam_idx, pt_idx, n_obs);
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
@@ -464,11 +520,13 @@ int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_id
     if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("project")
 }
 
 int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                                const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double norm,
                                void *workspace, double *out_sum, void *stream) {
+    C2B_API_BEGIN
     int rc = check_obs_args("reprojection_error_sum", camblk, pts4, cam_idx, pt_idx, n_obs);
     if (rc) return rc;
     if (!out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum: out_sum is NULL");
@@ -479,11 +537,13 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
     if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("reprojection_error_sum")
 }
 
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                           const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
                           double *Jp, double norm, void *workspace, void *stream) {
+    C2B_API_BEGIN
     int rc = check_obs_args("residual_jacobian", camblk, pts4, cam_idx, pt_idx, n_obs);
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
@@ -497,11 +557,13 @@ int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32
     if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("residual_jacobian")
 }
 
 int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                               const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
                               double *Jp, double norm, void *workspace, double *out_sum, void *stream) {
+    C2B_API_BEGIN
     int rc = check_obs_args("residual_jacobian_sum", camblk, pts4, cam_idx, pt_idx, n_obs);
     if (rc) return rc;
     if (!out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_sum: out_sum is NULL");
@@ -513,9 +575,11 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
     if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("residual_jacobian_sum")
 }
 
 int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, void *stream) {
+    C2B_API_BEGIN
     if (n_obs < 0 || (n_obs && (!r || !Jc || !Jp)) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
         return fail(C2B_ERR_INVALID_ARGUMENT, "calib_store_pattern: bad arguments");
     if (n_obs < 64) return C2B_OK;
@@ -524,9 +588,11 @@ int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, vo
                        reinterpret_cast<double2 *>(r), Jc, Jp);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("calib_store_pattern")
 }
 
 int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
+    C2B_API_BEGIN
     if (bytes < 0 || (bytes && (!src || !dst)) || !aligned16(src) || !aligned16(dst) || (bytes & 15))
         return fail(C2B_ERR_INVALID_ARGUMENT, "calib_copy: NULL, misaligned or not a multiple of 16 bytes");
     if (!bytes) return C2B_OK;
@@ -534,20 +600,24 @@ int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
                        reinterpret_cast<double2 *>(dst), bytes / 16);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("calib_copy")
 }
 
 int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, void *stream) {
+    C2B_API_BEGIN
     if (n_obs < 0 || !out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: bad arguments");
     if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
     if (!workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "error_sum_finish: workspace is NULL");
     HIP_TRY(hipMemcpyAsync(out_sum, reinterpret_cast<const double *>(workspace) + kWsFinal, sizeof(double),
                            hipMemcpyDeviceToDevice, S(stream)));
     return C2B_OK;
+    C2B_API_END("error_sum_finish")
 }
 
 int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                          const uint32_t *pt_idx, int64_t n_pairs, double max_dist, double *uv_out,
                          uint8_t *keep, void *stream) {
+    C2B_API_BEGIN
     int rc = check_obs_args("visibility_pairs", camblk, pts4, cam_idx, pt_idx, n_pairs);
     if (rc) return rc;
     if (!n_pairs) return C2B_OK;
@@ -556,10 +626,12 @@ int c2b_visibility_pairs(const double *camblk, const double *pts4, const uint32_
     if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("visibility_pairs")
 }
 
 int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                          int64_t n_obs, const float *tri9, int64_t n_tri, uint8_t *keep, void *stream) {
+    C2B_API_BEGIN
     int rc = check_obs_args("occlusion_filter", camblk, pts4, cam_idx, pt_idx, n_obs);
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
@@ -568,6 +640,7 @@ int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, n_obs, tri9, n_tri, keep);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("occlusion_filter")
 }
 
 struct c2b_bvh {
@@ -575,6 +648,7 @@ struct c2b_bvh {
 };
 
 int c2b_bvh_build(const float *tri9, int64_t n_tri, c2b_bvh **out) {
+    C2B_API_BEGIN
     if (!out || n_tri < 0 || (n_tri && !tri9)) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_build: bad arguments");
     *out = nullptr;
     if (n_tri >= ((int64_t)1 << 28)) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_build: more than 2^28 triangles");
@@ -595,115 +669,143 @@ int c2b_bvh_build(const float *tri9, int64_t n_tri, c2b_bvh **out) {
     }
     *out = h;
     return C2B_OK;
+    C2B_API_END("bvh_build")
 }
 
 int c2b_bvh_sizes(const c2b_bvh *b, int64_t *n_nodes, int64_t *n_slots, int *depth) {
+    C2B_API_BEGIN
     if (!b) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_sizes: bvh is NULL");
     if (n_nodes) *n_nodes = (int64_t)b->b.nodes.size();
     if (n_slots) *n_slots = (int64_t)b->b.order.size();
     if (depth) *depth = b->b.depth;
     return C2B_OK;
+    C2B_API_END("bvh_sizes")
 }
 
 int c2b_bvh_copy(const c2b_bvh *b, void *nodes, void *tris, uint32_t *order) {
+    C2B_API_BEGIN
     if (!b) return fail(C2B_ERR_INVALID_ARGUMENT, "bvh_copy: bvh is NULL");
     if (nodes) std::memcpy(nodes, b->b.nodes.data(), b->b.nodes.size() * sizeof(c2b_host::BvhNode));
     if (tris && !b->b.tris.empty()) std::memcpy(tris, b->b.tris.data(), b->b.tris.size() * sizeof(float));
     if (order && !b->b.order.empty()) std::memcpy(order, b->b.order.data(), b->b.order.size() * sizeof(uint32_t));
     return C2B_OK;
+    C2B_API_END("bvh_copy")
 }
 
 void c2b_bvh_free(c2b_bvh *b) { delete b; }
 
 int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                              int64_t n_obs, const void *nodes, int64_t n_nodes, const void *tris, int64_t n_slots,
-                             uint8_t *keep, void *stream) {
+                             uint8_t *keep, uint32_t *overflow, void *stream) {
+    C2B_API_BEGIN
     int rc = check_obs_args("occlusion_filter_bvh", camblk, pts4, cam_idx, pt_idx, n_obs);
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
-    if (!keep || !nodes || n_nodes < 1 || n_slots < 0 || (n_slots && !tris) || !aligned16(nodes) || (tris && !aligned16(tris)))
+    if (!keep || !overflow || !nodes || n_nodes < 1 || n_slots < 0 || (n_slots && !tris) || !aligned16(nodes) || (tris && !aligned16(tris)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "occlusion_filter_bvh: NULL/misaligned buffer");
     hipLaunchKernelGGL(k_occlusion_bvh, dim3(blocks_for(n_obs)), dim3(kBlock), 0, S(stream), camblk,
                        reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx, n_obs, reinterpret_cast<const float4 *>(nodes),
-                       reinterpret_cast<const float4 *>(tris), keep);
+                       reinterpret_cast<const float4 *>(tris), keep, overflow);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("occlusion_filter_bvh")
 }
 
 int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, void *workspace,
               double *stats, void *stream) {
+    C2B_API_BEGIN
     if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: bad arguments");
     if (n_cam + n_pts == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: empty problem (the reference's fold1().unwrap() panics)");
     if ((n_cam && !camblk) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: NULL input");
     const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
     return stats_impl(src, n_cam + n_pts, workspace, stats, S(stream));
+    C2B_API_END("stats")
 }
 
 int c2b_stats_f32(const float *cam15, int64_t n_cam, const float *pts4, int64_t n_pts, void *workspace,
                   double *stats, void *stream) {
+    C2B_API_BEGIN
     if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_f32: bad arguments");
     if (n_cam + n_pts == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_f32: empty problem");
     if ((n_cam && !cam15) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_f32: NULL input");
     const SrcState32 src{cam15, reinterpret_cast<const float4 *>(pts4), n_cam};
     return stats_impl(src, n_cam + n_pts, workspace, stats, S(stream));
+    C2B_API_END("stats_f32")
 }
 
 int c2b_convert_f64_to_f32(const double *src, int64_t n, float *dst, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!src || !dst))) return fail(C2B_ERR_INVALID_ARGUMENT, "convert_f64_to_f32: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), src, n, dst);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("convert_f64_to_f32")
 }
 
 int c2b_convert_f32_to_f64(const float *src, int64_t n, double *dst, void *stream) {
+    C2B_API_BEGIN
     if (n < 0 || (n && (!src || !dst))) return fail(C2B_ERR_INVALID_ARGUMENT, "convert_f32_to_f64: bad arguments");
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), src, n, dst);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("convert_f32_to_f64")
 }
 
 int c2b_add_drift(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *origin,
                   double strength, double angle_strength, double std, double dir_x, double dir_y, double dir_z,
                   uint64_t seed, void *stream) {
+    C2B_API_BEGIN
     return drift_impl<double>("add_drift", cam15, n_cam, pts4, n_pts, origin, nullptr, strength, angle_strength, std,
                               dir_x, dir_y, dir_z, seed, S(stream));
+    C2B_API_END("add_drift")
 }
 int c2b_add_drift_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *origin,
                       double strength, double angle_strength, double std, double dir_x, double dir_y, double dir_z,
                       uint64_t seed, void *stream) {
+    C2B_API_BEGIN
     return drift_impl<float>("add_drift_f32", cam15, n_cam, pts4, n_pts, origin, nullptr, strength, angle_strength, std,
                              dir_x, dir_y, dir_z, seed, S(stream));
+    C2B_API_END("add_drift_f32")
 }
 int c2b_add_drift_normalized(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats,
                              double strength, double angle_strength, double std, uint64_t seed, void *stream) {
+    C2B_API_BEGIN
     if (!stats) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized: stats is NULL");
     return drift_impl<double>("add_drift_normalized", cam15, n_cam, pts4, n_pts, stats + 15, stats, strength,
                               angle_strength, std, 0.0, 0.0, 0.0, seed, S(stream));
+    C2B_API_END("add_drift_normalized")
 }
 int c2b_add_drift_normalized_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats,
                                  double strength, double angle_strength, double std, uint64_t seed, void *stream) {
+    C2B_API_BEGIN
     if (!stats) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_normalized_f32: stats is NULL");
     return drift_impl<float>("add_drift_normalized_f32", cam15, n_cam, pts4, n_pts, stats + 15, stats, strength,
                              angle_strength, std, 0.0, 0.0, 0.0, seed, S(stream));
+    C2B_API_END("add_drift_normalized_f32")
 }
 
 int c2b_add_noise_entities(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats,
                            double translation_std, double rotation_std, double point_std, uint64_t seed,
                            void *stream) {
+    C2B_API_BEGIN
     return noise_entities_impl<double>("add_noise_entities", cam15, n_cam, pts4, n_pts, stats, translation_std,
                                        rotation_std, point_std, seed, S(stream));
+    C2B_API_END("add_noise_entities")
 }
 int c2b_add_noise_entities_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats,
                                double translation_std, double rotation_std, double point_std, uint64_t seed,
                                void *stream) {
+    C2B_API_BEGIN
     return noise_entities_impl<float>("add_noise_entities_f32", cam15, n_cam, pts4, n_pts, stats, translation_std,
                                       rotation_std, point_std, seed, S(stream));
+    C2B_API_END("add_noise_entities_f32")
 }
 
 int c2b_add_noise_observations(double *uv, int64_t n_obs, int64_t obs_base, double observations_std, uint64_t seed,
                                void *stream) {
+    C2B_API_BEGIN
     if (n_obs < 0 || obs_base < 0 || (n_obs && !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_observations: bad arguments");
     if (!(observations_std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise: standard deviations must be >= 0");
     if (!n_obs) return C2B_OK;
@@ -712,22 +814,28 @@ int c2b_add_noise_observations(double *uv, int64_t n_obs, int64_t obs_base, doub
                        reinterpret_cast<double2 *>(uv), n_obs, obs_base, observations_std, seed);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("add_noise_observations")
 }
 
 int c2b_add_sin_noise(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts, const double *stats, double dir_x,
                       double dir_y, double dir_z, double ndir_x, double ndir_y, double ndir_z, double strength,
                       double frequency, void *stream) {
+    C2B_API_BEGIN
     return sin_impl<double>("add_sin_noise", cam15, n_cam, pts4, n_pts, stats, dir_x, dir_y, dir_z, ndir_x, ndir_y, ndir_z,
                             strength, frequency, S(stream));
+    C2B_API_END("add_sin_noise")
 }
 int c2b_add_sin_noise_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats, double dir_x,
                           double dir_y, double dir_z, double ndir_x, double ndir_y, double ndir_z, double strength,
                           double frequency, void *stream) {
+    C2B_API_BEGIN
     return sin_impl<float>("add_sin_noise_f32", cam15, n_cam, pts4, n_pts, stats, dir_x, dir_y, dir_z, ndir_x, ndir_y,
                            ndir_z, strength, frequency, S(stream));
+    C2B_API_END("add_sin_noise_f32")
 }
 
 int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, int64_t *bounds) {
+    C2B_API_BEGIN
     if (!row_ptr || !bounds || n_cam < 0 || n_parts < 1) return fail(C2B_ERR_INVALID_ARGUMENT, "partition_cameras: bad arguments");
     const uint64_t total = row_ptr[n_cam];
     bounds[0] = 0;
@@ -745,6 +853,7 @@ int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, i
     }
     bounds[n_parts] = n_cam;
     return C2B_OK;
+    C2B_API_END("partition_cameras")
 }
 
 int64_t c2b_visibility_dense_tiles(int64_t n_pts) { return n_pts <= 0 ? 0 : (n_pts + kDenseTile - 1) / kDenseTile; }
@@ -773,6 +882,7 @@ static int dense_check(const char *who, const void *camblk, int64_t n_cam, const
 
 int c2b_visibility_dense_count(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, double max_dist,
                                uint32_t *tile_counts, uint64_t *cam_total, uint64_t *row_ptr, void *stream) {
+    C2B_API_BEGIN
     int rc = dense_check("visibility_dense_count", camblk, n_cam, pts4, n_pts);
     if (rc) return rc;
     if (!row_ptr) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_dense_count: row_ptr is NULL");
@@ -796,11 +906,13 @@ int c2b_visibility_dense_count(const double *camblk, int64_t n_cam, const double
     hipLaunchKernelGGL(k_dense_cam_scan, dim3(1), dim3(256), 0, S(stream), (const uint64_t *)cam_total, n_cam, row_ptr);
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("visibility_dense_count")
 }
 
 int c2b_visibility_dense_fill(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, double max_dist,
                               const uint32_t *tile_offsets, const uint64_t *row_ptr, uint32_t *pt_idx, double *uv,
                               void *stream) {
+    C2B_API_BEGIN
     int rc = dense_check("visibility_dense_fill", camblk, n_cam, pts4, n_pts);
     if (rc) return rc;
     const int64_t n_tiles = c2b_visibility_dense_tiles(n_pts);
@@ -815,20 +927,24 @@ int c2b_visibility_dense_fill(const double *camblk, int64_t n_cam, const double 
                        const_cast<uint32_t *>(tile_offsets), row_ptr, pt_idx, reinterpret_cast<double2 *>(uv));
     LAUNCH_CHECK();
     return C2B_OK;
+    C2B_API_END("visibility_dense_fill")
 }
 
 /* ------------------------------- host-side generator pieces -------------------------- */
 
 int c2b_synthetic_grid_sizes(int64_t cpb, int64_t ppb, int64_t blocks, int64_t *n_cam, int64_t *n_pts) {
+    C2B_API_BEGIN
     if (cpb < 0 || ppb < 0 || blocks < 0 || !n_cam || !n_pts)
         return fail(C2B_ERR_INVALID_ARGUMENT, "synthetic_grid_sizes: bad arguments");
     c2b_host::grid_sizes(cpb, ppb, blocks, n_cam, n_pts);
     return C2B_OK;
+    C2B_API_END("synthetic_grid_sizes")
 }
 
 int c2b_synthetic_grid_layout(int64_t cpb, int64_t ppb, int64_t blocks, double block_length, double block_inset,
                               double camera_height, double point_height, double *cam_pos3, double *cam_dir9,
                               double *pts3) {
+    C2B_API_BEGIN
     if (cpb < 0 || ppb < 0 || blocks < 0 || !cam_pos3 || !cam_dir9 || !pts3)
         return fail(C2B_ERR_INVALID_ARGUMENT, "synthetic_grid_layout: bad arguments");
     // assert!(block_inset * 2. < block_length, ...), src/synthetic.rs:177
@@ -839,14 +955,17 @@ int c2b_synthetic_grid_layout(int64_t cpb, int64_t ppb, int64_t blocks, double b
     c2b_host::grid_layout(cpb, ppb, blocks, block_length, block_inset, camera_height, point_height, cam_pos3,
                           cam_dir9, pts3);
     return C2B_OK;
+    C2B_API_END("synthetic_grid_layout")
 }
 
 int c2b_synthetic_line_layout(int64_t n_cam, int64_t n_pts, double length, double point_offset, double camera_height,
                               double point_height, double *cam_pos3, double *cam_dir9, double *pts3) {
+    C2B_API_BEGIN
     if (n_cam < 0 || n_pts < 0 || (n_cam && (!cam_pos3 || !cam_dir9)) || (n_pts && !pts3))
         return fail(C2B_ERR_INVALID_ARGUMENT, "synthetic_line_layout: bad arguments");
     c2b_host::line_layout(n_cam, n_pts, length, point_offset, camera_height, point_height, cam_pos3, cam_dir9, pts3);
     return C2B_OK;
+    C2B_API_END("synthetic_line_layout")
 }
 
 struct c2b_pairs {
@@ -856,6 +975,7 @@ struct c2b_pairs {
 int c2b_candidate_pairs(const double *centers3, int64_t n_cam, const double *pts3, int64_t n_pts, double max_dist,
                         int64_t cam_lo, int64_t cam_hi, int occlusion, double block_length, double block_inset,
                         int n_threads, c2b_pairs **out) {
+    C2B_API_BEGIN
     if (!out) return fail(C2B_ERR_INVALID_ARGUMENT, "candidate_pairs: out is NULL");
     *out = nullptr;
     if (n_cam < 0 || n_pts < 0 || cam_lo < 0 || cam_hi > n_cam || cam_lo > cam_hi || (n_cam && !centers3) ||
@@ -878,6 +998,7 @@ int c2b_candidate_pairs(const double *centers3, int64_t n_cam, const double *pts
     }
     *out = p;
     return C2B_OK;
+    C2B_API_END("candidate_pairs")
 }
 
 int64_t c2b_pairs_count(const c2b_pairs *p) { return p ? (int64_t)p->v.cam.size() : 0; }
@@ -891,6 +1012,7 @@ struct c2b_obj {
 };
 
 int c2b_obj_load(const char *path, c2b_obj **out) {
+    C2B_API_BEGIN
     if (!path || !out) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_load: bad arguments");
     *out = nullptr;
     c2b_obj *o = new (std::nothrow) c2b_obj();
@@ -905,6 +1027,7 @@ int c2b_obj_load(const char *path, c2b_obj **out) {
     if (!ok) { delete o; return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str()); }
     *out = o;
     return C2B_OK;
+    C2B_API_END("obj_load")
 }
 
 int64_t c2b_obj_model_count(const c2b_obj *o) { return o ? (int64_t)o->models.size() : 0; }
@@ -914,29 +1037,36 @@ const char *c2b_obj_model_name(const c2b_obj *o, int64_t m) {
 }
 
 int c2b_obj_model_sizes(const c2b_obj *o, int64_t m, int64_t *n_positions, int64_t *n_indices, int *is_lines) {
+    C2B_API_BEGIN
     if (!o || m < 0 || m >= (int64_t)o->models.size()) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_model_sizes: bad model index");
     const c2b_host::ObjModel &mod = o->models[(size_t)m];
     if (n_positions) *n_positions = (int64_t)(mod.positions.size() / 3);
     if (n_indices) *n_indices = (int64_t)mod.indices.size();
     if (is_lines) *is_lines = mod.lines ? 1 : 0;
     return C2B_OK;
+    C2B_API_END("obj_model_sizes")
 }
 
 int c2b_obj_model_copy(const c2b_obj *o, int64_t m, float *positions3, uint32_t *indices) {
+    C2B_API_BEGIN
     if (!o || m < 0 || m >= (int64_t)o->models.size()) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_model_copy: bad model index");
     const c2b_host::ObjModel &mod = o->models[(size_t)m];
     if (positions3) std::copy(mod.positions.begin(), mod.positions.end(), positions3);
     if (indices) std::copy(mod.indices.begin(), mod.indices.end(), indices);
     return C2B_OK;
+    C2B_API_END("obj_model_copy")
 }
 
 int c2b_obj_move_to_origin(c2b_obj *o, int64_t skip_model) {
+    C2B_API_BEGIN
     if (!o) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_move_to_origin: obj is NULL");
     c2b_host::move_to_origin(o->models, skip_model);
     return C2B_OK;
+    C2B_API_END("obj_move_to_origin")
 }
 
 int c2b_obj_triangles(const c2b_obj *o, int64_t skip_model, float *tri9, int64_t *n_tri) {
+    C2B_API_BEGIN
     if (!o || !n_tri) return fail(C2B_ERR_INVALID_ARGUMENT, "obj_triangles: bad arguments");
     std::vector<c2b_host::ObjModel> use;
     for (int64_t m = 0; m < (int64_t)o->models.size(); ++m)
@@ -946,12 +1076,14 @@ int c2b_obj_triangles(const c2b_obj *o, int64_t skip_model, float *tri9, int64_t
     *n_tri = (int64_t)(t.size() / 9);
     if (tri9) std::copy(t.begin(), t.end(), tri9);
     return C2B_OK;
+    C2B_API_END("obj_triangles")
 }
 
 void c2b_obj_free(c2b_obj *o) { delete o; }
 
 int c2b_generate_cameras_path(const c2b_obj *o, int64_t path_model, int64_t num_cameras, double step_size, uint64_t seed,
                               double *cam_pos3, double *cam_dir9) {
+    C2B_API_BEGIN
     if (!o || path_model < 0 || path_model >= (int64_t)o->models.size() || num_cameras < 0 || (num_cameras && (!cam_pos3 || !cam_dir9)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "generate_cameras_path: bad arguments");
     const c2b_host::ObjModel &path = o->models[(size_t)path_model];
@@ -965,10 +1097,12 @@ int c2b_generate_cameras_path(const c2b_obj *o, int64_t path_model, int64_t num_
     std::copy(cs.pos.begin(), cs.pos.end(), cam_pos3);
     std::copy(cs.dir.begin(), cs.dir.end(), cam_dir9);
     return C2B_OK;
+    C2B_API_END("generate_cameras_path")
 }
 
 int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_points, double height, double ground,
                                  uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out) {
+    C2B_API_BEGIN
     if (!tri9 || n_tri <= 0 || num_points < 0 || capacity < 0 || !n_out || (capacity && (!cam_pos3 || !cam_dir9)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "generate_cameras_poisson: bad arguments");
     const std::vector<float> tri(tri9, tri9 + 9 * n_tri);
@@ -981,16 +1115,20 @@ int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_p
     }
     *n_out = (int64_t)cs.size();
     return C2B_OK;
+    C2B_API_END("generate_cameras_poisson")
 }
 
 int c2b_modify_intrinsics(double *cams15, int64_t n_cam, const double start[3], const double end[3], uint64_t seed) {
+    C2B_API_BEGIN
     if (n_cam < 0 || (n_cam && !cams15) || !start || !end) return fail(C2B_ERR_INVALID_ARGUMENT, "modify_intrinsics: bad arguments");
     c2b_host::modify_intrinsics(cams15, n_cam, start, end, seed);
     return C2B_OK;
+    C2B_API_END("modify_intrinsics")
 }
 
 int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *centers3, int64_t n_cam, int64_t num_points,
                               double max_dist, uint64_t seed, double *pts3, int64_t *n_out) {
+    C2B_API_BEGIN
     if (!tri9 || n_tri < 0 || n_cam < 0 || (n_cam && !centers3) || num_points < 0 || !n_out || (num_points && !pts3))
         return fail(C2B_ERR_INVALID_ARGUMENT, "generate_world_points: bad arguments");
     const std::vector<float> tri(tri9, tri9 + 9 * n_tri);
@@ -1001,10 +1139,12 @@ int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *ce
     std::copy(pts.begin(), pts.end(), pts3);
     *n_out = (int64_t)(pts.size() / 3);
     return C2B_OK;
+    C2B_API_END("generate_world_points")
 }
 
 static int cull_host(int mode, int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
                      uint64_t *pt_idx, double *uv, int faithful) {
+    C2B_API_BEGIN
     if (!n_cam || !n_pts || !row_ptr || *n_cam < 0 || *n_pts < 0 || cam_stride < 0 || (*n_cam && cam_stride && !cams) ||
         (*n_pts && !pts3))
         return fail(C2B_ERR_INVALID_ARGUMENT, "cull: bad arguments");
@@ -1032,19 +1172,26 @@ static int cull_host(int mode, int64_t *n_cam, double *cams, int cam_stride, int
         return fail(C2B_ERR_OOM, "cull: out of host memory");
     }
     return C2B_OK;
+    C2B_API_END("cull_host")
 }
 
 int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
              uint64_t *pt_idx, double *uv, int faithful) {
+    C2B_API_BEGIN
     return cull_host(0, n_cam, cams, cam_stride, n_pts, pts3, row_ptr, pt_idx, uv, faithful);
+    C2B_API_END("cull")
 }
 int c2b_largest_connected_component(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
                                     uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful) {
+    C2B_API_BEGIN
     return cull_host(1, n_cam, cams, cam_stride, n_pts, pts3, row_ptr, pt_idx, uv, faithful);
+    C2B_API_END("largest_connected_component")
 }
 int c2b_remove_singletons(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3, uint64_t *row_ptr,
                           uint64_t *pt_idx, double *uv) {
+    C2B_API_BEGIN
     return cull_host(2, n_cam, cams, cam_stride, n_pts, pts3, row_ptr, pt_idx, uv, 1);
+    C2B_API_END("remove_singletons")
 }
 
 /* ---- index-corruption noise, host side ---- */
@@ -1058,6 +1205,7 @@ static int check_csr(const char *who, int64_t n_cam, const uint64_t *row_ptr) {
 
 int c2b_add_incorrect_correspondences(int64_t n_cam, const uint64_t *row_ptr, uint64_t *pt_idx, const double *uv,
                                       double mismatch_chance, uint64_t seed) {
+    C2B_API_BEGIN
     int rc = check_csr("add_incorrect_correspondences", n_cam, row_ptr);
     if (rc) return rc;
     if (row_ptr[n_cam] && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_incorrect_correspondences: NULL observations");
@@ -1069,9 +1217,11 @@ int c2b_add_incorrect_correspondences(int64_t n_cam, const uint64_t *row_ptr, ui
         return fail(C2B_ERR_OOM, "add_incorrect_correspondences: out of host memory");
     }
     return C2B_OK;
+    C2B_API_END("add_incorrect_correspondences")
 }
 
 int c2b_drop_features(int64_t n_cam, uint64_t *row_ptr, uint64_t *pt_idx, double *uv, double keep_fraction, uint64_t seed) {
+    C2B_API_BEGIN
     int rc = check_csr("drop_features", n_cam, row_ptr);
     if (rc) return rc;
     if (row_ptr[n_cam] && (!pt_idx || !uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "drop_features: NULL observations");
@@ -1082,10 +1232,12 @@ int c2b_drop_features(int64_t n_cam, uint64_t *row_ptr, uint64_t *pt_idx, double
         return fail(C2B_ERR_OOM, "drop_features: out of host memory");
     }
     return C2B_OK;
+    C2B_API_END("drop_features")
 }
 
 int c2b_split_landmarks(int64_t *n_pts, double *pts3, int64_t pts_capacity, int64_t n_obs, uint64_t *pt_idx,
                         double split_fraction, uint64_t seed) {
+    C2B_API_BEGIN
     if (!n_pts || *n_pts < 0 || n_obs < 0 || (*n_pts && !pts3) || (n_obs && !pt_idx) || split_fraction != split_fraction)
         return fail(C2B_ERR_INVALID_ARGUMENT, "split_landmarks: bad arguments");
     const uint64_t n = std::min<uint64_t>(c2b_host::fraction_of(split_fraction, (uint64_t)*n_pts), (uint64_t)*n_pts);
@@ -1100,9 +1252,11 @@ int c2b_split_landmarks(int64_t *n_pts, double *pts3, int64_t pts_capacity, int6
         return fail(C2B_ERR_OOM, "split_landmarks: out of host memory");
     }
     return C2B_OK;
+    C2B_API_END("split_landmarks")
 }
 
 int c2b_join_landmarks(int64_t n_pts, const double *pts3, int64_t n_obs, uint64_t *pt_idx, double join_fraction, uint64_t seed) {
+    C2B_API_BEGIN
     if (n_pts < 0 || n_obs < 0 || (n_pts && !pts3) || (n_obs && !pt_idx) || join_fraction != join_fraction)
         return fail(C2B_ERR_INVALID_ARGUMENT, "join_landmarks: bad arguments");
     for (int64_t o = 0; o < n_obs; ++o)
@@ -1115,6 +1269,7 @@ int c2b_join_landmarks(int64_t n_pts, const double *pts3, int64_t n_obs, uint64_
         return fail(C2B_ERR_OOM, "join_landmarks: out of host memory");
     }
     return C2B_OK;
+    C2B_API_END("join_landmarks")
 }
 
 struct c2b_balfile {
@@ -1132,6 +1287,7 @@ static int bal_format(const char *path, int format, bool *binary) {
 }
 
 int c2b_bal_read_as(const char *path, int format, c2b_balfile **out) {
+    C2B_API_BEGIN
     if (!path || !out) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_read: bad arguments");
     *out = nullptr;
     bool binary = false;
@@ -1154,19 +1310,23 @@ int c2b_bal_read_as(const char *path, int format, c2b_balfile **out) {
     }
     *out = f;
     return C2B_OK;
+    C2B_API_END("bal_read_as")
 }
 
 int c2b_bal_read(const char *path, c2b_balfile **out) { return c2b_bal_read_as(path, -1, out); }
 
 int c2b_bal_sizes(const c2b_balfile *f, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs) {
+    C2B_API_BEGIN
     if (!f) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_sizes: file is NULL");
     if (n_cam) *n_cam = f->g.n_cam;
     if (n_pts) *n_pts = f->g.n_pts;
     if (n_obs) *n_obs = f->g.n_obs();
     return C2B_OK;
+    C2B_API_END("bal_sizes")
 }
 
 int c2b_bal_copy(const c2b_balfile *f, double *bal9, double *pts3, uint64_t *row_ptr, uint64_t *pt_idx, double *uv) {
+    C2B_API_BEGIN
     if (!f) return fail(C2B_ERR_INVALID_ARGUMENT, "bal_copy: file is NULL");
     if (bal9) std::copy(f->g.cams.begin(), f->g.cams.end(), bal9);
     if (pts3) std::copy(f->g.pts.begin(), f->g.pts.end(), pts3);
@@ -1174,12 +1334,14 @@ int c2b_bal_copy(const c2b_balfile *f, double *bal9, double *pts3, uint64_t *row
     if (pt_idx) std::copy(f->g.pt_idx.begin(), f->g.pt_idx.end(), pt_idx);
     if (uv) std::copy(f->g.uv.begin(), f->g.uv.end(), uv);
     return C2B_OK;
+    C2B_API_END("bal_copy")
 }
 
 void c2b_bal_close(c2b_balfile *f) { delete f; }
 
 int c2b_bal_write_as(const char *path, int format, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
                      const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    C2B_API_BEGIN
     if (!path || n_cam < 0 || n_pts < 0 || !row_ptr || (n_cam && !bal9) || (n_pts && !pts3))
         return fail(C2B_ERR_INVALID_ARGUMENT, "bal_write: bad arguments");
     bool binary = false;
@@ -1204,15 +1366,19 @@ int c2b_bal_write_as(const char *path, int format, int64_t n_cam, const double *
     }
     if (!ok) return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
     return C2B_OK;
+    C2B_API_END("bal_write_as")
 }
 
 int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
                   const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    C2B_API_BEGIN
     return c2b_bal_write_as(path, -1, n_cam, bal9, n_pts, pts3, row_ptr, pt_idx, uv);
+    C2B_API_END("bal_write")
 }
 
 int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,
                   const uint64_t *row_ptr, const uint64_t *pt_idx) {
+    C2B_API_BEGIN
     if (!path || n_cam < 0 || n_pts < 0 || (n_cam && (!centers3 || !row_ptr)) || (n_pts && !pts3))
         return fail(C2B_ERR_INVALID_ARGUMENT, "ply_write: bad arguments");
     if (n_cam && row_ptr[n_cam] && !pt_idx) return fail(C2B_ERR_INVALID_ARGUMENT, "ply_write: pt_idx is NULL");
@@ -1220,6 +1386,7 @@ int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64
     if (!c2b_host::write_ply(path, n_cam, centers3, n_pts, pts3, row_ptr, pt_idx, &err))
         return fail(C2B_ERR_INVALID_ARGUMENT, "%s", err.c_str());
     return C2B_OK;
+    C2B_API_END("ply_write")
 }
 
 /* ------------------------------- level 1 --------------------------------------------- */
@@ -1259,6 +1426,7 @@ static void free_buffers(c2b_problem *p) {
 }
 
 int c2b_problem_create(int device, c2b_problem **out) {
+    C2B_API_BEGIN
     if (!out) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_create: out is NULL");
     *out = nullptr;
     int n = 0;
@@ -1273,6 +1441,7 @@ int c2b_problem_create(int device, c2b_problem **out) {
     if (e != hipSuccess) { delete p; return fail(C2B_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = p;
     return C2B_OK;
+    C2B_API_END("problem_create")
 }
 
 void c2b_problem_destroy(c2b_problem *p) {
@@ -1364,20 +1533,26 @@ static int upload_common(c2b_problem *p, int64_t n_cam, const double *cams, bool
 
 int c2b_problem_upload(c2b_problem *p, int64_t n_cam, const double *cams15, int64_t n_pts, const double *pts3,
                        const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    C2B_API_BEGIN
     return upload_common(p, n_cam, cams15, false, n_pts, pts3, row_ptr, pt_idx, uv);
+    C2B_API_END("problem_upload")
 }
 
 int c2b_problem_upload_bal(c2b_problem *p, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
                            const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    C2B_API_BEGIN
     return upload_common(p, n_cam, bal9, true, n_pts, pts3, row_ptr, pt_idx, uv);
+    C2B_API_END("problem_upload_bal")
 }
 
 int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs) {
+    C2B_API_BEGIN
     if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_sizes: problem is NULL");
     if (n_cam) *n_cam = p->n_cam;
     if (n_pts) *n_pts = p->n_pts;
     if (n_obs) *n_obs = p->n_obs;
     return C2B_OK;
+    C2B_API_END("problem_sizes")
 }
 
 #define NEED_UPLOADED(p, who)                                                              \
@@ -1386,6 +1561,7 @@ int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int6
     HIP_TRY(hipSetDevice((p)->device));
 
 int c2b_problem_download(c2b_problem *p, double *cams15, double *pts3, double *uv) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_download");
     if (cams15 && p->n_cam)
         HIP_TRY(hipMemcpyAsync(cams15, p->cam15, sizeof(double) * 15 * p->n_cam, hipMemcpyDeviceToHost, p->stream));
@@ -1403,9 +1579,11 @@ int c2b_problem_download(c2b_problem *p, double *cams15, double *pts3, double *u
     if (d_p3) (void)hipFree(d_p3);
     if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_download: %s", hipGetErrorString(e));
     return C2B_OK;
+    C2B_API_END("problem_download")
 }
 
 int c2b_problem_download_bal(c2b_problem *p, double *bal9) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_download_bal");
     if (!bal9) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_download_bal: bal9 is NULL");
     if (!p->n_cam) return C2B_OK;
@@ -1417,10 +1595,12 @@ int c2b_problem_download_bal(c2b_problem *p, double *bal9) {
     HIP_TRY(hipMemcpyAsync(bal9, p->bal9, sizeof(double) * 9 * p->n_cam, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_download_bal")
 }
 
 int c2b_problem_from_position_direction(c2b_problem *p, int64_t n_cam, const double *pos3, const double *dir9,
                                         double *cams15) {
+    C2B_API_BEGIN
     if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_from_position_direction: problem is NULL");
     if (n_cam < 0 || (n_cam && (!pos3 || !dir9 || !cams15)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_from_position_direction: bad arguments");
@@ -1446,9 +1626,11 @@ int c2b_problem_from_position_direction(c2b_problem *p, int64_t n_cam, const dou
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_from_position_direction: %s", hipGetErrorString(e));
     return C2B_OK;
+    C2B_API_END("problem_from_position_direction")
 }
 
 int c2b_problem_centers(c2b_problem *p, double *centers3) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_centers");
     if (!p->n_cam) return C2B_OK;
     if (!centers3) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_centers: centers3 is NULL");
@@ -1459,9 +1641,11 @@ int c2b_problem_centers(c2b_problem *p, double *centers3) {
                              3 * sizeof(double), (size_t)p->n_cam, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_centers")
 }
 
 int c2b_problem_project(c2b_problem *p, double *uv_out) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_project");
     if (!p->n_obs) return C2B_OK;
     if (!uv_out) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_project: uv_out is NULL");
@@ -1477,9 +1661,11 @@ int c2b_problem_project(c2b_problem *p, double *uv_out) {
     if (rc) return rc;
     if (e != hipSuccess || e2 != hipSuccess) return fail(C2B_ERR_HIP, "problem_project: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return C2B_OK;
+    C2B_API_END("problem_project")
 }
 
 int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *out) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_total_reprojection_error");
     if (!out) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_error: out is NULL");
     int rc = ensure_camblk(p);
@@ -1492,9 +1678,11 @@ int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *ou
     HIP_TRY(hipStreamSynchronize(p->stream));
     *out = std::pow(sum, 1.0 / norm);          // .powf(1. / norm), src/baproblem.rs:278
     return C2B_OK;
+    C2B_API_END("problem_total_reprojection_error")
 }
 
 int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double *Jp) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_residual_jacobian");
     if (!p->n_obs) return C2B_OK;
     if (!r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_residual_jacobian: NULL output");
@@ -1521,6 +1709,7 @@ int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double 
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_residual_jacobian: %s", hipGetErrorString(e));
     return C2B_OK;
+    C2B_API_END("problem_residual_jacobian")
 }
 
 static int compute_stats(c2b_problem *p) {
@@ -1530,6 +1719,7 @@ static int compute_stats(c2b_problem *p) {
 }
 
 int c2b_problem_stats(c2b_problem *p, double *stats) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_stats");
     if (!stats) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_stats: stats is NULL");
     int rc = compute_stats(p);
@@ -1537,10 +1727,12 @@ int c2b_problem_stats(c2b_problem *p, double *stats) {
     HIP_TRY(hipMemcpyAsync(stats, p->stats, sizeof(double) * C2B_STATS_DOUBLES, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_stats")
 }
 
 int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx, const uint32_t *pt_idx,
                                  double max_dist, double *uv_out, uint8_t *keep) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_visibility_pairs");
     if (n_pairs < 0 || (n_pairs && (!cam_idx || !pt_idx || !uv_out || !keep)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_pairs: bad arguments");
@@ -1575,6 +1767,7 @@ int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_pairs: %s", hipGetErrorString(e));
     return C2B_OK;
+    C2B_API_END("problem_visibility_pairs")
 }
 
 /* ---- BAProblem::cull on the device (src/baproblem.rs:538-549) ---- */
@@ -1602,7 +1795,7 @@ hipError_t scan_flags(hipStream_t st, const uint32_t *flags, int64_t n, uint32_t
     if (n > 0) hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, flags, n, pos, tile_scratch);
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, st, tile_scratch, tiles, d_total);
     if (n > 0) hipLaunchKernelGGL(k_scan_add, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, pos, n, (const uint32_t *)tile_scratch);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_error();
     if (e == hipSuccess) e = hipMemcpyAsync(total_host, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     return e;
@@ -1646,7 +1839,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
         hipLaunchKernelGGL(k_uf_init, dim3(blocks_of(no, kBlock)), dim3(kBlock), 0, st, eorig[0].as<uint32_t>(), no);   // iota
         hipLaunchKernelGGL(k_uf_init, dim3(blocks_of(nc, kBlock)), dim3(kBlock), 0, st, corig[0].as<uint32_t>(), nc);
         hipLaunchKernelGGL(k_uf_init, dim3(blocks_of(np, kBlock)), dim3(kBlock), 0, st, porig[0].as<uint32_t>(), np);
-        e = hipGetLastError();
+        e = launch_error();
     }
 
     // renumber by the keep flags currently in keep_c / keep_p / keep_o
@@ -1668,7 +1861,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
                            pt[nxt].as<uint32_t>(), eorig[nxt].as<uint32_t>());
         cur = nxt;
         nc = nc_new; np = np_new; no = no_new;
-        return hipGetLastError();
+        return launch_error();
     };
     auto lcc_pass = [&]() -> hipError_t {
         if (nc == 0) return hipSuccess;                      // largest_connected_component returns self (:457-459)
@@ -1687,7 +1880,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
                            (const unsigned long long *)best.as<unsigned long long>(), (uint32_t)nc, (uint32_t)np,
                            (const uint32_t *)cam[cur].as<uint32_t>(), (const uint32_t *)pt[cur].as<uint32_t>(), no, faithful ? 1 : 0,
                            keep_c.as<uint32_t>(), keep_p.as<uint32_t>(), keep_o.as<uint32_t>());
-        s = hipGetLastError();
+        s = launch_error();
         return s == hipSuccess ? compact() : s;
     };
     auto singleton_pass = [&]() -> hipError_t {
@@ -1700,7 +1893,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
         hipLaunchKernelGGL(k_singleton_flags, dim3(blocks_of(big, kBlock)), dim3(kBlock), 0, st, (const uint32_t *)deg.as<uint32_t>(),
                            (const uint32_t *)cnt.as<uint32_t>(), (uint32_t)nc, (uint32_t)np, (const uint32_t *)cam[cur].as<uint32_t>(),
                            (const uint32_t *)pt[cur].as<uint32_t>(), no, keep_c.as<uint32_t>(), keep_p.as<uint32_t>(), keep_o.as<uint32_t>());
-        s = hipGetLastError();
+        s = launch_error();
         return s == hipSuccess ? compact() : s;
     };
     // culled = lcc().remove_singletons(); while the counts change: again (src/baproblem.rs:541-547)
@@ -1729,7 +1922,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
         if (p->bal_valid) gather(p->bal9, corig[cur], nc, 9, n_bal9);
         gather(p->pts4, porig[cur], np, 4, n_pts4);
         gather(p->uv, eorig[cur], no, 2, n_uv);
-        e = hipGetLastError();
+        e = launch_error();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (e != hipSuccess) {
@@ -1751,6 +1944,7 @@ int c2b_problem_largest_connected_component(c2b_problem *p, int faithful) { retu
 int c2b_problem_remove_singletons(c2b_problem *p) { return cull_impl(p, 1, 2); }
 
 int c2b_problem_adopt_visibility(c2b_problem *p) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_adopt_visibility");
     if (!p->dense_pt || !p->dense_uv || !p->dense_row)
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_adopt_visibility: no pending visibility result");
@@ -1770,9 +1964,11 @@ int c2b_problem_adopt_visibility(c2b_problem *p) {
     p->pt_idx = p->dense_pt; p->uv = p->dense_uv; p->n_obs = n;
     p->dense_pt = nullptr; p->dense_uv = nullptr; p->dense_row = nullptr; p->dense_n = 0;
     return C2B_OK;
+    C2B_API_END("problem_adopt_visibility")
 }
 
 int c2b_problem_download_graph(c2b_problem *p, uint64_t *row_ptr, uint64_t *pt_idx) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_download_graph");
     if (!row_ptr || (p->n_obs && !pt_idx)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_download_graph: bad arguments");
     const int64_t n_cam = p->n_cam, n_obs = p->n_obs;
@@ -1782,7 +1978,7 @@ int c2b_problem_download_graph(c2b_problem *p, uint64_t *row_ptr, uint64_t *pt_i
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_rows_from_sorted, dim3(blocks_for(n_obs + 1)), dim3(kBlock), 0, p->stream, (const uint32_t *)p->cam_idx, n_obs,
                            n_cam, d_row.as<uint64_t>());
-        e = hipGetLastError();
+        e = launch_error();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(row_ptr, d_row.ptr, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess && n_obs) e = hipMemcpyAsync(tmp.data(), p->pt_idx, sizeof(uint32_t) * (size_t)n_obs, hipMemcpyDeviceToHost, p->stream);
@@ -1791,6 +1987,7 @@ int c2b_problem_download_graph(c2b_problem *p, uint64_t *row_ptr, uint64_t *pt_i
     if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_download_graph: %s", hipGetErrorString(e));
     for (int64_t i = 0; i < n_obs; ++i) pt_idx[i] = tmp[(size_t)i];
     return C2B_OK;
+    C2B_API_END("problem_download_graph")
 }
 
 // Stable compaction of CSR lists (point index, uv) by a keep mask, on the device: kept count per row -> row scan ->
@@ -1817,7 +2014,7 @@ static hipError_t compact_rows_on_device(c2b_problem *p, const uint64_t *d_row_o
                 hipLaunchKernelGGL(k_keep_row_scatter, dim3(row_blocks), dim3(256), 0, p->stream, d_row_old,
                                    (const uint64_t *)*d_row_new, d_keep, d_pt, reinterpret_cast<const double2 *>(d_uv), n_cam,
                                    *d_pt_new, reinterpret_cast<double2 *>(*d_uv_new));
-                e = hipGetLastError();
+                e = launch_error();
             }
             if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
         }
@@ -1834,6 +2031,7 @@ static hipError_t compact_rows_on_device(c2b_problem *p, const uint64_t *d_row_o
 
 int c2b_problem_visibility_pairs_compact(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx, const uint32_t *pt_idx,
                                          double max_dist, uint64_t *row_ptr) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_visibility_pairs_compact");
     if (n_pairs < 0 || !row_ptr || (n_pairs && (!cam_idx || !pt_idx)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_pairs_compact: bad arguments");
@@ -1865,7 +2063,7 @@ int c2b_problem_visibility_pairs_compact(c2b_problem *p, int64_t n_pairs, const 
         if (!rc) {
             hipLaunchKernelGGL(k_rows_from_sorted, dim3(blocks_for(n_pairs + 1)), dim3(kBlock), 0, p->stream, (const uint32_t *)d_c,
                                n_pairs, n_cam, d_row);
-            e = hipGetLastError();
+            e = launch_error();
             if (e == hipSuccess)
                 e = compact_rows_on_device(p, d_row, d_k, d_p, d_uv, n_cam, row_ptr, &d_row_new, &d_pt_new, &d_uv_new, &w);
         }
@@ -1882,9 +2080,11 @@ int c2b_problem_visibility_pairs_compact(c2b_problem *p, int64_t n_pairs, const 
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_pairs_compact: %s", hipGetErrorString(e));
     return C2B_OK;
+    C2B_API_END("problem_visibility_pairs_compact")
 }
 
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_visibility_dense");
     if (!row_ptr) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense: row_ptr is NULL");
     if (!(max_dist >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense: max_dist must be >= 0");
@@ -1925,9 +2125,11 @@ int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense: %s", hipGetErrorString(e));
     return C2B_OK;
+    C2B_API_END("problem_visibility_dense")
 }
 
 int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int64_t n_tri, uint64_t *row_ptr) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_visibility_dense_occlude");
     if (!p->dense_pt || !p->dense_uv || !p->dense_row)
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: no sweep result");
@@ -1939,7 +2141,8 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
         return C2B_OK;
     }
     float *d_tri = nullptr;
-    uint32_t *d_cam = nullptr, *d_pt_new = nullptr;
+    uint32_t *d_cam = nullptr, *d_pt_new = nullptr, *d_flag = nullptr;
+    uint32_t stack_overflow = 0;
     uint8_t *d_keep = nullptr;
     uint64_t *d_tot = nullptr, *d_row_new = nullptr;
     double *d_uv_new = nullptr;
@@ -1960,17 +2163,25 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
     if (e == hipSuccess && use_bvh) e = hipMalloc(&d_nodes, (size_t)C2B_BVH_NODE_BYTES * (size_t)n_nodes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_cam, sizeof(uint32_t) * (size_t)n);
     if (e == hipSuccess) e = hipMalloc((void **)&d_keep, (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_flag, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), p->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_tri, tri_src, tri_bytes, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess && use_bvh)
         e = hipMemcpyAsync(d_nodes, bvh->b.nodes.data(), (size_t)C2B_BVH_NODE_BYTES * (size_t)n_nodes, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) {
         rc = c2b_expand_rows(p->dense_row, n_cam, 0, n, d_cam, p->stream);
         if (!rc)
-            rc = use_bvh ? c2b_occlusion_filter_bvh(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_nodes, n_nodes, d_tri, n_tri, d_keep, p->stream)
+            rc = use_bvh ? c2b_occlusion_filter_bvh(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_nodes, n_nodes, d_tri, n_tri, d_keep, d_flag, p->stream)
                          : c2b_occlusion_filter(p->camblk, p->pts4, d_cam, p->dense_pt, n, d_tri, n_tri, d_keep, p->stream);
         // Stable compaction of the survivor lists on the device (per-camera order of the sweep is kept): kept count per
         // row, row scan, scatter.  Only the new row pointer travels to the host.
-        if (!rc) {
+        if (!rc) {                                         // a traversal-stack overflow invalidates the whole mask
+            e = hipMemcpyAsync(&stack_overflow, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+            if (e == hipSuccess && stack_overflow)
+                rc = fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: hierarchy deeper than the traversal stack");
+        }
+        if (!rc && e == hipSuccess) {
             int64_t w = 0;
             e = compact_rows_on_device(p, p->dense_row, d_keep, p->dense_pt, p->dense_uv, n_cam, row_ptr, &d_row_new, &d_pt_new,
                                        &d_uv_new, &w);
@@ -1987,6 +2198,7 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
     if (d_nodes) (void)hipFree(d_nodes);
     if (d_cam) (void)hipFree(d_cam);
     if (d_keep) (void)hipFree(d_keep);
+    if (d_flag) (void)hipFree(d_flag);
     if (d_tot) (void)hipFree(d_tot);
     if (d_row_new) (void)hipFree(d_row_new);
     if (d_pt_new) (void)hipFree(d_pt_new);
@@ -1995,9 +2207,11 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense_occlude: %s", hipGetErrorString(e));
     return C2B_OK;
+    C2B_API_END("problem_visibility_dense_occlude")
 }
 
 int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double *uv) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_visibility_dense_fetch");
     if (!p->dense_pt || !p->dense_uv) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_fetch: no sweep result");
     const int64_t n = p->dense_n;
@@ -2011,12 +2225,14 @@ int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double 
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_visibility_dense_fetch")
 }
 
 static void cameras_mutated(c2b_problem *p) { p->bal_valid = false; p->blk_valid = false; }
 
 int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength, double std, const double dir[3],
                           uint64_t seed) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_add_drift");
     if (!dir) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_add_drift: dir is NULL");
     int rc = compute_stats(p);
@@ -2027,10 +2243,12 @@ int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength
     cameras_mutated(p);
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_add_drift")
 }
 
 int c2b_problem_add_drift_normalized(c2b_problem *p, double strength, double angle_strength, double std,
                                      uint64_t seed) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_add_drift_normalized");
     int rc = compute_stats(p);
     if (rc) return rc;
@@ -2040,10 +2258,12 @@ int c2b_problem_add_drift_normalized(c2b_problem *p, double strength, double ang
     cameras_mutated(p);
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_add_drift_normalized")
 }
 
 int c2b_problem_add_noise(c2b_problem *p, double translation_std, double rotation_std, double point_std,
                           double observations_std, uint64_t seed) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_add_noise");
     int rc = compute_stats(p);
     if (rc) return rc;
@@ -2055,10 +2275,12 @@ int c2b_problem_add_noise(c2b_problem *p, double translation_std, double rotatio
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_add_noise")
 }
 
 int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double noise_dir[3], double strength,
                               double frequency) {
+    C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_add_sin_noise");
     if (!dir || !noise_dir) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_add_sin_noise: NULL direction");
     int rc = compute_stats(p);
@@ -2069,6 +2291,7 @@ int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double 
     cameras_mutated(p);
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
+    C2B_API_END("problem_add_sin_noise")
 }
 
 }  // extern "C"

@@ -322,7 +322,10 @@ inline bool read_text(const char *path, Graph &g, std::string *err) {
         skip();
         if (p >= end || *p < '0' || *p > '9') return false;
         v = 0;
-        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0');
+        while (p < end && *p >= '0' && *p <= '9') {
+            if (v > (UINT64_MAX - 9) / 10) return false;         // would wrap: not a count or an index
+            v = v * 10 + (uint64_t)(*p++ - '0');
+        }
         return true;
     };
     auto get_d = [&](double &v) -> bool {
@@ -336,6 +339,14 @@ inline bool read_text(const char *path, Graph &g, std::string *err) {
     };
     uint64_t nc, np, no;
     if (!get_u(nc) || !get_u(np) || !get_u(no)) { *err = "ParseError: bad header"; return false; }
+    // The header is untrusted: every observation takes at least 8 bytes of text ("0 0 0 0\n"), every camera 18, every
+    // point 6, so counts beyond what the rest of the file can hold are rejected before anything is sized from them.
+    const uint64_t left = (uint64_t)(end - p);
+    if (no > left / 8 || nc > left / 18 || np > left / 6) {
+        *err = "ParseError: header counts (" + std::to_string(nc) + " cameras, " + std::to_string(np) + " points, " +
+               std::to_string(no) + " observations) exceed what a file of this size can hold";
+        return false;
+    }
     std::vector<uint64_t> oc((size_t)no), op((size_t)no);
     std::vector<double> ou((size_t)no * 2);
     for (uint64_t i = 0; i < no; ++i)
@@ -390,6 +401,9 @@ inline bool read_binary(const char *path, Graph &g, std::string *err) {
     };
     uint64_t nc, np, no;
     if (!get64(nc) || !get64(np) || !get64(no)) { *err = "Binary parse error"; return false; }
+    // untrusted header: a camera costs 8 + 72 bytes, a point 24, an observation 24 -- reject counts the file cannot hold
+    const uint64_t left = (uint64_t)(buf.size() - pos);
+    if (nc > left / 80 || np > left / 24 || no > left / 24) { *err = "Binary parse error: header counts exceed the file size"; return false; }
     g.stride = 9;
     g.n_cam = (int64_t)nc; g.n_pts = (int64_t)np;
     g.row_ptr.assign(1, 0);

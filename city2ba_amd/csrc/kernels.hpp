@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(kBlock) void k_occlusion_bvh(const double *__restri
                                                          const uint32_t *__restrict__ cam_idx,
                                                          const uint32_t *__restrict__ pt_idx, int64_t n,
                                                          const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
-                                                         uint8_t *__restrict__ keep) {
+                                                         uint8_t *__restrict__ keep, uint32_t *__restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const double *c = camblk + (int64_t)cam_idx[i] * kCamBlk + kCenter;
@@ -1363,7 +1363,9 @@ __global__ __launch_bounds__(kBlock) void k_occlusion_bvh(const double *__restri
             if (other >= 0) {
                 // both children are inner nodes: nearer first
                 if (t1 < t0) { const int tmp = next; next = other; other = tmp; }
-                if (sp < kBvhStack) stack[sp++] = other;
+                // a hierarchy deeper than the stack (never one built by c2b_bvh_build, which refuses them) would lose
+                // this subtree: say so instead of answering wrongly -- the caller must treat the whole mask as invalid
+                if (sp < kBvhStack) stack[sp++] = other; else *overflow = 1u;
             }
             node = next;
         } else {

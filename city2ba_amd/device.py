@@ -162,9 +162,14 @@ class OcclusionBVH:
         self.tris = torch.from_numpy(tris).to(device)
 
     def filter(self, camblk, pts4, cam_idx, pt_idx, keep):
+        """keep[i] = 1 iff observation i's ray reaches its point unoccluded.  Raises if a traversal overflowed its
+        stack (only possible for node arrays not made by c2b_bvh_build): the mask would be wrong."""
+        overflow = torch.zeros(1, dtype=torch.int32, device=keep.device)
         L.check(L.lib().c2b_occlusion_filter_bvh(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), cam_idx.shape[0],
                                                  _p(self.nodes), self.n_nodes, _p(self.tris), self.n_slots, _p(keep),
-                                                 _stream()))
+                                                 _p(overflow), _stream()))
+        if int(overflow.item()):
+            raise L.City2baError(L.ERR_INVALID_ARGUMENT, "occlusion_filter_bvh: hierarchy deeper than the traversal stack")
 
 
 def stats(camblk, pts4, ws, out=None):

@@ -161,7 +161,10 @@ int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_
  * over host triangles; c2b_bvh_copy fills host buffers of n_nodes * C2B_BVH_NODE_BYTES and n_slots *
  * C2B_BVH_TRI_BYTES bytes (and, optionally, order[n_slots] = input triangle of each slot) for the caller to place
  * in device memory (16-byte aligned); c2b_occlusion_filter_bvh traverses them.  Leaves run the triangle test of
- * c2b_occlusion_filter, so both filters return the same mask. */
+ * c2b_occlusion_filter, so both filters return the same mask.  overflow (device, one word, zeroed by the caller) is
+ * set to 1 if a ray's traversal needed more than the 64-entry stack -- impossible for a hierarchy from c2b_bvh_build
+ * (which refuses deeper ones), possible for caller-made node arrays; the mask is then invalid.  Level 1 turns a set
+ * flag into C2B_ERR_INVALID_ARGUMENT. */
 #define C2B_BVH_NODE_BYTES 64
 #define C2B_BVH_TRI_BYTES 48
 typedef struct c2b_bvh c2b_bvh;
@@ -171,7 +174,7 @@ int c2b_bvh_copy(const c2b_bvh *b, void *nodes, void *tris, uint32_t *order);
 void c2b_bvh_free(c2b_bvh *b);
 int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                              const uint32_t *pt_idx, int64_t n_obs, const void *nodes, int64_t n_nodes,
-                             const void *tris, int64_t n_slots, uint8_t *keep, void *stream);
+                             const void *tris, int64_t n_slots, uint8_t *keep, uint32_t *overflow, void *stream);
 
 /* BAProblem::mean/std/extent/dimensions (src/baproblem.rs:282-337) + add_drift's origin
  * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES]. */

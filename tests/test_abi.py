@@ -3,6 +3,7 @@ declares, binds with the declared signatures, and refuses to compute without a d
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -105,3 +106,26 @@ def test_workspace_and_partition_host_helpers(c2b):
             assert max(per) <= int(row_ptr[-1]) / parts + counts.max()
     assert L.c2b_partition_cameras(None, 3, 2, None) == -1
     assert b"partition_cameras" in L.c2b_last_error()
+
+
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+
+
+def test_product_library_has_no_tuning_hooks_and_no_undeclared_entry_points(c2b):
+    """kernel-variant selectors and timing-only ablations (whose outputs are wrong by construction) live
+    in libcity2ba_hip_tune.so only; every c2b_* symbol the product library exports is declared in the public header."""
+    import re
+    import __graft_entry__ as entry
+    header = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    declared = set(re.findall(r"\b(c2b_[a-z0-9_]+)\s*\(", header))
+    product = {s for s in _exported(entry.build_hip()) if s.startswith("c2b_")}
+    assert not [s for s in product if "tune" in s], "tuning hooks in the product library"
+    assert product <= declared, sorted(product - declared)
+    assert declared <= product, sorted(declared - product)
+    tune = {s for s in _exported(entry.build_tune()) if s.startswith("c2b_")}
+    assert {"c2b_tune_set_jacobian_variant", "c2b_tune_set_observation_variant"} <= tune
+    # nothing in the package, the tests' product fixtures or the bench refers to the tuning library
+    for rel in ("city2ba_amd/_lib.py", "city2ba_amd/device.py", "city2ba_amd/baproblem.py", "bench.py"):
+        assert "tune" not in open(os.path.join(ROOT, rel)).read(), rel

@@ -292,3 +292,54 @@ def test_cli_ply(c2b, cli, tmp_path):                       # run_ply, src/bin/c
     e = np.array([[int(x) for x in ln.split()] for ln in body[nc + npt:-1]])
     ci = np.repeat(np.arange(nc), np.diff(ba.row_ptr.astype(np.int64)))
     assert np.array_equal(e[:, 0], ci) and np.array_equal(e[:, 1], ba.pt_idx.astype(np.int64) + nc)
+
+
+def test_bvh_stack_overflow_is_flagged_not_silent(c2b):
+    """a hierarchy deeper than the 64-entry traversal stack (never one from c2b_bvh_build, which refuses
+    them -- but Level 0 takes caller-made node arrays) used to lose subtrees silently.  A comb of 70 levels whose two
+    children are both inner nodes with identical boxes makes the traversal push one entry per level: the kernel must
+    raise the overflow flag, and the Python wrapper turns it into an error."""
+    import torch
+    from city2ba_amd import device as D
+    from city2ba_amd import _lib as L
+    dev = torch.device("cuda", 0)
+    cams = O.camera_from_bal([0, 0, 0, 0, 0, 5.0, 1.0, 0, 0]).reshape(1, 15)       # centre (0, 0, -5)
+    pts = np.array([[0.0, 0.0, 5.0], [0.1, 0.1, 4.0]])
+    camblk = D.cameras_prepare_state(torch.from_numpy(cams).to(dev))
+    pts4 = D.points_pad(torch.from_numpy(pts).to(dev))
+    ci = torch.zeros(2, dtype=torch.int32, device=dev)
+    pi = torch.arange(2, dtype=torch.int32, device=dev)
+    tri = np.array([[100, 100, 100, 101, 100, 100, 100, 101, 100]], dtype=f32)      # far away: never hit
+    good = D.OcclusionBVH(tri, dev)
+
+    def comb(depth):
+        empty = np.int32(-2 ** 31)
+        nodes = np.zeros((2 * depth, 16), dtype=f32)
+        ints = nodes.view(np.int32)
+        box = [-10, -10, -10, 10, 10, 10]
+        for k in range(depth):
+            nodes[k, 0:6] = box
+            nodes[k, 6:12] = box
+            ints[k, 12] = k + 1 if k + 1 < depth else empty                        # child 0: the next comb node
+            ints[k, 13] = depth + k                                                 # child 1: a dead end (pushed)
+            nodes[depth + k, 0:12] = box + box
+            ints[depth + k, 12] = empty
+            ints[depth + k, 13] = empty
+        return nodes
+
+    for depth, expect_overflow in ((40, False), (70, True)):
+        bvh = D.OcclusionBVH(tri, dev)
+        nodes = comb(depth)
+        bvh.nodes = torch.from_numpy(nodes).to(dev)
+        bvh.n_nodes = len(nodes)
+        keep = torch.full((2,), 7, dtype=torch.uint8, device=dev)
+        if expect_overflow:
+            with pytest.raises(L.City2baError) as ei:
+                bvh.filter(camblk, pts4, ci, pi, keep)
+            assert ei.value.status == L.ERR_INVALID_ARGUMENT and "traversal stack" in str(ei.value)
+        else:
+            bvh.filter(camblk, pts4, ci, pi, keep)
+            assert keep.tolist() == [1, 1]                                          # nothing in the comb occludes
+    keep = torch.full((2,), 7, dtype=torch.uint8, device=dev)
+    good.filter(camblk, pts4, ci, pi, keep)
+    assert keep.tolist() == [1, 1]

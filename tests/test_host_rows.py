@@ -336,6 +336,30 @@ def test_text_reader_accepts_canonical_bal_layout(tmp_path):
     assert np.array_equal(uv, [[-0.1, 2], [5, 6], [0.5, 0.25], [3, 4]])
 
 
+def test_hostile_headers_are_status_codes_not_aborts(tmp_path):
+    """A corrupt header must not size an allocation (std::length_error / bad_alloc crossing the C ABI would abort the
+    host process): counts larger than the file can hold, and counts that overflow u64, are parse errors."""
+    import struct as st
+    cases = {
+        "huge_obs.bal": "1 1 18446744073709551615\n0 0 0.0 0.0\n" + "0 " * 9 + "\n0 0 0\n",
+        "huge_cams.bal": "4611686018427387904 1 1\n0 0 0.0 0.0\n" + "0 " * 9 + "\n0 0 0\n",
+        "wraps.bal": "1 1 99999999999999999999999999\n0 0 0.0 0.0\n",
+        "huge_pts.bal": "1 3074457345618258602 1\n0 0 0.0 0.0\n" + "0 " * 9 + "\n0 0 0\n",
+    }
+    for name, text in cases.items():
+        path = tmp_path / name
+        path.write_text(text)
+        with pytest.raises(L.City2baError) as ei:
+            read_bal(path)
+        assert ei.value.status == -1, name
+    for nc, np_, no in [(2 ** 63, 1, 1), (1, 2 ** 62, 1), (1, 1, 2 ** 61)]:
+        path = tmp_path / "h.bbal"
+        path.write_bytes(st.pack(">QQQ", nc, np_, no) + b"\0" * 200)
+        with pytest.raises(L.City2baError) as ei:
+            read_bal(path)
+        assert ei.value.status == -1
+
+
 def test_file_errors(tmp_path):
     bal9, pts, row_ptr, pt_idx, uv = _small_file_problem()
     with pytest.raises(L.City2baError) as ei:
