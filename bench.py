@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path (process group, side stream, all-reduce) even with one rank: "
+                         "how tests exercise the RCCL backend on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -307,8 +310,10 @@ def main():
     dev_index = 0 if os.environ.get("C2B_SHARE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -316,7 +321,7 @@ def main():
 
     sh = build_shard(args, rank, world, dev)
     bounds = None
-    if world > 1:
+    if dist_on:
         # re-split on the observation prefix sum and rebuild the shard for the balanced range
         bounds = balanced_bounds(sh, rank, world)
         if (int(bounds[rank]), int(bounds[rank + 1])) != (sh["cam_lo"], sh["cam_hi"]):
@@ -343,7 +348,7 @@ def main():
     def step(ev=None):
         k = counter[0] & 1
         counter[0] += 1
-        if world > 1 and reduced[k] is not None:
+        if dist_on and reduced[k] is not None:
             main.wait_event(reduced[k])            # err2[k] is free again (its all-reduce ran a whole step ago)
         if ev is not None:
             ev[0].record()
@@ -351,7 +356,7 @@ def main():
                                 err2[k])
         if ev is not None:
             ev[1].record()
-        if world == 1:
+        if not dist_on:
             return
         produced = ev[1] if ev is not None else produced_ev[k]      # the kernel-end timing event doubles as hand-off
         if ev is None:
@@ -365,7 +370,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     events = None
@@ -375,18 +380,18 @@ def main():
     for k in range(args.steps):
         step(events[k] if events is not None else None)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     last = (counter[0] - 1) & 1
     total_err = Dist.finish_error(err2[last].item(), 2.0)
     per_rank_obs = [n]
-    if world > 1:
+    if dist_on:
         per_rank_obs = [None] * world
         dist.all_gather_object(per_rank_obs, n)
 
@@ -415,6 +420,7 @@ def main():
                 "observations_per_rank": [int(x) for x in per_rank_obs],
                 "camera_bounds": [int(x) for x in bounds] if bounds is not None else [0, sh["n_cam"]],
                 "total_L2_error": total_err,
+                "collective": ("%s all_reduce(sum, 1 x f64) per step on a side stream" % backend) if dist_on else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": KERNEL_NAME, "achieved": round(achieved, 1),
@@ -440,7 +446,7 @@ def main():
             out["other_configs"] = other_configs(dev)
             out["other_configs"]["blocks128_uniform_random_point_gather"] = adversarial_gather(sh, r, Jc, Jp, ws)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

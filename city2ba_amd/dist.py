@@ -59,9 +59,10 @@ def exclusive_offset(count, group=None):
 
 
 def all_reduce_sum_(t, group=None):
-    """In-place sum all-reduce of a (1-element) tensor; a no-op for a single process."""
+    """In-place sum all-reduce of a (1-element) tensor; a no-op without a process group.  With a group of one rank
+    the collective is still issued (that is how the RCCL path is exercised on a 1-GPU box)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         if t.is_cuda and dist.get_backend(group) != "nccl":
             # gloo (single-GPU rehearsal of the multi-rank path): stage the scalar through the host
             h = t.cpu()
