@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group, side stream, all-reduce) even with one rank: "
                          "how tests exercise the RCCL backend on a 1-GPU box")
@@ -115,67 +115,52 @@ def algorithmic_bytes(n_obs, n_cam, n_pts):
 
 
 def cpu_baseline(sh, seconds):
-    """The oracle (C restatement of the reference CPU path + its Jacobian), one thread, on a camera-range
-    prefix of the same workload.  Baseline, not target."""
+    """The oracle (C restatement of the reference CPU path + its Jacobian) on this box's host cores, timed inside C
+    (oracle.bench_run; no Python in the loop).  Two storage layouts -- "faithful" = the reference's
+    Vec<Vec<(usize,(f64,f64))>> with powf per error term (src/baproblem.rs:256-279), "optimised" = flat CSR -- each on one
+    thread (a 2 M-observation prefix of the grid) and on all cores (the WHOLE grid, pthreads over equal contiguous camera
+    ranges like rayon's par_iter over cameras, src/synthetic.rs:268-269).  Flat keys: `value` is the faithful
+    single-thread figure.  Baseline, not target."""
     import numpy as np
     import oracle as O
     cam_idx = sh["cam_idx"].cpu().numpy().astype(np.int64)
-    target = min(len(cam_idx), 2_000_000)
-    c_end = int(cam_idx[target - 1]) + 1
-    n = int(np.searchsorted(cam_idx, c_end, side="left"))
-    counts = np.bincount(cam_idx[:n], minlength=c_end)
-    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
-    pt_idx = sh["pt_idx"][:n].cpu().numpy().astype(np.uint64)
-    uv = sh["uv"][:n].cpu().numpy()
-    cams15 = sh["cam15"][:c_end].cpu().numpy()
+    n_all, n_cam = len(cam_idx), sh["n_cam_local"]
+    row_ptr = np.concatenate([[0], np.cumsum(np.bincount(cam_idx, minlength=n_cam))]).astype(np.uint64)
+    pt_idx = sh["pt_idx"].cpu().numpy().astype(np.uint64)
+    uv = sh["uv"].cpu().numpy()
+    cams15 = sh["cam15"].cpu().numpy()
     pts = np.ascontiguousarray(sh["pts_host"])
-    r, Jc, Jp = np.empty((n, 2)), np.empty((n, 18)), np.empty((n, 6))
+    r, Jc, Jp = np.empty((n_all, 2)), np.empty((n_all, 18)), np.empty((n_all, 6))
+    cores = max(1, os.cpu_count() or 1)
+    # prefix of whole cameras holding ~2 M observations for the single-thread legs
+    c_end = int(np.searchsorted(row_ptr, min(n_all, 2_000_000), side="left"))
+    c_end = max(1, min(c_end, n_cam))
+    n1 = int(row_ptr[c_end])
     O.lib()
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        O.bench_residual_jacobian(cams15, pts, row_ptr, pt_idx, uv, r, Jc, Jp)
-        passes += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or passes >= 200:
-            break
-    one = {"value": round(n * passes / el / 1e6, 4), "unit": "Mobs/s", "cores": 1, "kind": "port",
-           "sample": "oracle/ C restatement (orc_bench_residual_jacobian: project + 2x12 Jacobian + L2 sum), "
-                     "first %d cameras / %d observations of the same grid, %d passes in %.1f s, 1 thread"
-                     % (c_end, n, passes, el)}
-    # "faithful-NT" of BASELINE.md: threads over contiguous camera ranges (static split), like rayon's par_iter over
-    # cameras in the reference's visibility loops; ctypes releases the GIL so plain threads suffice.
-    try:
-        from concurrent.futures import ThreadPoolExecutor
-        cores = max(1, os.cpu_count() or 1)
-        cuts = [c_end * k // cores for k in range(cores + 1)]
+    out = {"unit": "Mobs/s", "cores": 1, "kind": "port"}
 
-        def work(k):
-            lo, hi = cuts[k], cuts[k + 1]
-            a, b = int(row_ptr[lo]), int(row_ptr[hi])
-            if b == a:
-                return 0
-            O.bench_residual_jacobian(cams15[lo:hi], pts, (row_ptr[lo:hi + 1] - row_ptr[lo]).astype(np.uint64),
-                                      pt_idx[a:b], uv[a:b], r[a:b], Jc[a:b], Jp[a:b])
-            return b - a
-        reps, t0 = 0, time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            while True:
-                done = sum(ex.map(work, range(cores)))
-                reps += 1
-                el2 = time.perf_counter() - t0
-                if el2 >= max(2.0, seconds / 4) or reps >= 200:
-                    break
-        one["all_cores"] = {"value": round(done * reps / el2 / 1e6, 3), "unit": "Mobs/s", "cores": cores,
-                            "sample": "same sample, %d threads over contiguous camera ranges, %d passes in %.1f s"
-                                      % (cores, reps, el2)}
-    except Exception as exc:                      # the baseline is informational; never fail the bench on it
-        one["all_cores"] = {"error": str(exc)}
+    def leg(layout, threads, budget, whole):
+        ce, n = (n_cam, n_all) if whole else (c_end, n1)
+        args = (cams15[:ce], pts, row_ptr[:ce + 1], pt_idx[:n], uv[:n], r[:n], Jc[:n], Jp[:n])
+        O.bench_run(layout, threads, 0.0, *args, max_passes=1)            # touch the output pages once, untimed
+        passes, el, _ = O.bench_run(layout, threads, budget, *args)
+        return round(n * passes / el / 1e6, 3), "%d cameras / %d observations, %d passes in %.1f s, %d thread%s" % (
+            ce, n, passes, el, threads, "" if threads == 1 else "s")
+
+    out["value"], s1 = leg("faithful", 1, seconds * 0.4, False)
+    out["value_all_cores"], sa = leg("faithful", cores, seconds * 0.2, True)
+    out["cores_all"] = cores
+    out["value_optimised_1t"], so1 = leg("optimised", 1, seconds * 0.2, False)
+    out["value_optimised_all_cores"], soa = leg("optimised", cores, seconds * 0.2, True)
+    out["sample"] = ("oracle/ C restatement of project + 2x12 Jacobian + L2 sum on the same grid, timed inside C; faithful "
+                     "layout = Vec<Vec<(usize,(f64,f64))>> + powf per term: 1 thread: %s; all cores: %s.  optimised "
+                     "(flat CSR) layout: 1 thread: %s; all cores: %s" % (s1, sa, so1, soa))
     try:
         with open("/proc/cpuinfo") as fh:
-            one["cpu_model"] = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
+            out["cpu_model"] = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
     except Exception:
-        one["cpu_model"] = None
-    return one
+        out["cpu_model"] = None
+    return out
 
 
 def other_configs(dev):

@@ -81,6 +81,10 @@ def lib():
     sig("orc_add_noise", None, _dp, _i64, _dp, _i64, _dp, _i64, _u64, _d, _d, _d, _d, _u64)
     sig("orc_add_sin_noise", None, _dp, _i64, _dp, _i64, _dp, _dp, _d, _d)
     sig("orc_bench_residual_jacobian", _d, _dp, _i64, _dp, _u64p, _u64p, _dp, _dp, _dp, _dp)
+    sig("orc_visgraph_from_csr", C.c_void_p, _i64, _u64p, _u64p, _dp)
+    sig("orc_visgraph_free", None, C.c_void_p)
+    sig("orc_bench_run", _i64, C.c_int, C.c_int, _d, _i64, _dp, _i64, _dp, _u64p, _u64p, _dp, C.c_void_p, _d, _dp, _dp, _dp,
+        C.POINTER(_d), C.POINTER(_d))
     _lib = L
     return L
 
@@ -269,6 +273,29 @@ def bench_residual_jacobian(cams15, pts, row_ptr, pt_idx, uv, r, Jc, Jp):
     row_ptr, pt_idx = _csr(row_ptr, pt_idx)
     return lib().orc_bench_residual_jacobian(cams15, len(cams15), _f(pts), row_ptr, pt_idx,
                                              _f(uv), r, Jc, Jp)
+
+
+def bench_run(layout, threads, seconds, cams15, pts, row_ptr, pt_idx, uv, r, Jc, Jp, norm=2.0, max_passes=1000):
+    """bench.py's cpu_baseline leg: whole passes of residual + Jacobian + error sum over the given cameras, timed inside
+    C.  layout "faithful" = the reference's Vec<Vec<(usize,(f64,f64))>> storage and powf per term, "optimised" = flat
+    CSR; threads = pthreads over equal contiguous camera ranges.  Returns (passes, seconds, error_sum)."""
+    cams15 = _f(cams15).reshape(-1, 15); pts = _f(pts).reshape(-1, 3)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64); pt_idx = np.ascontiguousarray(pt_idx, dtype=np.uint64)
+    uv = _f(uv)
+    L = lib()
+    graph = None
+    if layout == "faithful":
+        graph = L.orc_visgraph_from_csr(len(cams15), row_ptr, pt_idx, uv)
+        assert graph, "out of memory building the Vec<Vec<>> graph"
+    el, tot = _d(0.0), _d(0.0)
+    try:
+        passes = L.orc_bench_run(0 if layout == "faithful" else 1, int(threads), float(seconds), int(max_passes), cams15,
+                                 len(cams15), pts, row_ptr, pt_idx, uv, graph, float(norm), r, Jc, Jp, C.byref(el), C.byref(tot))
+    finally:
+        if graph:
+            L.orc_visgraph_free(graph)
+    assert passes > 0
+    return int(passes), el.value, tot.value
 
 
 def mean(cams15, pts):

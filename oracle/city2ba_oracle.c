@@ -811,3 +811,134 @@ double orc_bench_residual_jacobian(const double *cams15, int64_t n_cam, const do
     }
     return total;
 }
+
+/* ------------------------------------------------------------------ */
+/* CPU baselines of bench.py (cpu_baseline leg only).  Timed INSIDE C  */
+/* so that no Python dispatch is in the numbers.                       */
+/*                                                                     */
+/* layout 0 "faithful": the reference's own storage -- vis_graph is    */
+/*   Vec<Vec<(usize, (f64, f64))>> (src/baproblem.rs:256-260): one heap */
+/*   allocation per camera holding 24-byte AoS records -- walked        */
+/*   camera-major with sequential per-camera sums and                   */
+/*   abs().powf(norm) per term like total_reprojection_error            */
+/*   (:265-279).  The Jacobian has no reference implementation; it is   */
+/*   the oracle's closed form in both layouts.                          */
+/* layout 1 "optimised-CPU": flat CSR arrays, r*r instead of pow.       */
+/* threads > 1: contiguous camera ranges of equal camera count, one     */
+/*   pthread each -- the static split rayon's par_iter makes over       */
+/*   cameras in the reference's visibility loops                        */
+/*   (src/synthetic.rs:268-269, src/generate.rs:434-435).               */
+/* ------------------------------------------------------------------ */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct { uint64_t idx; double u, v; } orc_obs_t;              /* (usize, (f64, f64)) */
+typedef struct { orc_obs_t *data; size_t len; } orc_obsvec_t;         /* Vec<(usize, (f64, f64))> */
+typedef struct { int64_t n_cam; orc_obsvec_t *rows; } orc_visgraph_t; /* Vec<Vec<..>> */
+
+orc_visgraph_t *orc_visgraph_from_csr(int64_t n_cam, const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
+    orc_visgraph_t *g = (orc_visgraph_t *)malloc(sizeof *g);
+    if (!g) return NULL;
+    g->n_cam = n_cam;
+    g->rows = (orc_obsvec_t *)calloc((size_t)(n_cam > 0 ? n_cam : 1), sizeof *g->rows);
+    if (!g->rows) { free(g); return NULL; }
+    for (int64_t c = 0; c < n_cam; ++c) {
+        const size_t len = (size_t)(row_ptr[c + 1] - row_ptr[c]);
+        g->rows[c].len = len;
+        g->rows[c].data = (orc_obs_t *)malloc((len ? len : 1) * sizeof(orc_obs_t));   /* one allocation per camera */
+        if (!g->rows[c].data) { g->rows[c].len = 0; continue; }
+        for (size_t k = 0; k < len; ++k) {
+            const uint64_t o = row_ptr[c] + k;
+            g->rows[c].data[k].idx = pt_idx[o];
+            g->rows[c].data[k].u = uv[2 * o];
+            g->rows[c].data[k].v = uv[2 * o + 1];
+        }
+    }
+    return g;
+}
+
+void orc_visgraph_free(orc_visgraph_t *g) {
+    if (!g) return;
+    for (int64_t c = 0; c < g->n_cam; ++c) free(g->rows[c].data);
+    free(g->rows);
+    free(g);
+}
+
+typedef struct {
+    int layout;
+    const double *cams15, *pts, *uv;
+    const uint64_t *row_ptr, *pt_idx;
+    const orc_visgraph_t *graph;
+    double norm;
+    double *r, *Jc, *Jp;
+    int64_t c0, c1;
+    double total;
+} orc_job_t;
+
+static void *orc_bench_range(void *arg) {
+    orc_job_t *j = (orc_job_t *)arg;
+    double total = 0.0;
+    for (int64_t c = j->c0; c < j->c1; ++c) {
+        const double *cam = &j->cams15[15 * c];
+        double cam_sum = 0.0, w[3];
+        orc_to_rodrigues(cam, w);
+        const uint64_t o0 = j->row_ptr[c];
+        if (j->layout == 0) {
+            const orc_obsvec_t *row = &j->graph->rows[c];
+            for (size_t k = 0; k < row->len; ++k) {
+                const uint64_t o = o0 + k;
+                const double ob[2] = { row->data[k].u, row->data[k].v };
+                orc_residual_jacobian_one(cam, w, &j->pts[3 * row->data[k].idx], ob, &j->r[2 * o], &j->Jc[18 * o], &j->Jp[6 * o]);
+                cam_sum += pow(fabs(j->r[2 * o]), j->norm) + pow(fabs(j->r[2 * o + 1]), j->norm);
+            }
+        } else {
+            for (uint64_t o = o0; o < j->row_ptr[c + 1]; ++o) {
+                orc_residual_jacobian_one(cam, w, &j->pts[3 * j->pt_idx[o]], &j->uv[2 * o], &j->r[2 * o], &j->Jc[18 * o], &j->Jp[6 * o]);
+                cam_sum += j->r[2 * o] * j->r[2 * o] + j->r[2 * o + 1] * j->r[2 * o + 1];
+            }
+        }
+        total += cam_sum;
+    }
+    j->total = total;
+    return NULL;
+}
+
+/* Runs whole passes over cameras [0, n_cam) until `seconds` have elapsed (at least one, at most max_passes); returns
+ * the number of passes, *elapsed the wall time of exactly those passes, *total the reduced error sum of the last one. */
+int64_t orc_bench_run(int layout, int threads, double seconds, int64_t max_passes, const double *cams15, int64_t n_cam,
+                      const double *pts, const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv,
+                      const orc_visgraph_t *graph, double norm, double *r, double *Jc, double *Jp, double *elapsed,
+                      double *total) {
+    if (threads < 1) threads = 1;
+    if (threads > n_cam && n_cam > 0) threads = (int)n_cam;
+    orc_job_t *jobs = (orc_job_t *)calloc((size_t)threads, sizeof *jobs);
+    pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof *tids);
+    if (!jobs || !tids) { free(jobs); free(tids); return -1; }
+    for (int t = 0; t < threads; ++t) {
+        orc_job_t j = { layout, cams15, pts, uv, row_ptr, pt_idx, graph, norm, r, Jc, Jp,
+                        n_cam * t / threads, n_cam * (t + 1) / threads, 0.0 };
+        jobs[t] = j;
+    }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int64_t passes = 0;
+    double el = 0.0, sum = 0.0;
+    do {
+        if (threads == 1) {
+            orc_bench_range(&jobs[0]);
+        } else {
+            for (int t = 0; t < threads; ++t) pthread_create(&tids[t], NULL, orc_bench_range, &jobs[t]);
+            for (int t = 0; t < threads; ++t) pthread_join(tids[t], NULL);
+        }
+        sum = 0.0;
+        for (int t = 0; t < threads; ++t) sum += jobs[t].total;
+        ++passes;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    } while (el < seconds && passes < max_passes);
+    *elapsed = el;
+    *total = sum;
+    free(jobs);
+    free(tids);
+    return passes;
+}

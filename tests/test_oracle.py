@@ -247,3 +247,20 @@ def test_occlusion_filter_wall_and_float64_agreement():
             assert keep[k] == (0 if hit else 1)
             checked += 1
     assert checked > 300 and 0 < keep.sum() < 400
+
+
+def test_cpu_baseline_runner_layouts_and_threads_agree():
+    """bench.py's cpu_baseline leg (oracle.bench_run): the reference-shaped Vec<Vec<>> layout and the flat CSR layout, on
+    one thread and on several, all write the same residuals / Jacobians as the plain oracle and reduce the same sum."""
+    P = random_problem(257, 3000, 11, seed=21, noise=1e-2, empty_every=7)
+    n = len(P["pt_idx"])
+    r0, Jc0, Jp0 = O.residual_jacobian(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    want = O.reprojection_error_sum(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], 2.0)
+    for layout in ("faithful", "optimised"):
+        for threads in (1, 3, 8):
+            r, Jc, Jp = np.full((n, 2), np.nan), np.full((n, 18), np.nan), np.full((n, 6), np.nan)
+            passes, el, tot = O.bench_run(layout, threads, 0.0, P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"],
+                                          r, Jc, Jp, max_passes=1)
+            assert passes == 1 and el > 0
+            assert np.array_equal(r, r0) and np.array_equal(Jc, Jc0.reshape(n, 18)) and np.array_equal(Jp, Jp0.reshape(n, 6))
+            assert abs(tot - want) <= 1e-12 * want
