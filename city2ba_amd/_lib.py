@@ -46,6 +46,8 @@ SIGNATURES = {
     "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp]),
     "c2b_error_sum_finish": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_residual_jacobian_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "c2b_host_alloc": (_int, [C.POINTER(_vp), _i64]),
+    "c2b_host_free": (None, [_vp]),
     "c2b_calib_store_pattern": (_int, [_i64, _vp, _vp, _vp, _vp]),
     "c2b_calib_copy": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),

@@ -156,11 +156,21 @@ class BAProblem:
         L.check(L.lib().c2b_problem_total_reprojection_error(self._h, float(norm), C.byref(out)))
         return out.value
 
-    def residual_jacobian(self):
-        """r [n,2], Jc [n,2,9] (w t f k1 k2 columns), Jp [n,2,3].  Build-defined: the reference has
-        no Jacobian."""
+    def residual_jacobian(self, out=None, pinned=False):
+        """r [n,2], Jc [n,2,9] (w t f k1 k2 columns), Jp [n,2,3].  Build-defined: the reference has no Jacobian.
+        out = (r, Jc, Jp) reuses the caller's arrays; pinned=True returns arrays in page-locked memory
+        (pinned_empty), which receive the results at PCIe speed -- keep them and pass them back as `out` when
+        calling repeatedly."""
         n = self.num_observations()
-        r, Jc, Jp = np.empty((n, 2)), np.empty((n, 2, 9)), np.empty((n, 2, 3))
+        if out is not None:
+            r, Jc, Jp = out
+            for a, shape in ((r, (n, 2)), (Jc, (n, 2, 9)), (Jp, (n, 2, 3))):
+                if a.dtype != np.float64 or a.shape != shape or not a.flags.c_contiguous:
+                    raise L.City2baError(L.ERR_INVALID_ARGUMENT, "residual_jacobian: out arrays must be C-contiguous float64 of shapes (n,2), (n,2,9), (n,2,3)")
+        elif pinned:
+            r, Jc, Jp = pinned_empty((n, 2)), pinned_empty((n, 2, 9)), pinned_empty((n, 2, 3))
+        else:
+            r, Jc, Jp = np.empty((n, 2)), np.empty((n, 2, 9)), np.empty((n, 2, 3))
         L.check(L.lib().c2b_problem_residual_jacobian(self._h, _ptr(r), _ptr(Jc), _ptr(Jp)))
         return r, Jc, Jp
 
@@ -341,6 +351,33 @@ class BAProblem:
         uv = np.empty((n, 2))
         L.check(L.lib().c2b_problem_visibility_dense_fetch(self._h, _ptr(kept), _ptr(uv)))
         return row_ptr, kept, uv
+
+
+class _PinnedBlock:
+    """owner of one c2b_host_alloc block; arrays made from it keep it alive through their .base chain"""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        L.check(L.lib().c2b_host_alloc(C.byref(self.ptr), self.nbytes))
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr.value or 0, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                L.lib().c2b_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """np.empty in page-locked host memory (c2b_host_alloc): the destination that takes device results at link speed"""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    if n == 0:
+        return np.empty(shape, dtype=dtype)
+    return np.asarray(_PinnedBlock(n)).view(dtype).reshape(shape)
 
 
 # ---- host-array helpers over the C ABI (no GPU involved) ------------------------------------------------

@@ -1405,6 +1405,12 @@ struct c2b_problem {
     double *dense_uv = nullptr;
     uint64_t *dense_row = nullptr;  // its CSR row pointer [n_cam + 1], kept for the occlusion filter
     int64_t dense_n = 0;
+    // residual + Jacobian to host buffers: a ring of chunk-sized device buffers, a copy stream, per-slot events
+    static constexpr int kJacSlots = 3;
+    static constexpr int64_t kJacChunk = 256 * 1024;       // observations per chunk (53 MB of results)
+    double *jac_ring = nullptr;                            // kJacSlots x kJacChunk x 26 doubles
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_done[kJacSlots] = {nullptr, nullptr, nullptr}, ev_free[kJacSlots] = {nullptr, nullptr, nullptr};
 };
 
 static void free_dense(c2b_problem *p) {
@@ -1415,8 +1421,9 @@ static void free_dense(c2b_problem *p) {
 }
 
 static void free_buffers(c2b_problem *p) {
-    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar};
+    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar, p->jac_ring};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    p->jac_ring = nullptr;
     free_dense(p);
     p->cam15 = p->bal9 = p->camblk = p->pts4 = p->uv = nullptr;
     p->cam_idx = p->pt_idx = nullptr;
@@ -1448,6 +1455,11 @@ void c2b_problem_destroy(c2b_problem *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     free_buffers(p);
+    for (int k = 0; k < c2b_problem::kJacSlots; ++k) {
+        if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]);
+        if (p->ev_free[k]) (void)hipEventDestroy(p->ev_free[k]);
+    }
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -1681,6 +1693,11 @@ int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *ou
     C2B_API_END("problem_total_reprojection_error")
 }
 
+// Results leave in chunks of kJacChunk observations through a ring of kJacSlots device buffers: the kernel of chunk
+// k + 1 is queued before the copies of chunk k start, copies run on their own stream, so PCIe and the kernel overlap
+// and the device never holds more than the ring (159 MB) whatever the problem size.  Host buffers from
+// c2b_host_alloc (pinned) take the copies at link speed; ordinary pageable memory works too, at the runtime's staged
+// rate.  The ring, the copy stream and the events are created on first use and live as long as the problem.
 int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double *Jp) {
     C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_residual_jacobian");
@@ -1688,28 +1705,61 @@ int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double 
     if (!r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_residual_jacobian: NULL output");
     int rc = ensure_camblk(p);
     if (rc) return rc;
-    double *d_r = nullptr, *d_Jc = nullptr, *d_Jp = nullptr;
-    hipError_t e = hipMalloc((void **)&d_r, sizeof(double) * 2 * p->n_obs);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_Jc, sizeof(double) * 18 * p->n_obs);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_Jp, sizeof(double) * 6 * p->n_obs);
-    if (e == hipSuccess) {
-        rc = c2b_residual_jacobian(p->camblk, p->pts4, p->cam_idx, p->pt_idx, p->uv, p->n_obs, d_r, d_Jc, d_Jp, 2.0,
-                                   nullptr, p->stream);
-        if (!rc) {
-            e = hipMemcpyAsync(r, d_r, sizeof(double) * 2 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(Jc, d_Jc, sizeof(double) * 18 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(Jp, d_Jp, sizeof(double) * 6 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
-        }
-        hipError_t e2 = hipStreamSynchronize(p->stream);
-        if (e == hipSuccess) e = e2;
+    constexpr int kSlots = c2b_problem::kJacSlots;
+    constexpr int64_t kChunk = c2b_problem::kJacChunk;
+    if (!p->jac_ring) HIP_TRY(hipMalloc((void **)&p->jac_ring, sizeof(double) * 26 * (size_t)kChunk * kSlots));
+    if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < kSlots; ++k) {
+        if (!p->ev_done[k]) HIP_TRY(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
+        if (!p->ev_free[k]) HIP_TRY(hipEventCreateWithFlags(&p->ev_free[k], hipEventDisableTiming));
     }
-    if (d_r) (void)hipFree(d_r);
-    if (d_Jc) (void)hipFree(d_Jc);
-    if (d_Jp) (void)hipFree(d_Jp);
+    const int64_t n = p->n_obs, n_chunks = (n + kChunk - 1) / kChunk;
+    auto slot_r = [&](int s) { return p->jac_ring + (size_t)s * 26 * kChunk; };
+    auto slot_Jc = [&](int s) { return slot_r(s) + 2 * kChunk; };
+    auto slot_Jp = [&](int s) { return slot_r(s) + 20 * kChunk; };
+    auto launch = [&](int64_t k) -> int {
+        const int s = (int)(k % kSlots);
+        const int64_t o0 = k * kChunk, m = (n - o0 < kChunk) ? n - o0 : kChunk;
+        if (k >= kSlots) { HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_free[s], 0)); }      // its previous copies are out
+        int rc2 = c2b_residual_jacobian(p->camblk, p->pts4, p->cam_idx + o0, p->pt_idx + o0, p->uv + 2 * o0, m, slot_r(s),
+                                        slot_Jc(s), slot_Jp(s), 2.0, nullptr, p->stream);
+        if (rc2) return rc2;
+        HIP_TRY(hipEventRecord(p->ev_done[s], p->stream));
+        return C2B_OK;
+    };
+    hipError_t e = hipSuccess;
+    rc = launch(0);
+    for (int64_t k = 0; k < n_chunks && !rc && e == hipSuccess; ++k) {
+        if (k + 1 < n_chunks) rc = launch(k + 1);            // queued BEFORE chunk k's copies: they overlap
+        if (rc) break;
+        const int s = (int)(k % kSlots);
+        const int64_t o0 = k * kChunk, m = (n - o0 < kChunk) ? n - o0 : kChunk;
+        e = hipStreamWaitEvent(p->copy_stream, p->ev_done[s], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(r + 2 * o0, slot_r(s), sizeof(double) * 2 * m, hipMemcpyDeviceToHost, p->copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(Jc + 18 * o0, slot_Jc(s), sizeof(double) * 18 * m, hipMemcpyDeviceToHost, p->copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(Jp + 6 * o0, slot_Jp(s), sizeof(double) * 6 * m, hipMemcpyDeviceToHost, p->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(p->ev_free[s], p->copy_stream);
+    }
+    const hipError_t e1 = hipStreamSynchronize(p->copy_stream), e2 = hipStreamSynchronize(p->stream);
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_residual_jacobian: %s", hipGetErrorString(e));
     return C2B_OK;
     C2B_API_END("problem_residual_jacobian")
+}
+
+int c2b_host_alloc(void **ptr, int64_t bytes) {
+    C2B_API_BEGIN
+    if (!ptr || bytes < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "host_alloc: bad arguments");
+    *ptr = nullptr;
+    if (!bytes) return C2B_OK;
+    HIP_TRY(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+    return C2B_OK;
+    C2B_API_END("host_alloc")
+}
+
+void c2b_host_free(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 static int compute_stats(c2b_problem *p) {

@@ -383,8 +383,14 @@ int c2b_problem_centers(c2b_problem *p, double *centers3);
 int c2b_problem_project(c2b_problem *p, double *uv_out);
 int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *out);
 /* Jacobian columns refer to the uploaded 9-vector's w while cameras are unmodified since
- * c2b_problem_upload_bal, otherwise to w = to_rodrigues(R) (what to_vec would write). */
+ * c2b_problem_upload_bal, otherwise to w = to_rodrigues(R) (what to_vec would write).
+ * r [n_obs][2], Jc [n_obs][18], Jp [n_obs][6] are HOST buffers: the results leave the device in chunks whose copies
+ * overlap the kernel of the next chunk.  Buffers from c2b_host_alloc (pinned) receive them at link speed (PCIe);
+ * pageable memory works at the runtime's staged rate (about a third of that). */
 int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double *Jp);
+/* page-locked host memory for buffers that cross PCIe often (hipHostMalloc / hipHostFree) */
+int c2b_host_alloc(void **ptr, int64_t bytes);
+void c2b_host_free(void *ptr);
 int c2b_problem_stats(c2b_problem *p, double *stats /* C2B_STATS_DOUBLES */);
 /* BAProblem::cull (src/baproblem.rs:538-549) of the resident problem, on the device and in place: union-find
  * components, singleton counts and order-preserving renumbering by scans; same result as c2b_cull (same `faithful`

@@ -421,3 +421,39 @@ def test_large_problem_properties(c2b):
     assert np.allclose(r, -shift, rtol=0, atol=1e-12)
     assert np.array_equal(Jc[:m], Jc[m:2 * m]) and np.array_equal(Jp[:m], Jp[-m:])
     assert np.all(np.isfinite(Jc)) and np.all(np.isfinite(Jp))
+
+
+def test_level1_jacobian_leaves_in_chunks_pageable_and_pinned(c2b):
+    """c2b_problem_residual_jacobian streams its results out in 256k-observation chunks through a ring of device
+    buffers (copies overlapped with the next chunk's kernel).  A problem of several chunks, with a ragged last one,
+    into fresh pageable arrays, caller-owned arrays, and page-locked arrays: all equal the oracle's."""
+    from city2ba_amd.baproblem import pinned_empty
+    P = random_problem(700, 30000, 137, seed=31, noise=1e-3)
+    # every camera's observation list repeated 19 times (with different observed uv): 570 000 observations
+    reps, counts = 19, np.diff(P["row_ptr"].astype(np.int64))
+    rng = np.random.default_rng(32)
+    P["pt_idx"] = np.concatenate([np.tile(P["pt_idx"][a:a + k], reps) for a, k in zip(P["row_ptr"][:-1].astype(np.int64), counts)])
+    P["uv"] = np.concatenate([np.tile(P["uv"][a:a + k], (reps, 1)) for a, k in zip(P["row_ptr"][:-1].astype(np.int64), counts)])
+    P["uv"] = P["uv"] + rng.normal(scale=1e-3, size=P["uv"].shape)
+    P["row_ptr"] = np.concatenate([[0], np.cumsum(counts * reps)]).astype(np.uint64)
+    n = len(P["pt_idx"])
+    assert n > 2 * 256 * 1024 and n % (256 * 1024) != 0
+    r0, Jc0, Jp0 = O.residual_jacobian(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    ba = _upload(c2b, P)
+    scale = max(1.0, float(np.max(np.abs(Jc0))))
+    outs = [ba.residual_jacobian(), ba.residual_jacobian(pinned=True)]
+    mine = (np.full((n, 2), np.nan), np.full((n, 2, 9), np.nan), np.full((n, 2, 3), np.nan))
+    outs.append(ba.residual_jacobian(out=mine))
+    assert outs[2][0] is mine[0]
+    pin = (pinned_empty((n, 2)), pinned_empty((n, 2, 9)), pinned_empty((n, 2, 3)))
+    for _ in range(2):                                           # reuse: ring slots and events are recycled
+        outs.append(ba.residual_jacobian(out=pin))
+    for r, Jc, Jp in outs:
+        assert np.array_equal(r, outs[0][0]) and np.array_equal(Jc, outs[0][1]) and np.array_equal(Jp, outs[0][2])
+    r, Jc, Jp = outs[0]
+    assert np.max(np.abs(r - r0)) < 1e-12
+    # 1e-9: this sample holds a camera with |w| = 8e-4, where to_rodrigues(R) (state mode) is worth ~1e-10 relative
+    assert np.max(np.abs(Jc.reshape(n, 18) - Jc0.reshape(n, 18))) / scale < 1e-9
+    assert np.max(np.abs(Jp.reshape(n, 6) - Jp0.reshape(n, 6))) / scale < 1e-9
+    with pytest.raises(c2b.City2baError):
+        ba.residual_jacobian(out=(np.empty((n, 2), dtype=np.float32), mine[1], mine[2]))
