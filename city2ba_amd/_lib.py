@@ -15,7 +15,7 @@ ERR_INDEX_OUT_OF_RANGE = -2
 ERR_HIP = -3
 ERR_OOM = -4
 ERR_NO_DEVICE = -5
-CAMBLK_DOUBLES = 28
+CAMBLK_DOUBLES = 32
 STATS_DOUBLES = 20
 
 _vp = C.c_void_p

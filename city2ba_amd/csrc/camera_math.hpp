@@ -16,7 +16,10 @@ namespace c2b {
 
 #define C2B_DEV __device__ __forceinline__
 
-constexpr int kCamBlk = 28;       // doubles per camblk record (C2B_CAMBLK_DOUBLES)
+// 32 doubles = 256 B = two 128-B lines per record: line 0 holds everything projection needs (R, t, intrinsics: the
+// light kernels read exactly one line per camera when the table is 256-B aligned), line 1 the rest of J_l and the
+// centre.  (28-double records straddled lines: 1.75 lines per camera for the first 128 bytes.)
+constexpr int kCamBlk = 32;       // doubles per camblk record (C2B_CAMBLK_DOUBLES)
 constexpr int kCamHot = 24;       // leading doubles the per-observation kernels stage in LDS
 // camblk offsets
 constexpr int kR = 0, kT = 9, kIntr = 12, kJl = 15, kCenter = 24;
@@ -200,7 +203,9 @@ C2B_DEV void fill_camblk(const double *cam15, double w0, double w1, double w2, d
     left_jacobian(w0, w1, w2, blk + kJl);
     double c[3];
     cm_center(cam15, cam15[9], cam15[10], cam15[11], c);
-    blk[24] = c[0]; blk[25] = c[1]; blk[26] = c[2]; blk[27] = 0.0;
+    blk[24] = c[0]; blk[25] = c[1]; blk[26] = c[2];
+#pragma unroll
+    for (int i = 27; i < kCamBlk; ++i) blk[i] = 0.0;
 }
 
 // ---- per-observation hot path ----------------------------------------------------------
@@ -231,6 +236,32 @@ C2B_DEV double pow4_cr(double x) {
 // one ulp and cannot be reproduced without being glibc -- measured in tests/test_pow4.py).  With
 // k2 = 0 the term is k2 * n^4 = 0 whatever the rounding of n^4, so that (wave-uniform on the generators' cameras)
 // case skips the square root.
+// q1 = a1 / b and q2 = a2 / b, both IEEE-correct and bit-identical to the compiler's own expansion of `/` (the
+// v_div_scale / v_rcp / 4 FMA / v_div_fmas / v_div_fixup sequence, restated with the same builtins in the same order),
+// with the refined reciprocal of the shared denominator computed once: 16 instructions and one v_rcp_f64 instead of 22
+// and two.  v_div_scale's scaled denominator depends on the numerator only in the extreme-exponent cases it exists for;
+// if the two numerators would scale the denominator differently the second quotient takes the ordinary path.
+C2B_DEV void div2_shared(double a1, double a2, double b, double &q1, double &q2) {
+    bool f1, f2, fd;
+    const double d = __builtin_amdgcn_div_scale(a1, b, false, &fd);        // scaled denominator (w.r.t. a1)
+    const double d2 = __builtin_amdgcn_div_scale(a2, b, false, &fd);       // ... w.r.t. a2
+    double r = __builtin_amdgcn_rcp(d);
+    const double e0 = fma(-d, r, 1.0);
+    r = fma(r, e0, r);
+    const double e1 = fma(-d, r, 1.0);
+    r = fma(r, e1, r);
+    const double n1 = __builtin_amdgcn_div_scale(a1, b, true, &f1);        // scaled numerator + the fmas flag
+    const double m1 = n1 * r;
+    q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(fma(-d, m1, n1), r, m1, f1), b, a1);
+    if (__builtin_expect(__double_as_longlong(d2) == __double_as_longlong(d), 1)) {
+        const double n2 = __builtin_amdgcn_div_scale(a2, b, true, &f2);
+        const double m2 = n2 * r;
+        q2 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(fma(-d, m2, n2), r, m2, f2), b, a2);
+    } else {
+        q2 = a2 / b;
+    }
+}
+
 // P is a pointer to double in any address space: a generic pointer, or one typed LDS-only / global-only (lds_cptr /
 // glb_cptr) so that the loads compile to ds_read / global_load and two call sites can never be merged into FLAT loads.
 typedef const __attribute__((address_space(3))) double *lds_cptr;
@@ -242,8 +273,7 @@ C2B_DEV Proj project_obs(P cam, double X, double Y, double Z) {
     p.qx = dot3(cam[0], cam[1], cam[2], X, Y, Z) + cam[9];
     p.qy = dot3(cam[3], cam[4], cam[5], X, Y, Z) + cam[10];
     p.qz = dot3(cam[6], cam[7], cam[8], X, Y, Z) + cam[11];
-    p.px = -p.qx / p.qz;
-    p.py = -p.qy / p.qz;
+    div2_shared(-p.qx, -p.qy, p.qz, p.px, p.py);            // -q.x / q.z, -q.y / q.z (src/baproblem.rs:146)
     p.n = p.px * p.px + p.py * p.py;
     const double k2 = cam[14];
     double n4 = p.n * p.n;

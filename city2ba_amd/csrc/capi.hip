@@ -223,6 +223,10 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
         case 208: launch_obs_v<MODE, 2, 8, false>(C2B_ARGS); return C2B_OK;
         case 1108: launch_obs_v<MODE, 1, 8, true>(C2B_ARGS); return C2B_OK;
         case 1216: launch_obs_v<MODE, 2, 16, true>(C2B_ARGS); return C2B_OK;
+        case 1204: launch_obs_v<MODE, 2, 4, true>(C2B_ARGS); return C2B_OK;
+        case 1202: launch_obs_v<MODE, 2, 2, true>(C2B_ARGS); return C2B_OK;
+        case 1104: launch_obs_v<MODE, 1, 4, true>(C2B_ARGS); return C2B_OK;
+        case 1304: launch_obs_v<MODE, 3, 4, true>(C2B_ARGS); return C2B_OK;
         case 1408: launch_obs_v<MODE, 4, 8, true>(C2B_ARGS); return C2B_OK;
         case 2004: launch_obs_p<MODE, 4>(C2B_ARGS); return C2B_OK;       // persistent pipelined forms (obs_pipeline.hpp)
         case 2008: launch_obs_p<MODE, 8>(C2B_ARGS); return C2B_OK;
@@ -1648,7 +1652,7 @@ int c2b_problem_centers(c2b_problem *p, double *centers3) {
     if (!centers3) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_centers: centers3 is NULL");
     int rc = ensure_camblk(p);
     if (rc) return rc;
-    // camblk rows are 28 doubles; the center sits at [24..26]
+    // camblk rows are C2B_CAMBLK_DOUBLES doubles; the center sits at [24..26]
     HIP_TRY(hipMemcpy2DAsync(centers3, 3 * sizeof(double), p->camblk + kCenter, kCamBlk * sizeof(double),
                              3 * sizeof(double), (size_t)p->n_cam, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observations_p(
     const uint32_t *__restrict__ pt_idx, const double2 *__restrict__ uv_obs, int n, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ block_part,
     unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
-    constexpr int HOT = MODE == MODE_VISIBILITY ? kCamBlk : kCamLight;
+    constexpr int HOT = MODE == MODE_VISIBILITY ? 28 : kCamLight;     // visibility also needs the centre at [24..26]
     constexpr bool UV = MODE == MODE_ERROR;
     __shared__ __attribute__((aligned(16))) double sCamAll[WPB * 128];   // 64 x 16-byte chunks per wave
 

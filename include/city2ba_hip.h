@@ -20,8 +20,9 @@
  *           camera-major: row_ptr[n_cam+1] (u64), pt_idx[n_obs] (u64 host / u32 device),
  *           uv[n_obs][2].  cam_idx[n_obs] (u32) is the COO expansion of row_ptr, i.e. the
  *           camera column of a .bal observation line (src/baproblem.rs:718-722).
- *   camblk  derived per-camera record, C2B_CAMBLK_DOUBLES doubles:
- *           R row-major[9] | t[3] | f,k1,k2 | J_l(w) row-major[9] | center[3] | pad.
+ *   camblk  derived per-camera record, C2B_CAMBLK_DOUBLES doubles (256 bytes; allocate the table 256-byte aligned
+ *           so that a record's first 128-byte line is exactly what projection needs):
+ *           R row-major[9] | t[3] | f,k1,k2 | J_l(w) row-major[9] | center[3] | pad[5].
  *   Jacobian (NOT in the reference; build-defined): residual r = project(project_world(X))
  *           - uv_obs (sign of src/baproblem.rs:273).  Jc[n_obs][2][9] row-major, columns in
  *           to_vec order (w0 w1 w2 t0 t1 t2 f k1 k2); Jp[n_obs][2][3] (d/dX).
@@ -45,7 +46,7 @@ extern "C" {
 #define C2B_ERR_OOM                 -4
 #define C2B_ERR_NO_DEVICE           -5
 
-#define C2B_CAMBLK_DOUBLES 28
+#define C2B_CAMBLK_DOUBLES 32
 #define C2B_STATS_DOUBLES  20  /* mean[3] std[3] min[3] max[3] dim[3] origin[3] origin_idx |std| */
 
 const char *c2b_version(void);

@@ -457,3 +457,39 @@ def test_level1_jacobian_leaves_in_chunks_pageable_and_pinned(c2b):
     assert np.max(np.abs(Jp.reshape(n, 6) - Jp0.reshape(n, 6))) / scale < 1e-9
     with pytest.raises(c2b.City2baError):
         ba.residual_jacobian(out=(np.empty((n, 2), dtype=np.float32), mine[1], mine[2]))
+
+
+def test_shared_reciprocal_division_is_ieee_exact_over_the_whole_exponent_range(c2b):
+    """project() divides -q.x and -q.y by the same q.z (src/baproblem.rs:146); the device computes the refined
+    reciprocal of the scaled denominator once for both (camera_math.hpp: div2_shared).  With an identity camera,
+    f = 1 and no distortion, uv IS the pair of quotients: they must equal the CPU's IEEE divisions bit for bit for
+    operands anywhere in the exponent range -- quotients that are subnormal, that overflow, denominators whose
+    reciprocal is subnormal, numerators that need opposite scalings (the fallback path)."""
+    rng = np.random.default_rng(123)
+    n = 200_000
+    mant = rng.uniform(1.0, 2.0, (n, 3)) * rng.choice([-1.0, 1.0], (n, 3))
+    expo = rng.integers(-1000, 1000, (n, 3))
+    expo[: n // 4] = rng.integers(-60, 60, (n // 4, 3))                   # a quarter in the ordinary range
+    expo[n // 4: n // 2, 2] = rng.integers(-1022, -900, n // 4)           # tiny denominators
+    expo[n // 2: 3 * n // 4, 0] = expo[n // 2: 3 * n // 4, 2] - rng.integers(1000, 1070, n // 4)   # subnormal quotients
+    pts = np.ldexp(mant, np.clip(expo, -1073, 1023))
+    special = np.array([[0.0, 1.0, 2.0], [1.0, 0.0, -3.0], [5e-324, 1.0, 1.0], [1.0, 1.0, 5e-324], [1e308, -1e308, 1e-308],
+                        [1e-308, 1e308, 1e308], [3.0, -7.0, 1.7976931348623157e308], [2.2250738585072014e-308, 1.0, 3.0]])
+    pts = np.vstack([pts, special])
+    cam = O.camera_from_bal([0, 0, 0, 0, 0, 0, 1.0, 0.0, 0.0]).reshape(1, 15)
+    row_ptr = np.array([0, len(pts)], dtype=np.uint64)
+    pt_idx = np.arange(len(pts), dtype=np.uint64)
+    with np.errstate(all="ignore"):
+        want = np.column_stack([-pts[:, 0] / pts[:, 2], -pts[:, 1] / pts[:, 2]])   # numpy = IEEE division
+    want_o = O.project_observations(cam, pts, row_ptr, pt_idx)
+    fin = np.isfinite(want).all(axis=1) & (np.abs(want) < 1e70).all(axis=1)        # beyond that |p|^4 overflows and 0 * inf = NaN
+    assert np.array_equal(want_o[fin].view(np.uint64), want[fin].view(np.uint64))    # the oracle agrees with plain IEEE
+    ba = c2b.BAProblem.from_visibility(cam, pts, row_ptr, pt_idx, np.zeros((len(pts), 2)))
+    got = ba.project()
+    assert np.array_equal(got[fin].view(np.uint64), want[fin].view(np.uint64))
+    assert fin.sum() > 0.5 * len(pts)
+    sub = fin & (np.abs(want[:, 0]) < 2.3e-308) & (want[:, 0] != 0)
+    assert sub.sum() > 1000                                                       # subnormal quotients were exercised
+    # everything, finite or not, equals the oracle's projection (same NaN / inf classes)
+    both_nan = np.isnan(got) & np.isnan(want_o)
+    assert np.array_equal(np.where(both_nan, 0.0, got).view(np.uint64), np.where(both_nan, 0.0, want_o).view(np.uint64))
