@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_NAME = "k_residual_jacobian_w<NORM_2, true, 8, 2, true, 0, 2, true>"     # the launch the roofline object describes
+KERNEL_NAME = "k_residual_jacobian_w<2, true, 8, 2, true, 0, 2, true>"   # <NORM_2, WITH_ERR, WPB, SPLIT, NT, ABL, OPL, LDSCAM>, as rocprofv3 prints it     # the launch the roofline object describes
 
 
 def parse():
@@ -234,7 +234,8 @@ def pmc_traffic():
     try:
         with open(path) as fh:
             j = json.load(fh)
-        if KERNEL_NAME.split("<")[0] not in str(j.get("kernel", "")):
+        profiled = str((j.get("dominant_kernel") or {}).get("name", "")).replace(" ", "")
+        if KERNEL_NAME.split("   ")[0].replace(" ", "") not in profiled:
             return None, None
         return j.get("traffic_bytes_per_launch"), j.get("tag")
     except Exception:

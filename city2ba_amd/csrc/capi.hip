@@ -127,7 +127,7 @@ unsigned *ticket_slot() {
 // Tuning build only (libcity2ba_hip_tune.so, tools/tune_*.py): kernel variants, including timing-only ablations
 // whose outputs are wrong by construction.  None of this exists in the product library.
 int g_jac_variant = 14;
-int g_obs_variant = 1208;
+int g_obs_variant = 308;
 
 template <typename K>
 int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
@@ -189,16 +189,16 @@ void launch_jac_p(const double *camblk, const double *pts4, const uint32_t *cam_
 }
 #endif
 
-// one-shot launch of k_observations<MODE, NK, OPL, WPB, LDSCAM>: one workgroup per WPB * OPL tiles of 64 observations
-template <int MODE, int OPL, int WPB, bool LDSCAM>
+// one-shot launch of k_observations<MODE, NK, OPL, WPB>: one workgroup per WPB * OPL tiles of 64 observations
+template <int MODE, int OPL, int WPB>
 void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
-    const int64_t tiles = ((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL);
+    const int tiles = (int)(((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, LDSCAM>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,       \
+    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,              \
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                               \
-                       reinterpret_cast<const double2 *>(uv_obs), n, tiles, norm, max_dist,                            \
+                       reinterpret_cast<const double2 *>(uv_obs), (int)n, tiles, norm, max_dist,                       \
                        reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum)
     if constexpr (MODE != MODE_ERROR) { C2B_GO(NORM_2); }
     else if (norm == 2.0) C2B_GO(NORM_2);
@@ -219,22 +219,18 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st
 #ifdef C2B_TUNE
     switch (g_obs_variant) {
-        case 108: launch_obs_v<MODE, 1, 8, false>(C2B_ARGS); return C2B_OK;
-        case 208: launch_obs_v<MODE, 2, 8, false>(C2B_ARGS); return C2B_OK;
-        case 1108: launch_obs_v<MODE, 1, 8, true>(C2B_ARGS); return C2B_OK;
-        case 1216: launch_obs_v<MODE, 2, 16, true>(C2B_ARGS); return C2B_OK;
-        case 1204: launch_obs_v<MODE, 2, 4, true>(C2B_ARGS); return C2B_OK;
-        case 1202: launch_obs_v<MODE, 2, 2, true>(C2B_ARGS); return C2B_OK;
-        case 1104: launch_obs_v<MODE, 1, 4, true>(C2B_ARGS); return C2B_OK;
-        case 1304: launch_obs_v<MODE, 3, 4, true>(C2B_ARGS); return C2B_OK;
-        case 1408: launch_obs_v<MODE, 4, 8, true>(C2B_ARGS); return C2B_OK;
+        case 108: launch_obs_v<MODE, 1, 8>(C2B_ARGS); return C2B_OK;
+        case 216: launch_obs_v<MODE, 2, 16>(C2B_ARGS); return C2B_OK;
+        case 204: launch_obs_v<MODE, 2, 4>(C2B_ARGS); return C2B_OK;
+        case 208: launch_obs_v<MODE, 2, 8>(C2B_ARGS); return C2B_OK;
+        case 408: launch_obs_v<MODE, 4, 8>(C2B_ARGS); return C2B_OK;
         case 2004: launch_obs_p<MODE, 4>(C2B_ARGS); return C2B_OK;       // persistent pipelined forms (obs_pipeline.hpp)
         case 2008: launch_obs_p<MODE, 8>(C2B_ARGS); return C2B_OK;
         case 2016: launch_obs_p<MODE, 16>(C2B_ARGS); return C2B_OK;
         default: break;
     }
 #endif
-    launch_obs_v<MODE, 2, 8, true>(C2B_ARGS);                           // shipped
+    launch_obs_v<MODE, 3, 8>(C2B_ARGS);                                 // shipped (308): three tiles of 64 per wave
 #undef C2B_ARGS
     return C2B_OK;
 }

@@ -25,6 +25,8 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kRedBlocks = 1024;     // grid of the entity reductions
 constexpr int kStatRec = 16;         // doubles per stats partial record
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
 // ---- XCD-aware tile map (bijective for any n_tiles; cdna guide T1) -----------------------
 C2B_DEV int64_t xcd_tile(int64_t bid, int64_t n_tiles) {
     const int64_t q = n_tiles >> 3, r = n_tiles & 7;
@@ -235,96 +237,122 @@ enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2 };
 constexpr int kObsWPB = 8;                     // waves per workgroup
 constexpr int kCamLight = 16;
 
-constexpr int kObsOPL = 2;                     // observations per lane (both tiles' loads issued up front)
+constexpr int kObsOPL = 3;                     // observations per lane (all tiles' loads issued up front)
 
 // NK (camera_math.hpp: NORM_1 / NORM_2 / NORM_ANY) fixes the error norm at compile time; MODE_ERROR folds
 // sum |du|^norm + |dv|^norm over ALL observations into out_sum[0] in this one launch (ticket_fold).
-template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, bool LDSCAM = true>
+//
+// These kernels are issue-bound as much as memory-bound (SQ counters, profiles/r02a_light_sq.json: ~240 vector
+// instructions per wave of 128 observations, ~70 % of the SIMD's issue slots with 8 waves resident), so the code
+// around the ~69 f64 operations of a projection is kept lean: 32-bit observation indices (a launch holds < 2^31),
+// loads of lanes past the end clamped to the last observation instead of predicated (only stores are), ONE inlined
+// copy of the arithmetic per tile reading its camera from LDS (lanes whose camera was not staged -- unsorted input,
+// or > kCamW cameras in 128 observations -- are served in extra rounds, one restaged camera at a time).
+C2B_DEV int xcd_tile32(int bid, int n_tiles) {
+    const int q = n_tiles >> 3, r = n_tiles & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB>
 __global__ __launch_bounds__(WPB * 64) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
-    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm, double max_dist,
+    const double2 *__restrict__ uv_obs, int n, int n_btiles, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ block_part,
     unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
-    __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kCamW * kCamLight];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * WPB + wave) * OPL;
-    const int64_t base = wt0 * 64;
+    // per staged camera: R, t, intrinsics (16 doubles) and, for the visibility predicate, the centre (camblk 24..27)
+    constexpr int HOT = MODE == MODE_VISIBILITY ? 20 : kCamLight;
+    constexpr int CH = HOT / 2;                                           // 16-byte chunks per camera
+    __shared__ __attribute__((aligned(16))) double sCamAll[WPB * (kCamW + 1) * HOT];   // + 1: the slow path's slot
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
     double eacc = 0.0;
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
-
-    uint32_t ci[OPL], pi[OPL];
-    double2 ob[OPL];
-    double4 X[OPL];
-    bool valid[OPL];
+        uint32_t ci[OPL], pi[OPL];
+        double2 ob[OPL];
+        double4 X[OPL];
 #pragma unroll
-    for (int t = 0; t < OPL; ++t) {
-        const int64_t o = base + t * 64 + lane;
-        valid[t] = o < n;
-        ci[t] = 0; pi[t] = 0; ob[t] = make_double2(0, 0);
-        if (valid[t]) { ci[t] = cam_idx[o]; pi[t] = pt_idx[o]; }
-        if (MODE == MODE_ERROR && valid[t]) ob[t] = uv_obs[o];
-    }
-#pragma unroll
-    for (int t = 0; t < OPL; ++t) {
-        X[t] = make_double4(0, 0, -1, 0);
-        if (valid[t]) X[t] = pts4[pi[t]];
-    }
-
-    // wave-private camera tile covering both tiles
-    double *sCam = sCamAll + wave * kCamW * kCamLight;
-    const int64_t n_here = n - base < 64 * OPL ? n - base : 64 * OPL;
-    const int last_t = (int)((n_here - 1) >> 6), last_l = (int)((n_here - 1) & 63);
-    uint32_t ci_last = ci[0];
-#pragma unroll
-    for (int t = 0; t < OPL; ++t) if (t == last_t) ci_last = ci[t];
-    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
-    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci_last, last_l, 64));
-    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
-    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
-    for (int ch = lane; ch < (int)n_staged * (kCamLight / 2); ch += 64) {
-        const int k = ch / (kCamLight / 2), j = ch % (kCamLight / 2);
-        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
-        *reinterpret_cast<double2 *>(sCam + k * kCamLight + 2 * j) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-#pragma unroll
-    for (int t = 0; t < OPL; ++t) {
-        const int64_t wave0 = base + t * 64;
-        if (wave0 >= n) break;                                           // wave-uniform
-        const int64_t o = wave0 + lane;
-        double e = 0.0;
-        const uint32_t local = ci[t] - c_first;
-        const bool in_tile = valid[t] && local < n_staged;
-        // wave-uniform fast path reads the camera with ds_read; only the mixed LDS / global fallback needs FLAT loads
-        Proj p;
-        if (LDSCAM && __builtin_amdgcn_ballot_w64(valid[t] && !in_tile) == 0ull) {
-            p = project_obs(sCam + (in_tile ? local : 0u) * kCamLight, X[t].x, X[t].y, X[t].z);
-        } else {
-            const double *cam = in_tile ? (sCam + local * kCamLight) : (camblk + (int64_t)ci[t] * kCamBlk);
-            p = project_obs(cam, X[t].x, X[t].y, X[t].z);
+        for (int t = 0; t < OPL; ++t) {
+            int o = base + t * 64 + lane;
+            o = o < n ? o : n - 1;                                       // clamped, not predicated
+            ci[t] = cam_idx[o];
+            pi[t] = pt_idx[o];
+            if (MODE == MODE_ERROR) ob[t] = uv_obs[o];
         }
-        if (valid[t]) {
+#pragma unroll
+        for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
+
+        // wave-private camera tile covering all OPL tiles: cameras ci[0](lane 0) .. ci[OPL-1](lane 63) on sorted input
+        double *sCam = sCamAll + wave * (kCamW + 1) * HOT;
+        const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
+        const uint32_t c_last = __builtin_amdgcn_readlane(ci[OPL - 1], 63);
+        uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
+        if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
+        for (int ch = lane; ch < (int)n_staged * CH; ch += 64) {
+            const int k = ch / CH, j = ch % CH;
+            const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
+            *reinterpret_cast<d2_t *>(sCam + k * HOT + 2 * j) =
+                *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * kCamBlk + src);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+        for (int t = 0; t < OPL; ++t) {
+            const int tile0 = base + t * 64;
+            if (tile0 >= n) break;                                       // wave-uniform
+            const int o = tile0 + lane;
+            const bool valid = o < n;
+            Proj p;
+            p.qz = 1.0; p.u = 0.0; p.v = 0.0;
+            double gx = 0.0, gy = 0.0, gz = 0.0;
+            // one pass serves every lane whose camera is staged (all of them on camera-major input); leftovers are
+            // served one camera at a time through the extra slot, with the same LDS-only arithmetic
+            uint32_t cf = c_first, ns = n_staged;
+            int slot0 = 0;
+            uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+            for (;;) {
+                const uint32_t local = ci[t] - cf;
+                const bool in = ((todo >> lane) & 1ull) != 0 && local < ns;
+                if (in) {
+                    const lds_cptr cam = (lds_cptr)sCam + (slot0 + local) * HOT;
+                    p = project_obs(cam, X[t].x, X[t].y, X[t].z);
+                    if (MODE == MODE_VISIBILITY) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
+                }
+                todo &= ~__builtin_amdgcn_ballot_w64(in);
+                if (todo == 0) break;
+                cf = __builtin_amdgcn_readlane(ci[t], (int)__builtin_ctzll(todo));
+                ns = 1;
+                slot0 = kCamW;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < CH) {
+                    const int src = lane < kCamLight / 2 ? 2 * lane : kCenter + 2 * (lane - kCamLight / 2);
+                    *reinterpret_cast<d2_t *>(sCam + kCamW * HOT + 2 * lane) =
+                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)cf * kCamBlk + src);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             if (MODE == MODE_VISIBILITY) {
-                // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1
-                const double *g = camblk + (int64_t)ci[t] * kCamBlk + kCenter;
-                const double dx = g[0] - X[t].x, dy = g[1] - X[t].y, dz = g[2] - X[t].z;
+                // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1   (src/synthetic.rs:285-291, src/generate.rs:448-454)
+                const double dx = gx - X[t].x, dy = gy - X[t].y, dz = gz - X[t].z;
                 const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
                 const bool front = dist < max_dist && p.qz <= 0.0;
                 const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
                 const double nan = __longlong_as_double(0x7ff8000000000000LL);
-                uv_out[o] = front ? make_double2(p.u, p.v) : make_double2(nan, nan);
-                keep[o] = k ? 1 : 0;
+                if (valid) {
+                    uv_out[o] = front ? make_double2(p.u, p.v) : make_double2(nan, nan);
+                    keep[o] = k ? 1 : 0;
+                }
             } else if (MODE == MODE_PROJECT) {
-                uv_out[o] = make_double2(p.u, p.v);
+                if (valid) uv_out[o] = make_double2(p.u, p.v);
             } else {
-                e = abs_pow_k<NK>(p.u - ob[t].x, norm) + abs_pow_k<NK>(p.v - ob[t].y, norm);
+                eacc += valid ? abs_pow_k<NK>(p.u - ob[t].x, norm) + abs_pow_k<NK>(p.v - ob[t].y, norm) : 0.0;
             }
         }
-        if (MODE == MODE_ERROR) eacc += e;
-    }
     }
     if (MODE == MODE_ERROR) ticket_fold(wave_sum(eacc), sCamAll, block_part, ticket, out_sum);
 }
@@ -336,7 +364,6 @@ __global__ __launch_bounds__(WPB * 64) void k_observations(
 // partial per tile.  With OPL = 2 each lane carries two observations: both tiles' index / uv loads, then
 // both point gathers, are issued up front, so the second tile's memory latency hides behind the first
 // tile's arithmetic and stores (the index -> gather chain is two dependent round trips per tile otherwise).
-typedef double d2_t __attribute__((ext_vector_type(2)));
 
 template <bool NT>
 C2B_DEV void store16(char *dst, const double2 v) {

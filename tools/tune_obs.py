@@ -20,7 +20,7 @@ from city2ba_amd import device as D  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--blocks", type=int, default=128)
-ap.add_argument("--variants", default="1208,2008,2004,2016")
+ap.add_argument("--variants", default="308,208,408,2008")
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=20)
 a = ap.parse_args()
