@@ -56,7 +56,12 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     e_alone = torch.zeros(1, dtype=torch.float64, device=dev)
     D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, e_alone)
     torch.cuda.synchronize()
-    assert e_fused.item() == e_alone.item()
+    # (the two kernels group observations differently -- 2 vs 3 tiles per wave -- so the sums agree to rounding only)
+    assert abs(e_fused.item() - e_alone.item()) <= 1e-13 * e_alone.item()
+    e_again = torch.zeros(1, dtype=torch.float64, device=dev)
+    D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, e_again)
+    torch.cuda.synchronize()
+    assert e_again.item() == e_alone.item()                    # but each kernel reproduces its own bits
     assert abs(e_fused.item() - float((r * r).sum().item())) / e_fused.item() < 1e-11
 
     # tiling independence at both ends (different tile origin => different wave / XCD assignment)
