@@ -267,6 +267,13 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         case 9: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, false>(C2B_ARGS); return C2B_OK;
         case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, false>(C2B_ARGS); return C2B_OK;     // FLAT camera reads
         case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(C2B_ARGS); return C2B_OK;
+        case 17: launch_jac_w<WITH_ERR, 8, 2, false, 0, 2, true>(C2B_ARGS); return C2B_OK;    // shipped structure, plain (not nt) stores
+        case 18: launch_jac_w<WITH_ERR, 4, 2, true, 0, 2, true>(C2B_ARGS); return C2B_OK;     // 256-thread workgroups
+        case 31: {                                                                                  // store pattern only, plain stores
+            const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
+            hipLaunchKernelGGL((k_store_pattern<false, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp);
+            return C2B_OK;
+        }
         case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2, false>(C2B_ARGS); return C2B_OK;     // no Jacobian stores
         case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2, false>(C2B_ARGS); return C2B_OK;     // no arithmetic
         case 100: launch_jac_p<WITH_ERR, 8, 4>(C2B_ARGS); return C2B_OK;     // persistent pipelined forms (obs_pipeline.hpp)

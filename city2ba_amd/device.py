@@ -112,6 +112,46 @@ def calib_copy(src, dst):
     L.check(L.lib().c2b_calib_copy(_p(src), _p(dst), nbytes, _stream()))
 
 
+def alloc_jacobian_outputs(n_obs, device, max_attempts=8, fast_store_GBs=6800.0):
+    """r [n,2], Jc [n,18], Jp [n,6] for residual_jacobian*, placed for streaming stores.
+
+    Measured on MI355X (tools/probe_placement*.py): the SAME kernel writing the SAME bytes takes 740 us or 880 us
+    depending only on which device allocation its outputs live in -- the store pattern alone runs at ~7.0 TB/s in some
+    allocations and ~5.75 TB/s in others of identical size, alignment and virtual layout, in one process, on one
+    device; a freed and re-made allocation keeps its speed, a different one rolls the dice again (physical placement /
+    page-table fragment size are the suspects; nothing visible from user space predicts it).  So: allocate, time the
+    store pattern (c2b_calib_store_pattern, ~0.6 ms per repetition), keep the set if it streams at fast_store_GBs or
+    better, otherwise hold it (so that the allocator cannot hand the same memory back) and try again; the best of
+    max_attempts wins and the rest are released.  Returns ((r, Jc, Jp), log) with log = store GB/s of every attempt."""
+    held, log, best = [], [], None
+    for _ in range(max(1, int(max_attempts))):
+        bufs = (torch.empty((n_obs, 2), dtype=torch.float64, device=device),
+                torch.empty((n_obs, 18), dtype=torch.float64, device=device),
+                torch.empty((n_obs, 6), dtype=torch.float64, device=device))
+        if n_obs < 1_000_000:                       # too small for the store rate to mean anything
+            return bufs, log
+        for _ in range(2):
+            calib_store_pattern(*bufs)
+        torch.cuda.synchronize(device)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(4):
+            calib_store_pattern(*bufs)
+        e.record()
+        torch.cuda.synchronize(device)
+        rate = n_obs * 208 / (s.elapsed_time(e) / 4 * 1e-3) / 1e9
+        log.append(round(rate, 1))
+        if best is None or rate > best[0]:
+            best = (rate, bufs)
+        held.append(bufs)
+        if rate >= fast_store_GBs:
+            break
+    chosen = best[1]
+    del held, bufs, best
+    torch.cuda.empty_cache()                        # the rejected allocations go back to the driver
+    return chosen, log
+
+
 def error_sum_finish(ws, n_obs, out_sum):
     L.check(L.lib().c2b_error_sum_finish(_p(ws), int(n_obs), _p(out_sum), _stream()))
     return out_sum

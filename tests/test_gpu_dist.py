@@ -1,5 +1,5 @@
 """bench.py's multi-rank code path on a ONE-GPU box (the 8-GPU scaling run is the driver's):
-  * world size 1 over nccl (= RCCL): the process group, the side stream, the double-buffered error scalar and a real
+  * world size 1 over nccl (= RCCL): the process group, the observation-balanced split and a real
     RCCL all_reduce per step -- the reduced scalar must equal the plain single-process run's bit for bit;
   * two ranks sharing GPU 0 over gloo, launched by torch.distributed.run exactly like the driver launches N ranks:
     observation-balanced camera ranges, every rank exits 0 (round 1's bench crashed on ranks >= 1 after the timed

@@ -117,3 +117,29 @@ def test_camera_trait_methods_batched(env):
     torch.cuda.synchronize()
     want = np.array([O.transform(P["cams15"][i], dR[i], dl[i]) for i in range(64)])
     assert np.array_equal(moved.cpu().numpy(), want)
+
+
+def test_alloc_jacobian_outputs_returns_usable_buffers():
+    """device.alloc_jacobian_outputs places r / Jc / Jp by measuring the store pattern (bench.py set-up).  Whatever
+    allocation it settles on, the buffers have the right shapes, are distinct, and the kernel's results in them equal
+    the results in plainly allocated ones."""
+    import argparse
+    import torch
+    import bench
+    from city2ba_amd import device as D
+    dev = torch.device("cuda", 0)
+    small, log = D.alloc_jacobian_outputs(5000, dev)
+    assert [tuple(t.shape) for t in small] == [(5000, 2), (5000, 18), (5000, 6)] and log == []
+    sh = bench.build_shard(argparse.Namespace(blocks=32), 0, 1, dev)
+    n = sh["n_obs"]
+    (r, Jc, Jp), log = D.alloc_jacobian_outputs(n, dev, max_attempts=3)
+    assert 1 <= len(log) <= 3 and all(x > 100.0 for x in log)
+    assert len({r.data_ptr(), Jc.data_ptr(), Jp.data_ptr()}) == 3
+    r0, Jc0, Jp0 = torch.empty_like(r), torch.empty_like(Jc), torch.empty_like(Jp)
+    ws = D.workspace(n, dev)
+    e0, e1 = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    a = (sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"])
+    D.residual_jacobian_sum(*a, r0, Jc0, Jp0, 2.0, ws, e0)
+    D.residual_jacobian_sum(*a, r, Jc, Jp, 2.0, ws, e1)
+    torch.cuda.synchronize()
+    assert torch.equal(r, r0) and torch.equal(Jc, Jc0) and torch.equal(Jp, Jp0) and e0.item() == e1.item()
