@@ -116,6 +116,31 @@ def algorithmic_bytes(n_obs, n_cam, n_pts):
     return n_obs * (4 + 16 + 16 + 192) + (n_cam + 1) * 8 + n_cam * 72 + n_pts * 24
 
 
+def usable_cores():
+    """CPUs this process can really use: its affinity mask, capped by the cgroup CPU quota (cpu.max).  The GPU boxes
+    show 256 logical CPUs but grant a quota of 16; 256 threads there just get throttled."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    note = "affinity mask: %d CPUs" % n
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, note = q, note + ", cgroup CPU quota: %d" % q
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), note
+
+
 def cpu_baseline(sh, seconds):
     """The oracle (C restatement of the reference CPU path + its Jacobian) on this box's host cores, timed inside C
     (oracle.bench_run; no Python in the loop).  Two storage layouts -- "faithful" = the reference's
@@ -133,7 +158,7 @@ def cpu_baseline(sh, seconds):
     cams15 = sh["cam15"].cpu().numpy()
     pts = np.ascontiguousarray(sh["pts_host"])
     r, Jc, Jp = np.empty((n_all, 2)), np.empty((n_all, 18)), np.empty((n_all, 6))
-    cores = max(1, os.cpu_count() or 1)
+    cores, cores_note = usable_cores()
     # prefix of whole cameras holding ~2 M observations for the single-thread legs
     c_end = int(np.searchsorted(row_ptr, min(n_all, 2_000_000), side="left"))
     c_end = max(1, min(c_end, n_cam))
@@ -152,6 +177,7 @@ def cpu_baseline(sh, seconds):
     out["value"], s1 = leg("faithful", 1, seconds * 0.4, False)
     out["value_all_cores"], sa = leg("faithful", cores, seconds * 0.2, True)
     out["cores_all"] = cores
+    out["cores_all_note"] = cores_note
     out["value_optimised_1t"], so1 = leg("optimised", 1, seconds * 0.2, False)
     out["value_optimised_all_cores"], soa = leg("optimised", cores, seconds * 0.2, True)
     out["sample"] = ("oracle/ C restatement of project + 2x12 Jacobian + L2 sum on the same grid, timed inside C; faithful "
