@@ -254,8 +254,9 @@ C2B_DEV int xcd_tile32(int bid, int n_tiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB>
-__global__ __launch_bounds__(WPB * 64) void k_observations(
+// MINW = waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument)
+template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1>
+__global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int n, int n_btiles, double norm, double max_dist,
@@ -271,7 +272,6 @@ __global__ __launch_bounds__(WPB * 64) void k_observations(
     double eacc = 0.0;
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];
-        double2 ob[OPL];
         double4 X[OPL];
 #pragma unroll
         for (int t = 0; t < OPL; ++t) {
@@ -279,7 +279,6 @@ __global__ __launch_bounds__(WPB * 64) void k_observations(
             o = o < n ? o : n - 1;                                       // clamped, not predicated
             ci[t] = cam_idx[o];
             pi[t] = pt_idx[o];
-            if (MODE == MODE_ERROR) ob[t] = uv_obs[o];
         }
 #pragma unroll
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
@@ -305,27 +304,23 @@ __global__ __launch_bounds__(WPB * 64) void k_observations(
             if (tile0 >= n) break;                                       // wave-uniform
             const int o = tile0 + lane;
             const bool valid = o < n;
-            Proj p;
-            p.qz = 1.0; p.u = 0.0; p.v = 0.0;
+            // the observed uv of THIS tile is requested only now: holding all OPL of them from the start costs 12
+            // VGPRs and the eighth wave per SIMD (measured: 119 us held, 111 us requested per tile)
+            double2 ob = make_double2(0.0, 0.0);
+            if (MODE == MODE_ERROR) ob = uv_obs[valid ? o : n - 1];
+            // First pass, unmasked: every lane projects through a staged camera -- its own if that is staged, camera 0
+            // of the tile otherwise (valid operands, result discarded).  On camera-major input that serves every lane
+            // and nothing below runs.  Leftover lanes (unsorted input, or more cameras than were staged) are then
+            // served one camera at a time through the extra slot by the same LDS-only arithmetic, merged under a mask.
+            uint32_t local = ci[t] - c_first;
+            bool in = local < n_staged;
+            lds_cptr cam = (lds_cptr)sCam + (in ? local : 0u) * HOT;
+            Proj p = project_obs(cam, X[t].x, X[t].y, X[t].z);
             double gx = 0.0, gy = 0.0, gz = 0.0;
-            // one pass serves every lane whose camera is staged (all of them on camera-major input); leftovers are
-            // served one camera at a time through the extra slot, with the same LDS-only arithmetic
-            uint32_t cf = c_first, ns = n_staged;
-            int slot0 = 0;
-            uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
-            for (;;) {
-                const uint32_t local = ci[t] - cf;
-                const bool in = ((todo >> lane) & 1ull) != 0 && local < ns;
-                if (in) {
-                    const lds_cptr cam = (lds_cptr)sCam + (slot0 + local) * HOT;
-                    p = project_obs(cam, X[t].x, X[t].y, X[t].z);
-                    if (MODE == MODE_VISIBILITY) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
-                }
-                todo &= ~__builtin_amdgcn_ballot_w64(in);
-                if (todo == 0) break;
-                cf = __builtin_amdgcn_readlane(ci[t], (int)__builtin_ctzll(todo));
-                ns = 1;
-                slot0 = kCamW;
+            if (MODE == MODE_VISIBILITY) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
+            uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
+            while (todo != 0) {                                          // wave-uniform; never taken on sorted input
+                const uint32_t cf = __builtin_amdgcn_readlane(ci[t], (int)__builtin_ctzll(todo));
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (lane < CH) {
@@ -335,6 +330,14 @@ __global__ __launch_bounds__(WPB * 64) void k_observations(
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                in = ((todo >> lane) & 1ull) != 0 && ci[t] == cf;
+                cam = (lds_cptr)sCam + kCamW * HOT;
+                const Proj q = project_obs(cam, X[t].x, X[t].y, X[t].z);
+                if (in) {
+                    p = q;
+                    if (MODE == MODE_VISIBILITY) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
+                }
+                todo &= ~__builtin_amdgcn_ballot_w64(in);
             }
             if (MODE == MODE_VISIBILITY) {
                 // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1   (src/synthetic.rs:285-291, src/generate.rs:448-454)
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observations(
             } else if (MODE == MODE_PROJECT) {
                 if (valid) uv_out[o] = make_double2(p.u, p.v);
             } else {
-                eacc += valid ? abs_pow_k<NK>(p.u - ob[t].x, norm) + abs_pow_k<NK>(p.v - ob[t].y, norm) : 0.0;
+                eacc += valid ? abs_pow_k<NK>(p.u - ob.x, norm) + abs_pow_k<NK>(p.v - ob.y, norm) : 0.0;
             }
         }
     }
