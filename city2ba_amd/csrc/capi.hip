@@ -126,7 +126,7 @@ unsigned *ticket_slot() {
 #ifdef C2B_TUNE
 // Tuning build only (libcity2ba_hip_tune.so, tools/tune_*.py): kernel variants, including timing-only ablations
 // whose outputs are wrong by construction.  None of this exists in the product library.
-int g_jac_variant = 14;
+int g_jac_variant = 40;
 int g_obs_variant = 308;
 
 template <typename K>
@@ -236,6 +236,7 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
     return C2B_OK;
 }
 
+#ifdef C2B_TUNE
 template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL, int OPL, bool LDSCAM>
 void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
@@ -247,6 +248,24 @@ void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r), \
                        Jc, Jp, block_part, ticket, out_sum)
+    if constexpr (!WITH_ERR) { C2B_GO(NORM_2); }
+    else if (norm == 2.0) C2B_GO(NORM_2);
+    else if (norm == 1.0) C2B_GO(NORM_1);
+    else C2B_GO(NORM_ANY);
+#undef C2B_GO
+}
+#endif
+
+template <bool WITH_ERR, int WPB, int OPL, int MINW>
+void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
+                  const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
+                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
+    const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
+#define C2B_GO(NK)                                                                                                      \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW>), dim3((unsigned)btiles),             \
+                       dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
+                       reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
+                       reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum)
     if constexpr (!WITH_ERR) { C2B_GO(NORM_2); }
     else if (norm == 2.0) C2B_GO(NORM_2);
     else if (norm == 1.0) C2B_GO(NORM_1);
@@ -265,6 +284,7 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st
 #ifdef C2B_TUNE
     switch (g_jac_variant) {
+        case 14: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(C2B_ARGS); return C2B_OK;      // rounds 1-2a: two code paths (LDS / FLAT fallback), 64-bit indices
         case 9: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, false>(C2B_ARGS); return C2B_OK;
         case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, false>(C2B_ARGS); return C2B_OK;     // FLAT camera reads
         case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(C2B_ARGS); return C2B_OK;
@@ -277,6 +297,10 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         }
         case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2, false>(C2B_ARGS); return C2B_OK;     // no Jacobian stores
         case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2, false>(C2B_ARGS); return C2B_OK;     // no arithmetic
+        case 40: launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS); return C2B_OK;      // lean form, natural register count
+        case 41: launch_jac_l<WITH_ERR, 8, 2, 5>(C2B_ARGS); return C2B_OK;      // lean form, capped for 5 waves per SIMD
+        case 42: launch_jac_l<WITH_ERR, 8, 1, 1>(C2B_ARGS); return C2B_OK;      // one tile per wave
+        case 43: launch_jac_l<WITH_ERR, 8, 3, 1>(C2B_ARGS); return C2B_OK;      // three tiles per wave
         case 100: launch_jac_p<WITH_ERR, 8, 4>(C2B_ARGS); return C2B_OK;     // persistent pipelined forms (obs_pipeline.hpp)
         case 104: launch_jac_p<WITH_ERR, 4, 1>(C2B_ARGS); return C2B_OK;     // 12 waves per CU at the natural register count
         case 105: launch_jac_p<WITH_ERR, 4, 4>(C2B_ARGS); return C2B_OK;     // 16 waves per CU (spills)
@@ -285,7 +309,7 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         default: break;
     }
 #endif
-    launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(C2B_ARGS);             // shipped: two tiles per wave, LDS-only camera reads
+    launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS);                            // shipped: lean form, two tiles per wave (= variant 40)
 #undef C2B_ARGS
     return C2B_OK;
 }

@@ -563,6 +563,132 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
     if (WITH_ERR) ticket_fold(wave_sum(eacc), reinterpret_cast<double *>(smem), block_part, ticket, out_sum);
 }
 
+// ---- residual + Jacobian, lean form --------------------------------------------------------------------
+// The same wave-centric structure as k_residual_jacobian_w with the light kernels' economies: 32-bit observation
+// indices, clamped (not predicated) loads, ONE inlined copy of the arithmetic per tile reading its camera through an
+// LDS-typed pointer (first pass unmasked; lanes whose camera was not staged are served in extra rounds through a
+// spare LDS slot and merged under a mask -- never taken on camera-major input), the observed uv requested per tile.
+template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW>
+__global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
+    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
+    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
+    const double2 *__restrict__ uv_obs, int n, int n_btiles, double norm,
+    double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
+    double *__restrict__ block_part, unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
+    constexpr int kSlab = 64 * 144 / 2;                                  // half a tile's 2x9 blocks (two rounds)
+    constexpr int kCamBytes = (kCamW + 1) * kCamHot * 8;                 // + 1: the slow path's slot
+    __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
+    double eacc = 0.0;
+    if (base < n) {                                                      // wave-uniform; waves past the end only fold
+        uint32_t ci[OPL], pi[OPL];
+        double4 X[OPL];
+#pragma unroll
+        for (int t = 0; t < OPL; ++t) {
+            int o = base + t * 64 + lane;
+            o = o < n ? o : n - 1;
+            ci[t] = cam_idx[o];
+            pi[t] = pt_idx[o];
+        }
+#pragma unroll
+        for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
+
+        char *slab = smem + wave * (kSlab + kCamBytes);
+        double *sCam = reinterpret_cast<double *>(slab + kSlab);
+        const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
+        const uint32_t c_last = __builtin_amdgcn_readlane(ci[OPL - 1], 63);
+        uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
+        if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
+        for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
+            const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
+            *reinterpret_cast<d2_t *>(sCam + k * kCamHot + 2 * j) =
+                *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+        for (int t = 0; t < OPL; ++t) {
+            const int tile0 = base + t * 64;
+            if (tile0 >= n) break;                                       // wave-uniform
+            const int o = tile0 + lane;
+            const bool valid = o < n;
+            const int n_wave = n - tile0 < 64 ? n - tile0 : 64;
+            const double2 ob = uv_obs[valid ? o : n - 1];
+            uint32_t local = ci[t] - c_first;
+            bool in = local < n_staged;
+            double r0, r1, jc[18], jp[6];
+            jacobian_obs<0>((lds_cptr)sCam + (in ? local : 0u) * kCamHot, X[t], ob, r0, r1, jc, jp);
+            uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
+            while (todo != 0) {                                          // wave-uniform; never taken on sorted input
+                const uint32_t cf = __builtin_amdgcn_readlane(ci[t], (int)__builtin_ctzll(todo));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < kCamHot / 2)
+                    *reinterpret_cast<d2_t *>(sCam + kCamW * kCamHot + 2 * lane) =
+                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)cf * kCamBlk + 2 * lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                in = ((todo >> lane) & 1ull) != 0 && ci[t] == cf;
+                double q0, q1, qc[18], qp[6];
+                jacobian_obs<0>((lds_cptr)sCam + kCamW * kCamHot, X[t], ob, q0, q1, qc, qp);
+                if (in) {
+                    r0 = q0; r1 = q1;
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) jc[k] = qc[k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) jp[k] = qp[k];
+                }
+                todo &= ~__builtin_amdgcn_ballot_w64(in);
+            }
+
+            if (valid) store16<NT>(reinterpret_cast<char *>(r_out + o), make_double2(r0, r1));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((lane >> 5) == h) {
+                    double2 *w = reinterpret_cast<double2 *>(slab + (lane & 31) * 144);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) w[k] = make_double2(jc[2 * k], jc[2 * k + 1]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                char *dst = reinterpret_cast<char *>(Jc) + ((int64_t)tile0 + h * 32) * 144;
+                int nv = n_wave - h * 32;
+                nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
+                const int bytes = nv * 144;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int off = (k * 64 + lane) * 16;
+                    if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            {
+                double2 *w = reinterpret_cast<double2 *>(slab + lane * 48);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w[k] = make_double2(jp[2 * k], jp[2 * k + 1]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                char *dst = reinterpret_cast<char *>(Jp) + (int64_t)tile0 * 48;
+                const int bytes = n_wave * 48;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int off = (k * 64 + lane) * 16;
+                    if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (WITH_ERR) eacc += valid ? abs_pow_k<NK>(r0, norm) + abs_pow_k<NK>(r1, norm) : 0.0;
+        }
+    }
+    if (WITH_ERR) ticket_fold(wave_sum(eacc), reinterpret_cast<double *>(smem), block_part, ticket, out_sum);
+}
+
 // ---- stats over camera centers ++ points ------------------------------------------------------------
 // record: [0..2] sum(x/num) | [3..5] min | [6..8] max | [9] best dist | [10] best index
 //
