@@ -256,13 +256,13 @@ void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_
 }
 #endif
 
-template <bool WITH_ERR, int WPB, int OPL, int MINW>
+template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0>
 void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
     const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW>), dim3((unsigned)btiles),             \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK>), dim3((unsigned)btiles),             \
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
                        reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum)
@@ -300,6 +300,16 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         case 40: launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS); return C2B_OK;      // lean form, natural register count
         case 41: launch_jac_l<WITH_ERR, 8, 2, 5>(C2B_ARGS); return C2B_OK;      // lean form, capped for 5 waves per SIMD
         case 42: launch_jac_l<WITH_ERR, 8, 1, 1>(C2B_ARGS); return C2B_OK;      // one tile per wave
+        case 44: launch_jac_l<WITH_ERR, 8, 2, 1, 1>(C2B_ARGS); return C2B_OK;     // tiles in launch order (no XCD-aware map)
+        case 45: launch_jac_l<WITH_ERR, 8, 2, 1, 4>(C2B_ARGS); return C2B_OK;     // chunked XCD map, K = 4
+        case 46: launch_jac_l<WITH_ERR, 8, 2, 1, 16>(C2B_ARGS); return C2B_OK;    // K = 16
+        case 47: launch_jac_l<WITH_ERR, 8, 2, 1, 64>(C2B_ARGS); return C2B_OK;    // K = 64
+        case 48: launch_jac_l<WITH_ERR, 8, 2, 1, 256>(C2B_ARGS); return C2B_OK;   // K = 256
+        case 32: {                                                                 // store pattern only, tiles in launch order
+            const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
+            hipLaunchKernelGGL((k_store_pattern<true, 8, false>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp);
+            return C2B_OK;
+        }
         case 43: launch_jac_l<WITH_ERR, 8, 3, 1>(C2B_ARGS); return C2B_OK;      // three tiles per wave
         case 100: launch_jac_p<WITH_ERR, 8, 4>(C2B_ARGS); return C2B_OK;     // persistent pipelined forms (obs_pipeline.hpp)
         case 104: launch_jac_p<WITH_ERR, 4, 1>(C2B_ARGS); return C2B_OK;     // 12 waves per CU at the natural register count

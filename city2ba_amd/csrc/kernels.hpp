@@ -255,6 +255,19 @@ C2B_DEV int xcd_tile32(int bid, int n_tiles) {
 }
 
 // MINW = waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument)
+// Chunked XCD map: consecutive workgroups go round-robin over the 8 XCDs; XCD x takes K consecutive tile-blocks of
+// every super-tile of 8K, so each XCD's L2 sees K neighbouring blocks (camera / point reuse) while the whole chip writes
+// inside one moving window of 8K blocks (DRAM locality of the output streams).  K = 1 is launch order, K = n/8 the
+// contiguous-eighths map of xcd_tile32.  Blocks past the last whole super-tile keep launch order.  Bijective.
+template <int K>
+C2B_DEV int xcd_tile_chunked(int bid, int n_tiles) {
+    if (K <= 1) return bid;
+    const int whole = n_tiles / (8 * K) * (8 * K);
+    if (bid >= whole) return bid;
+    const int xcd = bid & 7, k = bid >> 3;
+    return (k / K) * (8 * K) + xcd * K + (k % K);
+}
+
 template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
@@ -568,7 +581,8 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
 // indices, clamped (not predicated) loads, ONE inlined copy of the arithmetic per tile reading its camera through an
 // LDS-typed pointer (first pass unmasked; lanes whose camera was not staged are served in extra rounds through a
 // spare LDS slot and merged under a mask -- never taken on camera-major input), the observed uv requested per tile.
-template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW>
+// XK: tile map -- 0 = contiguous eighths per XCD (xcd_tile32), K >= 1 = xcd_tile_chunked<K>
+template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
+    const int base = ((XK == 0 ? xcd_tile32(blockIdx.x, n_btiles) : xcd_tile_chunked<XK>(blockIdx.x, n_btiles)) * WPB + wave) * (OPL * 64);
     double eacc = 0.0;
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];
@@ -1297,11 +1311,11 @@ __global__ __launch_bounds__(256) void k_dense_cam_scan(const uint64_t *__restri
 namespace c2b {
 // the residual + Jacobian kernel's 208 B/observation store geometry (1-KiB non-temporal stores of whole lines) with no
 // loads, no LDS and no arithmetic: the floor its stores alone would take
-template <bool NT, int WPB>
+template <bool NT, int WPB, bool XCD = true>
 __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n_btiles, double2 *__restrict__ r_out,
                                                            double *__restrict__ Jc, double *__restrict__ Jp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wt = xcd_tile(blockIdx.x, n_btiles) * WPB + wave;
+    const int64_t wt = (XCD ? xcd_tile(blockIdx.x, n_btiles) : (int64_t)blockIdx.x) * WPB + wave;
     const int64_t wave0 = wt * 64;
     if (wave0 + 64 > n) return;
     const double2 v = make_double2((double)lane, (double)wave);

@@ -60,8 +60,8 @@ Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
 Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
 t = timed(lambda: D.residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, 2.0, ws))
 report("residual_jacobian+err", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
-t = timed(lambda: D.error_sum_finish(ws, n, err))
-report("error_sum_finish", t, n / 64, n / 64 * 8, "partials")
+t = timed(lambda: D.residual_jacobian_sum(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, 2.0, ws, err))
+report("residual_jacobian_sum (one launch)", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
 del r, Jc, Jp
 
 # visibility predicate on a candidate list of the same size class as the generator's
@@ -77,7 +77,7 @@ st = torch.empty(20, dtype=torch.float64, device=dev)
 t = timed(lambda: D.stats(camblk, pts4, ws, st))
 report("stats(mean,std,extent,origin)", t, n_cam + n_pts, 2 * (n_cam * 24 + n_pts * 24), "entities")
 t = timed(lambda: D.cameras_prepare_state(cam15, camblk))
-report("cameras_prepare_state", t, n_cam, n_cam * (120 + 224), "cams")
+report("cameras_prepare_state", t, n_cam, n_cam * (120 + 256), "cams")
 bal9 = D.cameras_to_bal(cam15)
 t = timed(lambda: D.cameras_to_bal(cam15))
 report("cameras_to_bal", t, n_cam, n_cam * (120 + 72), "cams")
