@@ -61,6 +61,10 @@ SIGNATURES = {
     "c2b_bvh_free": (None, [_vp]),
     "c2b_occlusion_filter_bvh": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "c2b_stats_partial_pass1": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "c2b_stats_partial_pass2": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_add_drift_sharded": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _d, _d, _d, _d, _d, _d, _u64, _vp]),
+    "c2b_add_noise_entities_sharded": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
     "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
     "c2b_add_drift_normalized": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
     "c2b_add_noise_entities": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),

@@ -329,13 +329,14 @@ int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStr
     double *rec = reinterpret_cast<double *>(workspace);
     int grid = (int)((n + kBlock - 1) / kBlock);
     if (grid > kRedBlocks) grid = kRedBlocks;
-    hipLaunchKernelGGL(k_stats_pass1<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, rec);
+    const ShardMap whole{src.n_cam, 0, src.n_cam, 0};
+    hipLaunchKernelGGL(k_stats_pass1<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, (double)n, rec);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold1<Src>, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, src, stats);
+    hipLaunchKernelGGL(k_stats_fold1<Src>, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, src, whole, stats);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_stats_pass2<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, (const double *)stats, rec);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold2, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, n, stats);
+    hipLaunchKernelGGL(k_stats_fold2<false>, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, n, stats);
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -343,7 +344,7 @@ int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStr
 template <typename T>
 int drift_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts, const double *origin,
                const double *stats_norm, double strength, double angle_strength, double std, double dx, double dy,
-               double dz, uint64_t seed, hipStream_t st) {
+               double dz, uint64_t seed, hipStream_t st, int64_t cam_base = 0) {
     if (n_cam < 0 || n_pts < 0 || !origin || (n_cam && !cam15) || (n_pts && !pts4))
         return fail(C2B_ERR_INVALID_ARGUMENT, "%s: bad arguments", who);
     if (!(std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: std must be >= 0 (rand's Normal::new panics)", who);
@@ -351,14 +352,15 @@ int drift_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts,
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_add_drift<T>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam15, n_cam,
                        reinterpret_cast<typename V4<T>::type *>(pts4), n_pts, origin, strength, angle_strength, std, dx,
-                       dy, dz, stats_norm, seed);
+                       dy, dz, stats_norm, seed, cam_base);
     LAUNCH_CHECK();
     return C2B_OK;
 }
 
 template <typename T>
 int noise_entities_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts, const double *stats,
-                        double translation_std, double rotation_std, double point_std, uint64_t seed, hipStream_t st) {
+                        double translation_std, double rotation_std, double point_std, uint64_t seed, hipStream_t st,
+                        int64_t cam_base = 0) {
     if (n_cam < 0 || n_pts < 0 || !stats || (n_cam && !cam15) || (n_pts && !pts4))
         return fail(C2B_ERR_INVALID_ARGUMENT, "%s: bad arguments", who);
     if (!(translation_std >= 0.0) || !(rotation_std >= 0.0) || !(point_std >= 0.0))
@@ -367,7 +369,7 @@ int noise_entities_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64
     if (!n) return C2B_OK;
     hipLaunchKernelGGL(k_add_noise_entities<T>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam15, n_cam,
                        reinterpret_cast<typename V4<T>::type *>(pts4), n_pts, stats, translation_std, rotation_std,
-                       point_std, seed);
+                       point_std, seed, cam_base);
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -762,6 +764,67 @@ int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n
     const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
     return stats_impl(src, n_cam + n_pts, workspace, stats, S(stream));
     C2B_API_END("stats")
+}
+
+int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+                            const double *pts4, int64_t n_pts, int64_t pt_base, int64_t n_entities_global,
+                            void *workspace, double *part, void *stream) {
+    C2B_API_BEGIN
+    if (n_cam < 0 || n_pts < 0 || cam_base < 0 || pt_base < 0 || n_cam_global < cam_base + n_cam || n_entities_global < 1 ||
+        !part || !workspace || (n_cam && !camblk) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass1: bad arguments");
+    const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
+    const int64_t n = n_cam + n_pts;
+    double *rec = reinterpret_cast<double *>(workspace);
+    int grid = (int)((n + kBlock - 1) / kBlock);
+    if (grid > kRedBlocks) grid = kRedBlocks;
+    if (grid < 1) grid = 1;
+    const ShardMap map{n_cam, cam_base, n_cam_global, pt_base};
+    hipLaunchKernelGGL(k_stats_pass1<SrcBlk>, dim3(grid), dim3(kBlock), 0, S(stream), src, n, (double)n_entities_global, rec);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_fold1<SrcBlk>, dim3(1), dim3(kRedBlocks), 0, S(stream), (const double *)rec, grid, src, map, part);
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("stats_partial_pass1")
+}
+
+int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, const double *mean3,
+                            void *workspace, double *sumsq3, void *stream) {
+    C2B_API_BEGIN
+    if (n_cam < 0 || n_pts < 0 || !mean3 || !sumsq3 || !workspace || (n_cam && !camblk) || (n_pts && !pts4))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass2: bad arguments");
+    const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
+    const int64_t n = n_cam + n_pts;
+    double *rec = reinterpret_cast<double *>(workspace);
+    int grid = (int)((n + kBlock - 1) / kBlock);
+    if (grid > kRedBlocks) grid = kRedBlocks;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_stats_pass2<SrcBlk>, dim3(grid), dim3(kBlock), 0, S(stream), src, n, mean3, rec);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stats_fold2<true>, dim3(1), dim3(kRedBlocks), 0, S(stream), (const double *)rec, grid, n, sumsq3);
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("stats_partial_pass2")
+}
+
+int c2b_add_drift_sharded(double *cam15, int64_t n_cam, int64_t cam_base, double *pts4, int64_t n_pts, const double *stats,
+                          int normalized, double strength, double angle_strength, double std, double dir_x, double dir_y,
+                          double dir_z, uint64_t seed, void *stream) {
+    C2B_API_BEGIN
+    if (!stats || cam_base < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "add_drift_sharded: bad arguments");
+    return drift_impl<double>("add_drift_sharded", cam15, n_cam, pts4, n_pts, stats + 15, normalized ? stats : nullptr,
+                              strength, angle_strength, std, dir_x, dir_y, dir_z, seed, S(stream), cam_base);
+    C2B_API_END("add_drift_sharded")
+}
+
+int c2b_add_noise_entities_sharded(double *cam15, int64_t n_cam, int64_t cam_base, double *pts4, int64_t n_pts,
+                                   const double *stats, double translation_std, double rotation_std, double point_std,
+                                   uint64_t seed, void *stream) {
+    C2B_API_BEGIN
+    if (cam_base < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_entities_sharded: bad arguments");
+    return noise_entities_impl<double>("add_noise_entities_sharded", cam15, n_cam, pts4, n_pts, stats, translation_std,
+                                       rotation_std, point_std, seed, S(stream), cam_base);
+    C2B_API_END("add_noise_entities_sharded")
 }
 
 int c2b_stats_f32(const float *cam15, int64_t n_cam, const float *pts4, int64_t n_pts, void *workspace,

@@ -742,6 +742,17 @@ struct SrcState32 {                              // f32: cam15 (float) + pts4 (f
     }
 };
 
+// Sharded statistics: a rank holds cameras [cam_base, cam_base + n_cam_local) of n_cam_global and
+// reduces points [pt_base, ...) of the replicated table.  Entity order of the reference = cameras, then points
+// (src/baproblem.rs:282-289), so the GLOBAL index of local entity i is:
+struct ShardMap {
+    int64_t n_cam_local, cam_base, n_cam_global, pt_base;
+    C2B_DEV double global_index(double local) const {
+        const int64_t i = (int64_t)local;
+        return (double)(i < n_cam_local ? cam_base + i : n_cam_global + pt_base + (i - n_cam_local));
+    }
+};
+
 // closest to origin with fold1's semantics (src/noise.rs:80-86): strict <, ties -> later index.
 // Only (distance, index) travel through the reduction; the winner's coordinates are re-read by
 // index afterwards.  (Carrying xyz through a branchy merge was miscompiled by hipcc 7.2 -O3: the
@@ -756,9 +767,8 @@ C2B_DEV Best best_merge(Best a, Best b) {
 }
 
 template <typename Src>
-__global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, double *__restrict__ rec) {
+__global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, double num, double *__restrict__ rec) {
     __shared__ double sh[kWaves][kStatRec];
-    const double num = (double)n;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double s0 = 0, s1 = 0, s2 = 0, mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
     Best best = {0.0, -1.0};
@@ -814,7 +824,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
 // Fixed shuffle / LDS order => deterministic.
 template <typename Src>
 __global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__restrict__ rec, int n_rec, Src src,
-                                                          double *__restrict__ stats) {
+                                                          ShardMap map, double *__restrict__ stats) {
     __shared__ double sh[kRedBlocks / 64][12];
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double t[9] = {0, 0, 0, inf, inf, inf, -inf, -inf, -inf};
@@ -856,7 +866,9 @@ __global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__rest
         stats[12 + k] = t[6 + k] - t[3 + k];
     }
     stats[15] = x; stats[16] = y; stats[17] = z;
-    stats[18] = b.i;
+    stats[18] = b.i >= 0.0 ? map.global_index(b.i) : -1.0;
+    stats[19] = b.i >= 0.0 ? b.d : inf;          // the winner's distance (sharded runs compare it across ranks); the
+                                                 // unsharded path overwrites this slot with |std| in k_stats_fold2
 }
 
 template <typename Src>
@@ -880,6 +892,9 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass2(Src src, int64_t n, cons
     }
 }
 
+// RAW: leave the three sums of squared deviations in out[0..2] (a shard's share; the ranks' sums are all-reduced and
+// finished on the host) instead of finishing std / |std| in stats[3..5], [19].
+template <bool RAW>
 __global__ __launch_bounds__(kRedBlocks) void k_stats_fold2(const double *__restrict__ rec, int n_rec, int64_t n_ent,
                                                           double *__restrict__ stats) {
     __shared__ double sh[kRedBlocks / 64][3];
@@ -894,6 +909,7 @@ __global__ __launch_bounds__(kRedBlocks) void k_stats_fold2(const double *__rest
     __syncthreads();
     if (threadIdx.x != 0) return;
     for (int w = 1; w < kRedBlocks / 64; ++w) { t0 += sh[w][0]; t1 += sh[w][1]; t2 += sh[w][2]; }
+    if (RAW) { stats[0] = t0; stats[1] = t1; stats[2] = t2; return; }
     const double num = (double)n_ent;
     const double a = sqrt(t0 / num), b = sqrt(t1 / num), c = sqrt(t2 / num);
     stats[3] = a; stats[4] = b; stats[5] = c;
@@ -911,7 +927,7 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(T *__restrict__ cam15, int
                                                      const double *__restrict__ origin, double strength_d,
                                                      double angle_strength_d, double std_d, double dx_d, double dy_d,
                                                      double dz_d, const double *__restrict__ stats_norm,
-                                                     uint64_t seed) {
+                                                     uint64_t seed, int64_t cam_base) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
     if (stats_norm) {
@@ -932,7 +948,7 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(T *__restrict__ cam15, int
         cm_center(c, c[9], c[10], c[11], ctr);
         const T ex = ctr[0] - ox, ey = ctr[1] - oy, ez = ctr[2] - oz;
         const T distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
-        normal_pair(seed, kStreamDriftCam, (uint64_t)i, 0, z0, z1);
+        normal_pair(seed, kStreamDriftCam, (uint64_t)(cam_base + i), 0, z0, z1);     // draws keyed by the GLOBAL camera index
         const T va = (T)(1.0 + std_d * z0);             // angle draw first (src/noise.rs:104-107)
         const T vt = (T)(1.0 + std_d * z1);
         const T angle = angle_strength * va * pow(distance, (T)1.2);
@@ -964,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ c
                                                               typename V4<T>::type *__restrict__ pts4, int64_t n_pts,
                                                               const double *__restrict__ stats,
                                                               double translation_std, double rotation_std,
-                                                              double point_std, uint64_t seed) {
+                                                              double point_std, uint64_t seed, int64_t cam_base) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
     if (i < n_cam) {
@@ -973,10 +989,10 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ c
         double a0, a1, a2, rot, b0, b1, b2, tr;
 #pragma unroll
         for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
-        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 0, a0, a1);
-        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 1, a2, rot);
-        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 2, b0, b1);
-        normal_pair(seed, kStreamNoiseCam, (uint64_t)i, 3, b2, tr);
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)(cam_base + i), 0, a0, a1);
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)(cam_base + i), 1, a2, rot);
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)(cam_base + i), 2, b0, b1);
+        normal_pair(seed, kStreamNoiseCam, (uint64_t)(cam_base + i), 3, b2, tr);
         const T A0 = (T)a0, A1 = (T)a1, A2 = (T)a2, B0 = (T)b0, B1 = (T)b1, B2 = (T)b2;
         const T ia = (T)1.0 / sqrt(dot3(A0, A1, A2, A0, A1, A2));
         const T ib = (T)1.0 / sqrt(dot3(B0, B1, B2, B0, B1, B2));

@@ -218,6 +218,37 @@ def stats(camblk, pts4, ws, out=None):
     return out
 
 
+def stats_partial_pass1(camblk, cam_base, n_cam_global, pts4_slice, pt_base, n_entities_global, ws, part=None):
+    """this shard's share of the statistics (c2b_stats_partial_pass1); pts4_slice = the rows of the point table this
+    rank reduces"""
+    part = part if part is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=camblk.device)
+    L.check(L.lib().c2b_stats_partial_pass1(_p(camblk), camblk.shape[0], int(cam_base), int(n_cam_global), _p(pts4_slice),
+                                            pts4_slice.shape[0], int(pt_base), int(n_entities_global), _p(ws), _p(part),
+                                            _stream()))
+    return part
+
+
+def stats_partial_pass2(camblk, pts4_slice, mean3, ws, out=None):
+    out = out if out is not None else torch.empty(3, dtype=torch.float64, device=camblk.device)
+    L.check(L.lib().c2b_stats_partial_pass2(_p(camblk), camblk.shape[0], _p(pts4_slice), pts4_slice.shape[0], _p(mean3),
+                                            _p(ws), _p(out), _stream()))
+    return out
+
+
+def add_drift_sharded(cam15, cam_base, pts4, stats_, strength, angle_strength, std, seed, direction=None):
+    """direction None = add_drift_normalized (src/noise.rs:47-56), else add_drift with that direction"""
+    d = (0.0, 0.0, 0.0) if direction is None else [float(x) for x in direction]
+    L.check(L.lib().c2b_add_drift_sharded(_p(cam15), cam15.shape[0], int(cam_base), _p(pts4), pts4.shape[0], _p(stats_),
+                                          1 if direction is None else 0, float(strength), float(angle_strength),
+                                          float(std), d[0], d[1], d[2], int(seed), _stream()))
+
+
+def add_noise_entities_sharded(cam15, cam_base, pts4, stats_, translation_std, rotation_std, point_std, seed):
+    L.check(L.lib().c2b_add_noise_entities_sharded(_p(cam15), cam15.shape[0], int(cam_base), _p(pts4), pts4.shape[0],
+                                                   _p(stats_), float(translation_std), float(rotation_std),
+                                                   float(point_std), int(seed), _stream()))
+
+
 def add_drift_normalized(cam15, pts4, stats_, strength, angle_strength, std, seed):
     L.check(L.lib().c2b_add_drift_normalized(_p(cam15), cam15.shape[0], _p(pts4), pts4.shape[0], _p(stats_),
                                              float(strength), float(angle_strength), float(std), int(seed), _stream()))

@@ -73,6 +73,74 @@ def all_reduce_sum_(t, group=None):
     return t
 
 
+def combine_stats_partials(parts, n_entities):
+    """parts [world][20] = every rank's c2b_stats_partial_pass1 record, in rank order -> (mean3, min3, max3,
+    origin3, origin_global_index).  mean: the shares summed in rank order; origin: smallest distance, ties to the
+    larger global index (fold1 with strict <, src/noise.rs:80-86).  Pure numpy: the host half of the collective."""
+    parts = np.asarray(parts, dtype=np.float64).reshape(-1, 20)
+    mean = np.zeros(3)
+    for p in parts:
+        mean = mean + p[0:3]
+    mn, mx = parts[:, 6:9].min(axis=0), parts[:, 9:12].max(axis=0)
+    best = None
+    for p in parts:
+        if p[18] < 0:
+            continue
+        if best is None or p[19] < best[19] or (p[19] == best[19] and p[18] > best[18]):
+            best = p
+    if best is None:
+        raise L.City2baError(L.ERR_INVALID_ARGUMENT, "stats: empty problem")
+    return mean, mn, mx, best[15:18].copy(), int(best[18])
+
+
+def finish_stats(mean, mn, mx, origin, origin_index, sumsq, n_entities):
+    """the 20-double statistics record of c2b_stats from the combined pieces (std = sqrt(sum of squares / n))"""
+    st = np.zeros(20)
+    st[0:3], st[6:9], st[9:12], st[12:15] = mean, mn, mx, mx - mn
+    st[3:6] = np.sqrt(np.asarray(sumsq, dtype=np.float64) / float(n_entities))
+    st[15:18], st[18] = origin, float(origin_index)
+    st[19] = np.sqrt((st[3] * st[3] + st[4] * st[4]) + st[5] * st[5])
+    return st
+
+
+def _all_gather_rows(row, group=None):
+    """every rank's 1-D float64 numpy row, in rank order, as a [world, len] array"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return np.asarray(row, dtype=np.float64)[None, :]
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.from_numpy(np.ascontiguousarray(row, dtype=np.float64)).to(dev)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    return np.stack([t.cpu().numpy() for t in every])
+
+
+def stats_sharded(camblk, cam_base, n_cam_global, pts4, ws, group=None):
+    """BAProblem::mean/std/extent/dimensions + add_drift's origin (src/baproblem.rs:282-337, src/noise.rs:75-87) when
+    cameras are sharded: this rank's camblk holds cameras [cam_base, cam_base + len) of n_cam_global, pts4 is the whole
+    replicated table and rank r of W reduces its r-th slice.  Two small all-gathers (20 and 3 doubles per rank), no
+    other traffic.  Returns the statistics record as a device tensor, identical on every rank (sums in rank order)."""
+    import torch
+    import torch.distributed as dist
+    from . import device as D
+    on = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if on else (1, 0)
+    n_pts = pts4.shape[0]
+    lo, hi = n_pts * rank // world, n_pts * (rank + 1) // world
+    n_ent = int(n_cam_global) + int(n_pts)
+    part = D.stats_partial_pass1(camblk, cam_base, n_cam_global, pts4[lo:hi], lo, n_ent, ws)
+    parts = _all_gather_rows(part.cpu().numpy(), group)
+    mean, mn, mx, origin, oidx = combine_stats_partials(parts, n_ent)
+    mean_d = torch.from_numpy(mean).to(camblk.device)
+    sq = D.stats_partial_pass2(camblk, pts4[lo:hi], mean_d, ws)
+    sumsq = np.zeros(3)
+    for row in _all_gather_rows(sq.cpu().numpy(), group):       # rank-ordered sum, identical on every rank
+        sumsq = sumsq + row
+    return torch.from_numpy(finish_stats(mean, mn, mx, origin, oidx, sumsq, n_ent)).to(camblk.device)
+
+
 def finish_error(total_sum, norm):
     """.powf(1. / norm), src/baproblem.rs:278"""
     return float(total_sum) ** (1.0 / float(norm))

@@ -182,6 +182,30 @@ int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uin
 int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
               void *workspace, double *stats, void *stream);
 
+/* The same statistics when cameras are sharded over GPUs: this rank holds cameras
+ * [cam_base, cam_base + n_cam) of n_cam_global and reduces points [pt_base, pt_base + n_pts) of the replicated table
+ * (pts4 points at the first of them).  Pass 1 leaves this shard's share in part[C2B_STATS_DOUBLES]:
+ * [0..2] sum of x / n_entities_global, [6..8] min, [9..11] max, [15..17] its entity closest to the world origin,
+ * [18] that entity's GLOBAL index (cameras first, then points; -1 if the shard is empty), [19] its distance.
+ * The host sums [0..2] over ranks, takes min / max, picks the smallest [19] (ties: the larger [18], like fold1 at
+ * src/noise.rs:80-86) and hands the global mean to pass 2, which leaves the shard's three sums of squared
+ * deviations in sumsq3; std = sqrt(sum over ranks / n_entities_global).  city2ba_amd/dist.py: stats_sharded. */
+int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+                            const double *pts4, int64_t n_pts, int64_t pt_base, int64_t n_entities_global,
+                            void *workspace, double *part, void *stream);
+int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
+                            const double *mean3, void *workspace, double *sumsq3, void *stream);
+/* add_drift[_normalized] / add_noise on a shard: cam15 holds cameras [cam_base, cam_base + n_cam) and every draw
+ * is keyed by the GLOBAL camera index, so the sharded result equals the unsharded one row for row; pts4 is the
+ * whole replicated table (every rank perturbs it identically: same counters, no traffic).  stats = the GLOBAL
+ * statistics (device).  normalized != 0: direction and scale from stats (src/noise.rs:47-56), dir_* ignored. */
+int c2b_add_drift_sharded(double *cam15, int64_t n_cam, int64_t cam_base, double *pts4, int64_t n_pts,
+                          const double *stats, int normalized, double strength, double angle_strength, double std,
+                          double dir_x, double dir_y, double dir_z, uint64_t seed, void *stream);
+int c2b_add_noise_entities_sharded(double *cam15, int64_t n_cam, int64_t cam_base, double *pts4, int64_t n_pts,
+                                   const double *stats, double translation_std, double rotation_std,
+                                   double point_std, uint64_t seed, void *stream);
+
 /* noise::add_drift (src/noise.rs:68-116), in place.  `origin` = device pointer to 3 doubles
  * (stats + 15).  Draws: Philox4x32-10 keyed by (seed; stream, entity, slot) -- the reference
  * is unseeded, see DESIGN.md. */

@@ -50,6 +50,34 @@ def _worker(rank, world, port, out):
         _, _, uv_all = O.add_noise(P["cams15"], P["pts"], P["uv"], 0, 0, 0, 0.1, seed=5)
         _, _, uv_part = O.add_noise(P["cams15"][lo:hi], P["pts"], uv, 0, 0, 0, 0.1, seed=5, obs_offset=base)
         assert np.array_equal(uv_part, uv_all[base:base + len(uv)])
+        # sharded statistics: every rank's share of the sums / extrema / closest entity, combined
+        # by dist.combine_stats_partials after an all-gather, equals the oracle's mean / std / extent / drift origin.
+        # (The shares come from numpy here -- no GPU in this container; on the GPU they come from
+        # c2b_stats_partial_pass1/2, tests/test_gpu_level0.py.)
+        centers = O.centers(P["cams15"])
+        n_ent = len(centers) + len(P["pts"])
+        plo, phi = len(P["pts"]) * rank // world, len(P["pts"]) * (rank + 1) // world
+        mine = np.vstack([centers[lo:hi], P["pts"][plo:phi]])
+        gidx = np.concatenate([np.arange(lo, hi), len(centers) + np.arange(plo, phi)])
+        part = np.zeros(20)
+        for row in mine:
+            part[0:3] += row / n_ent
+        part[6:9], part[9:12] = mine.min(axis=0), mine.max(axis=0)
+        d = np.sqrt((mine[:, 0] ** 2 + mine[:, 1] ** 2) + mine[:, 2] ** 2)
+        k = max(np.nonzero(d == d.min())[0])                    # ties -> the later element
+        part[15:18], part[18], part[19] = mine[k], gidx[k], d[k]
+        parts = D._all_gather_rows(part)
+        assert parts.shape == (world, 20) and np.array_equal(parts[rank], part)
+        mean, mn, mx, origin, oidx = D.combine_stats_partials(parts, n_ent)
+        sq = ((mine - mean) ** 2).sum(axis=0)
+        sumsq = D._all_gather_rows(sq).sum(axis=0)
+        st = D.finish_stats(mean, mn, mx, origin, oidx, sumsq, n_ent)
+        assert np.allclose(st[0:3], O.mean(P["cams15"], P["pts"]), rtol=1e-12, atol=1e-12)
+        assert np.allclose(st[3:6], O.std(P["cams15"], P["pts"]), rtol=1e-12)
+        e_mn, e_mx = O.extent(P["cams15"], P["pts"])
+        assert np.array_equal(st[6:9], e_mn) and np.array_equal(st[9:12], e_mx)
+        o_xyz, o_idx = O.drift_origin(P["cams15"], P["pts"])
+        assert int(st[18]) == o_idx and np.array_equal(st[15:18], o_xyz)
         out[rank] = (lo, hi, len(pt_idx), res[2.0])
     finally:
         dist.destroy_process_group()
@@ -76,3 +104,14 @@ def test_single_process_helpers():
     t = torch.tensor([3.0], dtype=torch.float64)
     assert D.all_reduce_sum_(t).item() == 3.0
     assert D.finish_error(9.0, 2.0) == 3.0
+    # origin tie-break: equal distances -> the larger global index (fold1 with strict <); empty shards are skipped
+    a, b, c = np.zeros(20), np.zeros(20), np.zeros(20)
+    a[15:18], a[18], a[19] = (1, 0, 0), 4, 1.0
+    b[15:18], b[18], b[19] = (0, 1, 0), 9, 1.0
+    c[18], c[19] = -1, np.inf
+    for x in (a, b, c):
+        x[6:9], x[9:12] = (0, 0, 0), (1, 1, 1)
+    mean, mn, mx, origin, oidx = D.combine_stats_partials([a, c, b], 10)
+    assert oidx == 9 and list(origin) == [0, 1, 0]
+    st = D.finish_stats(mean, mn, mx, origin, oidx, [10.0, 40.0, 90.0], 10)
+    assert np.allclose(st[3:6], [1, 2, 3]) and abs(st[19] - 14 ** 0.5) < 1e-15 and list(st[12:15]) == [1, 1, 1]

@@ -143,3 +143,86 @@ def test_alloc_jacobian_outputs_returns_usable_buffers():
     D.residual_jacobian_sum(*a, r, Jc, Jp, 2.0, ws, e1)
     torch.cuda.synchronize()
     assert torch.equal(r, r0) and torch.equal(Jc, Jc0) and torch.equal(Jp, Jp0) and e0.item() == e1.item()
+
+
+def _sharded_setup(seed=77):
+    import torch
+    from city2ba_amd import device as D
+    from _problems import random_problem
+    P = random_problem(211, 3000, 9, seed=seed, noise=1e-2)
+    dev = torch.device("cuda", 0)
+    cam15 = torch.from_numpy(P["cams15"]).to(dev)
+    pts4 = D.points_pad(torch.from_numpy(P["pts"]).to(dev))
+    return P, dev, cam15, pts4
+
+
+def test_sharded_statistics_equal_unsharded():
+    """cameras sharded over ranks, points replicated.  Three shards processed one after the other on
+    this GPU through c2b_stats_partial_pass1/2 and combined by the host half of the collective
+    (dist.combine_stats_partials / finish_stats -- the same functions the ranks call after their all-gathers) give
+    the statistics of the whole problem: min / max / origin exactly, mean / std to rounding."""
+    import torch
+    import oracle as O
+    from city2ba_amd import device as D
+    from city2ba_amd import dist as Dist
+    P, dev, cam15, pts4 = _sharded_setup()
+    n_cam, n_pts = cam15.shape[0], pts4.shape[0]
+    n_ent = n_cam + n_pts
+    ws = D.workspace(0, dev)
+    whole = D.stats(D.cameras_prepare_state(cam15), pts4, ws).cpu().numpy()
+    world = 3
+    cb = [0, 70, 70, n_cam]                                      # uneven, one EMPTY camera shard
+    shards = []
+    for r in range(world):
+        camblk = D.cameras_prepare_state(cam15[cb[r]:cb[r + 1]].contiguous())
+        lo, hi = n_pts * r // world, n_pts * (r + 1) // world
+        shards.append((camblk, cb[r], pts4[lo:hi], lo))
+    parts = np.stack([D.stats_partial_pass1(c, base, n_cam, p, lo, n_ent, ws).cpu().numpy() for c, base, p, lo in shards])
+    mean, mn, mx, origin, oidx = Dist.combine_stats_partials(parts, n_ent)
+    mean_d = torch.from_numpy(mean).to(dev)
+    sumsq = np.zeros(3)
+    for c, base, p, lo in shards:
+        sumsq = sumsq + D.stats_partial_pass2(c, p, mean_d, ws).cpu().numpy()
+    st = Dist.finish_stats(mean, mn, mx, origin, oidx, sumsq, n_ent)
+    assert np.array_equal(st[6:15], whole[6:15])                 # min, max, dimensions: exact
+    assert int(st[18]) == int(whole[18]) and np.array_equal(st[15:18], whole[15:18])
+    assert np.allclose(st[0:6], whole[0:6], rtol=1e-13, atol=1e-13) and abs(st[19] - whole[19]) <= 1e-13 * whole[19]
+    assert np.allclose(st[0:3], O.mean(P["cams15"], P["pts"]), rtol=1e-12, atol=1e-12)
+    assert np.allclose(st[3:6], O.std(P["cams15"], P["pts"]), rtol=1e-12)
+    # world size 1 through the same entry point is the unsharded result
+    one = Dist.stats_sharded(D.cameras_prepare_state(cam15), 0, n_cam, pts4, ws).cpu().numpy()
+    assert np.array_equal(one[6:19], whole[6:19]) and np.allclose(one[0:6], whole[0:6], rtol=1e-13, atol=1e-13)
+
+
+def test_sharded_drift_and_noise_equal_unsharded_row_for_row():
+    """Every draw is keyed by the GLOBAL camera index (cam_base + i): perturbing camera shards separately -- each with
+    the whole, replicated point table -- gives bit for bit the cameras and points of the unsharded call."""
+    import torch
+    from city2ba_amd import device as D
+    P, dev, cam15, pts4 = _sharded_setup(seed=78)
+    n_cam = cam15.shape[0]
+    ws = D.workspace(0, dev)
+    st = D.stats(D.cameras_prepare_state(cam15), pts4, ws)
+    bounds = [0, 1, 64, 65, n_cam]
+    for what in ("drift_normalized", "drift", "noise"):
+        c_ref, p_ref = cam15.clone(), pts4.clone()
+        if what == "drift_normalized":
+            D.add_drift_normalized(c_ref, p_ref, st, 1e-3, 2e-3, 0.2, 42)
+        elif what == "drift":
+            D.add_drift_sharded(c_ref, 0, p_ref, st, 1e-3, 2e-3, 0.2, 42, direction=(0.3, -0.5, 0.8))
+        else:
+            D.add_noise_entities(c_ref, p_ref, st, 0.05, 0.02, 0.1, 99)
+        assert not torch.equal(c_ref, cam15) and not torch.equal(p_ref, pts4)
+        rows, pts_out = [], []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            c, p = cam15[lo:hi].contiguous(), pts4.clone()
+            if what == "drift_normalized":
+                D.add_drift_sharded(c, lo, p, st, 1e-3, 2e-3, 0.2, 42)
+            elif what == "drift":
+                D.add_drift_sharded(c, lo, p, st, 1e-3, 2e-3, 0.2, 42, direction=(0.3, -0.5, 0.8))
+            else:
+                D.add_noise_entities_sharded(c, lo, p, st, 0.05, 0.02, 0.1, 99)
+            rows.append(c)
+            pts_out.append(p)
+        assert torch.equal(torch.cat(rows), c_ref), what
+        assert all(torch.equal(p, p_ref) for p in pts_out), what
