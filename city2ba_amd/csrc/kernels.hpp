@@ -239,6 +239,27 @@ constexpr int kCamLight = 16;
 
 constexpr int kObsOPL = 3;                     // observations per lane (all tiles' loads issued up front)
 
+// ---- the slow path of the per-observation kernels: lanes whose camera was not staged ---------------------------
+// (unsorted input, or more than kCamW cameras among a wave's observations).  One round serves up to kCamW DISTINCT
+// cameras: they are picked from the leftover lanes (lowest lane first), their ids go to a small LDS table, their rows
+// are staged into kCamW spare slots with the ordinary cooperative copy, and every lane whose camera was picked runs the
+// same LDS-only arithmetic once.  A randomly ordered list (64 different cameras per tile) takes 6 rounds, not 64.
+// Returns the number of cameras picked; `my` = this lane's slot or -1.
+C2B_DEV int pick_cameras(uint64_t todo, uint32_t ci, int lane, uint32_t *sIdx, int &my) {
+    my = -1;
+    int ns = 0;
+    uint64_t rest = todo;
+    while (rest != 0 && ns < kCamW) {
+        const uint32_t cf = __builtin_amdgcn_readlane(ci, (int)__builtin_ctzll(rest));
+        const bool mine = ((rest >> lane) & 1ull) != 0 && ci == cf;
+        if (mine) my = ns;
+        if (lane == 0) sIdx[ns] = cf;
+        rest &= ~__builtin_amdgcn_ballot_w64(mine);
+        ++ns;
+    }
+    return ns;
+}
+
 // NK (camera_math.hpp: NORM_1 / NORM_2 / NORM_ANY) fixes the error norm at compile time; MODE_ERROR folds
 // sum |du|^norm + |dv|^norm over ALL observations into out_sum[0] in this one launch (ticket_fold).
 //
@@ -278,7 +299,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     // per staged camera: R, t, intrinsics (16 doubles) and, for the visibility predicate, the centre (camblk 24..27)
     constexpr int HOT = MODE == MODE_VISIBILITY ? 20 : kCamLight;
     constexpr int CH = HOT / 2;                                           // 16-byte chunks per camera
-    __shared__ __attribute__((aligned(16))) double sCamAll[WPB * (kCamW + 1) * HOT];   // + 1: the slow path's slot
+    constexpr int kPerWave = 2 * kCamW * HOT + 8;                        // staged cameras | slow-path slots | picked ids
+    __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kPerWave];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
@@ -297,7 +319,9 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
 
         // wave-private camera tile covering all OPL tiles: cameras ci[0](lane 0) .. ci[OPL-1](lane 63) on sorted input
-        double *sCam = sCamAll + wave * (kCamW + 1) * HOT;
+        double *sCam = sCamAll + wave * kPerWave;
+        double *sSlow = sCam + kCamW * HOT;
+        uint32_t *sIdx = reinterpret_cast<uint32_t *>(sSlow + kCamW * HOT);
         const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
         const uint32_t c_last = __builtin_amdgcn_readlane(ci[OPL - 1], 63);
         uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
@@ -333,18 +357,22 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             if (MODE == MODE_VISIBILITY) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
             uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
             while (todo != 0) {                                          // wave-uniform; never taken on sorted input
-                const uint32_t cf = __builtin_amdgcn_readlane(ci[t], (int)__builtin_ctzll(todo));
+                int my;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (lane < CH) {
-                    const int src = lane < kCamLight / 2 ? 2 * lane : kCenter + 2 * (lane - kCamLight / 2);
-                    *reinterpret_cast<d2_t *>(sCam + kCamW * HOT + 2 * lane) =
-                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)cf * kCamBlk + src);
+                const int ns = pick_cameras(todo, ci[t], lane, sIdx, my);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int ch = lane; ch < ns * CH; ch += 64) {
+                    const int k = ch / CH, j = ch % CH;
+                    const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
+                    *reinterpret_cast<d2_t *>(sSlow + k * HOT + 2 * j) =
+                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)sIdx[k] * kCamBlk + src);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                in = ((todo >> lane) & 1ull) != 0 && ci[t] == cf;
-                cam = (lds_cptr)sCam + kCamW * HOT;
+                in = my >= 0;
+                cam = (lds_cptr)sSlow + (in ? my : 0) * HOT;
                 const Proj q = project_obs(cam, X[t].x, X[t].y, X[t].z);
                 if (in) {
                     p = q;
@@ -590,7 +618,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
     double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
     double *__restrict__ block_part, unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
     constexpr int kSlab = 64 * 144 / 2;                                  // half a tile's 2x9 blocks (two rounds)
-    constexpr int kCamBytes = (kCamW + 1) * kCamHot * 8;                 // + 1: the slow path's slot
+    constexpr int kCamBytes = 2 * kCamW * kCamHot * 8 + 64;              // staged cameras | slow-path slots | picked ids
     __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
 
     const int lane = threadIdx.x & 63;
@@ -612,6 +640,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
 
         char *slab = smem + wave * (kSlab + kCamBytes);
         double *sCam = reinterpret_cast<double *>(slab + kSlab);
+        double *sSlow = sCam + kCamW * kCamHot;
+        uint32_t *sIdx = reinterpret_cast<uint32_t *>(sSlow + kCamW * kCamHot);
         const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
         const uint32_t c_last = __builtin_amdgcn_readlane(ci[OPL - 1], 63);
         uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
@@ -638,17 +668,22 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
             jacobian_obs<0>((lds_cptr)sCam + (in ? local : 0u) * kCamHot, X[t], ob, r0, r1, jc, jp);
             uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
             while (todo != 0) {                                          // wave-uniform; never taken on sorted input
-                const uint32_t cf = __builtin_amdgcn_readlane(ci[t], (int)__builtin_ctzll(todo));
+                int my;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (lane < kCamHot / 2)
-                    *reinterpret_cast<d2_t *>(sCam + kCamW * kCamHot + 2 * lane) =
-                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)cf * kCamBlk + 2 * lane);
+                const int ns = pick_cameras(todo, ci[t], lane, sIdx, my);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                in = ((todo >> lane) & 1ull) != 0 && ci[t] == cf;
+                for (int ch = lane; ch < ns * (kCamHot / 2); ch += 64) {
+                    const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
+                    *reinterpret_cast<d2_t *>(sSlow + k * kCamHot + 2 * j) =
+                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)sIdx[k] * kCamBlk + 2 * j);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                in = my >= 0;
                 double q0, q1, qc[18], qp[6];
-                jacobian_obs<0>((lds_cptr)sCam + kCamW * kCamHot, X[t], ob, q0, q1, qc, qp);
+                jacobian_obs<0>((lds_cptr)sSlow + (in ? my : 0) * kCamHot, X[t], ob, q0, q1, qc, qp);
                 if (in) {
                     r0 = q0; r1 = q1;
 #pragma unroll
