@@ -216,6 +216,20 @@ def other_configs(dev):
     t = timed(lambda: D.project(s4["camblk"], s4["pts4"], s4["cam_idx"], s4["pt_idx"], uv4), 500)
     res["blocks4_project_only"] = {"n_observations": s4["n_obs"], "us_per_launch": round(t * 1e6, 2),
                                    "Mobs/s": round(s4["n_obs"] / t / 1e6, 1)}
+    # the same launch-bound case replayed from a HIP graph (20 launches per graph): what a caller that loops over
+    # small problems gets by capturing its loop -- the kernels are capture-safe (tests/test_gpu_level0.py)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(20):
+                    D.project(s4["camblk"], s4["pts4"], s4["cam_idx"], s4["pt_idx"], uv4)
+        torch.cuda.synchronize()
+        tg = timed(g.replay, 50) / 20
+        res["blocks4_project_only"]["us_per_launch_in_hip_graph"] = round(tg * 1e6, 2)
+    except Exception as exc:                                      # informational
+        res["blocks4_project_only"]["us_per_launch_in_hip_graph"] = "failed: %s" % exc
     s32 = build_shard(_ap.Namespace(blocks=32), 0, 1, dev)
     n = s32["n_obs"]
     r = torch.empty((n, 2), dtype=torch.float64, device=dev)

@@ -226,3 +226,40 @@ def test_sharded_drift_and_noise_equal_unsharded_row_for_row():
             pts_out.append(p)
         assert torch.equal(torch.cat(rows), c_ref), what
         assert all(torch.equal(p, p_ref) for p in pts_out), what
+
+
+def test_one_launch_step_is_graph_capturable_and_replays_cleanly():
+    """The fused step (residual + Jacobian + folded error sum) inside a HIP graph: the ticket slot is chosen at capture
+    and frozen into the graph, the last workgroup of every replay resets it, so each replay folds correctly -- with
+    inputs changed in place between replays the replayed sum tracks the eager one bit for bit."""
+    import argparse
+    import torch
+    import bench
+    from city2ba_amd import device as D
+    dev = torch.device("cuda", 0)
+    sh = bench.build_shard(argparse.Namespace(blocks=4), 0, 1, dev)
+    n = sh["n_obs"]
+    r, Jc, Jp = (torch.empty((n, k), dtype=torch.float64, device=dev) for k in (2, 18, 6))
+    ws = D.workspace(n, dev)
+    err_g, err_e = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    uv = sh["uv"].clone()
+    args = (sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], uv)
+    D.residual_jacobian_sum(*args, r, Jc, Jp, 2.0, ws, err_g)         # warm-up: the ticket pool is allocated here
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            D.residual_jacobian_sum(*args, r, Jc, Jp, 2.0, ws, err_g)
+    torch.cuda.synchronize()
+    seen = set()
+    for k in range(6):
+        uv.add_(1e-3 * (k + 1))                                      # the graph reads uv in place
+        g.replay()
+        torch.cuda.synchronize()
+        got = err_g.item()
+        D.residual_jacobian_sum(*args, r, Jc, Jp, 2.0, ws, err_e)
+        torch.cuda.synchronize()
+        assert got == err_e.item() and got > 0
+        seen.add(got)
+    assert len(seen) == 6
