@@ -256,13 +256,13 @@ void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_
 }
 #endif
 
-template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0>
+template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true>
 void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
     const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK>), dim3((unsigned)btiles),             \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK, OBUP>), dim3((unsigned)btiles),             \
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
                        reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum)
@@ -297,7 +297,9 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         }
         case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2, false>(C2B_ARGS); return C2B_OK;     // no Jacobian stores
         case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2, false>(C2B_ARGS); return C2B_OK;     // no arithmetic
-        case 40: launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS); return C2B_OK;      // lean form, natural register count
+        case 40: launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS); return C2B_OK;      // lean form, observed uv requested up front
+        case 49: launch_jac_l<WITH_ERR, 8, 2, 1, 0, false>(C2B_ARGS); return C2B_OK;   // ... requested per tile
+        case 50: launch_jac_l<WITH_ERR, 8, 2, 4, 0, true>(C2B_ARGS); return C2B_OK;    // up front, registers capped for 4 waves per SIMD
         case 41: launch_jac_l<WITH_ERR, 8, 2, 5>(C2B_ARGS); return C2B_OK;      // lean form, capped for 5 waves per SIMD
         case 42: launch_jac_l<WITH_ERR, 8, 1, 1>(C2B_ARGS); return C2B_OK;      // one tile per wave
         case 44: launch_jac_l<WITH_ERR, 8, 2, 1, 1>(C2B_ARGS); return C2B_OK;     // tiles in launch order (no XCD-aware map)

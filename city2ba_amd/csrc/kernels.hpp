@@ -610,7 +610,8 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
 // LDS-typed pointer (first pass unmasked; lanes whose camera was not staged are served in extra rounds through a
 // spare LDS slot and merged under a mask -- never taken on camera-major input), the observed uv requested per tile.
 // XK: tile map -- 0 = contiguous eighths per XCD (xcd_tile32), K >= 1 = xcd_tile_chunked<K>
-template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0>
+// OBUP: request every tile's observed uv up front with the indices (true) or when that tile's arithmetic starts (false)
+template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0, bool OBUP = true>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
     double eacc = 0.0;
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];
+        double2 obs_up[OPL];
         double4 X[OPL];
 #pragma unroll
         for (int t = 0; t < OPL; ++t) {
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
             o = o < n ? o : n - 1;
             ci[t] = cam_idx[o];
             pi[t] = pt_idx[o];
+            if (OBUP) obs_up[t] = uv_obs[o];
         }
 #pragma unroll
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
             const int o = tile0 + lane;
             const bool valid = o < n;
             const int n_wave = n - tile0 < 64 ? n - tile0 : 64;
-            const double2 ob = uv_obs[valid ? o : n - 1];
+            const double2 ob = OBUP ? obs_up[t] : uv_obs[valid ? o : n - 1];
             uint32_t local = ci[t] - c_first;
             bool in = local < n_staged;
             double r0, r1, jc[18], jp[6];
