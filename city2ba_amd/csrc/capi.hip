@@ -300,7 +300,6 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         case 40: launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS); return C2B_OK;      // lean form, observed uv requested up front
         case 49: launch_jac_l<WITH_ERR, 8, 2, 1, 0, false>(C2B_ARGS); return C2B_OK;   // ... requested per tile
         case 50: launch_jac_l<WITH_ERR, 8, 2, 4, 0, true>(C2B_ARGS); return C2B_OK;    // up front, registers capped for 4 waves per SIMD
-        case 41: launch_jac_l<WITH_ERR, 8, 2, 5>(C2B_ARGS); return C2B_OK;      // lean form, capped for 5 waves per SIMD
         case 42: launch_jac_l<WITH_ERR, 8, 1, 1>(C2B_ARGS); return C2B_OK;      // one tile per wave
         case 44: launch_jac_l<WITH_ERR, 8, 2, 1, 1>(C2B_ARGS); return C2B_OK;     // tiles in launch order (no XCD-aware map)
         case 45: launch_jac_l<WITH_ERR, 8, 2, 1, 4>(C2B_ARGS); return C2B_OK;     // chunked XCD map, K = 4
