@@ -190,13 +190,13 @@ void launch_jac_p(const double *camblk, const double *pts4, const uint32_t *cam_
 #endif
 
 // one-shot launch of k_observations<MODE, NK, OPL, WPB>: one workgroup per WPB * OPL tiles of 64 observations
-template <int MODE, int OPL, int WPB, int MINW = 1>
+template <int MODE, int OPL, int WPB, int MINW = 1, bool FAKECI = false>
 void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
     const int tiles = (int)(((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,              \
+    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, FAKECI>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,              \
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                               \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n, tiles, norm, max_dist,                       \
                        reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum)
@@ -224,6 +224,7 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
         case 204: launch_obs_v<MODE, 2, 4>(C2B_ARGS); return C2B_OK;
         case 208: launch_obs_v<MODE, 2, 8>(C2B_ARGS); return C2B_OK;
         case 1308: launch_obs_v<MODE, 3, 8, 8>(C2B_ARGS); return C2B_OK;    // 3 tiles per wave, registers capped for 8 waves per SIMD
+        case 9308: launch_obs_v<MODE, 3, 8, 1, true>(C2B_ARGS); return C2B_OK;   // ablation: camera index computed, not loaded (wrong outputs)
         case 408: launch_obs_v<MODE, 4, 8>(C2B_ARGS); return C2B_OK;
         case 2004: launch_obs_p<MODE, 4>(C2B_ARGS); return C2B_OK;       // persistent pipelined forms (obs_pipeline.hpp)
         case 2008: launch_obs_p<MODE, 8>(C2B_ARGS); return C2B_OK;

@@ -289,7 +289,9 @@ C2B_DEV int xcd_tile_chunked(int bid, int n_tiles) {
     return (k / K) * (8 * K) + xcd * K + (k % K);
 }
 
-template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1>
+// FAKECI (tuning library only; WRONG outputs): derive the camera index from the observation index instead of loading
+// it -- what the kernels would cost if cam_idx were not 4 of their ~25 bytes per observation.
+template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1, bool FAKECI = false>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         for (int t = 0; t < OPL; ++t) {
             int o = base + t * 64 + lane;
             o = o < n ? o : n - 1;                                       // clamped, not predicated
-            ci[t] = cam_idx[o];
+            ci[t] = FAKECI ? (uint32_t)(((uint64_t)(uint32_t)o * 146585185ull) >> 32) : cam_idx[o];   // o / 29.3 (stays below n_cam on the bench grid)
             pi[t] = pt_idx[o];
         }
 #pragma unroll
