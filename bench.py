@@ -390,7 +390,10 @@ def main():
     if dist_on:
         # re-split on the observation prefix sum and rebuild the shard for the balanced range
         bounds = balanced_bounds(sh, rank, world)
-        if (int(bounds[rank]), int(bounds[rank + 1])) != (sh["cam_lo"], sh["cam_hi"]):
+        # build_shard contains a collective (the observation offsets), so the decision to rebuild must be the SAME on
+        # every rank: rebuild everywhere if ANY range moved (the bounds array is identical on all ranks)
+        equal = Dist.camera_count_bounds(sh["n_cam"], world)
+        if any(int(a) != int(b) for a, b in zip(bounds, equal)):
             del sh
             torch.cuda.empty_cache()
             sh = build_shard(args, rank, world, dev, bounds=bounds)
