@@ -190,16 +190,18 @@ void launch_jac_p(const double *camblk, const double *pts4, const uint32_t *cam_
 #endif
 
 // one-shot launch of k_observations<MODE, NK, OPL, WPB>: one workgroup per WPB * OPL tiles of 64 observations
-template <int MODE, int OPL, int WPB, int MINW = 1, bool FAKECI = false>
+// CSR: cam_idx = the camera of every 64th observation, row_ptr / n_cam = the lists' boundaries (kernels.hpp)
+template <int MODE, int OPL, int WPB, int MINW = 1, bool FAKECI = false, bool CSR = false>
 void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
+                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
+                  const uint64_t *row_ptr = nullptr, int64_t n_cam = 0) {
     const int tiles = (int)(((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, FAKECI>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,              \
+    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, FAKECI, CSR>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,         \
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                               \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n, tiles, norm, max_dist,                       \
-                       reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum)
+                       reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum, row_ptr, (int)n_cam)
     if constexpr (MODE != MODE_ERROR) { C2B_GO(NORM_2); }
     else if (norm == 2.0) C2B_GO(NORM_2);
     else if (norm == 1.0) C2B_GO(NORM_1);
@@ -212,10 +214,15 @@ void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_
 template <int MODE>
 int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-               void *workspace, double *out_sum, hipStream_t st) {
+               void *workspace, double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
     unsigned *ticket = nullptr;
     if (MODE == MODE_ERROR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool");
+    if (row_ptr) {          // the *_rows entry points: cam_idx = the tile records of c2b_rows_pack
+        launch_obs_v<MODE, 3, 8, 1, false, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part,
+                                                 ticket, out_sum, st, row_ptr, n_cam);
+        return C2B_OK;
+    }
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st
 #ifdef C2B_TUNE
     switch (g_obs_variant) {
@@ -584,6 +591,81 @@ int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const u
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("reprojection_error_sum")
+}
+
+// ---- camera-major lists addressed through the row structure (no per-observation camera index) ----
+int64_t c2b_rows_tiles_bytes(int64_t n_obs) { return n_obs <= 0 ? 0 : (n_obs + 63) / 64 * 16; }
+
+static int check_rows_args(const char *who, const uint64_t *row_ptr, int64_t n_cam, const void *tiles, int64_t n) {
+    if (n_cam < 0 || n_cam >= (int64_t)1 << 31) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: n_cam out of range", who);
+    if (n && (!row_ptr || !tiles || n_cam == 0)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: NULL row_ptr / tiles, or no cameras", who);
+    if (n && !aligned16(tiles)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: tiles must be 16-byte aligned", who);
+    return C2B_OK;
+}
+
+int c2b_rows_pack(const uint64_t *row_ptr, int64_t n_cam, int64_t n_obs, void *tiles, void *stream) {
+    C2B_API_BEGIN
+    if (n_obs < 0 || n_obs > (int64_t)0x7fffffff - 4096 * 64) return fail(C2B_ERR_INVALID_ARGUMENT, "rows_pack: observation count out of range");
+    int rc = check_rows_args("rows_pack", row_ptr, n_cam, tiles, n_obs);
+    if (rc) return rc;
+    if (!n_obs) return C2B_OK;
+    const int64_t n_tiles = (n_obs + 63) / 64;
+    hipLaunchKernelGGL(k_rows_pack, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, S(stream), row_ptr, (int)n_cam, (int)n_obs,
+                       reinterpret_cast<uint4 *>(tiles));
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("rows_pack")
+}
+
+int c2b_project_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam, const void *tiles,
+                     const uint32_t *pt_idx, int64_t n_obs, double *uv_out, void *stream) {
+    C2B_API_BEGIN
+    int rc = check_obs_args("project_rows", camblk, pts4, tiles, pt_idx, n_obs);
+    if (!rc) rc = check_rows_args("project_rows", row_ptr, n_cam, tiles, n_obs);
+    if (rc) return rc;
+    if (!n_obs) return C2B_OK;
+    if (!uv_out || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "project_rows: uv_out NULL or misaligned");
+    rc = launch_obs<MODE_PROJECT>(camblk, pts4, reinterpret_cast<const uint32_t *>(tiles), pt_idx, nullptr, n_obs, 0.0, 0.0, uv_out,
+                                  nullptr, nullptr, nullptr, S(stream), row_ptr, n_cam);
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("project_rows")
+}
+
+int c2b_reprojection_error_sum_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                                    const void *tiles, const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                                    double norm, void *workspace, double *out_sum, void *stream) {
+    C2B_API_BEGIN
+    int rc = check_obs_args("reprojection_error_sum_rows", camblk, pts4, tiles, pt_idx, n_obs);
+    if (!rc) rc = check_rows_args("reprojection_error_sum_rows", row_ptr, n_cam, tiles, n_obs);
+    if (rc) return rc;
+    if (!out_sum) return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum_rows: out_sum is NULL");
+    if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream))); return C2B_OK; }
+    if (!uv_obs || !aligned16(uv_obs) || !workspace)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sum_rows: uv_obs/workspace NULL or misaligned");
+    rc = launch_obs<MODE_ERROR>(camblk, pts4, reinterpret_cast<const uint32_t *>(tiles), pt_idx, uv_obs, n_obs, norm, 0.0, nullptr,
+                                nullptr, workspace, out_sum, S(stream), row_ptr, n_cam);
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("reprojection_error_sum_rows")
+}
+
+int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam, const void *tiles,
+                        const uint32_t *pt_idx, int64_t n_pairs, double max_dist, double *uv_out, uint8_t *keep, void *stream) {
+    C2B_API_BEGIN
+    int rc = check_obs_args("visibility_rows", camblk, pts4, tiles, pt_idx, n_pairs);
+    if (!rc) rc = check_rows_args("visibility_rows", row_ptr, n_cam, tiles, n_pairs);
+    if (rc) return rc;
+    if (!n_pairs) return C2B_OK;
+    if (!uv_out || !keep || !aligned16(uv_out)) return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_rows: NULL or misaligned output");
+    rc = launch_obs<MODE_VISIBILITY>(camblk, pts4, reinterpret_cast<const uint32_t *>(tiles), pt_idx, nullptr, n_pairs, 0.0, max_dist,
+                                     uv_out, keep, nullptr, nullptr, S(stream), row_ptr, n_cam);
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("visibility_rows")
 }
 
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,

@@ -206,6 +206,35 @@ __global__ void k_expand_rows(const uint64_t *__restrict__ row_ptr, int64_t n_ca
     cam_idx[o] = (uint32_t)(lo - 1);
 }
 
+// the camera whose list holds observation o: (first c with row_ptr[c] > o) - 1, as k_expand_rows
+C2B_DEV uint32_t csr_search(const uint64_t *__restrict__ row_ptr, int n_cam, uint64_t o) {
+    int lo = 0, hi = n_cam + 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row_ptr[mid] > o) hi = mid; else lo = mid + 1;
+    }
+    return (uint32_t)(lo - 1);
+}
+
+// The row structure as the per-observation kernels read it (k_observations<..., CSR = true>): one 16-byte record per
+// 64 observations = { mask of the lanes whose observation opens a new camera's list (bit 0 unused), the camera of the
+// tile's first observation, 0 }.  Bit 31 of the camera marks a tile with an EMPTY list inside it (two boundaries on
+// one observation cannot be one mask bit); the kernels search row_ptr for those.  One wave per tile.
+__global__ __launch_bounds__(256) void k_rows_pack(const uint64_t *__restrict__ row_ptr, int n_cam, int n,
+                                                   uint4 *__restrict__ tiles) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((int64_t)tile * 64 >= n) return;                                 // wave-uniform
+    const int o = tile * 64 + lane;
+    const bool valid = o < n;
+    const uint32_t c = csr_search(row_ptr, n_cam, (uint64_t)(valid ? o : n - 1));
+    const uint32_t prev = __shfl_up(c, 1, 64);
+    const bool inner = valid && lane > 0;
+    const uint64_t first = __builtin_amdgcn_ballot_w64(inner && c != prev);
+    const uint64_t gap = __builtin_amdgcn_ballot_w64(inner && c - prev > 1u);
+    if (lane == 0) tiles[tile] = make_uint4((uint32_t)first, (uint32_t)(first >> 32), c | (gap ? 0x80000000u : 0u), 0u);
+}
+
 // ---- wave-private camera tile ------------------------------------------------------------------------
 // A wave's 64 consecutive observations touch a short run of consecutive cameras (3-4 on the grid).  The
 // wave copies the first HOT doubles of those records into its own LDS tile and every lane then reads its
@@ -291,13 +320,19 @@ C2B_DEV int xcd_tile_chunked(int bid, int n_tiles) {
 
 // FAKECI (tuning library only; WRONG outputs): derive the camera index from the observation index instead of loading
 // it -- what the kernels would cost if cam_idx were not 4 of their ~25 bytes per observation.
-template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1, bool FAKECI = false>
+//
+// CSR: the camera of an observation comes from the reference's own structure -- one list per camera, i.e. row_ptr
+// (src/baproblem.rs:256-260) -- instead of a 4-byte index per observation: `cam_idx` then points at the tile records
+// k_csr_pack derives from row_ptr (16 bytes per 64 observations).  SURVEY 8(d)'s algorithmic bytes assume exactly
+// this: 4 B of point index per observation and the row structure once.
+template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1, bool FAKECI = false,
+          bool CSR = false>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int n, int n_btiles, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ block_part,
-    unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
+    unsigned *__restrict__ ticket, double *__restrict__ out_sum, const uint64_t *__restrict__ row_ptr, int n_cam) {
     // per staged camera: R, t, intrinsics (16 doubles) and, for the visibility predicate, the centre (camblk 24..27)
     constexpr int HOT = MODE == MODE_VISIBILITY ? 20 : kCamLight;
     constexpr int CH = HOT / 2;                                           // 16-byte chunks per camera
@@ -314,8 +349,30 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         for (int t = 0; t < OPL; ++t) {
             int o = base + t * 64 + lane;
             o = o < n ? o : n - 1;                                       // clamped, not predicated
-            ci[t] = FAKECI ? (uint32_t)(((uint64_t)(uint32_t)o * 146585185ull) >> 32) : cam_idx[o];   // o / 29.3 (stays below n_cam on the bench grid)
+            if (!CSR) ci[t] = FAKECI ? (uint32_t)(((uint64_t)(uint32_t)o * 146585185ull) >> 32) : cam_idx[o];   // o / 29.3 (stays below n_cam on the bench grid)
             pi[t] = pt_idx[o];
+        }
+        if (CSR) {
+            // One 16-byte record per 64 observations, read with scalar loads: the camera of the tile's first
+            // observation and a 64-bit mask of the lanes whose observation opens a new camera's list.  A lane's camera
+            // is that first camera plus the number of set bits at or below it: two v_mbcnt per tile, nothing per
+            // observation.  Bit 31 of the camera marks a tile the mask cannot describe (an empty list inside it).
+            const int last_tile = (n - 1) >> 6;
+#pragma unroll
+            for (int t = 0; t < OPL; ++t) {
+                int ti = (base >> 6) + t;
+                ti = ti < last_tile ? ti : last_tile;                    // tiles past the end repeat the last one (results discarded)
+                const uint4 rec = reinterpret_cast<const uint4 *>(cam_idx)[ti];
+                if (rec.z & 0x80000000u) {                               // wave-uniform
+                    int o = ti * 64 + lane;
+                    o = o < n ? o : n - 1;
+                    ci[t] = csr_search(row_ptr, n_cam, (uint64_t)o);
+                } else {
+                    // bits 1..63 of the mask, moved down one place: mbcnt counts the set bits BELOW a lane
+                    const uint32_t lo = (rec.x >> 1) | (rec.y << 31), hi = rec.y >> 1;
+                    ci[t] = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, rec.z));
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];

@@ -87,6 +87,40 @@ def reprojection_error_sum(camblk, pts4, cam_idx, pt_idx, uv, norm, ws, out_sum)
     return out_sum
 
 
+class Rows:
+    """A camera-major observation list addressed through its row structure -- the reference's one list per camera
+    (vis_graph, src/baproblem.rs:256-260) -- instead of a 4-byte camera index per observation: row_ptr [n_cam + 1]
+    (int64 tensor holding the u64 values) plus the tile records c2b_rows_pack derives from it (16 bytes per 64
+    observations).  The *_rows launchers give the same bits as their cam_idx forms and read ~3.7 bytes per observation
+    less."""
+
+    def __init__(self, row_ptr, n_obs=None):
+        _chk(row_ptr, torch.int64, "row_ptr")
+        self.row_ptr = row_ptr
+        self.n_cam = row_ptr.shape[0] - 1
+        self.n_obs = int(row_ptr[-1].item()) if n_obs is None else int(n_obs)
+        self.tiles = torch.empty((L.lib().c2b_rows_tiles_bytes(self.n_obs) // 16, 4), dtype=torch.int32, device=row_ptr.device)
+        L.check(L.lib().c2b_rows_pack(_p(row_ptr), self.n_cam, self.n_obs, _p(self.tiles), _stream()))
+
+
+def project_rows(camblk, pts4, rows, pt_idx, uv_out):
+    L.check(L.lib().c2b_project_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(rows.tiles), _p(pt_idx),
+                                     rows.n_obs, _p(uv_out), _stream()))
+    return uv_out
+
+
+def reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, norm, ws, out_sum):
+    L.check(L.lib().c2b_reprojection_error_sum_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(rows.tiles),
+                                                    _p(pt_idx), _p(uv), rows.n_obs, float(norm), _p(ws), _p(out_sum),
+                                                    _stream()))
+    return out_sum
+
+
+def visibility_rows(camblk, pts4, rows, pt_idx, max_dist, uv_out, keep):
+    L.check(L.lib().c2b_visibility_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(rows.tiles), _p(pt_idx),
+                                        rows.n_obs, float(max_dist), _p(uv_out), _p(keep), _stream()))
+
+
 def residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None):
     """ws != None -> the same launch also folds sum |r|^norm into ws (see error_sum_finish)."""
     L.check(L.lib().c2b_residual_jacobian(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv), cam_idx.shape[0],

@@ -62,9 +62,8 @@ int c2b_device_count(int *count);
  * ===================================================================================== */
 
 /* Bytes of scratch the reductions below need for a problem with n_obs observations.  The workspace needs no
- * initialisation (the in-kernel arrival ticket is tagged with a per-launch epoch, so stale or garbage contents
- * count as "no arrivals").  One workspace serves one stream at a time: two launches that may run concurrently
- * must not share it. */
+ * initialisation (the arrival counters of the in-kernel folds live in a pool the library owns and keeps zeroed).
+ * One workspace serves one stream at a time: two launches that may run concurrently must not share it. */
 int64_t c2b_workspace_bytes(int64_t n_obs);
 
 /* SnavelyCamera::from_vec / from_rodrigues (src/baproblem.rs:78-90, 180-186) */
@@ -106,6 +105,25 @@ int c2b_project(const double *camblk, const double *pts4, const uint32_t *cam_id
 int c2b_reprojection_error_sum(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                                const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
                                double norm, void *workspace, double *out_sum, void *stream);
+
+/* The same three per-observation passes for a camera-major list addressed through its ROW STRUCTURE -- the
+ * reference's own representation, one list per camera (vis_graph, src/baproblem.rs:256-260) -- instead of a 4-byte
+ * camera index per observation.  row_ptr [n_cam + 1] (row_ptr[0] = 0, row_ptr[n_cam] = n_obs, non-decreasing; lists
+ * may be empty) and `tiles`, c2b_rows_tiles_bytes(n_obs) bytes (16-byte aligned) filled once per list by
+ * c2b_rows_pack: per 64 observations the camera of the first one and a mask of the lanes that open a new list.
+ * Results are bit-identical to c2b_project / c2b_reprojection_error_sum / c2b_visibility_pairs on the expanded list;
+ * the kernels read 0.25 instead of 4 bytes of camera addressing per observation (SURVEY section 8(d) counts the
+ * algorithmic bytes of these passes this way: 4 B of point index per observation, the row structure once). */
+int64_t c2b_rows_tiles_bytes(int64_t n_obs);
+int c2b_rows_pack(const uint64_t *row_ptr, int64_t n_cam, int64_t n_obs, void *tiles, void *stream);
+int c2b_project_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                     const void *tiles, const uint32_t *pt_idx, int64_t n_obs, double *uv_out, void *stream);
+int c2b_reprojection_error_sum_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                                    const void *tiles, const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                                    double norm, void *workspace, double *out_sum, void *stream);
+int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                        const void *tiles, const uint32_t *pt_idx, int64_t n_pairs, double max_dist,
+                        double *uv_out, uint8_t *keep, void *stream);
 
 /* residual + 2x9 camera block + 2x3 point block per observation (no reference equivalent).
  * With workspace != NULL the same launch also folds sum |du|^norm + |dv|^norm (fused error reduce, same fold

@@ -1,0 +1,141 @@
+"""The row-structure forms of the per-observation passes (c2b_rows_pack, c2b_project_rows,
+c2b_reprojection_error_sum_rows, c2b_visibility_rows): a camera-major list addressed by row_ptr -- the reference's
+one list per camera, src/baproblem.rs:256-260 -- must give the SAME BITS as the cam_idx forms on the expanded list,
+whatever the shape of the lists: empty lists (at the start, inside a tile, several in a row, at the end), one
+observation per camera (64 cameras in a wave: the kernels' slow path), one huge list, ragged ends.  The tile records
+themselves are checked against a numpy restatement of their definition."""
+import numpy as np
+import pytest
+
+from _problems import random_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as entry
+    entry.build()
+    import torch
+    import city2ba_amd
+    from city2ba_amd import device as D
+    assert city2ba_amd.device_count() > 0
+    return dict(torch=torch, D=D, dev=torch.device("cuda", 0))
+
+
+def _np_tiles(counts):
+    """tile records from their definition: per 64 observations {mask of lanes > 0 whose camera differs from the lane
+    before, camera of lane 0 | bit 31 when some step inside the tile skips a camera}"""
+    cam_of = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+    n = len(cam_of)
+    n_t = (n + 63) // 64
+    rec = np.zeros((n_t, 4), dtype=np.uint32)
+    for t in range(n_t):
+        c = cam_of[64 * t:64 * t + 64]
+        d = np.diff(c)
+        mask = 0
+        for l in np.nonzero(d != 0)[0]:
+            mask |= 1 << int(l + 1)
+        rec[t] = (mask & 0xFFFFFFFF, mask >> 32, int(c[0]) | (0x80000000 if np.any(d > 1) else 0), 0)
+    return rec
+
+
+def _lists(kind, rng):
+    if kind == "ragged":
+        return rng.integers(1, 60, size=300)
+    if kind == "empties":                                   # empty lists everywhere, runs of them too
+        c = rng.integers(0, 50, size=400)
+        c[rng.random(400) < 0.3] = 0
+        c[:3] = 0
+        c[-2:] = 0
+        c[100:120] = 0
+        return c
+    if kind == "singles":                                   # one observation per camera: 64 cameras per tile
+        return np.ones(1000, dtype=np.int64)
+    if kind == "singles_with_gaps":
+        c = np.ones(1500, dtype=np.int64)
+        c[rng.random(1500) < 0.2] = 0
+        return c
+    if kind == "one_list":
+        return np.array([777])
+    if kind == "tiny":
+        return np.array([0, 1, 0])
+    if kind == "tile_edges":                                # boundaries exactly on multiples of 64 and 192
+        return np.array([64, 64, 64, 128, 192, 1, 63, 191, 1, 0, 64])
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("kind", ["ragged", "empties", "singles", "singles_with_gaps", "one_list", "tiny", "tile_edges"])
+def test_rows_forms_give_the_bits_of_the_index_forms(env, kind):
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    rng = np.random.default_rng(sum(kind.encode()))
+    counts = np.asarray(_lists(kind, rng), dtype=np.int64)
+    n_cam, n = len(counts), int(counts.sum())
+    P = random_problem(n_cam, 2000, 3, seed=11, noise=1e-3)            # cameras and points; the lists are ours
+    pt = rng.integers(0, 2000, size=n)
+    uv = rng.normal(size=(n, 2))
+    row_ptr = np.zeros(n_cam + 1, dtype=np.int64)
+    row_ptr[1:] = np.cumsum(counts)
+    cam_of = np.repeat(np.arange(n_cam), counts)
+
+    camblk = D.cameras_prepare_state(torch.from_numpy(P["cams15"]).to(dev))
+    pts4 = D.points_pad(torch.from_numpy(P["pts"]).to(dev))
+    ci = torch.from_numpy(cam_of.astype(np.int32)).to(dev)
+    pi = torch.from_numpy(pt.astype(np.int32)).to(dev)
+    uv_d = torch.from_numpy(uv).to(dev)
+    rows = D.Rows(torch.from_numpy(row_ptr).to(dev))
+    assert rows.n_obs == n and rows.n_cam == n_cam
+    torch.cuda.synchronize()
+    assert np.array_equal(rows.tiles.cpu().numpy().view(np.uint32), _np_tiles(counts))
+
+    a, b = (torch.full((n, 2), 7.0, dtype=torch.float64, device=dev) for _ in range(2))
+    D.project(camblk, pts4, ci, pi, a)
+    D.project_rows(camblk, pts4, rows, pi, b)
+    torch.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+
+    ws = D.workspace(n, dev)
+    for norm in (2.0, 1.0, 1.5):
+        ea, eb = (torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2))
+        D.reprojection_error_sum(camblk, pts4, ci, pi, uv_d, norm, ws, ea)
+        D.reprojection_error_sum_rows(camblk, pts4, rows, pi, uv_d, norm, ws, eb)
+        torch.cuda.synchronize()
+        assert ea.item() == eb.item() and np.isfinite(ea.item())
+
+    ka, kb = (torch.full((n,), 9, dtype=torch.uint8, device=dev) for _ in range(2))
+    D.visibility_pairs(camblk, pts4, ci, pi, 60.0, a, ka)
+    D.visibility_rows(camblk, pts4, rows, pi, 60.0, b, kb)
+    torch.cuda.synchronize()
+    assert np.array_equal(ka.cpu().numpy(), kb.cpu().numpy())
+    assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+    if n > 100:
+        assert 0 < int(ka.sum().item())
+
+
+def test_rows_on_the_bench_grid_and_their_argument_checks(env):
+    """blocks = 4 of the synthetic grid (cameras without observations exist there: no cull), and the ABI's checks"""
+    import argparse
+    import bench
+    from city2ba_amd import _lib as L
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    sh = bench.build_shard(argparse.Namespace(blocks=4), 0, 1, dev)
+    n, n_cam = sh["n_obs"], sh["camblk"].shape[0]
+    row_ptr = torch.zeros(n_cam + 1, dtype=torch.int64, device=dev)
+    row_ptr[1:] = torch.cumsum(torch.bincount(sh["cam_idx"].long(), minlength=n_cam), 0)
+    rows = D.Rows(row_ptr)
+    a, b = (torch.empty((n, 2), dtype=torch.float64, device=dev) for _ in range(2))
+    D.project(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], a)
+    D.project_rows(sh["camblk"], sh["pts4"], rows, sh["pt_idx"], b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+    lib = L.lib()
+    assert lib.c2b_rows_tiles_bytes(0) == 0 and lib.c2b_rows_tiles_bytes(1) == 16 and lib.c2b_rows_tiles_bytes(65) == 32
+    p = lambda t: t.data_ptr()
+    # misaligned tile records, no cameras, missing row_ptr: status codes, never a launch
+    assert lib.c2b_project_rows(p(sh["camblk"]), p(sh["pts4"]), p(row_ptr), n_cam, p(rows.tiles) + 4, p(sh["pt_idx"]), n, p(b), None) == L.ERR_INVALID_ARGUMENT
+    assert lib.c2b_project_rows(p(sh["camblk"]), p(sh["pts4"]), p(row_ptr), 0, p(rows.tiles), p(sh["pt_idx"]), n, p(b), None) == L.ERR_INVALID_ARGUMENT
+    assert lib.c2b_project_rows(p(sh["camblk"]), p(sh["pts4"]), None, n_cam, p(rows.tiles), p(sh["pt_idx"]), n, p(b), None) == L.ERR_INVALID_ARGUMENT
+    assert lib.c2b_rows_pack(p(row_ptr), 1 << 31, n, p(rows.tiles), None) == L.ERR_INVALID_ARGUMENT
+    assert lib.c2b_rows_pack(p(row_ptr), n_cam, 0, None, None) == L.OK                  # an empty list is fine
+    assert lib.c2b_project_rows(None, None, None, 0, None, None, 0, None, None) == L.OK

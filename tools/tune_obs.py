@@ -36,12 +36,27 @@ ws = D.workspace(n, dev)
 err = torch.zeros(1, dtype=torch.float64, device=dev)
 camblk, pts4, ci, pi, uv = sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"]
 uv_out = torch.empty_like(uv)
+# the row-structure forms (camera from row_ptr + tile records instead of a 4-byte index per observation): extra modes,
+# not variants -- they are product entry points
+n_cam = camblk.shape[0]
+row_ptr = torch.zeros(n_cam + 1, dtype=torch.int64, device=dev)
+row_ptr[1:] = torch.cumsum(torch.bincount(ci.long(), minlength=n_cam), 0)
+rows = D.Rows(row_ptr)
+uv_rows = torch.empty_like(uv)
 keep = torch.empty(n, dtype=torch.uint8, device=dev)
+keep_rows = torch.empty(n, dtype=torch.uint8, device=dev)
+err_rows = torch.zeros(1, dtype=torch.float64, device=dev)
+print("tiles %d, with an empty list inside %d" % (rows.tiles.shape[0], int((rows.tiles[:, 2] < 0).sum())))
 
 modes = {
     "project": lambda: D.project(camblk, pts4, ci, pi, uv_out),
     "error_L2": lambda: D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, err),
     "visibility": lambda: D.visibility_pairs(camblk, pts4, ci, pi, 10.0, uv_out, keep),
+}
+row_modes = {
+    "project_rows": lambda: D.project_rows(camblk, pts4, rows, pi, uv_rows),
+    "error_L2_rows": lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pi, uv, 2.0, ws, err_rows),
+    "visibility_rows": lambda: D.visibility_rows(camblk, pts4, rows, pi, 10.0, uv_rows, keep_rows),
 }
 
 ref = {}
@@ -63,8 +78,28 @@ for v in variants:
         print("variant %d: project bit-equal %s, keep equal %s, error rel diff %.1e" %
               (v, torch.equal(p, ref["p"]), torch.equal(k, ref["k"]), abs(e - ref["e"]) / max(ref["e"], 1e-300)))
 
+raw.c2b_tune_set_observation_variant(variants[0])
+modes["project"](); row_modes["project_rows"]()
+torch.cuda.synchronize()
+eq_p = torch.equal(uv_out, uv_rows)
+modes["visibility"](); row_modes["visibility_rows"](); modes["error_L2"](); row_modes["error_L2_rows"]()
+torch.cuda.synchronize()
+print("rows forms: project bit-equal %s, keep equal %s, uv equal %s, error equal %s" %
+      (eq_p, torch.equal(keep, keep_rows), torch.equal(uv_out.view(torch.int64), uv_rows.view(torch.int64)), err.item() == err_rows.item()))
+
 times = {(m, v): [] for m in modes for v in variants}
+times.update({(m, 0): [] for m in row_modes})
 for _ in range(a.rounds):
+    for m, fn in row_modes.items():
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(a.reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        times[(m, 0)].append(s.elapsed_time(e) / a.reps * 1e3)
     for m, fn in modes.items():
         for v in variants:
             raw.c2b_tune_set_observation_variant(v)
@@ -82,3 +117,6 @@ for m in modes:
     for v in variants:
         t = sorted(times[(m, v)])
         print("%-10s OPL=%d WPB=%-2d: median %.1f us  min %.1f us  %.1f Gobs/s" % (m, v // 100, v % 100, t[len(t) // 2], t[0], n / t[len(t) // 2] / 1e3))
+for m in row_modes:
+    t = sorted(times[(m, 0)])
+    print("%-16s      : median %.1f us  min %.1f us  %.1f Gobs/s" % (m, t[len(t) // 2], t[0], n / t[len(t) // 2] / 1e3))
