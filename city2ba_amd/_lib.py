@@ -48,6 +48,7 @@ SIGNATURES = {
     "c2b_project_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "c2b_reprojection_error_sum_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_visibility_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
+    "c2b_residual_jacobian_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
     "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp]),
     "c2b_error_sum_finish": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_residual_jacobian_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),

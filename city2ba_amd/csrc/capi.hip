@@ -264,16 +264,19 @@ void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_
 }
 #endif
 
-template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true>
+// CSR: cam_idx = the tile records of c2b_rows_pack for this launch's first observation (= observation obs_base of
+// the list row_ptr describes)
+template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false>
 void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
-                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
+                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
+                  const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0) {
     const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK, OBUP>), dim3((unsigned)btiles),             \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK, OBUP, CSR>), dim3((unsigned)btiles),        \
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
-                       reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum)
+                       reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum, row_ptr, (int)n_cam, obs_base)
     if constexpr (!WITH_ERR) { C2B_GO(NORM_2); }
     else if (norm == 2.0) C2B_GO(NORM_2);
     else if (norm == 1.0) C2B_GO(NORM_1);
@@ -285,10 +288,15 @@ void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_
 template <bool WITH_ERR>
 int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                     const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
-                    double *out_sum, hipStream_t st) {
+                    double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
     unsigned *ticket = nullptr;
     if (WITH_ERR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool");
+    if (row_ptr) {          // the *_rows entry points
+        launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket,
+                                                       out_sum, st, row_ptr, n_cam, obs_base);
+        return C2B_OK;
+    }
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st
 #ifdef C2B_TUNE
     switch (g_jac_variant) {
@@ -704,6 +712,36 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("residual_jacobian_sum")
+}
+
+int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                               const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
+                               int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
+                               double *out_sum, void *stream) {
+    C2B_API_BEGIN
+    int rc = check_obs_args("residual_jacobian_rows", camblk, pts4, tiles, pt_idx, n_obs);
+    if (!rc) rc = check_rows_args("residual_jacobian_rows", row_ptr, n_cam, tiles, n_obs);
+    if (rc) return rc;
+    if (obs_base < 0 || (obs_base & 63)) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows: obs_base must be a non-negative multiple of 64");
+    if (out_sum && !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows: out_sum needs a workspace");
+    if (!n_obs) {
+        if (out_sum) HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(double), S(stream)));
+        return C2B_OK;
+    }
+    if (!uv_obs || !r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows: NULL buffer");
+    if (!aligned16(uv_obs) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows: uv/r/Jc/Jp must be 16-byte aligned");
+    const uint32_t *rec = reinterpret_cast<const uint32_t *>(tiles);
+    if (workspace) {
+        double *dst = out_sum ? out_sum : reinterpret_cast<double *>(workspace) + kWsFinal;
+        rc = launch_jacobian<true>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, dst, S(stream), row_ptr, n_cam, obs_base);
+    } else {
+        rc = launch_jacobian<false>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr, nullptr, S(stream), row_ptr, n_cam, obs_base);
+    }
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("residual_jacobian_rows")
 }
 
 int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, void *stream) {
@@ -1590,6 +1628,10 @@ struct c2b_problem {
     double *stats = nullptr, *scalar = nullptr;
     bool bal_valid = false;     // bal9 still describes the cameras (no mutation since upload_bal)
     bool blk_valid = false;     // camblk matches cam15 (and bal_valid mode)
+    // the row structure of the observation list for the *_rows launchers, rebuilt on demand after the list changed
+    uint64_t *rows_ptr = nullptr;
+    void *rows_tiles = nullptr;
+    bool rows_valid = false;
     uint32_t *dense_pt = nullptr;   // survivors of the last dense visibility sweep
     double *dense_uv = nullptr;
     uint64_t *dense_row = nullptr;  // its CSR row pointer [n_cam + 1], kept for the occlusion filter
@@ -1609,11 +1651,19 @@ static void free_dense(c2b_problem *p) {
     p->dense_pt = nullptr; p->dense_uv = nullptr; p->dense_row = nullptr; p->dense_n = 0;
 }
 
+// the observation list changed (upload, cull, adopted visibility): its row structure is rebuilt by the next user
+static void drop_rows(c2b_problem *p) {
+    if (p->rows_ptr) (void)hipFree(p->rows_ptr);
+    if (p->rows_tiles) (void)hipFree(p->rows_tiles);
+    p->rows_ptr = nullptr; p->rows_tiles = nullptr; p->rows_valid = false;
+}
+
 static void free_buffers(c2b_problem *p) {
     void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar, p->jac_ring};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->jac_ring = nullptr;
     free_dense(p);
+    drop_rows(p);
     p->cam15 = p->bal9 = p->camblk = p->pts4 = p->uv = nullptr;
     p->cam_idx = p->pt_idx = nullptr;
     p->ws = nullptr; p->stats = p->scalar = nullptr;
@@ -1845,16 +1895,32 @@ int c2b_problem_centers(c2b_problem *p, double *centers3) {
     C2B_API_END("problem_centers")
 }
 
+// row_ptr (from the camera-major cam_idx) and the tile records of the current observation list
+static int ensure_rows(c2b_problem *p) {
+    if (p->rows_valid || !p->n_obs) return C2B_OK;
+    drop_rows(p);
+    HIP_TRY(hipMalloc((void **)&p->rows_ptr, sizeof(uint64_t) * (size_t)(p->n_cam + 1)));
+    HIP_TRY(hipMalloc(&p->rows_tiles, (size_t)c2b_rows_tiles_bytes(p->n_obs)));
+    hipLaunchKernelGGL(k_rows_from_sorted, dim3(blocks_for(p->n_obs + 1)), dim3(kBlock), 0, p->stream, (const uint32_t *)p->cam_idx,
+                       p->n_obs, p->n_cam, p->rows_ptr);
+    LAUNCH_CHECK();
+    const int rc = c2b_rows_pack(p->rows_ptr, p->n_cam, p->n_obs, p->rows_tiles, p->stream);
+    if (rc) return rc;
+    p->rows_valid = true;
+    return C2B_OK;
+}
+
 int c2b_problem_project(c2b_problem *p, double *uv_out) {
     C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_project");
     if (!p->n_obs) return C2B_OK;
     if (!uv_out) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_project: uv_out is NULL");
     int rc = ensure_camblk(p);
+    if (!rc) rc = ensure_rows(p);
     if (rc) return rc;
     double *d_uv = nullptr;
     HIP_TRY(hipMalloc((void **)&d_uv, sizeof(double) * 2 * p->n_obs));
-    rc = c2b_project(p->camblk, p->pts4, p->cam_idx, p->pt_idx, p->n_obs, d_uv, p->stream);
+    rc = c2b_project_rows(p->camblk, p->pts4, p->rows_ptr, p->n_cam, p->rows_tiles, p->pt_idx, p->n_obs, d_uv, p->stream);
     hipError_t e = hipSuccess;
     if (!rc) e = hipMemcpyAsync(uv_out, d_uv, sizeof(double) * 2 * p->n_obs, hipMemcpyDeviceToHost, p->stream);
     hipError_t e2 = hipStreamSynchronize(p->stream);
@@ -1870,9 +1936,10 @@ int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *ou
     NEED_UPLOADED(p, "problem_total_reprojection_error");
     if (!out) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_error: out is NULL");
     int rc = ensure_camblk(p);
+    if (!rc) rc = ensure_rows(p);
     if (rc) return rc;
-    rc = c2b_reprojection_error_sum(p->camblk, p->pts4, p->cam_idx, p->pt_idx, p->uv, p->n_obs, norm, p->ws,
-                                    p->scalar, p->stream);
+    rc = c2b_reprojection_error_sum_rows(p->camblk, p->pts4, p->rows_ptr, p->n_cam, p->rows_tiles, p->pt_idx, p->uv, p->n_obs,
+                                         norm, p->ws, p->scalar, p->stream);
     if (rc) return rc;
     double sum = 0.0;
     HIP_TRY(hipMemcpyAsync(&sum, p->scalar, sizeof(double), hipMemcpyDeviceToHost, p->stream));
@@ -1893,6 +1960,7 @@ int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double 
     if (!p->n_obs) return C2B_OK;
     if (!r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_residual_jacobian: NULL output");
     int rc = ensure_camblk(p);
+    if (!rc) rc = ensure_rows(p);
     if (rc) return rc;
     constexpr int kSlots = c2b_problem::kJacSlots;
     constexpr int64_t kChunk = c2b_problem::kJacChunk;
@@ -1910,8 +1978,10 @@ int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double 
         const int s = (int)(k % kSlots);
         const int64_t o0 = k * kChunk, m = (n - o0 < kChunk) ? n - o0 : kChunk;
         if (k >= kSlots) { HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_free[s], 0)); }      // its previous copies are out
-        int rc2 = c2b_residual_jacobian(p->camblk, p->pts4, p->cam_idx + o0, p->pt_idx + o0, p->uv + 2 * o0, m, slot_r(s),
-                                        slot_Jc(s), slot_Jp(s), 2.0, nullptr, p->stream);
+        // kJacChunk is a multiple of 64: every chunk starts on a tile record
+        int rc2 = c2b_residual_jacobian_rows(p->camblk, p->pts4, p->rows_ptr, p->n_cam, (const char *)p->rows_tiles + (o0 >> 6) * 16, o0,
+                                             p->pt_idx + o0, p->uv + 2 * o0, m, slot_r(s), slot_Jc(s), slot_Jp(s), 2.0, nullptr,
+                                             nullptr, p->stream);
         if (rc2) return rc2;
         HIP_TRY(hipEventRecord(p->ev_done[s], p->stream));
         return C2B_OK;
@@ -2173,6 +2243,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
     p->cam15 = (double *)n_cam15.release(); p->bal9 = (double *)n_bal9.release(); p->camblk = (double *)n_camblk.release();
     p->pts4 = (double *)n_pts4.release(); p->uv = (double *)n_uv.release(); p->ws = n_ws.release();
     p->cam_idx = (uint32_t *)cam[cur].release(); p->pt_idx = (uint32_t *)pt[cur].release();
+    drop_rows(p);
     p->n_cam = nc; p->n_pts = np; p->n_obs = no;
     p->blk_valid = false;                                     // camblk is rebuilt on demand from the gathered cameras
     return C2B_OK;
@@ -2199,6 +2270,7 @@ int c2b_problem_adopt_visibility(c2b_problem *p) {
     void *old[] = {p->uv, p->cam_idx, p->pt_idx, p->ws, p->dense_row};
     for (void *q : old) if (q) (void)hipFree(q);
     p->cam_idx = (uint32_t *)cam_idx.release();
+    drop_rows(p);
     p->ws = ws.release();
     p->pt_idx = p->dense_pt; p->uv = p->dense_uv; p->n_obs = n;
     p->dense_pt = nullptr; p->dense_uv = nullptr; p->dense_row = nullptr; p->dense_n = 0;

@@ -235,6 +235,31 @@ __global__ __launch_bounds__(256) void k_rows_pack(const uint64_t *__restrict__ 
     if (lane == 0) tiles[tile] = make_uint4((uint32_t)first, (uint32_t)(first >> 32), c | (gap ? 0x80000000u : 0u), 0u);
 }
 
+// The cameras of a wave's OPL tiles from the tile records (wave-uniform scalar loads): a lane's camera is the tile's
+// first camera plus the number of mask bits at or below the lane -- two v_mbcnt per tile, nothing per observation.
+// `tiles` / `base` / `n` are relative to the launch's first observation, which is observation obs_base of the list
+// row_ptr describes (only the search for flagged tiles needs that).  Tiles past the end repeat the last one.
+template <int OPL>
+C2B_DEV void rows_cameras(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ row_ptr, int n_cam, int base,
+                          int n, int64_t obs_base, int lane, uint32_t (&ci)[OPL]) {
+    const int last_tile = (n - 1) >> 6;
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) {
+        int ti = (base >> 6) + t;
+        ti = ti < last_tile ? ti : last_tile;
+        const uint4 rec = tiles[ti];
+        if (rec.z & 0x80000000u) {                                       // wave-uniform: an empty list inside this tile
+            int o = ti * 64 + lane;
+            o = o < n ? o : n - 1;
+            ci[t] = csr_search(row_ptr, n_cam, (uint64_t)(obs_base + o));
+        } else {
+            // bits 1..63 of the mask, moved down one place: mbcnt counts the set bits BELOW a lane
+            const uint32_t lo = (rec.x >> 1) | (rec.y << 31), hi = rec.y >> 1;
+            ci[t] = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, rec.z));
+        }
+    }
+}
+
 // ---- wave-private camera tile ------------------------------------------------------------------------
 // A wave's 64 consecutive observations touch a short run of consecutive cameras (3-4 on the grid).  The
 // wave copies the first HOT doubles of those records into its own LDS tile and every lane then reads its
@@ -352,28 +377,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             if (!CSR) ci[t] = FAKECI ? (uint32_t)(((uint64_t)(uint32_t)o * 146585185ull) >> 32) : cam_idx[o];   // o / 29.3 (stays below n_cam on the bench grid)
             pi[t] = pt_idx[o];
         }
-        if (CSR) {
-            // One 16-byte record per 64 observations, read with scalar loads: the camera of the tile's first
-            // observation and a 64-bit mask of the lanes whose observation opens a new camera's list.  A lane's camera
-            // is that first camera plus the number of set bits at or below it: two v_mbcnt per tile, nothing per
-            // observation.  Bit 31 of the camera marks a tile the mask cannot describe (an empty list inside it).
-            const int last_tile = (n - 1) >> 6;
-#pragma unroll
-            for (int t = 0; t < OPL; ++t) {
-                int ti = (base >> 6) + t;
-                ti = ti < last_tile ? ti : last_tile;                    // tiles past the end repeat the last one (results discarded)
-                const uint4 rec = reinterpret_cast<const uint4 *>(cam_idx)[ti];
-                if (rec.z & 0x80000000u) {                               // wave-uniform
-                    int o = ti * 64 + lane;
-                    o = o < n ? o : n - 1;
-                    ci[t] = csr_search(row_ptr, n_cam, (uint64_t)o);
-                } else {
-                    // bits 1..63 of the mask, moved down one place: mbcnt counts the set bits BELOW a lane
-                    const uint32_t lo = (rec.x >> 1) | (rec.y << 31), hi = rec.y >> 1;
-                    ci[t] = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, rec.z));
-                }
-            }
-        }
+        if (CSR) rows_cameras<OPL>(reinterpret_cast<const uint4 *>(cam_idx), row_ptr, n_cam, base, n, 0, lane, ci);
 #pragma unroll
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
 
@@ -670,13 +674,16 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
 // spare LDS slot and merged under a mask -- never taken on camera-major input), the observed uv requested per tile.
 // XK: tile map -- 0 = contiguous eighths per XCD (xcd_tile32), K >= 1 = xcd_tile_chunked<K>
 // OBUP: request every tile's observed uv up front with the indices (true) or when that tile's arithmetic starts (false)
-template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0, bool OBUP = true>
+// CSR: cam_idx points at the tile records of k_rows_pack (for this launch's first observation, which is observation
+//      obs_base of the list row_ptr describes) instead of one camera index per observation
+template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int n, int n_btiles, double norm,
     double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
-    double *__restrict__ block_part, unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
+    double *__restrict__ block_part, unsigned *__restrict__ ticket, double *__restrict__ out_sum,
+    const uint64_t *__restrict__ row_ptr, int n_cam, int64_t obs_base) {
     constexpr int kSlab = 64 * 144 / 2;                                  // half a tile's 2x9 blocks (two rounds)
     constexpr int kCamBytes = 2 * kCamW * kCamHot * 8 + 64;              // staged cameras | slow-path slots | picked ids
     __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
@@ -693,10 +700,11 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
         for (int t = 0; t < OPL; ++t) {
             int o = base + t * 64 + lane;
             o = o < n ? o : n - 1;
-            ci[t] = cam_idx[o];
+            if (!CSR) ci[t] = cam_idx[o];
             pi[t] = pt_idx[o];
             if (OBUP) obs_up[t] = uv_obs[o];
         }
+        if (CSR) rows_cameras<OPL>(reinterpret_cast<const uint4 *>(cam_idx), row_ptr, n_cam, base, n, obs_base, lane, ci);
 #pragma unroll
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
 

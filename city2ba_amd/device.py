@@ -121,6 +121,18 @@ def visibility_rows(camblk, pts4, rows, pt_idx, max_dist, uv_out, keep):
                                         rows.n_obs, float(max_dist), _p(uv_out), _p(keep), _stream()))
 
 
+def residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None, out_sum=None, obs_base=0,
+                           n_obs=None):
+    """residual + Jacobian (+ sum |r|^norm when ws is given: into out_sum, or into ws for error_sum_finish) of the
+    observations [obs_base, obs_base + n_obs) of the list `rows` describes; pt_idx / uv / r / Jc / Jp are that slice."""
+    n = rows.n_obs - int(obs_base) if n_obs is None else int(n_obs)
+    tiles = rows.tiles[int(obs_base) // 64:]
+    L.check(L.lib().c2b_residual_jacobian_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(tiles),
+                                               int(obs_base), _p(pt_idx), _p(uv), n, _p(r), _p(Jc), _p(Jp),
+                                               float(norm), _p(ws), _p(out_sum), _stream()))
+    return out_sum
+
+
 def residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None):
     """ws != None -> the same launch also folds sum |r|^norm into ws (see error_sum_finish)."""
     L.check(L.lib().c2b_residual_jacobian(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv), cam_idx.shape[0],

@@ -124,6 +124,14 @@ int c2b_reprojection_error_sum_rows(const double *camblk, const double *pts4, co
 int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
                         const void *tiles, const uint32_t *pt_idx, int64_t n_pairs, double max_dist,
                         double *uv_out, uint8_t *keep, void *stream);
+/* c2b_residual_jacobian / _sum in the row-structure form, for the whole list (obs_base = 0) or a slice of it: tiles,
+ * pt_idx, uv_obs, r, Jc, Jp all point at observation obs_base (a multiple of 64) of the list row_ptr describes and
+ * n_obs observations are processed.  workspace == NULL: no error sum.  Otherwise sum |r|^norm goes to out_sum[0]
+ * (device pointer), or into the workspace (c2b_error_sum_finish) when out_sum is NULL. */
+int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                               const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
+                               int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
+                               double *out_sum, void *stream);
 
 /* residual + 2x9 camera block + 2x3 point block per observation (no reference equivalent).
  * With workspace != NULL the same launch also folds sum |du|^norm + |dv|^norm (fused error reduce, same fold

@@ -102,6 +102,20 @@ def test_rows_forms_give_the_bits_of_the_index_forms(env, kind):
         torch.cuda.synchronize()
         assert ea.item() == eb.item() and np.isfinite(ea.item())
 
+    # residual + Jacobian: the whole list, then the same list in two launches cut at a multiple of 64
+    out = [[torch.full((n, w), 5.0, dtype=torch.float64, device=dev) for w in (2, 18, 6)] for _ in range(3)]
+    ea, eb = (torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2))
+    D.residual_jacobian_sum(camblk, pts4, ci, pi, uv_d, *out[0], 2.0, ws, ea)
+    D.residual_jacobian_rows(camblk, pts4, rows, pi, uv_d, *out[1], 2.0, ws, eb)
+    cut = (n // 2) // 64 * 64
+    D.residual_jacobian_rows(camblk, pts4, rows, pi[:cut], uv_d[:cut], *[o[:cut] for o in out[2]], n_obs=cut)
+    D.residual_jacobian_rows(camblk, pts4, rows, pi[cut:], uv_d[cut:], *[o[cut:] for o in out[2]], obs_base=cut)
+    torch.cuda.synchronize()
+    assert ea.item() == eb.item()
+    for w in range(3):
+        assert torch.equal(out[0][w].view(torch.int64), out[1][w].view(torch.int64))
+        assert torch.equal(out[0][w].view(torch.int64), out[2][w].view(torch.int64))
+
     ka, kb = (torch.full((n,), 9, dtype=torch.uint8, device=dev) for _ in range(2))
     D.visibility_pairs(camblk, pts4, ci, pi, 60.0, a, ka)
     D.visibility_rows(camblk, pts4, rows, pi, 60.0, b, kb)

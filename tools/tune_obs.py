@@ -53,7 +53,12 @@ modes = {
     "error_L2": lambda: D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, err),
     "visibility": lambda: D.visibility_pairs(camblk, pts4, ci, pi, 10.0, uv_out, keep),
 }
+r_o = torch.empty((n, 2), dtype=torch.float64, device=dev)
+Jc_o = torch.empty((n, 18), dtype=torch.float64, device=dev)
+Jp_o = torch.empty((n, 6), dtype=torch.float64, device=dev)
+modes["jacobian_sum"] = lambda: D.residual_jacobian_sum(camblk, pts4, ci, pi, uv, r_o, Jc_o, Jp_o, 2.0, ws, err)
 row_modes = {
+    "jacobian_sum_rows": lambda: D.residual_jacobian_rows(camblk, pts4, rows, pi, uv, r_o, Jc_o, Jp_o, 2.0, ws, err_rows),
     "project_rows": lambda: D.project_rows(camblk, pts4, rows, pi, uv_rows),
     "error_L2_rows": lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pi, uv, 2.0, ws, err_rows),
     "visibility_rows": lambda: D.visibility_rows(camblk, pts4, rows, pi, 10.0, uv_rows, keep_rows),
@@ -86,6 +91,14 @@ modes["visibility"](); row_modes["visibility_rows"](); modes["error_L2"](); row_
 torch.cuda.synchronize()
 print("rows forms: project bit-equal %s, keep equal %s, uv equal %s, error equal %s" %
       (eq_p, torch.equal(keep, keep_rows), torch.equal(uv_out.view(torch.int64), uv_rows.view(torch.int64)), err.item() == err_rows.item()))
+
+modes["jacobian_sum"]()
+torch.cuda.synchronize()
+ja = (r_o.clone(), Jc_o[::97].clone(), Jp_o[::89].clone(), err.item())
+row_modes["jacobian_sum_rows"]()
+torch.cuda.synchronize()
+print("rows Jacobian: r equal %s, Jc sample equal %s, Jp sample equal %s, sum equal %s" %
+      (torch.equal(ja[0], r_o), torch.equal(ja[1], Jc_o[::97]), torch.equal(ja[2], Jp_o[::89]), ja[3] == err_rows.item()))
 
 times = {(m, v): [] for m in modes for v in variants}
 times.update({(m, 0): [] for m in row_modes})
