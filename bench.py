@@ -6,8 +6,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian_sum (residual, Jc, Jp and
-the folded sum of squared residuals, ONE launch) on every rank's shard, then ONE 1-element RCCL all-reduce
+One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian_rows (residual, Jc, Jp and
+the folded sum of squared residuals, ONE launch; the observation list addressed through its row structure, the
+reference's one list per camera) on every rank's shard, then ONE 1-element RCCL all-reduce
 (N > 1; queued behind the kernel on the same stream, completed inside the timed region).
 Inputs are resident in HBM before the timed region.  Strong scaling: the same `--blocks 128` problem is sharded
 over the ranks by contiguous camera ranges cut on the observation prefix sum (BASELINE.json configs[3]); at
@@ -25,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_NAME = "k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP>, as rocprofv3 prints it     # the launch the roofline object describes
+KERNEL_NAME = "k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true, true>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR>, as rocprofv3 prints it     # the launch the roofline object describes
 
 
 def parse():
@@ -86,8 +87,12 @@ def build_shard(args, rank, world, dev, bounds=None):
     # observation noise so that the reduced error is a non-trivial number (seeded, shard-independent)
     obs_base, n_obs_total = Dist.exclusive_offset(n_obs)
     D.add_noise_observations(uv, obs_base, 1e-3, seed=20243)
+    # the list's row structure (what the reference holds: one list per camera) for the *_rows launchers
+    row_ptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
+    row_ptr[1:] = torch.cumsum(torch.bincount(cam_idx.long(), minlength=hi - lo), 0)
+    rows = D.Rows(row_ptr, n_obs)
     torch.cuda.synchronize()
-    return dict(camblk=camblk, cam15=cam15, pts4=pts4, cam_idx=cam_idx, pt_idx=pt_idx, uv=uv, n_obs=n_obs,
+    return dict(camblk=camblk, cam15=cam15, pts4=pts4, cam_idx=cam_idx, pt_idx=pt_idx, uv=uv, n_obs=n_obs, rows=rows,
                 n_obs_total=n_obs_total, n_cam=n_cam, n_pts=n_pts, n_cam_local=hi - lo, n_candidates=n_cand,
                 pts_host=pts, cam_lo=lo, cam_hi=hi, obs_base=obs_base)
 
@@ -213,7 +218,7 @@ def other_configs(dev):
     res = {}
     s4 = build_shard(_ap.Namespace(blocks=4), 0, 1, dev)
     uv4 = torch.empty_like(s4["uv"])
-    t = timed(lambda: D.project(s4["camblk"], s4["pts4"], s4["cam_idx"], s4["pt_idx"], uv4), 500)
+    t = timed(lambda: D.project_rows(s4["camblk"], s4["pts4"], s4["rows"], s4["pt_idx"], uv4), 500)
     res["blocks4_project_only"] = {"n_observations": s4["n_obs"], "us_per_launch": round(t * 1e6, 2),
                                    "Mobs/s": round(s4["n_obs"] / t / 1e6, 1)}
     # the same launch-bound case replayed from a HIP graph (20 launches per graph): what a caller that loops over
@@ -224,7 +229,7 @@ def other_configs(dev):
         with torch.cuda.stream(side):
             with torch.cuda.graph(g, stream=side):
                 for _ in range(20):
-                    D.project(s4["camblk"], s4["pts4"], s4["cam_idx"], s4["pt_idx"], uv4)
+                    D.project_rows(s4["camblk"], s4["pts4"], s4["rows"], s4["pt_idx"], uv4)
         torch.cuda.synchronize()
         tg = timed(g.replay, 50) / 20
         res["blocks4_project_only"]["us_per_launch_in_hip_graph"] = round(tg * 1e6, 2)
@@ -236,8 +241,8 @@ def other_configs(dev):
     Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
     Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
     ws = D.workspace(n, dev)
-    t = timed(lambda: D.residual_jacobian(s32["camblk"], s32["pts4"], s32["cam_idx"], s32["pt_idx"], s32["uv"], r, Jc, Jp,
-                                          2.0, ws), 200)
+    t = timed(lambda: D.residual_jacobian_rows(s32["camblk"], s32["pts4"], s32["rows"], s32["pt_idx"], s32["uv"], r, Jc, Jp,
+                                               2.0, ws), 200)
     alg = algorithmic_bytes(n, s32["n_cam"], s32["n_pts"])
     res["blocks32_residual_jacobian"] = {"n_observations": n, "us_per_launch": round(t * 1e6, 2),
                                          "Mobs/s": round(n / t / 1e6, 1), "algorithmic_GB/s": round(alg / t / 1e9, 1)}
@@ -254,7 +259,7 @@ def adversarial_gather(sh, r, Jc, Jp, ws):
     rnd = torch.randint(0, sh["n_pts"], (sh["n_obs"],), dtype=torch.int32, device=sh["pt_idx"].device, generator=g)
 
     def run():
-        D.residual_jacobian(sh["camblk"], sh["pts4"], sh["cam_idx"], rnd, sh["uv"], r, Jc, Jp, 2.0, ws)
+        D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], rnd, sh["uv"], r, Jc, Jp, 2.0, ws)
     run()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -287,19 +292,19 @@ def pmc_traffic():
 def place_inputs(sh, r, Jc, Jp, ws, err):
     """The input arrays come out of build_shard as slices of whatever blocks the caching allocator had at hand; a copy
     in an allocation of its own is sometimes read faster by the very same kernel (tools/probe_placement4.py: 801 ->
-    750 us over uv, camblk, pt_idx, cam_idx).  Greedy and empirical: copy one array, time the kernel, keep the copy
+    750 us over uv, camblk, pt_idx).  Greedy and empirical: copy one array, time the kernel, keep the copy
     if the kernel got faster.  Untimed set-up; the log goes into roofline.input_placement."""
     import torch
     from city2ba_amd import device as D
 
     def kernel_us(reps=6):
         for _ in range(2):
-            D.residual_jacobian_sum(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
+            D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(reps):
-            D.residual_jacobian_sum(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
+            D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
         e.record()
         torch.cuda.synchronize()
         return s.elapsed_time(e) / reps * 1e3
@@ -308,7 +313,7 @@ def place_inputs(sh, r, Jc, Jp, ws, err):
         return {}
     log = {"kernel_us_before": round(kernel_us(), 1)}
     best = log["kernel_us_before"]
-    for name in ("uv", "camblk", "pt_idx", "cam_idx", "pts4"):
+    for name in ("uv", "camblk", "pt_idx", "pts4"):
         old = sh[name]
         sh[name] = old.clone()
         t = kernel_us()
@@ -414,7 +419,7 @@ def main():
     def step(ev=None):
         if ev is not None:
             ev[0].record()
-        D.residual_jacobian_sum(sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
+        D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
         if ev is not None:
             ev[1].record()
         if dist_on:

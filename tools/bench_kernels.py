@@ -30,18 +30,27 @@ uv_out = torch.empty_like(uv)
 entity_bytes = n_cam * 72 + n_pts * 24
 
 
-def timed(fn, reps=a.reps):
-    fn()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
+def timed(fn, reps=a.reps, rounds=5):
+    """median over `rounds` of the mean of `reps` back-to-back launches; the first round is a warm-up and is dropped
+    (a kernel timed cold right after set-up reads 5-8 % slow: clocks and caches)"""
+    ts = []
+    for k in range(rounds + 1):
         fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / reps * 1e-3
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        if k:
+            ts.append(s.elapsed_time(e) / reps * 1e-3)
+    return sorted(ts)[len(ts) // 2]
 
 
+for _ in range(300):                                   # bring the device to its working clocks before anything is timed
+    D.project(camblk, pts4, cam_idx, pt_idx, uv_out)
+torch.cuda.synchronize()
 out = {"blocks": a.blocks, "n_obs": n, "n_cameras": n_cam, "n_points": n_pts, "kernels": {}}
 
 
@@ -52,9 +61,14 @@ def report(name, secs, units, alg_bytes, unit_name):
 
 t = timed(lambda: D.project(camblk, pts4, cam_idx, pt_idx, uv_out))
 report("project", t, n, n * (4 + 16) + entity_bytes, "obs")
+rows = sh["rows"]                      # the row-structure forms: camera from row_ptr tile records, no cam_idx stream
+t = timed(lambda: D.project_rows(camblk, pts4, rows, pt_idx, uv_out))
+report("project_rows", t, n, n * (4 + 16) + entity_bytes, "obs")
 for norm in (2.0, 1.0, 1.5):
     t = timed(lambda: D.reprojection_error_sum(camblk, pts4, cam_idx, pt_idx, uv, norm, ws, err))
     report("error_sum(norm=%g)" % norm, t, n, n * (4 + 16) + entity_bytes, "obs")
+    t = timed(lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, norm, ws, err))
+    report("error_sum_rows(norm=%g)" % norm, t, n, n * (4 + 16) + entity_bytes, "obs")
 r = torch.empty((n, 2), dtype=torch.float64, device=dev)
 Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
 Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
@@ -62,12 +76,18 @@ t = timed(lambda: D.residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, 
 report("residual_jacobian+err", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
 t = timed(lambda: D.residual_jacobian_sum(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, 2.0, ws, err))
 report("residual_jacobian_sum (one launch)", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
+t = timed(lambda: D.residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r, Jc, Jp, 2.0, ws, err))
+report("residual_jacobian_rows (one launch, bench step)", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
 del r, Jc, Jp
 
 # visibility predicate on a candidate list of the same size class as the generator's
 keep = torch.empty(n, dtype=torch.uint8, device=dev)
 t = timed(lambda: D.visibility_pairs(camblk, pts4, cam_idx, pt_idx, 10.0, uv_out, keep))
 report("visibility_pairs", t, n, n * (8 + 16 + 1) + entity_bytes, "pairs")
+t = timed(lambda: D.visibility_rows(camblk, pts4, rows, pt_idx, 10.0, uv_out, keep))
+report("visibility_rows", t, n, n * (4 + 16 + 1) + entity_bytes, "pairs")
+t = timed(lambda: D.Rows(rows.row_ptr, n), 3, 2)
+report("rows_pack (once per list)", t, n, n_cam * 8 + n // 4, "obs")
 
 uv2 = uv.clone()
 t = timed(lambda: D.add_noise_observations(uv2, 0, 1e-6, 7))

@@ -34,5 +34,10 @@ for _ in range(a.reps):
     D.visibility_pairs(camblk, pts4, ci, pi, 10.0, uv_out, keep)
     D.residual_jacobian(camblk, pts4, ci, pi, uv, r, Jc, Jp, 2.0, ws)
     D.add_noise_observations(uv_out, 0, 0.0, 1)
+    # the row-structure forms (separate template instances: they show up under their own kernel names)
+    D.project_rows(camblk, pts4, sh["rows"], pi, uv_out)
+    D.reprojection_error_sum_rows(camblk, pts4, sh["rows"], pi, uv, 2.0, ws, err)
+    D.visibility_rows(camblk, pts4, sh["rows"], pi, 10.0, uv_out, keep)
+    D.residual_jacobian_rows(camblk, pts4, sh["rows"], pi, uv, r, Jc, Jp, 2.0, ws)
 torch.cuda.synchronize()
 print("n_obs", n)

@@ -60,6 +60,8 @@ modes["jacobian_sum"] = lambda: D.residual_jacobian_sum(camblk, pts4, ci, pi, uv
 row_modes = {
     "jacobian_sum_rows": lambda: D.residual_jacobian_rows(camblk, pts4, rows, pi, uv, r_o, Jc_o, Jp_o, 2.0, ws, err_rows),
     "project_rows": lambda: D.project_rows(camblk, pts4, rows, pi, uv_rows),
+    "project_rows_same_output": lambda: D.project_rows(camblk, pts4, rows, pi, uv_out),
+    "project_rows_shard_rows": lambda: D.project_rows(camblk, pts4, sh["rows"], pi, uv_out),
     "error_L2_rows": lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pi, uv, 2.0, ws, err_rows),
     "visibility_rows": lambda: D.visibility_rows(camblk, pts4, rows, pi, 10.0, uv_rows, keep_rows),
 }
