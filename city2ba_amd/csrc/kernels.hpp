@@ -206,13 +206,16 @@ __global__ void k_expand_rows(const uint64_t *__restrict__ row_ptr, int64_t n_ca
     cam_idx[o] = (uint32_t)(lo - 1);
 }
 
-// the camera whose list holds observation o: (first c with row_ptr[c] > o) - 1, as k_expand_rows
+// the camera whose list holds observation o: (first c with row_ptr[c] > o) - 1, as k_expand_rows -- clamped into
+// [0, n_cam) so that a row_ptr that does not cover o (row_ptr[0] > o, row_ptr[n_cam] <= o: a caller's bug) yields a
+// wrong but valid camera, never an out-of-range record address
 C2B_DEV uint32_t csr_search(const uint64_t *__restrict__ row_ptr, int n_cam, uint64_t o) {
     int lo = 0, hi = n_cam + 1;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (row_ptr[mid] > o) hi = mid; else lo = mid + 1;
     }
+    lo = lo < 1 ? 1 : (lo > n_cam ? n_cam : lo);
     return (uint32_t)(lo - 1);
 }
 

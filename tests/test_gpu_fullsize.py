@@ -44,6 +44,14 @@ def test_synthetic_blocks_properties(blocks, n_expected):
         torch.cuda.synchronize()
         assert e_one.item() == e_fused.item()
     assert torch.equal(r_b, r) and torch.equal(Jc_b, Jc) and torch.equal(Jp_b, Jp)
+    # ... and so does the row-structure form (the bench step since r02h): the list addressed by row_ptr + tile
+    # records instead of cam_idx, here at full size (byte offsets beyond 2^31, tiles with an empty list inside)
+    rows = sh["rows"]
+    Jc_b.fill_(float("nan")); Jp_b.fill_(float("nan")); r_b.fill_(float("nan"))
+    D.residual_jacobian_rows(camblk, pts4, rows, pi, uv, r_b, Jc_b, Jp_b, 2.0, ws, e_one)
+    torch.cuda.synchronize()
+    assert e_one.item() == e_fused.item()
+    assert torch.equal(r_b, r) and torch.equal(Jc_b, Jc) and torch.equal(Jp_b, Jp)
     del r_b, Jc_b, Jp_b
     assert bool(torch.isfinite(Jc).all()) and bool(torch.isfinite(Jp).all())      # every row written, incl. the tail
 
@@ -51,6 +59,10 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     proj = torch.empty((n, 2), dtype=torch.float64, device=dev)
     D.project(camblk, pts4, ci, pi, proj)
     assert torch.equal(r, proj - uv)
+    proj_rows = torch.full_like(proj, float("nan"))
+    D.project_rows(camblk, pts4, rows, pi, proj_rows)
+    assert torch.equal(proj_rows, proj)
+    del proj_rows
 
     # error: fused partials == stand-alone kernel; both == sum r^2 up to summation order
     e_alone = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -62,6 +74,9 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     D.reprojection_error_sum(camblk, pts4, ci, pi, uv, 2.0, ws, e_again)
     torch.cuda.synchronize()
     assert e_again.item() == e_alone.item()                    # but each kernel reproduces its own bits
+    D.reprojection_error_sum_rows(camblk, pts4, rows, pi, uv, 2.0, ws, e_again)
+    torch.cuda.synchronize()
+    assert e_again.item() == e_alone.item()                    # the row-structure form: same grid, same bits
     assert abs(e_fused.item() - float((r * r).sum().item())) / e_fused.item() < 1e-11
 
     # tiling independence at both ends (different tile origin => different wave / XCD assignment)

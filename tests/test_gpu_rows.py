@@ -143,6 +143,17 @@ def test_rows_on_the_bench_grid_and_their_argument_checks(env):
     torch.cuda.synchronize()
     assert torch.equal(a, b)
 
+    # a row_ptr that does not cover the list (a caller's bug: the last lists cut short, the first one starting late)
+    # must give wrong cameras, not wild addresses: every camera the kernels derive stays inside [0, n_cam)
+    bad = row_ptr.clone()
+    bad[-3:] = bad[-4]
+    bad[0] = 5
+    rows_bad = D.Rows(bad, n)
+    D.project_rows(sh["camblk"], sh["pts4"], rows_bad, sh["pt_idx"], b)
+    torch.cuda.synchronize()
+    cams = rows_bad.tiles[:, 2] & 0x7FFFFFFF
+    assert int(cams.max()) < n_cam and int(cams.min()) >= 0
+
     lib = L.lib()
     assert lib.c2b_rows_tiles_bytes(0) == 0 and lib.c2b_rows_tiles_bytes(1) == 16 and lib.c2b_rows_tiles_bytes(65) == 32
     p = lambda t: t.data_ptr()
