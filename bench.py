@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_NAME = "k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true, true>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR>, as rocprofv3 prints it     # the launch the roofline object describes
+KERNEL_NAME = "k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true, true, 0>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it     # the launch the roofline object describes
 
 
 def parse():

@@ -43,6 +43,7 @@ SIGNATURES = {
     "c2b_expand_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "c2b_project": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "c2b_reprojection_error_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
+    "c2b_selfcheck_tickets": (_int, [C.POINTER(_i64)]),
     "c2b_rows_tiles_bytes": (_i64, [_i64]),
     "c2b_rows_pack": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "c2b_project_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),

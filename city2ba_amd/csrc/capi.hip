@@ -105,28 +105,34 @@ inline int64_t block_part_slots(int64_t n_obs) {
 // library, one pool per device, allocated on first use.  A launch takes the next word of the pool; its last
 // workgroup resets it.  Launches that could run concurrently take different slots (128 before a slot repeats).
 constexpr unsigned kTicketSlots = 128;
+static std::mutex g_ticket_mu;
+static unsigned *g_ticket_pool[64] = {nullptr};
+static std::atomic<unsigned> g_ticket_next{0};
 unsigned *ticket_slot() {
-    static std::mutex mu;
-    static unsigned *pool[64] = {nullptr};
-    static std::atomic<unsigned> next{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!pool[dev]) {
-        std::lock_guard<std::mutex> g(mu);
-        if (!pool[dev]) {
+    if (!g_ticket_pool[dev]) {
+        std::lock_guard<std::mutex> g(g_ticket_mu);
+        if (!g_ticket_pool[dev]) {
             unsigned *p = nullptr;
             if (hipMalloc((void **)&p, kTicketSlots * kTicketWords * sizeof(unsigned)) != hipSuccess) return nullptr;
-            if (hipMemset(p, 0, kTicketSlots * kTicketWords * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-            pool[dev] = p;
+            // hipMemset on device memory only ENQUEUES the fill on the null stream; a first user on a non-blocking stream
+            // (every Level-1 problem has one) would otherwise race it -- counters wiped under a running fold lose that
+            // launch's sum and leave the slot dirty for its 128th successor.  Drain before the pool is published.
+            if (hipMemset(p, 0, kTicketSlots * kTicketWords * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                (void)hipFree(p);
+                return nullptr;
+            }
+            g_ticket_pool[dev] = p;
         }
     }
-    return pool[dev] + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketWords;
+    return g_ticket_pool[dev] + (size_t)(g_ticket_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketWords;
 }
 
 #ifdef C2B_TUNE
 // Tuning build only (libcity2ba_hip_tune.so, tools/tune_*.py): kernel variants, including timing-only ablations
 // whose outputs are wrong by construction.  None of this exists in the product library.
-int g_jac_variant = 40;
+int g_jac_variant = 0;        // 0 = the shipped kernel
 int g_obs_variant = 308;
 
 template <typename K>
@@ -191,14 +197,14 @@ void launch_jac_p(const double *camblk, const double *pts4, const uint32_t *cam_
 
 // one-shot launch of k_observations<MODE, NK, OPL, WPB>: one workgroup per WPB * OPL tiles of 64 observations
 // CSR: cam_idx = the camera of every 64th observation, row_ptr / n_cam = the lists' boundaries (kernels.hpp)
-template <int MODE, int OPL, int WPB, int MINW = 1, bool FAKECI = false, bool CSR = false>
+template <int MODE, int OPL, int WPB, int MINW = 1, bool FAKECI = false, bool CSR = false, bool NTS = false, int NTL = 0>
 void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
                   const uint64_t *row_ptr = nullptr, int64_t n_cam = 0) {
     const int tiles = (int)(((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, FAKECI, CSR>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,         \
+    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, FAKECI, CSR, NTS, NTL>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,    \
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                               \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n, tiles, norm, max_dist,                       \
                        reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum, row_ptr, (int)n_cam)
@@ -217,10 +223,26 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
                void *workspace, double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
     unsigned *ticket = nullptr;
-    if (MODE == MODE_ERROR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool");
+    if (MODE == MODE_ERROR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool (its first use must not be inside a stream capture)");
+    // Cache policy of the streams (A/B in profiles/r02i_ab_cache_policy.txt): results leave through non-temporal stores
+    // and the observed uv (read once) comes in through non-temporal loads, so that the tables every observation
+    // gathers from -- points, cameras -- keep the L2 / Infinity Cache; the 4-byte point index stays cached where the
+    // camera footprint is small (project, error: tables + indices of the --blocks 128 problem fit the 256 MB cache and
+    // the next call finds them there) and is non-temporal where it is not (visibility, Jacobian: 256 B per camera).
+    constexpr int kNTL = MODE == MODE_ERROR ? 2 : (MODE == MODE_VISIBILITY ? 1 : 0);
     if (row_ptr) {          // the *_rows entry points: cam_idx = the tile records of c2b_rows_pack
-        launch_obs_v<MODE, 3, 8, 1, false, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part,
-                                                 ticket, out_sum, st, row_ptr, n_cam);
+#define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st, row_ptr, n_cam
+#ifdef C2B_TUNE
+        switch (g_obs_variant) {
+            case 20308: launch_obs_v<MODE, 3, 8, 1, false, true, false, 0>(C2B_ROWS_ARGS); return C2B_OK;   // everything cached (r02h)
+            case 21308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;    // non-temporal stores only
+            case 22308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;    // ... + observed uv
+            case 23308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;    // ... + point index
+            default: break;
+        }
+#endif
+        launch_obs_v<MODE, 3, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS);
+#undef C2B_ROWS_ARGS
         return C2B_OK;
     }
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st
@@ -233,13 +255,15 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
         case 1308: launch_obs_v<MODE, 3, 8, 8>(C2B_ARGS); return C2B_OK;    // 3 tiles per wave, registers capped for 8 waves per SIMD
         case 9308: launch_obs_v<MODE, 3, 8, 1, true>(C2B_ARGS); return C2B_OK;   // ablation: camera index computed, not loaded (wrong outputs)
         case 408: launch_obs_v<MODE, 4, 8>(C2B_ARGS); return C2B_OK;
+        case 20308: launch_obs_v<MODE, 3, 8>(C2B_ARGS); return C2B_OK;                              // everything cached (r02h)
+        case 23308: launch_obs_v<MODE, 3, 8, 1, false, false, true, 3>(C2B_ARGS); return C2B_OK;   // every stream non-temporal
         case 2004: launch_obs_p<MODE, 4>(C2B_ARGS); return C2B_OK;       // persistent pipelined forms (obs_pipeline.hpp)
         case 2008: launch_obs_p<MODE, 8>(C2B_ARGS); return C2B_OK;
         case 2016: launch_obs_p<MODE, 16>(C2B_ARGS); return C2B_OK;
         default: break;
     }
 #endif
-    launch_obs_v<MODE, 3, 8>(C2B_ARGS);                                 // shipped (308): three tiles of 64 per wave
+    launch_obs_v<MODE, 3, 8, 1, false, false, true, kNTL>(C2B_ARGS);    // shipped (308): three tiles of 64 per wave
 #undef C2B_ARGS
     return C2B_OK;
 }
@@ -266,14 +290,14 @@ void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_
 
 // CSR: cam_idx = the tile records of c2b_rows_pack for this launch's first observation (= observation obs_base of
 // the list row_ptr describes)
-template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false>
+template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false, int NTL = 0>
 void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
                   const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0) {
     const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK, OBUP, CSR>), dim3((unsigned)btiles),        \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK, OBUP, CSR, NTL>), dim3((unsigned)btiles),        \
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
                        reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum, row_ptr, (int)n_cam, obs_base)
@@ -291,10 +315,21 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
                     double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
     unsigned *ticket = nullptr;
-    if (WITH_ERR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool");
+    if (WITH_ERR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool (its first use must not be inside a stream capture)");
     if (row_ptr) {          // the *_rows entry points
-        launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket,
-                                                       out_sum, st, row_ptr, n_cam, obs_base);
+#define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base
+#ifdef C2B_TUNE
+        switch (g_jac_variant) {
+            case 52: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;    // non-temporal observed uv
+            case 53: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;    // ... and point index
+            default: break;
+        }
+#endif
+        // Loads stay cached here (results leave non-temporally).  Non-temporal index / uv loads were measured
+        // (profiles/r02i_ab_cache_policy*.txt): -3 % at --blocks 128, where they let the 232 MB of camera and point
+        // records own the 256 MB Infinity Cache, but +2 % at --blocks 208 and +12 % at --blocks 32 -- a gain at one size.
+        launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS);
+#undef C2B_ROWS_ARGS
         return C2B_OK;
     }
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st
@@ -421,6 +456,26 @@ int c2b_device_count(int *count) {
     *count = n;
     return C2B_OK;
     C2B_API_END("device_count")
+}
+
+// Diagnostic: the arrival counters of the in-kernel folds must all be zero whenever no launch is in flight (the last
+// workgroup of every launch resets its own).  Synchronises the device, then counts the non-zero words of the current
+// device's pool; a non-zero count means a launch did not complete its fold and the slot's next user would lose its sum.
+int c2b_selfcheck_tickets(int64_t *nonzero_words) {
+    C2B_API_BEGIN
+    if (!nonzero_words) return fail(C2B_ERR_INVALID_ARGUMENT, "selfcheck_tickets: NULL argument");
+    *nonzero_words = 0;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !g_ticket_pool[dev]) return C2B_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned> host((size_t)kTicketSlots * kTicketWords);
+    HIP_TRY(hipMemcpy(host.data(), g_ticket_pool[dev], host.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    int64_t c = 0;
+    for (unsigned v : host) c += v != 0;
+    *nonzero_words = c;
+    return C2B_OK;
+    C2B_API_END("selfcheck_tickets")
 }
 
 int64_t c2b_workspace_bytes(int64_t n_obs) {

@@ -288,6 +288,16 @@ C2B_DEV const double *wave_camera(const double *__restrict__ camblk, uint32_t ci
     return (valid && local < n_staged) ? (sCam + local * HOT) : (camblk + (int64_t)ci * kCamBlk);
 }
 
+template <bool NT>
+C2B_DEV void store16(char *dst, const double2 v) {
+    if (NT) {
+        d2_t t; t.x = v.x; t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(dst));
+    } else {
+        *reinterpret_cast<double2 *>(dst) = v;
+    }
+}
+
 // ---- project / error / visibility: the light per-observation kernels ----------------------------
 // Wave-centric like the Jacobian kernel; they need R, t, intrinsics only (15 doubles, staged as 16).
 enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2 };
@@ -354,7 +364,7 @@ C2B_DEV int xcd_tile_chunked(int bid, int n_tiles) {
 // k_csr_pack derives from row_ptr (16 bytes per 64 observations).  SURVEY 8(d)'s algorithmic bytes assume exactly
 // this: 4 B of point index per observation and the row structure once.
 template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1, bool FAKECI = false,
-          bool CSR = false>
+          bool CSR = false, bool NTS = false, int NTL = 0>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -377,8 +387,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         for (int t = 0; t < OPL; ++t) {
             int o = base + t * 64 + lane;
             o = o < n ? o : n - 1;                                       // clamped, not predicated
-            if (!CSR) ci[t] = FAKECI ? (uint32_t)(((uint64_t)(uint32_t)o * 146585185ull) >> 32) : cam_idx[o];   // o / 29.3 (stays below n_cam on the bench grid)
-            pi[t] = pt_idx[o];
+            if (!CSR) ci[t] = FAKECI ? (uint32_t)(((uint64_t)(uint32_t)o * 146585185ull) >> 32) : ((NTL & 1) ? __builtin_nontemporal_load(cam_idx + o) : cam_idx[o]);   // o / 29.3 (stays below n_cam on the bench grid)
+            pi[t] = (NTL & 1) ? __builtin_nontemporal_load(pt_idx + o) : pt_idx[o];
         }
         if (CSR) rows_cameras<OPL>(reinterpret_cast<const uint4 *>(cam_idx), row_ptr, n_cam, base, n, 0, lane, ci);
 #pragma unroll
@@ -410,7 +420,14 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             // the observed uv of THIS tile is requested only now: holding all OPL of them from the start costs 12
             // VGPRs and the eighth wave per SIMD (measured: 119 us held, 111 us requested per tile)
             double2 ob = make_double2(0.0, 0.0);
-            if (MODE == MODE_ERROR) ob = uv_obs[valid ? o : n - 1];
+            if (MODE == MODE_ERROR) {
+                if (NTL & 2) {
+                    const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(uv_obs + (valid ? o : n - 1)));
+                    ob = make_double2(t2.x, t2.y);
+                } else {
+                    ob = uv_obs[valid ? o : n - 1];
+                }
+            }
             // First pass, unmasked: every lane projects through a staged camera -- its own if that is staged, camera 0
             // of the tile otherwise (valid operands, result discarded).  On camera-major input that serves every lane
             // and nothing below runs.  Leftover lanes (unsorted input, or more cameras than were staged) are then
@@ -454,11 +471,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
                 const double nan = __longlong_as_double(0x7ff8000000000000LL);
                 if (valid) {
-                    uv_out[o] = front ? make_double2(p.u, p.v) : make_double2(nan, nan);
-                    keep[o] = k ? 1 : 0;
+                    store16<NTS>(reinterpret_cast<char *>(uv_out + o), front ? make_double2(p.u, p.v) : make_double2(nan, nan));
+                    if (NTS) __builtin_nontemporal_store((uint8_t)(k ? 1 : 0), keep + o);
+                    else keep[o] = k ? 1 : 0;
                 }
             } else if (MODE == MODE_PROJECT) {
-                if (valid) uv_out[o] = make_double2(p.u, p.v);
+                if (valid) store16<NTS>(reinterpret_cast<char *>(uv_out + o), make_double2(p.u, p.v));
             } else {
                 eacc += valid ? abs_pow_k<NK>(p.u - ob.x, norm) + abs_pow_k<NK>(p.v - ob.y, norm) : 0.0;
             }
@@ -474,16 +492,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
 // partial per tile.  With OPL = 2 each lane carries two observations: both tiles' index / uv loads, then
 // both point gathers, are issued up front, so the second tile's memory latency hides behind the first
 // tile's arithmetic and stores (the index -> gather chain is two dependent round trips per tile otherwise).
-
-template <bool NT>
-C2B_DEV void store16(char *dst, const double2 v) {
-    if (NT) {
-        d2_t t; t.x = v.x; t.y = v.y;
-        __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(dst));
-    } else {
-        *reinterpret_cast<double2 *>(dst) = v;
-    }
-}
 
 // one observation: projection (reference order) + the 2x9 / 2x3 blocks (explicit FMAs)
 template <int ABL, typename P>
@@ -679,7 +687,8 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
 // OBUP: request every tile's observed uv up front with the indices (true) or when that tile's arithmetic starts (false)
 // CSR: cam_idx points at the tile records of k_rows_pack (for this launch's first observation, which is observation
 //      obs_base of the list row_ptr describes) instead of one camera index per observation
-template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false>
+// NTL: bit 0 = non-temporal loads of the index streams, bit 1 = of the observed uv (streams read once per launch)
+template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false, int NTL = 0>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -703,9 +712,16 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
         for (int t = 0; t < OPL; ++t) {
             int o = base + t * 64 + lane;
             o = o < n ? o : n - 1;
-            if (!CSR) ci[t] = cam_idx[o];
-            pi[t] = pt_idx[o];
-            if (OBUP) obs_up[t] = uv_obs[o];
+            if (!CSR) ci[t] = (NTL & 1) ? __builtin_nontemporal_load(cam_idx + o) : cam_idx[o];
+            pi[t] = (NTL & 1) ? __builtin_nontemporal_load(pt_idx + o) : pt_idx[o];
+            if (OBUP) {
+                if (NTL & 2) {
+                    const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(uv_obs + o));
+                    obs_up[t] = make_double2(t2.x, t2.y);
+                } else {
+                    obs_up[t] = uv_obs[o];
+                }
+            }
         }
         if (CSR) rows_cameras<OPL>(reinterpret_cast<const uint4 *>(cam_idx), row_ptr, n_cam, base, n, obs_base, lane, ci);
 #pragma unroll

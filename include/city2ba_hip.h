@@ -65,6 +65,9 @@ int c2b_device_count(int *count);
  * initialisation (the arrival counters of the in-kernel folds live in a pool the library owns and keeps zeroed).
  * One workspace serves one stream at a time: two launches that may run concurrently must not share it. */
 int64_t c2b_workspace_bytes(int64_t n_obs);
+/* Diagnostic: synchronises the current device and counts the non-zero arrival counters of the library's pool.  Zero
+ * whenever no launch is in flight; anything else means a launch did not complete its in-kernel fold. */
+int c2b_selfcheck_tickets(int64_t *nonzero_words);
 
 /* SnavelyCamera::from_vec / from_rodrigues (src/baproblem.rs:78-90, 180-186) */
 int c2b_cameras_from_bal(const double *bal9, int64_t n_cam, double *cam15, void *stream);

@@ -51,6 +51,26 @@ def timed(fn, reps=a.reps, rounds=5):
 for _ in range(300):                                   # bring the device to its working clocks before anything is timed
     D.project(camblk, pts4, cam_idx, pt_idx, uv_out)
 torch.cuda.synchronize()
+flush_src = torch.empty(1 << 27, dtype=torch.float64, device=dev)          # 1 GiB: four times the Infinity Cache
+flush_dst = torch.empty_like(flush_src)
+
+
+def timed_cold(fn, reps=7):
+    """one launch at a time, the caches flushed by a 1-GiB copy before each: what a single call on a problem nobody
+    has touched since costs (the back-to-back figure finds the previous launch's inputs in the 256 MB Infinity Cache
+    when results leave non-temporally)"""
+    ts = []
+    for _ in range(reps):
+        D.calib_copy(flush_src, flush_dst)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e-3)
+    return sorted(ts)[len(ts) // 2]
+
+
 out = {"blocks": a.blocks, "n_obs": n, "n_cameras": n_cam, "n_points": n_pts, "kernels": {}}
 
 
@@ -64,11 +84,16 @@ report("project", t, n, n * (4 + 16) + entity_bytes, "obs")
 rows = sh["rows"]                      # the row-structure forms: camera from row_ptr tile records, no cam_idx stream
 t = timed(lambda: D.project_rows(camblk, pts4, rows, pt_idx, uv_out))
 report("project_rows", t, n, n * (4 + 16) + entity_bytes, "obs")
+t = timed_cold(lambda: D.project_rows(camblk, pts4, rows, pt_idx, uv_out))
+report("project_rows, caches flushed before every launch", t, n, n * (4 + 16) + entity_bytes, "obs")
 for norm in (2.0, 1.0, 1.5):
     t = timed(lambda: D.reprojection_error_sum(camblk, pts4, cam_idx, pt_idx, uv, norm, ws, err))
     report("error_sum(norm=%g)" % norm, t, n, n * (4 + 16) + entity_bytes, "obs")
     t = timed(lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, norm, ws, err))
     report("error_sum_rows(norm=%g)" % norm, t, n, n * (4 + 16) + entity_bytes, "obs")
+    if norm == 2.0:
+        t = timed_cold(lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, norm, ws, err))
+        report("error_sum_rows(norm=2), caches flushed before every launch", t, n, n * (4 + 16) + entity_bytes, "obs")
 r = torch.empty((n, 2), dtype=torch.float64, device=dev)
 Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
 Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
@@ -78,6 +103,8 @@ t = timed(lambda: D.residual_jacobian_sum(camblk, pts4, cam_idx, pt_idx, uv, r, 
 report("residual_jacobian_sum (one launch)", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
 t = timed(lambda: D.residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r, Jc, Jp, 2.0, ws, err))
 report("residual_jacobian_rows (one launch, bench step)", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
+t = timed_cold(lambda: D.residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r, Jc, Jp, 2.0, ws, err))
+report("residual_jacobian_rows, caches flushed before every launch", t, n, bench.algorithmic_bytes(n, n_cam, n_pts), "obs")
 del r, Jc, Jp
 
 # visibility predicate on a candidate list of the same size class as the generator's
@@ -86,6 +113,8 @@ t = timed(lambda: D.visibility_pairs(camblk, pts4, cam_idx, pt_idx, 10.0, uv_out
 report("visibility_pairs", t, n, n * (8 + 16 + 1) + entity_bytes, "pairs")
 t = timed(lambda: D.visibility_rows(camblk, pts4, rows, pt_idx, 10.0, uv_out, keep))
 report("visibility_rows", t, n, n * (4 + 16 + 1) + entity_bytes, "pairs")
+t = timed_cold(lambda: D.visibility_rows(camblk, pts4, rows, pt_idx, 10.0, uv_out, keep))
+report("visibility_rows, caches flushed before every launch", t, n, n * (4 + 16 + 1) + entity_bytes, "pairs")
 t = timed(lambda: D.Rows(rows.row_ptr, n), 3, 2)
 report("rows_pack (once per list)", t, n, n_cam * 8 + n // 4, "obs")
 

@@ -20,7 +20,7 @@ from city2ba_amd import device as D  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--blocks", type=int, default=128)
-ap.add_argument("--variants", default="40,14,104,-1,-2")   # -1 = store pattern only, -2 = 16-B copy of the same bytes
+ap.add_argument("--variants", default="0,40,14,104,-1,-2")   # 0 = the shipped kernel (index form), 40 = the same with cached loads   # -1 = store pattern only, -2 = 16-B copy of the same bytes
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--no-err", action="store_true", help="launch without the fused error reduce")
