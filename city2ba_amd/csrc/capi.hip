@@ -662,7 +662,8 @@ int64_t c2b_rows_tiles_bytes(int64_t n_obs) { return n_obs <= 0 ? 0 : (n_obs + 6
 static int check_rows_args(const char *who, const uint64_t *row_ptr, int64_t n_cam, const void *tiles, int64_t n) {
     if (n_cam < 0 || n_cam >= (int64_t)1 << 31) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: n_cam out of range", who);
     if (n && (!row_ptr || !tiles || n_cam == 0)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: NULL row_ptr / tiles, or no cameras", who);
-    if (n && !aligned16(tiles)) return fail(C2B_ERR_INVALID_ARGUMENT, "%s: tiles must be 16-byte aligned", who);
+    if (n && (!aligned16(tiles) || (reinterpret_cast<uintptr_t>(row_ptr) & 7)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "%s: tiles must be 16-byte aligned, row_ptr 8-byte aligned", who);
     return C2B_OK;
 }
 
