@@ -126,6 +126,49 @@ def test_rows_forms_give_the_bits_of_the_index_forms(env, kind):
         assert 0 < int(ka.sum().item())
 
 
+def test_rows_property_random_list_shapes(env):
+    """hypothesis over list shapes (runs of empty lists, lists longer than a tile, boundaries on tile edges): the tile
+    records equal their definition and every row-structure launcher gives the index form's bits"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    P = random_problem(40, 500, 3, seed=5, noise=1e-3)
+    camblk_all = D.cameras_prepare_state(torch.from_numpy(P["cams15"]).to(dev))
+    pts4 = D.points_pad(torch.from_numpy(P["pts"]).to(dev))
+    run_len = st.one_of(st.just(0), st.just(0), st.integers(1, 5), st.integers(60, 70), st.integers(120, 200), st.just(64), st.just(128))
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.lists(run_len, min_size=1, max_size=40), st.integers(0, 2 ** 31 - 1))
+    def run(counts, seed):
+        counts = np.asarray(counts, dtype=np.int64)
+        n_cam, n = len(counts), int(counts.sum())
+        if n == 0:
+            return
+        rng = np.random.default_rng(seed)
+        row_ptr = np.zeros(n_cam + 1, dtype=np.int64)
+        row_ptr[1:] = np.cumsum(counts)
+        camblk = camblk_all[:n_cam]
+        ci = torch.from_numpy(np.repeat(np.arange(n_cam), counts).astype(np.int32)).to(dev)
+        pi = torch.from_numpy(rng.integers(0, 500, size=n).astype(np.int32)).to(dev)
+        uv = torch.from_numpy(rng.normal(size=(n, 2))).to(dev)
+        rows = D.Rows(torch.from_numpy(row_ptr).to(dev))
+        assert np.array_equal(rows.tiles.cpu().numpy().view(np.uint32), _np_tiles(counts))
+        a, b = (torch.full((n, 2), 3.0, dtype=torch.float64, device=dev) for _ in range(2))
+        D.project(camblk, pts4, ci, pi, a)
+        D.project_rows(camblk, pts4, rows, pi, b)
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+        ws = D.workspace(n, dev)
+        ea, eb = (torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(2))
+        out = [[torch.full((n, w), 5.0, dtype=torch.float64, device=dev) for w in (2, 18, 6)] for _ in range(2)]
+        D.residual_jacobian_sum(camblk, pts4, ci, pi, uv, *out[0], 2.0, ws, ea)
+        D.residual_jacobian_rows(camblk, pts4, rows, pi, uv, *out[1], 2.0, ws, eb)
+        assert ea.item() == eb.item()
+        for w in range(3):
+            assert torch.equal(out[0][w].view(torch.int64), out[1][w].view(torch.int64))
+
+    run()
+
+
 def test_rows_on_the_bench_grid_and_their_argument_checks(env):
     """blocks = 4 of the synthetic grid (cameras without observations exist there: no cull), and the ABI's checks"""
     import argparse
