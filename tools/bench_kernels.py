@@ -51,17 +51,17 @@ def timed(fn, reps=a.reps, rounds=5):
 for _ in range(300):                                   # bring the device to its working clocks before anything is timed
     D.project(camblk, pts4, cam_idx, pt_idx, uv_out)
 torch.cuda.synchronize()
-flush_src = torch.empty(1 << 27, dtype=torch.float64, device=dev)          # 1 GiB: four times the Infinity Cache
-flush_dst = torch.empty_like(flush_src)
+flush_src = torch.zeros(1 << 27, dtype=torch.float64, device=dev)          # 1 GiB: four times the Infinity Cache
 
 
 def timed_cold(fn, reps=7):
-    """one launch at a time, the caches flushed by a 1-GiB copy before each: what a single call on a problem nobody
-    has touched since costs (the back-to-back figure finds the previous launch's inputs in the 256 MB Infinity Cache
-    when results leave non-temporally)"""
+    """one launch at a time, the caches swept by a 1-GiB read before each (a read, not a copy: a copy would leave the
+    caches full of dirty lines and charge their write-back to the kernel): what a single call on a problem nobody has
+    touched since costs (the back-to-back figure finds the previous launch's inputs in the 256 MB Infinity Cache when
+    results leave non-temporally)"""
     ts = []
     for _ in range(reps):
-        D.calib_copy(flush_src, flush_dst)
+        flush_src.sum()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
