@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_NAME = "k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true, true, 0>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it     # the launch the roofline object describes
+KERNEL_FMT = "k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; NTL = c2b_jacobian_stream_policy of the launch
+KERNEL_NAME = KERNEL_FMT % 3     # the launch the roofline object describes (set in main() from the shard's sizes)
 
 
 def parse():
@@ -272,7 +273,7 @@ def adversarial_gather(sh, r, Jc, Jp, ws):
     return {"us_per_launch": round(t * 1e6, 2), "Mobs/s": round(sh["n_obs"] / t / 1e6, 1)}
 
 
-def pmc_traffic():
+def pmc_traffic(kernel_name=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (profiles/, produced
     by tools/profile_bench.sh with the guide's gfx950 FETCH_SIZE correction).  PMC counters cannot be collected
     from inside the timed run, so this is a figure from a SEPARATE run of the same command; it is only reported when
@@ -282,7 +283,7 @@ def pmc_traffic():
         with open(path) as fh:
             j = json.load(fh)
         profiled = str((j.get("dominant_kernel") or {}).get("name", "")).replace(" ", "")
-        if KERNEL_NAME.split("   ")[0].replace(" ", "") not in profiled:
+        if (kernel_name or KERNEL_NAME).replace(" ", "") not in profiled:
             return None, None
         return j.get("traffic_bytes_per_launch"), j.get("tag")
     except Exception:
@@ -459,7 +460,9 @@ def main():
         value = n_total * args.steps / elapsed / 1e6
         alg = algorithmic_bytes(n, sh["n_cam_local"], sh["n_pts"])
         achieved = alg / kern_avg_s / 1e9
-        traffic, traffic_tag = pmc_traffic() if (world == 1 and args.blocks == 128) else (None, None)
+        policy = D.jacobian_stream_policy(n, sh["n_cam_local"], sh["n_pts"])
+        kernel_name = KERNEL_FMT % policy
+        traffic, traffic_tag = pmc_traffic(kernel_name) if (world == 1 and args.blocks == 128) else (None, None)
         out = {
             "metric": "million observations/sec (project+Jacobian)",
             "value": round(value, 3), "unit": "Mobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -480,7 +483,9 @@ def main():
                 "collective": ("%s all_reduce(sum, 1 x f64) per step, same stream as the kernel" % backend) if dist_on else None,
             },
             "roofline": {
-                "bound": "hbm", "kernel": KERNEL_NAME, "achieved": round(achieved, 1),
+                "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
+                "stream_policy": {0: "every load cached", 2: "observed uv non-temporal", 3: "observed uv and point index non-temporal"}[policy]
+                + " (c2b_jacobian_stream_policy: tables and streams of this launch against the 256 MB Infinity Cache)",
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": ("separate rocprofv3 --pmc run, profiles/ tag %s" % traffic_tag)
                 if traffic is not None else None,

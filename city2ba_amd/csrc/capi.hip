@@ -308,11 +308,28 @@ void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_
 #undef C2B_GO
 }
 
+// Which of the Jacobian launch's once-read streams bypass the caches (0 none, 2 the observed uv, 3 uv and point index).
+// The kernel gathers from two tables (camera records, points) and streams 20 bytes of input per observation; its 208
+// bytes of results per observation always leave non-temporally.  When everything fits the 256 MB Infinity Cache the
+// next launch finds its inputs there, so everything stays cached.  When the tables fit but tables + streams do not,
+// cached streams would wash the tables out: the uv stream (16 B per observation) then goes non-temporal, and the point
+// index too once tables + indices alone exceed the cache.  When not even the tables fit, nothing is gained and cached
+// loads are 2 % faster.  Measured at --blocks 32 ... 208 (profiles/r02j_ab_jacobian_stream_policy.txt): the rule picks
+// the fastest of the three at every size but one (--blocks 140: 1.4 % behind).  n_pts <= 0 (unknown): cached.
+static int jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts) {
+    constexpr int64_t kInfinityCache = 256ll << 20;                      // MI355X
+    if (n_pts <= 0 || n_cam <= 0) return 0;
+    const int64_t tables = n_cam * (int64_t)(kCamBlk * sizeof(double)) + n_pts * 32, idx = n_obs * 4, uv = n_obs * 16;
+    if (tables > kInfinityCache || tables + idx + uv <= kInfinityCache) return 0;
+    return tables + idx > kInfinityCache ? 3 : 2;
+}
+
 // residual + Jacobian; WITH_ERR also folds sum |r|^norm into out_sum (device pointer) in the same launch
 template <bool WITH_ERR>
 int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                     const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
-                    double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0) {
+                    double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0,
+                    int64_t n_pts = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
     unsigned *ticket = nullptr;
     if (WITH_ERR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool (its first use must not be inside a stream capture)");
@@ -320,15 +337,17 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
 #define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base
 #ifdef C2B_TUNE
         switch (g_jac_variant) {
+            case 51: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;    // every load cached
             case 52: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;    // non-temporal observed uv
             case 53: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;    // ... and point index
             default: break;
         }
 #endif
-        // Loads stay cached here (results leave non-temporally).  Non-temporal index / uv loads were measured
-        // (profiles/r02i_ab_cache_policy*.txt): -3 % at --blocks 128, where they let the 232 MB of camera and point
-        // records own the 256 MB Infinity Cache, but +2 % at --blocks 208 and +12 % at --blocks 32 -- a gain at one size.
-        launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS);
+        switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
+            case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
+            case 2: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
+            default: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+        }
 #undef C2B_ROWS_ARGS
         return C2B_OK;
     }
@@ -770,7 +789,9 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
     C2B_API_END("residual_jacobian_sum")
 }
 
-int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts) { return jacobian_stream_policy(n_obs, n_cam, n_pts); }
+
+int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
                                int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
                                double *out_sum, void *stream) {
@@ -790,9 +811,9 @@ int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, const u
     const uint32_t *rec = reinterpret_cast<const uint32_t *>(tiles);
     if (workspace) {
         double *dst = out_sum ? out_sum : reinterpret_cast<double *>(workspace) + kWsFinal;
-        rc = launch_jacobian<true>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, dst, S(stream), row_ptr, n_cam, obs_base);
+        rc = launch_jacobian<true>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, dst, S(stream), row_ptr, n_cam, obs_base, n_pts);
     } else {
-        rc = launch_jacobian<false>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr, nullptr, S(stream), row_ptr, n_cam, obs_base);
+        rc = launch_jacobian<false>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr, nullptr, S(stream), row_ptr, n_cam, obs_base, n_pts);
     }
     if (rc) return rc;
     LAUNCH_CHECK();
@@ -2035,7 +2056,8 @@ int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double 
         const int64_t o0 = k * kChunk, m = (n - o0 < kChunk) ? n - o0 : kChunk;
         if (k >= kSlots) { HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_free[s], 0)); }      // its previous copies are out
         // kJacChunk is a multiple of 64: every chunk starts on a tile record
-        int rc2 = c2b_residual_jacobian_rows(p->camblk, p->pts4, p->rows_ptr, p->n_cam, (const char *)p->rows_tiles + (o0 >> 6) * 16, o0,
+        // (n_pts = 0: a chunk's working set is small and this path is bound by the PCIe copies; loads stay cached)
+        int rc2 = c2b_residual_jacobian_rows(p->camblk, p->pts4, 0, p->rows_ptr, p->n_cam, (const char *)p->rows_tiles + (o0 >> 6) * 16, o0,
                                              p->pt_idx + o0, p->uv + 2 * o0, m, slot_r(s), slot_Jc(s), slot_Jp(s), 2.0, nullptr,
                                              nullptr, p->stream);
         if (rc2) return rc2;

@@ -127,10 +127,15 @@ def residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r, Jc, Jp, norm=2.0, 
     observations [obs_base, obs_base + n_obs) of the list `rows` describes; pt_idx / uv / r / Jc / Jp are that slice."""
     n = rows.n_obs - int(obs_base) if n_obs is None else int(n_obs)
     tiles = rows.tiles[int(obs_base) // 64:]
-    L.check(L.lib().c2b_residual_jacobian_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(tiles),
+    L.check(L.lib().c2b_residual_jacobian_rows(_p(camblk), _p(pts4), pts4.shape[0], _p(rows.row_ptr), rows.n_cam, _p(tiles),
                                                int(obs_base), _p(pt_idx), _p(uv), n, _p(r), _p(Jc), _p(Jp),
                                                float(norm), _p(ws), _p(out_sum), _stream()))
     return out_sum
+
+
+def jacobian_stream_policy(n_obs, n_cam, n_pts):
+    """0 / 2 / 3: which once-read streams of a residual_jacobian_rows launch of this size bypass the caches"""
+    return int(L.lib().c2b_jacobian_stream_policy(int(n_obs), int(n_cam), int(n_pts)))
 
 
 def residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None):

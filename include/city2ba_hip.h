@@ -130,8 +130,13 @@ int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t
 /* c2b_residual_jacobian / _sum in the row-structure form, for the whole list (obs_base = 0) or a slice of it: tiles,
  * pt_idx, uv_obs, r, Jc, Jp all point at observation obs_base (a multiple of 64) of the list row_ptr describes and
  * n_obs observations are processed.  workspace == NULL: no error sum.  Otherwise sum |r|^norm goes to out_sum[0]
- * (device pointer), or into the workspace (c2b_error_sum_finish) when out_sum is NULL. */
-int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+ * (device pointer), or into the workspace (c2b_error_sum_finish) when out_sum is NULL.
+ * n_pts = rows of pts4, or 0 if unknown: together with n_cam and n_obs it sizes the launch's working set against the
+ * 256 MB Infinity Cache, which decides whether the once-read streams (observed uv, point index) bypass the caches so
+ * that the camera and point tables stay in them (c2b_jacobian_stream_policy returns that decision: 0 none, 2 uv,
+ * 3 uv and index; results are identical under every policy). */
+int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts);
+int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
                                int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
                                double *out_sum, void *stream);

@@ -129,3 +129,20 @@ def test_product_library_has_no_tuning_hooks_and_no_undeclared_entry_points(c2b)
     # nothing in the package, the tests' product fixtures or the bench refers to the tuning library
     for rel in ("city2ba_amd/_lib.py", "city2ba_amd/device.py", "city2ba_amd/baproblem.py", "bench.py"):
         assert "tune" not in open(os.path.join(ROOT, rel)).read(), rel
+
+
+def test_jacobian_stream_policy_follows_the_working_set(c2b):
+    """c2b_jacobian_stream_policy is host arithmetic (no GPU): tables = 256 B per camera + 32 B per point, streams =
+    4 + 16 B per observation, against the 256 MiB Infinity Cache.  The synthetic grid has 40 B (B + 1) cameras,
+    120 B (B + 1) points; observation counts as generated."""
+    from city2ba_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    lib.c2b_jacobian_stream_policy.argtypes = [C.c_int64] * 3
+    grid = lambda B: (40 * B * (B + 1), 120 * B * (B + 1))
+    for B, n_obs, want in ((4, 21_629, 0), (32, 1_225_066, 0), (64, 4_860_000, 0), (100, 11_800_000, 2), (115, 15_600_000, 2),
+                           (128, 19_302_494, 3), (150, 26_500_000, 0), (208, 50_868_906, 0)):
+        n_cam, n_pts = grid(B)
+        assert lib.c2b_jacobian_stream_policy(n_obs, n_cam, n_pts) == want, B
+    assert lib.c2b_jacobian_stream_policy(19_302_494, 660_480, 0) == 0          # unknown point count: cached
+    # one rank of eight on the headline problem: its cameras, every point, an eighth of the observations -- all of it fits
+    assert lib.c2b_jacobian_stream_policy(19_302_494 // 8, 660_480 // 8, 1_981_440) == 0

@@ -52,6 +52,19 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     torch.cuda.synchronize()
     assert e_one.item() == e_fused.item()
     assert torch.equal(r_b, r) and torch.equal(Jc_b, Jc) and torch.equal(Jp_b, Jp)
+    if blocks == 32:
+        # every cache policy of the once-read streams writes the same bits.  n_pts only sizes the working set for
+        # that choice (c2b_jacobian_stream_policy), so claiming more points than there are selects the other kernels.
+        from city2ba_amd import _lib as L
+        lib, p = L.lib(), (lambda t: t.data_ptr())
+        for fake_n_pts, want in ((sh["n_pts"], 0), (7_600_000, 2), (8_000_000, 3)):
+            assert lib.c2b_jacobian_stream_policy(n, rows.n_cam, fake_n_pts) == want
+            Jc_b.fill_(float("nan")); Jp_b.fill_(float("nan")); r_b.fill_(float("nan")); e_one.fill_(-1.0)
+            assert lib.c2b_residual_jacobian_rows(p(camblk), p(pts4), fake_n_pts, p(rows.row_ptr), rows.n_cam, p(rows.tiles), 0,
+                                                  p(pi), p(uv), n, p(r_b), p(Jc_b), p(Jp_b), 2.0, p(ws), p(e_one), None) == L.OK
+            torch.cuda.synchronize()
+            assert e_one.item() == e_fused.item()
+            assert torch.equal(r_b, r) and torch.equal(Jc_b, Jc) and torch.equal(Jp_b, Jp)
     del r_b, Jc_b, Jp_b
     assert bool(torch.isfinite(Jc).all()) and bool(torch.isfinite(Jp).all())      # every row written, incl. the tail
 

@@ -28,6 +28,8 @@ ap.add_argument("--blocks", type=int, default=128)
 ap.add_argument("--variants", default="308,20308")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--only", default="", help="time only the modes whose name contains this")
+ap.add_argument("--place", action="store_true", help="place the Jacobian outputs by measured store rate, as bench.py does")
 a = ap.parse_args()
 variants = [int(v) for v in a.variants.split(",")]
 
@@ -43,9 +45,13 @@ err = torch.zeros(1, dtype=torch.float64, device=dev)
 camblk, pts4, ci, pi, uv, rows = sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], sh["rows"]
 uv_out = torch.empty_like(uv)
 keep = torch.empty(n, dtype=torch.uint8, device=dev)
-r_o = torch.empty((n, 2), dtype=torch.float64, device=dev)
-Jc_o = torch.empty((n, 18), dtype=torch.float64, device=dev)
-Jp_o = torch.empty((n, 6), dtype=torch.float64, device=dev)
+if a.place:
+    (r_o, Jc_o, Jp_o), log = D.alloc_jacobian_outputs(n, dev)
+    print("output placement:", log)
+else:
+    r_o = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    Jc_o = torch.empty((n, 18), dtype=torch.float64, device=dev)
+    Jp_o = torch.empty((n, 6), dtype=torch.float64, device=dev)
 print("n_obs=%d  tiles %d, with an empty list inside %d" % (n, rows.tiles.shape[0], int((rows.tiles[:, 2] < 0).sum())))
 
 
@@ -83,9 +89,12 @@ for k, (idx_fn, rows_fn) in kinds.items():
     for tag, v in POLICIES:
         modes["%s rows [%s]" % (k, tag)] = (k, with_obs(v, rows_fn))
 modes["jacobian idx [shipped]"] = ("jacobian", jac[0])
-modes["jacobian rows [shipped: cached loads]"] = ("jacobian", jac[1])
+modes["jacobian rows [shipped: policy %d by size]" % D.jacobian_stream_policy(n, rows.n_cam, pts4.shape[0])] = ("jacobian", jac[1])
+modes["jacobian rows [every load cached]"] = ("jacobian", with_jac(51, jac[1]))
 modes["jacobian rows [nt uv]"] = ("jacobian", with_jac(52, jac[1]))
 modes["jacobian rows [nt uv + point index]"] = ("jacobian", with_jac(53, jac[1]))
+if a.only:
+    modes = {k: v for k, v in modes.items() if a.only in k}
 
 
 def snapshot(kind):
