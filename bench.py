@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_FMT = "k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; NTL = c2b_jacobian_stream_policy of the launch
-KERNEL_NAME = KERNEL_FMT % 3     # the launch the roofline object describes (set in main() from the shard's sizes)
+KERNEL_FMT = "k_residual_jacobian_l<2, true, 8, true, %d, 1, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; OPL = c2b_jacobian_tiles_per_wave, NTL = c2b_jacobian_stream_policy of the launch
+KERNEL_NAME = KERNEL_FMT % (2, 3)     # the launch the roofline object describes (set in main() from the shard's sizes)
 
 
 def parse():
@@ -461,7 +461,7 @@ def main():
         alg = algorithmic_bytes(n, sh["n_cam_local"], sh["n_pts"])
         achieved = alg / kern_avg_s / 1e9
         policy = D.jacobian_stream_policy(n, sh["n_cam_local"], sh["n_pts"])
-        kernel_name = KERNEL_FMT % policy
+        kernel_name = KERNEL_FMT % (D.jacobian_tiles_per_wave(n), policy)
         traffic, traffic_tag = pmc_traffic(kernel_name) if (world == 1 and args.blocks == 128) else (None, None)
         out = {
             "metric": "million observations/sec (project+Jacobian)",

@@ -50,6 +50,7 @@ SIGNATURES = {
     "c2b_reprojection_error_sum_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_visibility_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_jacobian_stream_policy": (_int, [_i64, _i64, _i64]),
+    "c2b_jacobian_tiles_per_wave": (_int, [_i64]),
     "c2b_residual_jacobian_rows": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
     "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp]),
     "c2b_error_sum_finish": (_int, [_vp, _i64, _vp, _vp]),

@@ -324,6 +324,13 @@ static int jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts) {
     return tables + idx > kInfinityCache ? 3 : 2;
 }
 
+// Tiles of 64 observations per wave.  Two (both tiles' loads issued up front: the second tile's index -> gather chain
+// hides behind the first tile's stores) is the better shape once there are enough workgroups to keep every CU busy
+// through the last round; below ~6 M observations (< 24 workgroups of 1 024 per CU) the finer grain of one tile per
+// wave wins: 2.4 M observations -- a rank's share of the headline problem at 8 GPUs -- 97.9 -> 94.3 us, 1.2 M 47.4 ->
+// 46.4, 4.9 M 166.2 -> 164.3, against 332.5 -> 339.8 at 9.6 M (profiles/r02k_ab_jacobian_tiles_per_wave.txt).
+constexpr int64_t kJacOneTileBelow = 6000000;
+
 // residual + Jacobian; WITH_ERR also folds sum |r|^norm into out_sum (device pointer) in the same launch
 template <bool WITH_ERR>
 int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
@@ -340,13 +347,36 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
             case 51: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;    // every load cached
             case 52: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;    // non-temporal observed uv
             case 53: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;    // ... and point index
+            case 61:                                                                                      // one tile per wave whatever the size, streams by the size rule
+                switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
+                    case 3: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
+                    case 2: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
+                    default: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+                }
+                return C2B_OK;
+            case 64:                                                                                      // two tiles per wave whatever the size
+                switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
+                    case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
+                    case 2: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
+                    default: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+                }
+                return C2B_OK;
             default: break;
         }
 #endif
-        switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
-            case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
-            case 2: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
-            default: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+        const int policy = jacobian_stream_policy(n_obs, n_cam, n_pts);
+        if (n_obs < kJacOneTileBelow) {
+            switch (policy) {
+                case 3: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
+                case 2: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
+                default: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+            }
+        } else {
+            switch (policy) {
+                case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
+                case 2: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
+                default: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+            }
         }
 #undef C2B_ROWS_ARGS
         return C2B_OK;
@@ -390,7 +420,8 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         default: break;
     }
 #endif
-    launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS);                            // shipped: lean form, two tiles per wave (= variant 40)
+    if (n_obs < kJacOneTileBelow) launch_jac_l<WITH_ERR, 8, 1, 1>(C2B_ARGS);   // shipped: lean form, one tile per wave (= variant 42) ...
+    else launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS);                        // ... or two (= variant 40), by size
 #undef C2B_ARGS
     return C2B_OK;
 }
@@ -790,6 +821,7 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
 }
 
 int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts) { return jacobian_stream_policy(n_obs, n_cam, n_pts); }
+int c2b_jacobian_tiles_per_wave(int64_t n_obs) { return n_obs < kJacOneTileBelow ? 1 : 2; }
 
 int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,

@@ -138,6 +138,10 @@ def jacobian_stream_policy(n_obs, n_cam, n_pts):
     return int(L.lib().c2b_jacobian_stream_policy(int(n_obs), int(n_cam), int(n_pts)))
 
 
+def jacobian_tiles_per_wave(n_obs):
+    return int(L.lib().c2b_jacobian_tiles_per_wave(int(n_obs)))
+
+
 def residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None):
     """ws != None -> the same launch also folds sum |r|^norm into ws (see error_sum_finish)."""
     L.check(L.lib().c2b_residual_jacobian(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv), cam_idx.shape[0],

@@ -136,6 +136,10 @@ int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t
  * that the camera and point tables stay in them (c2b_jacobian_stream_policy returns that decision: 0 none, 2 uv,
  * 3 uv and index; results are identical under every policy). */
 int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts);
+/* tiles of 64 observations a wave of the residual + Jacobian launch takes: 1 below ~6 M observations, else 2
+ * (diagnostic: names the kernel instance a launch of this size runs; results do not depend on it, the rounding of
+ * the folded error sum does, like on any other change of the grid) */
+int c2b_jacobian_tiles_per_wave(int64_t n_obs);
 int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
                                int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,

@@ -90,6 +90,8 @@ for k, (idx_fn, rows_fn) in kinds.items():
         modes["%s rows [%s]" % (k, tag)] = (k, with_obs(v, rows_fn))
 modes["jacobian idx [shipped]"] = ("jacobian", jac[0])
 modes["jacobian rows [shipped: policy %d by size]" % D.jacobian_stream_policy(n, rows.n_cam, pts4.shape[0])] = ("jacobian", jac[1])
+modes["jacobian rows [one tile per wave]"] = ("jacobian", with_jac(61, jac[1]))
+modes["jacobian rows [two tiles per wave]"] = ("jacobian", with_jac(64, jac[1]))
 modes["jacobian rows [every load cached]"] = ("jacobian", with_jac(51, jac[1]))
 modes["jacobian rows [nt uv]"] = ("jacobian", with_jac(52, jac[1]))
 modes["jacobian rows [nt uv + point index]"] = ("jacobian", with_jac(53, jac[1]))
@@ -136,4 +138,4 @@ for _ in range(a.rounds):
         times[m].append(s.elapsed_time(e) / a.reps * 1e3)
 for m in modes:
     t = sorted(times[m])
-    print("%-40s: median %7.1f us  min %7.1f us  %6.1f Gobs/s" % (m, t[len(t) // 2], t[0], n / t[len(t) // 2] / 1e3))
+    print("%-58s: median %7.1f us  min %7.1f us  %6.1f Gobs/s" % (m, t[len(t) // 2], t[0], n / t[len(t) // 2] / 1e3))
