@@ -207,3 +207,40 @@ def test_rows_on_the_bench_grid_and_their_argument_checks(env):
     assert lib.c2b_rows_pack(p(row_ptr), 1 << 31, n, p(rows.tiles), None) == L.ERR_INVALID_ARGUMENT
     assert lib.c2b_rows_pack(p(row_ptr), n_cam, 0, None, None) == L.OK                  # an empty list is fine
     assert lib.c2b_project_rows(None, None, None, 0, None, None, 0, None, None) == L.OK
+
+
+def test_level1_rebuilds_its_row_structure_when_the_list_changes(env):
+    """The Level-1 problem derives row_ptr + tile records lazily and must drop them whenever the observation list
+    changes (cull, a second upload): project / total_reprojection_error / residual_jacobian after each change against
+    the oracle on what the problem then holds."""
+    import oracle as O
+    import city2ba_amd as c2b
+    from city2ba_amd import synthetic as S
+    g = S.synthetic_grid(3, 20, 3, 5.0, 1.0, 1.0, 1.0, 10.0, False, cull=False)   # un-culled grid: cameras without observations
+    uv = g.observations() + np.random.default_rng(3).normal(scale=1e-2, size=(g.num_observations(), 2))
+    ba = c2b.BAProblem.from_visibility(g.cameras(), g.points(), g.row_ptr.copy(), g.pt_idx.copy(), uv)
+    g.close()
+
+    def check(ba):
+        cams, pts, rp, pi, uv = ba.cameras(), ba.points(), ba.row_ptr, ba.pt_idx, ba.observations()
+        if len(pi) == 0:
+            assert ba.total_reprojection_error(2.0) == 0.0
+            return
+        with O.pow4_mode(1):                                                    # k2 != 0: correctly rounded |p|^4 on both sides
+            want = O.project_observations(cams, pts, rp, pi)
+        assert np.array_equal(ba.project(), want)
+        assert abs(ba.total_reprojection_error(2.0) - O.total_reprojection_error(cams, pts, rp, pi, uv, 2.0)) <= 1e-12 * max(1.0, ba.total_reprojection_error(2.0))
+        r, Jc, Jp = ba.residual_jacobian()
+        r0, Jc0, Jp0 = O.residual_jacobian(cams, pts, rp, pi, uv)
+        Jc = np.asarray(Jc).reshape(len(r0), 18)
+        assert np.max(np.abs(r - r0)) < 1e-12 and np.max(np.abs(Jc - Jc0)) / max(1.0, np.max(np.abs(Jc0))) < 1e-9
+
+    check(ba)
+    n0 = ba.num_observations()
+    ba.cull(False)         # (the faithful mode's index aliasing, src/baproblem.rs:523, empties a graph with isolated cameras)
+    assert 0 < ba.num_observations() <= n0
+    check(ba)                                                                   # rows of the culled list, not of the old one
+    Q = random_problem(9, 50, 5, seed=22, noise=1e-2)
+    ba._upload(Q["cams15"], False, Q["pts"], Q["row_ptr"], Q["pt_idx"], Q["uv"])   # a second upload into the same handle
+    check(ba)
+    ba.close()
