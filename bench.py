@@ -504,6 +504,18 @@ def main():
             out["roofline"]["kernel_over_same_run_store_floor"] = round(kern_avg_s * 1e6 / cal["same_run_algorithmic_floor_us"], 4)
             # the same-run copy moves exactly the launch's algorithmic byte count (read + write)
             out["roofline"]["kernel_over_same_run_copy"] = round(kern_avg_s * 1e6 / cal["same_run_copy_us"], 4)
+            # The timed steps run back to back on one problem, so the camera and point records (232 MB at --blocks 128)
+            # are found in the 256 MB Infinity Cache.  The same launch with the caches swept by a 1-GiB read before it:
+            sweep = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
+            cold = []
+            for _ in range(5):
+                sweep.sum()
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                step(ev)                                     # the events bracket the kernel, not the all-reduce
+                torch.cuda.synchronize()
+                cold.append(ev[0].elapsed_time(ev[1]))
+            del sweep
+            out["roofline"]["kernel_us_caches_swept_before_launch"] = round(sorted(cold)[2] * 1e3, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sh, args.cpu_seconds)
         else:
