@@ -238,6 +238,10 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
             case 21308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;    // non-temporal stores only
             case 22308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;    // ... + observed uv
             case 23308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;    // ... + point index
+            case 30108: launch_obs_v<MODE, 1, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // shipped policy, one tile per wave
+            case 30208: launch_obs_v<MODE, 2, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // two
+            case 30408: launch_obs_v<MODE, 4, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // four
+            case 30304: launch_obs_v<MODE, 3, 4, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // three, four waves per workgroup
             default: break;
         }
 #endif

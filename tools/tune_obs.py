@@ -81,7 +81,9 @@ kinds = {
 jac = (lambda: D.residual_jacobian_sum(camblk, pts4, ci, pi, uv, r_o, Jc_o, Jp_o, 2.0, ws, err),
        lambda: D.residual_jacobian_rows(camblk, pts4, rows, pi, uv, r_o, Jc_o, Jp_o, 2.0, ws, err))
 # cache policies of the row-structure forms (capi.hip: launch_obs / launch_jacobian)
-POLICIES = (("shipped", 308), ("all cached", 20308), ("nt stores", 21308), ("nt stores+uv", 22308), ("nt everything", 23308))
+POLICIES = (("shipped", 308), ("all cached", 20308), ("nt stores", 21308), ("nt stores+uv", 22308), ("nt everything", 23308),
+            ("shipped policy, 1 tile per wave", 30108), ("shipped policy, 2 tiles", 30208), ("shipped policy, 4 tiles", 30408),
+            ("shipped policy, 3 tiles, 4 waves per workgroup", 30304))
 modes = {}                                        # name -> (kind, callable)
 for k, (idx_fn, rows_fn) in kinds.items():
     for v in variants:
