@@ -30,6 +30,8 @@ SIGNATURES = {
     "c2b_last_error": (C.c_char_p, []),
     "c2b_device_count": (_int, [C.POINTER(_int)]),
     "c2b_workspace_bytes": (_i64, [_i64]),
+    "c2b_workspace_init": (_int, [_vp, _vp]),
+    "c2b_workspace_selfcheck": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "c2b_cameras_from_bal": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_to_bal": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_prepare_state": (_int, [_vp, _i64, _vp, _vp]),
@@ -43,7 +45,6 @@ SIGNATURES = {
     "c2b_expand_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "c2b_project": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "c2b_reprojection_error_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
-    "c2b_selfcheck_tickets": (_int, [C.POINTER(_i64)]),
     "c2b_rows_tiles_bytes": (_i64, [_i64]),
     "c2b_rows_pack": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "c2b_project_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),

@@ -91,42 +91,23 @@ inline unsigned blocks_for(int64_t n, int b = kBlock) { return (unsigned)((n + b
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // workspace layout (doubles): [stats records: kRedBlocks*kStatRec] [result slot of the fused error sum: 16]
+//                            [ticket block: arrival counters of the in-kernel folds + magic, kTicketWords u32]
 //                            [workgroup partials of the ticket fold: one per workgroup of the launch]
+// The counters sit in the workspace they count partials of: a workspace serves one launch at a time (the partials
+// already demand that), so launches from different streams, threads or graphs can never meet on the same counters.
+// c2b_workspace_init zeroes them and writes the magic once; every fold leaves them zero.
 constexpr int64_t kWsStatsDoubles = (int64_t)kRedBlocks * kStatRec;
 constexpr int64_t kWsFinal = kWsStatsDoubles;
-constexpr int64_t kWsBlockPart = kWsFinal + 16;
+constexpr int64_t kWsTicket = kWsFinal + 16;                               // 128-byte aligned when the workspace is
+constexpr int64_t kWsBlockPart = kWsTicket + kTicketWords / 2;
+static_assert((kWsTicket * 8) % 128 == 0 && kTicketWords % 2 == 0, "ticket lines must stay 128-byte aligned");
 // workgroups never hold fewer than 4 tiles of 64 observations (WPB * OPL >= 4 in every instantiation)
 inline int64_t block_part_slots(int64_t n_obs) {
     const int64_t one_shot = ((n_obs + 63) / 64 + 3) / 4 + 8;
     return one_shot > 4096 + 8 ? one_shot : 4096 + 8;        // 4096: the persistent grids of the tuning library
 }
-
-// Arrival tickets of the in-kernel folds (kernels.hpp: ticket_fold): a pool of zero-initialised words owned by the
-// library, one pool per device, allocated on first use.  A launch takes the next word of the pool; its last
-// workgroup resets it.  Launches that could run concurrently take different slots (128 before a slot repeats).
-constexpr unsigned kTicketSlots = 128;
-static std::mutex g_ticket_mu;
-static unsigned *g_ticket_pool[64] = {nullptr};
-static std::atomic<unsigned> g_ticket_next{0};
-unsigned *ticket_slot() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!g_ticket_pool[dev]) {
-        std::lock_guard<std::mutex> g(g_ticket_mu);
-        if (!g_ticket_pool[dev]) {
-            unsigned *p = nullptr;
-            if (hipMalloc((void **)&p, kTicketSlots * kTicketWords * sizeof(unsigned)) != hipSuccess) return nullptr;
-            // hipMemset on device memory only ENQUEUES the fill on the null stream; a first user on a non-blocking stream
-            // (every Level-1 problem has one) would otherwise race it -- counters wiped under a running fold lose that
-            // launch's sum and leave the slot dirty for its 128th successor.  Drain before the pool is published.
-            if (hipMemset(p, 0, kTicketSlots * kTicketWords * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-                (void)hipFree(p);
-                return nullptr;
-            }
-            g_ticket_pool[dev] = p;
-        }
-    }
-    return g_ticket_pool[dev] + (size_t)(g_ticket_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlots) * kTicketWords;
+inline unsigned *ws_ticket(void *workspace) {
+    return workspace ? reinterpret_cast<unsigned *>(reinterpret_cast<double *>(workspace) + kWsTicket) : nullptr;
 }
 
 #ifdef C2B_TUNE
@@ -222,8 +203,7 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
                const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
                void *workspace, double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
-    unsigned *ticket = nullptr;
-    if (MODE == MODE_ERROR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool (its first use must not be inside a stream capture)");
+    unsigned *ticket = ws_ticket(workspace);
     // Cache policy of the streams (A/B in profiles/r02i_ab_cache_policy.txt): results leave through non-temporal stores
     // and the observed uv (read once) comes in through non-temporal loads, so that the tables every observation
     // gathers from -- points, cameras -- keep the L2 / Infinity Cache; the 4-byte point index stays cached where the
@@ -342,8 +322,7 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
                     double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0,
                     int64_t n_pts = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
-    unsigned *ticket = nullptr;
-    if (WITH_ERR && !(ticket = ticket_slot())) return fail(C2B_ERR_OOM, "could not allocate the ticket pool (its first use must not be inside a stream capture)");
+    unsigned *ticket = ws_ticket(workspace);
     if (row_ptr) {          // the *_rows entry points
 #define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base
 #ifdef C2B_TUNE
@@ -430,19 +409,22 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
     return C2B_OK;
 }
 
+inline int stats_grid(int64_t n) {
+    int grid = (int)((n + kBlock - 1) / kBlock);
+    if (grid > kRedBlocks) grid = kRedBlocks;
+    return grid < 1 ? 1 : grid;
+}
+
+// mean / min / max / extent / origin, then std: two launches, each folded by its last workgroup (kernels.hpp)
 template <typename Src>
 int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStream_t st) {
     double *rec = reinterpret_cast<double *>(workspace);
-    int grid = (int)((n + kBlock - 1) / kBlock);
-    if (grid > kRedBlocks) grid = kRedBlocks;
+    const int grid = stats_grid(n);
     const ShardMap whole{src.n_cam, 0, src.n_cam, 0};
-    hipLaunchKernelGGL(k_stats_pass1<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, (double)n, rec);
+    hipLaunchKernelGGL(k_stats_pass1<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, (double)n, rec, ws_ticket(workspace), whole, stats);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold1<Src>, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, src, whole, stats);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_pass2<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, (const double *)stats, rec);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold2<false>, dim3(1), dim3(kRedBlocks), 0, st, (const double *)rec, grid, n, stats);
+    hipLaunchKernelGGL((k_stats_pass2<Src, false>), dim3(grid), dim3(kBlock), 0, st, src, n, (const double *)stats, rec,
+                       ws_ticket(workspace), stats);
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -512,24 +494,35 @@ int c2b_device_count(int *count) {
     C2B_API_END("device_count")
 }
 
-// Diagnostic: the arrival counters of the in-kernel folds must all be zero whenever no launch is in flight (the last
-// workgroup of every launch resets its own).  Synchronises the device, then counts the non-zero words of the current
-// device's pool; a non-zero count means a launch did not complete its fold and the slot's next user would lose its sum.
-int c2b_selfcheck_tickets(int64_t *nonzero_words) {
+// Zero the arrival counters of the workspace's in-kernel folds and write the magic that marks it initialised
+// (one tiny launch on `stream`; capture-safe).  Once per workspace, before its first use.
+int c2b_workspace_init(void *workspace, void *stream) {
     C2B_API_BEGIN
-    if (!nonzero_words) return fail(C2B_ERR_INVALID_ARGUMENT, "selfcheck_tickets: NULL argument");
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 127))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "workspace_init: workspace must be a 128-byte aligned device pointer");
+    hipLaunchKernelGGL(k_workspace_init, dim3(1), dim3(256), 0, S(stream), ws_ticket(workspace));
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("workspace_init")
+}
+
+// Diagnostic: the arrival counters of a workspace must all be zero whenever no launch that uses it is in flight (the
+// last workgroup of every fold resets them).  Synchronises `stream`, then counts the non-zero counter words; -1 if
+// the workspace carries no magic (c2b_workspace_init was never called on it).
+int c2b_workspace_selfcheck(const void *workspace, void *stream, int64_t *nonzero_words) {
+    C2B_API_BEGIN
+    if (!nonzero_words || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "workspace_selfcheck: NULL argument");
     *nonzero_words = 0;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !g_ticket_pool[dev]) return C2B_OK;
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<unsigned> host((size_t)kTicketSlots * kTicketWords);
-    HIP_TRY(hipMemcpy(host.data(), g_ticket_pool[dev], host.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    std::vector<unsigned> host((size_t)kTicketWords);
+    HIP_TRY(hipMemcpy(host.data(), reinterpret_cast<const double *>(workspace) + kWsTicket, host.size() * sizeof(unsigned),
+                      hipMemcpyDeviceToHost));
+    if (host[kTicketMagicAt] != kTicketMagic) { *nonzero_words = -1; return C2B_OK; }
     int64_t c = 0;
-    for (unsigned v : host) c += v != 0;
+    for (unsigned i = 0; i < kTicketWords; ++i) c += i != kTicketMagicAt && host[i] != 0;
     *nonzero_words = c;
     return C2B_OK;
-    C2B_API_END("selfcheck_tickets")
+    C2B_API_END("workspace_selfcheck")
 }
 
 int64_t c2b_workspace_bytes(int64_t n_obs) {
@@ -1011,13 +1004,9 @@ int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_bas
     const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
     const int64_t n = n_cam + n_pts;
     double *rec = reinterpret_cast<double *>(workspace);
-    int grid = (int)((n + kBlock - 1) / kBlock);
-    if (grid > kRedBlocks) grid = kRedBlocks;
-    if (grid < 1) grid = 1;
     const ShardMap map{n_cam, cam_base, n_cam_global, pt_base};
-    hipLaunchKernelGGL(k_stats_pass1<SrcBlk>, dim3(grid), dim3(kBlock), 0, S(stream), src, n, (double)n_entities_global, rec);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold1<SrcBlk>, dim3(1), dim3(kRedBlocks), 0, S(stream), (const double *)rec, grid, src, map, part);
+    hipLaunchKernelGGL(k_stats_pass1<SrcBlk>, dim3(stats_grid(n)), dim3(kBlock), 0, S(stream), src, n, (double)n_entities_global, rec,
+                       ws_ticket(workspace), map, part);
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("stats_partial_pass1")
@@ -1031,12 +1020,8 @@ int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *p
     const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
     const int64_t n = n_cam + n_pts;
     double *rec = reinterpret_cast<double *>(workspace);
-    int grid = (int)((n + kBlock - 1) / kBlock);
-    if (grid > kRedBlocks) grid = kRedBlocks;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_stats_pass2<SrcBlk>, dim3(grid), dim3(kBlock), 0, S(stream), src, n, mean3, rec);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_fold2<true>, dim3(1), dim3(kRedBlocks), 0, S(stream), (const double *)rec, grid, n, sumsq3);
+    hipLaunchKernelGGL((k_stats_pass2<SrcBlk, true>), dim3(stats_grid(n)), dim3(kBlock), 0, S(stream), src, n, mean3, rec,
+                       ws_ticket(workspace), sumsq3);
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("stats_partial_pass2")
@@ -1857,6 +1842,7 @@ static int upload_common(c2b_problem *p, int64_t n_cam, const double *cams, bool
     HIP_TRY(dalloc((void **)&p->cam_idx, sizeof(uint32_t) * n_obs));
     HIP_TRY(dalloc((void **)&p->pt_idx, sizeof(uint32_t) * n_obs));
     HIP_TRY(dalloc(&p->ws, (size_t)c2b_workspace_bytes(n_obs)));
+    if (int rc = c2b_workspace_init(p->ws, p->stream)) return rc;
     HIP_TRY(dalloc((void **)&p->stats, sizeof(double) * C2B_STATS_DOUBLES));
     HIP_TRY(dalloc((void **)&p->scalar, sizeof(double) * 2));
     p->n_cam = n_cam; p->n_pts = n_pts; p->n_obs = n_obs;
@@ -2336,6 +2322,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
         A(n_camblk, sizeof(double) * kCamBlk * (size_t)nc); A(n_pts4, sizeof(double) * 4 * (size_t)np);
         A(n_uv, sizeof(double) * 2 * (size_t)no); A(n_ws, (size_t)c2b_workspace_bytes(no));
     }
+    if (e == hipSuccess && c2b_workspace_init(n_ws.ptr, st) != C2B_OK) e = hipErrorUnknown;
     if (e == hipSuccess) {
         auto gather = [&](const double *in, const DevBuf &orig, int64_t n, int width, DevBuf &out) {
             if (n) hipLaunchKernelGGL(k_gather_rows, dim3(blocks_of(n * width, kBlock)), dim3(kBlock), 0, st, in,
@@ -2379,6 +2366,7 @@ int c2b_problem_adopt_visibility(c2b_problem *p) {
     if (e == hipSuccess) e = ws.alloc((size_t)c2b_workspace_bytes(n));
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_adopt_visibility: %s", hipGetErrorString(e));
     int rc = c2b_expand_rows(p->dense_row, p->n_cam, 0, n, cam_idx.as<uint32_t>(), p->stream);
+    if (!rc) rc = c2b_workspace_init(ws.ptr, p->stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     void *old[] = {p->uv, p->cam_idx, p->pt_idx, p->ws, p->dense_row};

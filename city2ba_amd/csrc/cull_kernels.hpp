@@ -22,11 +22,12 @@ constexpr int kScanPer = 4;                     // elements per thread
 constexpr int kScanTile = kScanBlock * kScanPer;
 
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
-    volatile uint32_t *vp = parent;             // other lanes hook roots while this one walks
+    // other lanes hook roots while this one walks: agent-scope atomic loads (global_load ... sc1; a volatile pointer
+    // compiled to system-scope FLAT loads)
     while (true) {
-        const uint32_t p = vp[x];
+        const uint32_t p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (p == x) return x;
-        const uint32_t gp = vp[p];
+        const uint32_t gp = __hip_atomic_load(parent + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gp != p) parent[x] = gp;            // path halving; a stale write still points at an ancestor
         x = p;
     }

@@ -56,17 +56,60 @@ C2B_DEV double wave_max(double v) {
 // (agent-scope store, drained) -> fetch_add on the launch's ticket words -> the workgroup that arrives last
 // reads all gridDim.x partials (plain loads behind ONE agent-scope acquire) and sums them in a fixed order:
 // thread t takes partials t, t + blockDim, ...; wave shuffle tree; waves in order.  Same grid => the same bits,
-// run to run; no float atomics; no second launch.  The ticket word comes from a zero-initialised pool owned by
-// the library (capi.hip: ticket_slot) and is reset by the last arriver, so caller memory needs no initialisation
-// and a replayed launch (hipGraph) starts clean.  Deliberately NO release fence per workgroup: its L2 write-back
-// costs microseconds and serialises chip-wide (measured +2 ms over 768 workgroups); a CAS loop on the ticket
-// serialises the same way -- one fetch_add does not.
+// run to run; no float atomics; no second launch.  The ticket words live in the CALLER'S WORKSPACE, next to the
+// partials they count (capi.hip: workspace layout): a workspace serves one launch at a time by contract, so no two
+// launches can ever meet on the same counters, whatever streams, threads or graphs they come from.
+// c2b_workspace_init zeroes them once and writes a magic word; the last arriver resets them, so every launch -- and
+// every replay of a captured launch -- starts clean.  A workspace that was never initialised has no magic: every
+// workgroup then skips the counters and writes NaN, so the sum is loudly NaN instead of silently stale.
+// Deliberately NO release fence per workgroup: its L2 write-back costs microseconds and serialises chip-wide
+// (measured +2.1 ms over 768 workgroups); a CAS loop on the ticket serialises the same way -- one fetch_add does not.
+// What replaces the release is gfx942 / gfx950 ISA behaviour, not the language memory model: the partial is an
+// agent-scope atomic store (global_store ... sc1: written through to memory past the non-coherent per-XCD L2) that
+// is drained (s_waitcnt vmcnt(0)) before the ticket's fetch_add is issued, and the last arriver's acquire is
+// buffer_inv sc1.  tests/test_isa_pins.py asserts exactly these instructions in the compiled kernels.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "ticket_fold's publish (sc1 write-through store + s_waitcnt instead of a release fence) is validated on gfx942 / gfx950 only"
+#endif
 // sRed: >= blockDim.x/64 + 1 doubles of LDS.  Every thread of every workgroup must call this.
 constexpr unsigned kTicketLine = 32;                 // words per 128-B line
-constexpr unsigned kTicketWords = 65 * kTicketLine;  // one launch's ticket: top word + 64 leaf words, a line each
+constexpr unsigned kTicketLeaves = 64;
+constexpr unsigned kTicketMagicAt = (1 + kTicketLeaves) * kTicketLine;   // its own line, after the top word and the leaves
+constexpr unsigned kTicketWords = (2 + kTicketLeaves) * kTicketLine;     // one workspace's ticket block (8 448 bytes)
+constexpr unsigned kTicketMagic = 0xC2B71C3Eu;
+
+// thread 0 of a workgroup: count this workgroup in; true for the ONE workgroup of the launch that arrives last (it has
+// then reset the counters and acquired every other workgroup's published data).  `magic` = the word at kTicketMagicAt
+// (a plain load the caller issues early: written by an earlier launch, so any cache level may serve it); without it
+// the workspace was never initialised and the counters are not touched.
+C2B_DEV bool ticket_arrive(unsigned *__restrict__ ticket, unsigned magic) {
+    if (magic != kTicketMagic) return false;
+    // Two-level arrival count: workgroup b arrives at leaf word b % 64 (each leaf in its own 128-B line), the
+    // workgroup that completes a leaf arrives at the top word.  18 849 workgroups adding to ONE word cost the
+    // light kernels +115 us (one same-address atomic per ~13 ns); 64 leaves spread them over 64 lines.
+    const unsigned leaf = blockIdx.x & (kTicketLeaves - 1u), leaf_n = (gridDim.x - leaf + kTicketLeaves - 1u) / kTicketLeaves;
+    unsigned *lw = ticket + kTicketLine * (1u + leaf);
+    bool last = false;
+    if (__hip_atomic_fetch_add(lw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaf_n - 1) {
+        __hip_atomic_store(lw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned top_n = gridDim.x < kTicketLeaves ? gridDim.x : kTicketLeaves;
+        if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == top_n - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = true;
+        }
+    }
+    if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    return last;
+}
+
 C2B_DEV void ticket_fold(double wave_value, double *sRed, double *__restrict__ block_part,
                          unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    unsigned magic = 0u;
+    if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];          // in flight across the barriers below
     __syncthreads();                                   // sRed may alias LDS other waves were still using
     if (lane == 0) sRed[wave] = wave_value;
     __syncthreads();
@@ -75,24 +118,8 @@ C2B_DEV void ticket_fold(double wave_value, double *sRed, double *__restrict__ b
         for (int w = 0; w < n_waves; ++w) b += sRed[w];
         __hip_atomic_store(block_part + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_waitcnt(0);                 // (a builtin, not inline asm: asm would halve the VGPR budget)
-        // Two-level arrival count: workgroup b arrives at leaf word b % 64 (each leaf in its own 128-B line), the
-        // workgroup that completes a leaf arrives at the top word.  18 849 workgroups adding to ONE word cost the
-        // light kernels +115 us (one same-address atomic per ~13 ns); 64 leaves spread them over 64 lines.
-        const unsigned leaf = blockIdx.x & 63u, leaf_n = (gridDim.x - leaf + 63u) >> 6;
-        unsigned *lw = ticket + kTicketLine * (1u + leaf);
-        bool last = false;
-        if (__hip_atomic_fetch_add(lw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaf_n - 1) {
-            __hip_atomic_store(lw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned top_n = gridDim.x < 64u ? gridDim.x : 64u;
-            if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == top_n - 1) {
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = true;
-            }
-        }
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __builtin_amdgcn_s_waitcnt(0);
-        }
+        const bool last = ticket_arrive(ticket, magic);
+        if (magic != kTicketMagic) out_sum[0] = __longlong_as_double(0x7ff8000000000000LL);
         sRed[n_waves] = last ? 1.0 : 0.0;
     }
     __syncthreads();
@@ -113,6 +140,11 @@ C2B_DEV void ticket_fold(double wave_value, double *sRed, double *__restrict__ b
         for (int i = 0; i < n_waves; ++i) t += sRed[i];
         out_sum[0] = t;
     }
+}
+
+// c2b_workspace_init: zero the arrival counters, write the magic (one workgroup)
+__global__ __launch_bounds__(256) void k_workspace_init(unsigned *__restrict__ ticket) {
+    for (unsigned i = threadIdx.x; i < kTicketWords; i += 256) ticket[i] = i == kTicketMagicAt ? kTicketMagic : 0u;
 }
 
 // ---- per-camera kernels ---------------------------------------------------------------------
@@ -890,154 +922,181 @@ C2B_DEV Best best_merge(Best a, Best b) {
     return r;
 }
 
-template <typename Src>
-__global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, double num, double *__restrict__ rec) {
-    __shared__ double sh[kWaves][kStatRec];
+// Statistics in TWO launches (the mean must exist before the deviations are summed; src/baproblem.rs:282-337): each
+// pass leaves one record per workgroup, published like ticket_fold's partials (agent-scope write-through stores,
+// drained, then the arrival count in the workspace's ticket block), and the workgroup that arrives last folds the
+// records in a fixed order -- thread t takes records t, t + 256, ...; wave shuffle tree; waves in order -- and writes
+// the result.  Rounds 1-2 used two more single-workgroup launches for the folds (73 us in all at --blocks 128, most of
+// it launch gaps; the 1024-thread fold kernel also spilled: 128 VGPRs, 724-788 B of scratch).
+struct StatRec {
+    double s[3], mn[3], mx[3];
+    Best best;
+};
+C2B_DEV StatRec stat_empty() {
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    double s0 = 0, s1 = 0, s2 = 0, mn0 = inf, mn1 = inf, mn2 = inf, mx0 = -inf, mx1 = -inf, mx2 = -inf;
-    Best best = {0.0, -1.0};
+    StatRec r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.s[k] = 0.0; r.mn[k] = inf; r.mx[k] = -inf; }
+    r.best.d = 0.0; r.best.i = -1.0;
+    return r;
+}
+C2B_DEV void stat_merge(StatRec &a, const StatRec &b) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.s[k] += b.s[k]; a.mn[k] = fmin(a.mn[k], b.mn[k]); a.mx[k] = fmax(a.mx[k], b.mx[k]); }
+    a.best = best_merge(a.best, b.best);
+}
+// all 64 lanes -> lane 0 (shuffle tree, fixed order)
+C2B_DEV void stat_wave_reduce(StatRec &r) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.s[k] = wave_sum(r.s[k]); r.mn[k] = wave_min(r.mn[k]); r.mx[k] = wave_max(r.mx[k]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.d = __shfl_down(r.best.d, off, 64);
+        o.i = __shfl_down(r.best.i, off, 64);
+        r.best = best_merge(r.best, o);
+    }
+}
+C2B_DEV void stat_to_lds(const StatRec &r, double *o) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = r.s[k]; o[3 + k] = r.mn[k]; o[6 + k] = r.mx[k]; }
+    o[9] = r.best.d; o[10] = r.best.i;
+}
+C2B_DEV StatRec stat_from(const double *o) {
+    StatRec r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.s[k] = o[k]; r.mn[k] = o[3 + k]; r.mx[k] = o[6 + k]; }
+    r.best.d = o[9]; r.best.i = o[10];
+    return r;
+}
+
+// the workgroup's waves (one record each, on lane 0) -> one record on thread 0, waves in order
+C2B_DEV StatRec stat_block_reduce(StatRec r, double (*sh)[kStatRec]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    stat_wave_reduce(r);
+    __syncthreads();
+    if (lane == 0) stat_to_lds(r, sh[wave]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        r = stat_from(sh[0]);
+        for (int w = 1; w < kWaves; ++w) stat_merge(r, stat_from(sh[w]));
+    }
+    return r;
+}
+
+// pass 1: stats[0..2]=mean, [6..8]=min, [9..11]=max, [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin's
+// GLOBAL index (map), [19]=its distance (sharded runs compare it across ranks; the unsharded pass 2 overwrites the slot
+// with |std|).  rec: gridDim.x records of kStatRec doubles in the workspace.
+template <typename Src>
+__global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, double num, double *__restrict__ rec,
+                                                       unsigned *__restrict__ ticket, ShardMap map,
+                                                       double *__restrict__ stats) {
+    __shared__ double sh[kWaves + 1][kStatRec];
+    unsigned magic = 0u;
+    if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
+    StatRec a = stat_empty();
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         double x, y, z;
         src.get(i, x, y, z);
-        s0 += x / num; s1 += y / num; s2 += z / num;
-        mn0 = fmin(mn0, x); mn1 = fmin(mn1, y); mn2 = fmin(mn2, z);
-        mx0 = fmax(mx0, x); mx1 = fmax(mx1, y); mx2 = fmax(mx2, z);
+        a.s[0] += x / num; a.s[1] += y / num; a.s[2] += z / num;
+        a.mn[0] = fmin(a.mn[0], x); a.mn[1] = fmin(a.mn[1], y); a.mn[2] = fmin(a.mn[2], z);
+        a.mx[0] = fmax(a.mx[0], x); a.mx[1] = fmax(a.mx[1], y); a.mx[2] = fmax(a.mx[2], z);
         const Best cand = {sqrt(dot3(x, y, z, x, y, z)), (double)i};
-        best = best_merge(best, cand);
+        a.best = best_merge(a.best, cand);
     }
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-    mn0 = wave_min(mn0); mn1 = wave_min(mn1); mn2 = wave_min(mn2);
-    mx0 = wave_max(mx0); mx1 = wave_max(mx1); mx2 = wave_max(mx2);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Best o;
-        o.d = __shfl_down(best.d, off, 64);
-        o.i = __shfl_down(best.i, off, 64);
-        best = best_merge(best, o);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        double *o = sh[wave];
-        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = mn0; o[4] = mn1; o[5] = mn2;
-        o[6] = mx0; o[7] = mx1; o[8] = mx2; o[9] = best.d; o[10] = best.i;
-#pragma unroll
-        for (int k = 11; k < kStatRec; ++k) o[k] = 0.0;
-    }
-    __syncthreads();
+    a = stat_block_reduce(a, sh);
     if (threadIdx.x == 0) {
+        double t[11];
+        stat_to_lds(a, t);
         double *o = rec + (int64_t)blockIdx.x * kStatRec;
-        double t[kStatRec];
 #pragma unroll
-        for (int k = 0; k < kStatRec; ++k) t[k] = sh[0][k];
-        Best b = {sh[0][9], sh[0][10]};
-        for (int w = 1; w < kWaves; ++w) {
-            t[0] += sh[w][0]; t[1] += sh[w][1]; t[2] += sh[w][2];
-            for (int k = 3; k < 6; ++k) t[k] = fmin(t[k], sh[w][k]);
-            for (int k = 6; k < 9; ++k) t[k] = fmax(t[k], sh[w][k]);
-            const Best o2 = {sh[w][9], sh[w][10]};
-            b = best_merge(b, o2);
+        for (int k = 0; k < 11; ++k) __hip_atomic_store(o + k, t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        const bool last = ticket_arrive(ticket, magic);
+        if (magic != kTicketMagic) {
+            const double nan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int k = 0; k < 20; ++k) stats[k] = nan;
         }
-        t[9] = b.d; t[10] = b.i;
-#pragma unroll
-        for (int k = 0; k < kStatRec; ++k) o[k] = t[k];
-    }
-}
-
-// one 1024-lane workgroup (record t on lane t; kRedBlocks <= 1024): fold the per-workgroup records ->
-// stats[0..2]=mean, [6..8]=min, [9..11]=max, [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin index.
-// Fixed shuffle / LDS order => deterministic.
-template <typename Src>
-__global__ __launch_bounds__(kRedBlocks) void k_stats_fold1(const double *__restrict__ rec, int n_rec, Src src,
-                                                          ShardMap map, double *__restrict__ stats) {
-    __shared__ double sh[kRedBlocks / 64][12];
-    const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    double t[9] = {0, 0, 0, inf, inf, inf, -inf, -inf, -inf};
-    Best b = {0.0, -1.0};
-    if ((int)threadIdx.x < n_rec) {
-        const double *r = rec + (int64_t)threadIdx.x * kStatRec;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) t[k] = r[k];
-        b.d = r[9]; b.i = r[10];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { t[k] = wave_sum(t[k]); t[3 + k] = wave_min(t[3 + k]); t[6 + k] = wave_max(t[6 + k]); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Best o;
-        o.d = __shfl_down(b.d, off, 64);
-        o.i = __shfl_down(b.i, off, 64);
-        b = best_merge(b, o);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) sh[wave][k] = t[k];
-        sh[wave][9] = b.d; sh[wave][10] = b.i; sh[wave][11] = 0.0;
+        sh[kWaves][0] = last ? 1.0 : 0.0;
     }
     __syncthreads();
+    if (sh[kWaves][0] == 0.0) return;                  // workgroup-uniform
+    StatRec f = stat_empty();
+    for (unsigned r = threadIdx.x; r < gridDim.x; r += kBlock) stat_merge(f, stat_from(rec + (int64_t)r * kStatRec));
+    f = stat_block_reduce(f, sh);
     if (threadIdx.x != 0) return;
-    for (int w = 1; w < kRedBlocks / 64; ++w) {
-        for (int k = 0; k < 3; ++k) { t[k] += sh[w][k]; t[3 + k] = fmin(t[3 + k], sh[w][3 + k]); t[6 + k] = fmax(t[6 + k], sh[w][6 + k]); }
-        const Best o = {sh[w][9], sh[w][10]};
-        b = best_merge(b, o);
-    }
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double x = 0, y = 0, z = 0;
-    if (b.i >= 0.0) src.get((int64_t)b.i, x, y, z);
+    if (f.best.i >= 0.0) src.get((int64_t)f.best.i, x, y, z);
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
-        stats[k] = t[k];
-        stats[6 + k] = t[3 + k];
-        stats[9 + k] = t[6 + k];
-        stats[12 + k] = t[6 + k] - t[3 + k];
+        stats[k] = f.s[k];
+        stats[6 + k] = f.mn[k];
+        stats[9 + k] = f.mx[k];
+        stats[12 + k] = f.mx[k] - f.mn[k];
     }
     stats[15] = x; stats[16] = y; stats[17] = z;
-    stats[18] = b.i >= 0.0 ? map.global_index(b.i) : -1.0;
-    stats[19] = b.i >= 0.0 ? b.d : inf;          // the winner's distance (sharded runs compare it across ranks); the
-                                                 // unsharded path overwrites this slot with |std| in k_stats_fold2
+    stats[18] = f.best.i >= 0.0 ? map.global_index(f.best.i) : -1.0;
+    stats[19] = f.best.i >= 0.0 ? f.best.d : inf;
 }
 
-template <typename Src>
-__global__ __launch_bounds__(kBlock) void k_stats_pass2(Src src, int64_t n, const double *__restrict__ stats,
-                                                       double *__restrict__ rec) {
-    __shared__ double sh[kWaves][3];
-    const double m0 = stats[0], m1 = stats[1], m2 = stats[2];
+// pass 2: sums of squared deviations from mean3.  RAW: leave the three sums in out[0..2] (a shard's share; the ranks'
+// sums are all-reduced and finished on the host) instead of finishing std in out[3..5] and |std| in out[19].
+template <typename Src, bool RAW>
+__global__ __launch_bounds__(kBlock) void k_stats_pass2(Src src, int64_t n, const double *__restrict__ mean3,
+                                                       double *__restrict__ rec, unsigned *__restrict__ ticket,
+                                                       double *__restrict__ out) {
+    __shared__ double sh[kWaves + 1][4];
+    unsigned magic = 0u;
+    if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
+    const double m0 = mean3[0], m1 = mean3[1], m2 = mean3[2];
     double s0 = 0, s1 = 0, s2 = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         double x, y, z;
         src.get(i, x, y, z);
         s0 += (x - m0) * (x - m0); s1 += (y - m1) * (y - m1); s2 += (z - m2) * (z - m2);
     }
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sh[wave][0] = s0; sh[wave][1] = s1; sh[wave][2] = s2; }
-    __syncthreads();
+    auto block_sum = [&](double &a, double &b, double &c) {          // -> thread 0
+        a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+        __syncthreads();
+        if (lane == 0) { sh[wave][0] = a; sh[wave][1] = b; sh[wave][2] = c; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+            b = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+            c = (sh[0][2] + sh[1][2]) + (sh[2][2] + sh[3][2]);
+        }
+    };
+    block_sum(s0, s1, s2);
     if (threadIdx.x == 0) {
         double *o = rec + (int64_t)blockIdx.x * kStatRec;
-        for (int k = 0; k < 3; ++k) o[k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+        __hip_atomic_store(o, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        const bool last = ticket_arrive(ticket, magic);
+        if (magic != kTicketMagic) {
+            const double nan = __longlong_as_double(0x7ff8000000000000LL);
+            if (RAW) { out[0] = nan; out[1] = nan; out[2] = nan; }
+            else { out[3] = nan; out[4] = nan; out[5] = nan; out[19] = nan; }
+        }
+        sh[kWaves][0] = last ? 1.0 : 0.0;
     }
-}
-
-// RAW: leave the three sums of squared deviations in out[0..2] (a shard's share; the ranks' sums are all-reduced and
-// finished on the host) instead of finishing std / |std| in stats[3..5], [19].
-template <bool RAW>
-__global__ __launch_bounds__(kRedBlocks) void k_stats_fold2(const double *__restrict__ rec, int n_rec, int64_t n_ent,
-                                                          double *__restrict__ stats) {
-    __shared__ double sh[kRedBlocks / 64][3];
-    double t0 = 0, t1 = 0, t2 = 0;
-    if ((int)threadIdx.x < n_rec) {
-        const double *r = rec + (int64_t)threadIdx.x * kStatRec;
-        t0 = r[0]; t1 = r[1]; t2 = r[2];
-    }
-    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sh[wave][0] = t0; sh[wave][1] = t1; sh[wave][2] = t2; }
     __syncthreads();
+    if (sh[kWaves][0] == 0.0) return;                  // workgroup-uniform
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (unsigned r = threadIdx.x; r < gridDim.x; r += kBlock) {
+        const double *q = rec + (int64_t)r * kStatRec;
+        t0 += q[0]; t1 += q[1]; t2 += q[2];
+    }
+    block_sum(t0, t1, t2);
     if (threadIdx.x != 0) return;
-    for (int w = 1; w < kRedBlocks / 64; ++w) { t0 += sh[w][0]; t1 += sh[w][1]; t2 += sh[w][2]; }
-    if (RAW) { stats[0] = t0; stats[1] = t1; stats[2] = t2; return; }
-    const double num = (double)n_ent;
+    if (RAW) { out[0] = t0; out[1] = t1; out[2] = t2; return; }
+    const double num = (double)n;
     const double a = sqrt(t0 / num), b = sqrt(t1 / num), c = sqrt(t2 / num);
-    stats[3] = a; stats[4] = b; stats[5] = c;
-    stats[19] = sqrt(dot3(a, b, c, a, b, c));            // |std()|  (InnerSpace::magnitude)
+    out[3] = a; out[4] = b; out[5] = c;
+    out[19] = sqrt(dot3(a, b, c, a, b, c));            // |std()|  (InnerSpace::magnitude)
 }
 
 // ---- noise kernels -------------------------------------------------------------------------------------

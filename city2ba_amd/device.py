@@ -22,9 +22,34 @@ def _chk(t, dtype, name):
     assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, name
 
 
+_live_workspaces = None     # weak references to every workspace made here (tests check their counters after each test)
+
+
 def workspace(n_obs, device):
+    """Scratch of the in-kernel folds for launches of up to n_obs observations, initialised on the current stream
+    (c2b_workspace_init: arrival counters zeroed, magic written).  One workspace serves one launch at a time."""
+    global _live_workspaces
+    import weakref
     nbytes = L.lib().c2b_workspace_bytes(int(n_obs))
-    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)      # torch allocations are 512-B aligned
+    with torch.cuda.device(ws.device):
+        L.check(L.lib().c2b_workspace_init(_p(ws), _stream()))
+    if _live_workspaces is None:
+        _live_workspaces = weakref.WeakSet()
+    _live_workspaces.add(ws)
+    return ws
+
+
+def workspace_selfcheck(ws):
+    """non-zero arrival counters left in ws (0 = clean; -1 = never initialised); synchronises the current stream"""
+    n = C.c_int64(-2)
+    with torch.cuda.device(ws.device):
+        L.check(L.lib().c2b_workspace_selfcheck(_p(ws), _stream(), C.byref(n)))
+    return n.value
+
+
+def live_workspaces():
+    return list(_live_workspaces) if _live_workspaces is not None else []
 
 
 def cameras_from_bal(bal9):

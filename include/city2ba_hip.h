@@ -61,13 +61,20 @@ int c2b_device_count(int *count);
  * Observations may come in any order; camera-major (CSR) order is the fast path.
  * ===================================================================================== */
 
-/* Bytes of scratch the reductions below need for a problem with n_obs observations.  The workspace needs no
- * initialisation (the arrival counters of the in-kernel folds live in a pool the library owns and keeps zeroed).
- * One workspace serves one stream at a time: two launches that may run concurrently must not share it. */
+/* Bytes of scratch the reductions below need for a problem with n_obs observations: allocate that many bytes of
+ * device memory, 128-byte aligned, and call c2b_workspace_init ONCE before the first use.  The workspace holds the
+ * per-workgroup partials of the in-kernel folds AND the arrival counters that count them (so two launches can only
+ * ever meet on the same counters by sharing a workspace, which the partials already forbid): one workspace serves one
+ * launch at a time -- launches that may run concurrently (other streams, other threads, a replayed graph next to eager
+ * launches) need a workspace each.  Every fold leaves the counters zero, so a workspace is initialised once, not per
+ * launch, and a captured launch replays cleanly.  A workspace that was never initialised makes every sum NaN (the
+ * kernels check a magic word), never a stale or partial value. */
 int64_t c2b_workspace_bytes(int64_t n_obs);
-/* Diagnostic: synchronises the current device and counts the non-zero arrival counters of the library's pool.  Zero
- * whenever no launch is in flight; anything else means a launch did not complete its in-kernel fold. */
-int c2b_selfcheck_tickets(int64_t *nonzero_words);
+/* zero the arrival counters, write the magic: one tiny launch on `stream` (capture-safe) */
+int c2b_workspace_init(void *workspace, void *stream);
+/* Diagnostic: synchronises `stream`, then counts the workspace's non-zero arrival counters.  Zero whenever no launch
+ * using it is in flight; anything else means a fold did not complete.  -1: the workspace was never initialised. */
+int c2b_workspace_selfcheck(const void *workspace, void *stream, int64_t *nonzero_words);
 
 /* SnavelyCamera::from_vec / from_rodrigues (src/baproblem.rs:78-90, 180-186) */
 int c2b_cameras_from_bal(const double *bal9, int64_t n_cam, double *cam15, void *stream);

@@ -21,13 +21,15 @@ def golden():
 
 @pytest.fixture(autouse=True)
 def _fold_counters_are_clean_after_every_gpu_test(request):
-    """Every in-kernel fold resets its arrival counters (kernels.hpp: ticket_fold); a launch that did not would make
-    the 128th launch after it lose its sum.  Checked after every GPU test so that the offender is named."""
+    """Every in-kernel fold resets the arrival counters of the workspace it ran in (kernels.hpp: ticket_fold); a launch
+    that did not would make the next launch on that workspace lose its sum.  Checked after every GPU test, over every
+    workspace device.workspace() handed out that is still alive, so that the offender is named."""
     yield
     if request.node.get_closest_marker("gpu") is None or os.environ.get("C2B_NO_SELFCHECK"):
         return
-    import ctypes as C
-    from city2ba_amd import _lib as L
-    n = C.c_int64(-1)
-    assert L.lib().c2b_selfcheck_tickets(C.byref(n)) == L.OK
-    assert n.value == 0, "%d arrival counters left non-zero by this test" % n.value
+    import torch
+    from city2ba_amd import device as D
+    torch.cuda.synchronize()
+    for ws in D.live_workspaces():
+        n = D.workspace_selfcheck(ws)
+        assert n == 0, "%d arrival counters left non-zero in a workspace by this test (-1: never initialised)" % n
