@@ -58,6 +58,10 @@ SIGNATURES = {
     "c2b_residual_jacobian_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
     "c2b_host_alloc": (_int, [C.POINTER(_vp), _i64]),
     "c2b_host_free": (None, [_vp]),
+    "c2b_jacobian_outputs_alloc": (_int, [_i64, _int, _d, _vp, C.POINTER(_vp)]),
+    "c2b_jacobian_outputs_pointers": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "c2b_jacobian_outputs_log": (_int, [_vp, _vp, _int, C.POINTER(_int), C.POINTER(_int)]),
+    "c2b_jacobian_outputs_free": (None, [_vp]),
     "c2b_calib_store_pattern": (_int, [_i64, _vp, _vp, _vp, _vp]),
     "c2b_calib_copy": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <atomic>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -873,6 +874,127 @@ int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("calib_copy")
+}
+
+// ---- output arrays of the residual + Jacobian launch, placed for streaming stores -------------------------------
+// Measured on MI355X ("what the spread really is"): the same kernel writing the same bytes takes
+// 690 or 860 us depending only on WHICH device allocation r / Jc / Jp live in -- the store pattern alone streams at
+// ~7.0 TB/s into some allocations and ~5.7 TB/s into others of identical size and alignment, in one process on one
+// device; a freed and re-made allocation keeps its speed, a different one rolls again.  Nothing visible from user
+// space predicts it, so the placement is chosen by measurement: allocate, time the kernel's own store pattern
+// (~0.6 ms per repetition), keep the set if it streams at fast_store_GBs or better, otherwise HOLD it (so that the
+// allocator cannot hand the same memory back) and try again; the best of max_attempts wins, the rest are freed.
+// Held memory is bounded (max_attempts <= 8 sets of 208 B per observation) and an out-of-memory attempt ends the
+// search with the best set so far instead of failing.
+struct c2b_jacobian_outputs {
+    int device = 0;
+    int64_t n_obs = 0;
+    double *r = nullptr, *Jc = nullptr, *Jp = nullptr;
+    int attempts = 0, chosen = -1;
+    double rate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+struct OutSet {
+    double *r = nullptr, *Jc = nullptr, *Jp = nullptr;
+    void free_all() { if (r) (void)hipFree(r); if (Jc) (void)hipFree(Jc); if (Jp) (void)hipFree(Jp); r = Jc = Jp = nullptr; }
+};
+hipError_t alloc_set(int64_t n, OutSet *s) {
+    const size_t k = (size_t)(n > 0 ? n : 1);
+    hipError_t e = hipMalloc((void **)&s->r, k * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->Jc, k * 144);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->Jp, k * 48);
+    if (e != hipSuccess) s->free_all();
+    return e;
+}
+}  // namespace
+
+int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_store_GBs, void *stream, c2b_jacobian_outputs **out) {
+    C2B_API_BEGIN
+    if (!out || n_obs < 0 || n_obs >= ((int64_t)1 << 31)) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_alloc: bad arguments");
+    *out = nullptr;
+    if (max_attempts < 1) max_attempts = 1;
+    if (max_attempts > 8) max_attempts = 8;
+    if (!(fast_store_GBs > 0.0)) fast_store_GBs = 6800.0;
+    hipStream_t st = S(stream);
+    std::unique_ptr<c2b_jacobian_outputs> h(new c2b_jacobian_outputs);
+    HIP_TRY(hipGetDevice(&h->device));
+    h->n_obs = n_obs;
+    OutSet sets[8];
+    auto free_sets = [&]() { for (auto &q : sets) q.free_all(); };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool measure = n_obs >= 1000000 && max_attempts > 1;      // below that the store rate means nothing
+    if (measure && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) {
+        if (e0) (void)hipEventDestroy(e0);
+        return fail(C2B_ERR_HIP, "jacobian_outputs_alloc: hipEventCreate failed");
+    }
+    int best = -1;
+    hipError_t err = hipSuccess;
+    for (int a = 0; a < (measure ? max_attempts : 1); ++a) {
+        err = alloc_set(n_obs, &sets[a]);
+        if (err != hipSuccess) {
+            if (best >= 0 && err == hipErrorOutOfMemory) { (void)hipGetLastError(); err = hipSuccess; }   // keep the best so far
+            break;
+        }
+        h->attempts = a + 1;
+        if (!measure) { best = a; break; }
+        const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
+        auto pattern = [&]() {
+            hipLaunchKernelGGL((k_store_pattern<true, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt,
+                               reinterpret_cast<double2 *>(sets[a].r), sets[a].Jc, sets[a].Jp);
+        };
+        pattern(); pattern();
+        err = hipEventRecord(e0, st);
+        for (int k = 0; k < 4; ++k) pattern();
+        if (err == hipSuccess) err = hipEventRecord(e1, st);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (err == hipSuccess) err = launch_error();
+        if (err != hipSuccess) break;
+        h->rate[a] = (double)n_obs * 208.0 / ((double)ms / 4.0 * 1e-3) / 1e9;
+        if (best < 0 || h->rate[a] > h->rate[best]) best = a;
+        if (h->rate[a] >= fast_store_GBs) break;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (err != hipSuccess || best < 0) {
+        free_sets();
+        return fail(err == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "jacobian_outputs_alloc: %s",
+                    hipGetErrorString(err == hipSuccess ? hipErrorUnknown : err));
+    }
+    h->r = sets[best].r; h->Jc = sets[best].Jc; h->Jp = sets[best].Jp;
+    sets[best] = OutSet();
+    free_sets();
+    h->chosen = best;
+    *out = h.release();
+    return C2B_OK;
+    C2B_API_END("jacobian_outputs_alloc")
+}
+
+int c2b_jacobian_outputs_pointers(const c2b_jacobian_outputs *h, double **r, double **Jc, double **Jp) {
+    if (!h || !r || !Jc || !Jp) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_pointers: NULL argument");
+    *r = h->r; *Jc = h->Jc; *Jp = h->Jp;
+    return C2B_OK;
+}
+
+int c2b_jacobian_outputs_log(const c2b_jacobian_outputs *h, double *store_GBs_per_attempt, int capacity, int *attempts, int *chosen) {
+    if (!h || capacity < 0 || (capacity && !store_GBs_per_attempt)) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_log: bad arguments");
+    for (int a = 0; a < h->attempts && a < capacity; ++a) store_GBs_per_attempt[a] = h->rate[a];
+    if (attempts) *attempts = h->attempts;
+    if (chosen) *chosen = h->chosen;
+    return C2B_OK;
+}
+
+void c2b_jacobian_outputs_free(c2b_jacobian_outputs *h) {
+    if (!h) return;
+    int prev = 0;
+    const bool sw = hipGetDevice(&prev) == hipSuccess && prev != h->device && hipSetDevice(h->device) == hipSuccess;
+    if (h->r) (void)hipFree(h->r);
+    if (h->Jc) (void)hipFree(h->Jc);
+    if (h->Jp) (void)hipFree(h->Jp);
+    if (sw) (void)hipSetDevice(prev);
+    delete h;
 }
 
 int c2b_error_sum_finish(const void *workspace, int64_t n_obs, double *out_sum, void *stream) {

@@ -192,44 +192,61 @@ def calib_copy(src, dst):
     L.check(L.lib().c2b_calib_copy(_p(src), _p(dst), nbytes, _stream()))
 
 
-def alloc_jacobian_outputs(n_obs, device, max_attempts=8, fast_store_GBs=6800.0):
-    """r [n,2], Jc [n,18], Jp [n,6] for residual_jacobian*, placed for streaming stores.
+class _DeviceArray:
+    """memory owned by a C-ABI handle, exposed to torch through __cuda_array_interface__ (zero copy; the tensor made
+    from it keeps this object, and through it the handle, alive)"""
 
-    Measured on MI355X (tools/probe_placement*.py): the SAME kernel writing the SAME bytes takes 740 us or 880 us
-    depending only on which device allocation its outputs live in -- the store pattern alone runs at ~7.0 TB/s in some
-    allocations and ~5.75 TB/s in others of identical size, alignment and virtual layout, in one process, on one
-    device; a freed and re-made allocation keeps its speed, a different one rolls the dice again (physical placement /
-    page-table fragment size are the suspects; nothing visible from user space predicts it).  So: allocate, time the
-    store pattern (c2b_calib_store_pattern, ~0.6 ms per repetition), keep the set if it streams at fast_store_GBs or
-    better, otherwise hold it (so that the allocator cannot hand the same memory back) and try again; the best of
-    max_attempts wins and the rest are released.  Returns ((r, Jc, Jp), log) with log = store GB/s of every attempt."""
-    held, log, best = [], [], None
-    for _ in range(max(1, int(max_attempts))):
-        bufs = (torch.empty((n_obs, 2), dtype=torch.float64, device=device),
-                torch.empty((n_obs, 18), dtype=torch.float64, device=device),
-                torch.empty((n_obs, 6), dtype=torch.float64, device=device))
-        if n_obs < 1_000_000:                       # too small for the store rate to mean anything
-            return bufs, log
-        for _ in range(2):
-            calib_store_pattern(*bufs)
-        torch.cuda.synchronize(device)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(4):
-            calib_store_pattern(*bufs)
-        e.record()
-        torch.cuda.synchronize(device)
-        rate = n_obs * 208 / (s.elapsed_time(e) / 4 * 1e-3) / 1e9
-        log.append(round(rate, 1))
-        if best is None or rate > best[0]:
-            best = (rate, bufs)
-        held.append(bufs)
-        if rate >= fast_store_GBs:
-            break
-    chosen = best[1]
-    del held, bufs, best
-    torch.cuda.empty_cache()                        # the rejected allocations go back to the driver
-    return chosen, log
+    def __init__(self, ptr, shape, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+        self._owner = owner
+
+
+class _OutputsHandle:
+    """owns one c2b_jacobian_outputs; freed when the last tensor viewing it (and the JacobianOutputs) is gone.  Kept
+    apart from JacobianOutputs so that tensor -> array -> handle holds no reference cycle through torch."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            L.lib().c2b_jacobian_outputs_free(h)
+
+
+class JacobianOutputs:
+    """c2b_jacobian_outputs: r [n,2], Jc [n,18], Jp [n,6] in device allocations chosen for streaming-store speed
+    (include/city2ba_hip.h).  .r / .Jc / .Jp are torch views of the handle's memory; .log = store
+    GB/s of every attempt, .chosen = the attempt kept."""
+
+    def __init__(self, n_obs, device, max_attempts=8, fast_store_GBs=6800.0):
+        own = self._own = _OutputsHandle()
+        dev = torch.device(device)
+        with torch.cuda.device(dev):
+            L.check(L.lib().c2b_jacobian_outputs_alloc(int(n_obs), int(max_attempts), float(fast_store_GBs), _stream(),
+                                                       C.byref(own.h)))
+        r, jc, jp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(L.lib().c2b_jacobian_outputs_pointers(own.h, C.byref(r), C.byref(jc), C.byref(jp)))
+        rates = (C.c_double * 8)()
+        na, ch = C.c_int(0), C.c_int(-1)
+        L.check(L.lib().c2b_jacobian_outputs_log(own.h, rates, 8, C.byref(na), C.byref(ch)))
+        self.log = [round(rates[i], 1) for i in range(na.value)] if n_obs >= 1_000_000 and max_attempts > 1 else []
+        self.chosen = ch.value
+        n = max(int(n_obs), 0)
+        if n == 0:
+            self.r, self.Jc, self.Jp = (torch.empty((0, k), dtype=torch.float64, device=dev) for k in (2, 18, 6))
+        else:
+            self.r = torch.as_tensor(_DeviceArray(r.value, (n, 2), own), device=dev)
+            self.Jc = torch.as_tensor(_DeviceArray(jc.value, (n, 18), own), device=dev)
+            self.Jp = torch.as_tensor(_DeviceArray(jp.value, (n, 6), own), device=dev)
+
+
+def alloc_jacobian_outputs(n_obs, device, max_attempts=8, fast_store_GBs=6800.0):
+    """((r, Jc, Jp), log): the output arrays of residual_jacobian*, placed for streaming stores by the library
+    (c2b_jacobian_outputs_alloc -- every caller of the C ABI gets the same placement, not just this wrapper)."""
+    out = JacobianOutputs(n_obs, device, max_attempts, fast_store_GBs)
+    return (out.r, out.Jc, out.Jp), out.log
 
 
 def error_sum_finish(ws, n_obs, out_sum):

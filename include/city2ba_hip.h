@@ -168,6 +168,25 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
                               double *r, double *Jc, double *Jp,
                               double norm, void *workspace, double *out_sum, void *stream);
 
+/* Output arrays of the residual + Jacobian launch -- r [n][2], Jc [n][2][9], Jp [n][2][3], 208 bytes per observation --
+ * as device allocations CHOSEN FOR STREAMING-STORE SPEED.  On MI355X the very same launch runs ~20 % faster or slower
+ * depending only on which allocation its outputs live in; nothing visible from user space
+ * predicts it, so this entry allocates a set, times the kernel's own store pattern into it (~4 ms), keeps it if it
+ * streams at fast_store_GBs (<= 0: 6800) or better and otherwise holds it and tries again, at most max_attempts
+ * (clamped to 1..8) times; the best set wins, the others are freed before it returns.  max_attempts = 1, or n_obs
+ * < 10^6, allocates without measuring.  An attempt that runs out of memory ends the search with the best set so far.
+ * Synchronises `stream`.  The handle owns the memory until c2b_jacobian_outputs_free.
+ * (No reference counterpart: the Jacobian itself is build-defined; a Rust host holds the handle next to its
+ * device mirror, INTEGRATION.md.) */
+typedef struct c2b_jacobian_outputs c2b_jacobian_outputs;
+int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_store_GBs, void *stream,
+                               c2b_jacobian_outputs **out);
+int c2b_jacobian_outputs_pointers(const c2b_jacobian_outputs *h, double **r, double **Jc, double **Jp);
+/* store rate (GB/s) measured for every attempt, how many there were, and which one was kept */
+int c2b_jacobian_outputs_log(const c2b_jacobian_outputs *h, double *store_GBs_per_attempt, int capacity, int *attempts,
+                             int *chosen);
+void c2b_jacobian_outputs_free(c2b_jacobian_outputs *h);
+
 /* Calibration (measurement aids, no reference counterpart; used by bench.py in the same process as the timed run so
  * that a slow device can be told from a slow kernel).  _store_pattern writes a fill pattern over r [n][2], Jc [n][18],
  * Jp [n][6] in exactly the residual+Jacobian kernel's store geometry with no loads and no arithmetic -- the time its

@@ -229,9 +229,9 @@ def test_sharded_drift_and_noise_equal_unsharded_row_for_row():
 
 
 def test_one_launch_step_is_graph_capturable_and_replays_cleanly():
-    """The fused step (residual + Jacobian + folded error sum) inside a HIP graph: the ticket slot is chosen at capture
-    and frozen into the graph, the last workgroup of every replay resets it, so each replay folds correctly -- with
-    inputs changed in place between replays the replayed sum tracks the eager one bit for bit."""
+    """The fused step (residual + Jacobian + folded error sum) inside a HIP graph: the arrival counters live in the
+    workspace the graph's launch was given, the last workgroup of every replay resets them, so each replay folds
+    correctly -- with inputs changed in place between replays the replayed sum tracks the eager one bit for bit."""
     import argparse
     import torch
     import bench
@@ -244,7 +244,7 @@ def test_one_launch_step_is_graph_capturable_and_replays_cleanly():
     err_g, err_e = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
     uv = sh["uv"].clone()
     args = (sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], uv)
-    D.residual_jacobian_sum(*args, r, Jc, Jp, 2.0, ws, err_g)         # warm-up: the ticket pool is allocated here
+    D.residual_jacobian_sum(*args, r, Jc, Jp, 2.0, ws, err_g)         # warm-up
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
     g = torch.cuda.CUDAGraph()

@@ -1,0 +1,130 @@
+"""The workspace contract of the in-kernel folds (include/city2ba_hip.h: c2b_workspace_init) and the placed output
+arrays (c2b_jacobian_outputs_*).
+
+The arrival counters of a fold live in the workspace the launch was given, so launches can only meet on the same
+counters by sharing a workspace -- which the contract forbids.  Tested here: thousands of fused launches in flight on
+two streams (each with its own workspace) at three grid sizes all give the bits of an isolated launch and leave their
+counters zero; a workspace that was never initialised gives NaN, not a stale number; the outputs handle round-trips."""
+import argparse
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from _problems import random_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as entry
+    entry.build()
+    import torch
+    import city2ba_amd
+    from city2ba_amd import _lib as L
+    from city2ba_amd import device as D
+    assert city2ba_amd.device_count() > 0
+    return dict(torch=torch, D=D, L=L, dev=torch.device("cuda", 0))
+
+
+def _problem(env, n_cam, n_pts, opc, seed):
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    P = random_problem(n_cam, n_pts, opc, seed=seed, noise=1e-3)
+    camblk = D.cameras_prepare_state(torch.from_numpy(P["cams15"]).to(dev))
+    pts4 = D.points_pad(torch.from_numpy(P["pts"]).to(dev))
+    row_ptr = torch.from_numpy(P["row_ptr"].astype(np.int64)).to(dev)
+    rows = D.Rows(row_ptr)
+    pt_idx = torch.from_numpy(P["pt_idx"].astype(np.int64).astype(np.int32)).to(dev)
+    uv = torch.from_numpy(P["uv"]).to(dev)
+    return P, camblk, pts4, rows, pt_idx, uv
+
+
+def test_uninitialised_workspace_gives_nan_not_a_stale_sum(env):
+    torch, D, L, dev = env["torch"], env["D"], env["L"], env["dev"]
+    P, camblk, pts4, rows, pt_idx, uv = _problem(env, 50, 800, 10, 5)
+    n = rows.n_obs
+    nbytes = L.lib().c2b_workspace_bytes(n)
+    raw = torch.full(((nbytes + 7) // 8,), 3.25, dtype=torch.float64, device=dev)     # garbage, never initialised
+    out = torch.full((1,), 7.0, dtype=torch.float64, device=dev)
+    D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, 2.0, raw, out)
+    torch.cuda.synchronize()
+    assert np.isnan(out.item())
+    assert D.workspace_selfcheck(raw) == -1
+    st = D.stats(camblk, pts4, raw)
+    assert bool(torch.isnan(st[0:3]).all())
+    # initialise it: the same memory now works, and stays clean
+    with torch.cuda.device(dev):
+        L.check(L.lib().c2b_workspace_init(C.c_void_p(raw.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, 2.0, raw, out)
+    want = O.total_reprojection_error(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], 2.0) ** 2
+    assert abs(out.item() - want) <= 1e-12 * want
+    assert D.workspace_selfcheck(raw) == 0
+    assert L.lib().c2b_workspace_init(C.c_void_p(raw.data_ptr() + 8), None) == L.ERR_INVALID_ARGUMENT     # misaligned
+
+
+@pytest.mark.parametrize("n_cam,opc", [(40, 6), (700, 12), (6000, 28)])      # 1, 6 and 111 workgroups of the light kernel
+def test_many_launches_in_flight_on_two_streams_all_fold_correctly(env, n_cam, opc):
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    P, camblk, pts4, rows, pt_idx, uv = _problem(env, n_cam, 5000, opc, 11)
+    n = rows.n_obs
+    r, Jc, Jp = (torch.empty((n, k), dtype=torch.float64, device=dev) for k in (2, 18, 6))
+    r2, Jc2, Jp2 = (torch.empty((n, k), dtype=torch.float64, device=dev) for k in (2, 18, 6))
+    ws_a, ws_b = D.workspace(n, dev), D.workspace(n, dev)
+    ref_e, ref_j = torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)
+    D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, 2.0, ws_a, ref_e)
+    D.residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r, Jc, Jp, 2.0, ws_a, ref_j)
+    torch.cuda.synchronize()
+    want = O.total_reprojection_error(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], 2.0) ** 2
+    assert abs(ref_e.item() - want) <= 1e-12 * want and abs(ref_j.item() - want) <= 1e-12 * want
+    reps = 2500
+    out_a = torch.zeros(reps, dtype=torch.float64, device=dev)
+    out_b = torch.zeros(reps, dtype=torch.float64, device=dev)
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for k in range(reps):                               # 5 000 launches queued without a host sync: both streams stay deep
+        with torch.cuda.stream(sa):
+            D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, 2.0, ws_a, out_a[k:k + 1])
+        with torch.cuda.stream(sb):
+            D.residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r2, Jc2, Jp2, 2.0, ws_b, out_b[k:k + 1])
+    torch.cuda.synchronize()
+    assert bool((out_a == ref_e).all()), "a light-kernel fold lost or reordered a partial"
+    assert bool((out_b == ref_j).all()), "a Jacobian-kernel fold lost or reordered a partial"
+    assert D.workspace_selfcheck(ws_a) == 0 and D.workspace_selfcheck(ws_b) == 0
+    assert torch.equal(r, r2) and torch.equal(Jc, Jc2) and torch.equal(Jp, Jp2)
+
+
+def test_jacobian_outputs_handle_round_trip(env):
+    torch, D, L, dev = env["torch"], env["D"], env["L"], env["dev"]
+    P, camblk, pts4, rows, pt_idx, uv = _problem(env, 120, 2000, 15, 9)
+    n = rows.n_obs
+    out = D.JacobianOutputs(n, dev, max_attempts=3)
+    assert out.log == [] and out.chosen == 0            # too small to measure: first allocation, no search
+    ws = D.workspace(n, dev)
+    D.residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, out.r, out.Jc, out.Jp, 2.0, ws)
+    r0, Jc0, Jp0 = O.residual_jacobian(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    scale = max(1.0, float(np.max(np.abs(Jc0))))
+    assert np.max(np.abs(out.r.cpu().numpy() - r0)) < 1e-9
+    assert np.max(np.abs(out.Jc.cpu().numpy() - Jc0)) / scale < 1e-10
+    assert np.max(np.abs(out.Jp.cpu().numpy() - Jp0)) / scale < 1e-10
+    keep = out.Jp                                       # a tensor alone keeps the handle's memory alive
+    del out
+    import gc
+    gc.collect()
+    assert np.max(np.abs(keep.cpu().numpy() - Jp0)) / scale < 1e-10
+    # argument checks
+    h = C.c_void_p()
+    assert L.lib().c2b_jacobian_outputs_alloc(-1, 1, 0.0, None, C.byref(h)) == L.ERR_INVALID_ARGUMENT
+    assert L.lib().c2b_jacobian_outputs_alloc(0, 1, 0.0, None, C.byref(h)) == L.OK
+    L.lib().c2b_jacobian_outputs_free(h)
+
+
+def test_jacobian_outputs_search_measures_and_keeps_the_best(env):
+    torch, D, dev = env["torch"], env["D"], env["dev"]
+    n = 1_500_000
+    out = D.JacobianOutputs(n, dev, max_attempts=3, fast_store_GBs=1e9)       # unreachable target: all three are tried
+    assert len(out.log) == 3 and all(1000.0 < x < 8000.0 for x in out.log), out.log
+    assert out.log[out.chosen] == max(out.log)
+    D.calib_store_pattern(out.r, out.Jc, out.Jp)
+    torch.cuda.synchronize()
+    assert out.Jc[64 * 7 + 5, 0].item() in (float(v) for v in range(64))       # the pattern landed in the handle's memory
