@@ -44,6 +44,13 @@ def parse():
                          "the best (1 = take the first; the line always ALSO reports the kernel in the first allocation)")
     ap.add_argument("--place-inputs", action="store_true",
                     help="also re-place the input arrays by measured kernel time (bench-only experiment, off by default)")
+    ap.add_argument("--collective", choices=("auto", "c2b", "torch"), default="auto",
+                    help="who issues the per-step all-reduce when N > 1: c2b = RCCL through this library's C ABI "
+                         "(c2b_comm_*; what a Rust host would call), torch = torch.distributed; auto = c2b over real "
+                         "per-rank GPUs (nccl backend), torch in the shared-GPU gloo rehearsal")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="replay the step (kernel + all-reduce) from a HIP graph: auto = when N > 1 (one graph launch "
+                         "instead of a kernel launch and a collective enqueue per step)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group, balanced split, all-reduce) even with one rank: "
                          "how tests exercise the RCCL backend on a 1-GPU box")
@@ -441,6 +448,35 @@ def main():
     # (tools/probe_host_overhead.py: kernel alone 90 us/step): all-reduce queued behind the kernel on the same stream
     # 96 us/step; round 1's arrangement -- all-reduce on a side stream overlapping the next kernel, double-buffered
     # scalar, three cross-stream event hand-offs per step -- 117 us/step.  The hand-offs cost more than they hide.
+    comm, collective, collective_note = None, None, None
+    if dist_on:
+        want = args.collective
+        if want == "auto":
+            want = "c2b" if backend == "nccl" else "torch"
+        if want == "c2b":
+            # RCCL through the C ABI.  The id travels over the process group that already exists; if ANY rank cannot
+            # join, every rank falls back to torch's collective together (the decision is all-reduced).
+            from city2ba_amd import comm as Comm
+            ok, why = 1, ""
+            try:
+                comm = Comm.Comm.from_process_group(dev_index)
+            except Exception as exc:                                  # noqa: BLE001 -- reported in the line
+                ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.destroy()
+                comm, collective_note = None, "c2b communicator unavailable (%s): fell back to torch.distributed" % (why or "another rank failed")
+        collective = ("c2b_comm_all_reduce_sum_f64 (%s), 1 x f64 per step, same stream as the kernel" % Comm.backend()) if comm is not None \
+            else "%s all_reduce(sum, 1 x f64) per step via torch.distributed, same stream as the kernel" % backend
+
+    def all_reduce():
+        if comm is not None:
+            comm.all_reduce_sum_(err)
+        else:
+            Dist.all_reduce_sum_(err)
+
     def step(ev=None):
         if ev is not None:
             ev[0].record()
@@ -448,13 +484,45 @@ def main():
         if ev is not None:
             ev[1].record()
         if dist_on:
-            Dist.all_reduce_sum_(err)
+            all_reduce()
             if ev is not None:
-                ev[2].record()                       # after the collective (torch joins its RCCL stream back into this one)
+                ev[2].record()                       # after the collective
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1) if dist_on else args.warmup):     # the first collective must not be captured
         step()
     torch.cuda.synchronize()
+
+    # N > 1: the step is launch-bound on top of a ~90 us kernel (a rank's eighth of the problem), so it is replayed from
+    # a HIP graph -- ONE graph launch per step instead of a kernel launch plus a collective enqueue.  The kernel's
+    # in-launch fold is replay-safe (its counters live in `ws` and every fold leaves them zero); RCCL collectives are
+    # capturable.  If capture fails on ANY rank every rank runs eagerly (decision all-reduced).
+    graph, graph_note = None, None
+    use_graph = args.graph == "on" or (args.graph == "auto" and dist_on and backend == "nccl")
+    if use_graph:
+        ok = 1
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    step()
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as exc:                                      # noqa: BLE001
+            ok, graph_note = 0, "capture failed (%s: %s): eager steps" % (type(exc).__name__, exc)
+        if dist_on:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                graph, graph_note = None, graph_note or "capture failed on another rank: eager steps"
+        elif not ok:
+            graph = None
+        if graph is not None:
+            for _ in range(2):
+                graph.replay()
+            torch.cuda.synchronize()
+
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -462,8 +530,16 @@ def main():
     if rank == 0:                                   # per-kernel HIP events only where the roofline is reported
         events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k] if events is not None else None)
+    if graph is not None:
+        for k in range(args.steps):
+            if events is not None:
+                events[k][0].record()
+            graph.replay()
+            if events is not None:
+                events[k][2].record()
+    else:
+        for k in range(args.steps):
+            step(events[k] if events is not None else None)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -473,6 +549,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    graph_step_us = None
+    if graph is not None:
+        # Events cannot be recorded inside a replayed graph, so the kernel / collective split of a step is measured
+        # right after the timed region on the same buffers, eagerly (every rank takes part: the step holds a collective).
+        if events is not None:
+            graph_step_us = sum(ev[0].elapsed_time(ev[2]) for ev in events) / len(events) * 1e3
+            events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(min(args.steps, 20))]
+        for k in range(min(args.steps, 20)):
+            step(events[k] if events is not None else None)
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
     total_err = Dist.finish_error(err.item(), 2.0)
     per_rank_obs = [n]
     if dist_on:
@@ -514,7 +602,12 @@ def main():
                 "observations_per_rank": [int(x) for x in per_rank_obs],
                 "camera_bounds": [int(x) for x in bounds] if bounds is not None else [0, sh["n_cam"]],
                 "total_L2_error": total_err,
-                "collective": ("%s all_reduce(sum, 1 x f64) per step, same stream as the kernel" % backend) if dist_on else None,
+                "collective": collective, "collective_note": collective_note,
+                "hip_graph": ("one graph launch per step (kernel + all-reduce captured); step on the GPU %.2f us"
+                              % graph_step_us) if graph is not None else (graph_note or False),
+                "kernel_time_source": "HIP events around the launch inside the timed region" if graph is None else
+                                      "HIP events around %d eager steps right after the timed region (a replayed graph "
+                                      "takes no event records)" % min(args.steps, 20),
                 # where rank 0's step goes (HIP events around the kernel and around the collective; the rest of the
                 # wall-clock step is launch gaps, host dispatch and waiting for the slowest rank)
                 **step_breakdown,
@@ -568,6 +661,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
+        if comm is not None:
+            comm.destroy()
         dist.destroy_process_group()
 
 

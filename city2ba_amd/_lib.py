@@ -15,6 +15,8 @@ ERR_INDEX_OUT_OF_RANGE = -2
 ERR_HIP = -3
 ERR_OOM = -4
 ERR_NO_DEVICE = -5
+ERR_RCCL = -6
+COMM_ID_BYTES = 128
 CAMBLK_DOUBLES = 32
 STATS_DOUBLES = 20
 
@@ -77,6 +79,19 @@ SIGNATURES = {
     "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_stats_partial_pass1": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "c2b_stats_partial_pass2": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_stats_combine_shares": (_int, [_vp, _int, _vp]),
+    "c2b_stats_finish_shares": (_int, [_vp, _int, _i64, _vp]),
+    "c2b_comm_backend": (C.c_char_p, []),
+    "c2b_comm_unique_id": (_int, [_vp]),
+    "c2b_comm_init_rank": (_int, [_vp, _int, _int, _int, C.POINTER(_vp)]),
+    "c2b_comm_init_all": (_int, [_int, _vp, _vp]),
+    "c2b_comm_group_start": (_int, []),
+    "c2b_comm_group_end": (_int, []),
+    "c2b_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    "c2b_comm_all_reduce_sum_f64": (_int, [_vp, _vp, _i64, _vp]),
+    "c2b_comm_all_gather_f64": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "c2b_comm_destroy": (None, [_vp]),
+    "c2b_stats_sharded": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_add_drift_sharded": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _d, _d, _d, _d, _d, _d, _u64, _vp]),
     "c2b_add_noise_entities_sharded": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
     "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
@@ -136,6 +151,7 @@ SIGNATURES = {
     "c2b_problem_centers": (_int, [_vp, _vp]),
     "c2b_problem_project": (_int, [_vp, _vp]),
     "c2b_problem_total_reprojection_error": (_int, [_vp, _d, C.POINTER(_d)]),
+    "c2b_problem_total_reprojection_error_sharded": (_int, [_vp, _vp, _d, C.POINTER(_d)]),
     "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_stats": (_int, [_vp, _vp]),
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),

@@ -1,0 +1,80 @@
+"""RCCL through the C ABI (include/city2ba_hip.h: c2b_comm_*): the collectives of the sharded path as a Rust host
+would use them -- no torch.distributed in the data path.  torch is only the messenger that carries the 128-byte
+communicator id from rank 0 to the other ranks when a process group already exists (any backend); a host without
+torch passes the id through a file, a pipe or MPI instead."""
+import ctypes as C
+
+from . import _lib as L
+
+
+def backend():
+    return L.lib().c2b_comm_backend().decode("utf-8", "replace")
+
+
+def unique_id():
+    buf = C.create_string_buffer(L.COMM_ID_BYTES)
+    L.check(L.lib().c2b_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+
+class Comm:
+    """one rank's membership of a communicator; collectives run on the CURRENT torch stream of `device`"""
+
+    def __init__(self, comm_id, rank, world, device):
+        self._h = C.c_void_p()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        buf = C.create_string_buffer(bytes(comm_id), L.COMM_ID_BYTES)
+        L.check(L.lib().c2b_comm_init_rank(buf, self.rank, self.world, self.device, C.byref(self._h)))
+
+    @classmethod
+    def from_process_group(cls, device, group=None):
+        """every rank of an initialised torch.distributed group joins one communicator: rank 0 makes the id, the
+        group's object broadcast carries it"""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], rank, world, device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def all_reduce_sum_(self, t):
+        import torch
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.device.index == self.device
+        L.check(L.lib().c2b_comm_all_reduce_sum_f64(self._h, C.c_void_p(t.data_ptr()), t.numel(), self._stream()))
+        return t
+
+    def all_gather(self, t):
+        import torch
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.device.index == self.device
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=torch.float64, device=t.device)
+        L.check(L.lib().c2b_comm_all_gather_f64(self._h, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(out.data_ptr()),
+                                                self._stream()))
+        return out
+
+    def stats_sharded(self, camblk, cam_base, n_cam_global, pts4, ws, out=None):
+        """c2b_stats_sharded: the statistics record over sharded cameras, identical bits on every rank"""
+        import torch
+        out = out if out is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=camblk.device)
+        L.check(L.lib().c2b_stats_sharded(self._h, C.c_void_p(camblk.data_ptr()), camblk.shape[0], int(cam_base),
+                                          int(n_cam_global), C.c_void_p(pts4.data_ptr()), pts4.shape[0],
+                                          C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def destroy(self):
+        h, self._h = self._h, C.c_void_p()
+        if h:
+            L.lib().c2b_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

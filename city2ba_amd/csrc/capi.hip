@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <atomic>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -26,6 +27,7 @@
 #include "obs_pipeline.hpp"      // persistent pipelined variants: measured slower, tuning library only
 #endif
 #include "cull_kernels.hpp"
+#include "comm_rccl.hpp"
 
 using namespace c2b;
 
@@ -1149,6 +1151,214 @@ int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *p
     C2B_API_END("stats_partial_pass2")
 }
 
+// ---- collectives of the sharded path (comm_rccl.hpp): RCCL behind the C ABI -----------------------------------
+#define RCCL_TRY(who, expr)                                                                                  \
+    do {                                                                                                     \
+        const ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                               \
+            return fail(C2B_ERR_RCCL, who ": %s: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); \
+    } while (0)
+#define NEED_RCCL(who)                                                                                       \
+    if (!rccl().ok()) return fail(C2B_ERR_RCCL, who ": %s", rccl().error.c_str())
+
+const char *c2b_comm_backend(void) {
+    static thread_local char text[256];
+    if (!rccl().ok()) { snprintf(text, sizeof text, "unavailable: %s", rccl().error.c_str()); return text; }
+    int v = 0;
+    (void)rccl().GetVersion(&v);
+    snprintf(text, sizeof text, "RCCL %d.%d.%d (%s)", v / 10000, (v / 100) % 100, v % 100, rccl().path.c_str());
+    return text;
+}
+
+int c2b_comm_unique_id(void *id128) {
+    C2B_API_BEGIN
+    if (!id128) return fail(C2B_ERR_INVALID_ARGUMENT, "comm_unique_id: NULL argument");
+    NEED_RCCL("comm_unique_id");
+    static_assert(sizeof(ncclUniqueId) == C2B_COMM_ID_BYTES, "C2B_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+    ncclUniqueId id;
+    RCCL_TRY("comm_unique_id", rccl().GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return C2B_OK;
+    C2B_API_END("comm_unique_id")
+}
+
+int c2b_comm_init_rank(const void *id128, int rank, int world, int device, c2b_comm **out) {
+    C2B_API_BEGIN
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world || device < 0)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "comm_init_rank: bad arguments");
+    *out = nullptr;
+    NEED_RCCL("comm_init_rank");
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    std::unique_ptr<c2b_comm> c(new c2b_comm);
+    c->rank = rank; c->world = world; c->device = device;
+    RCCL_TRY("comm_init_rank", rccl().CommInitRank(&c->comm, world, id, rank));
+    *out = c.release();
+    return C2B_OK;
+    C2B_API_END("comm_init_rank")
+}
+
+int c2b_comm_init_all(int n_dev, const int *dev_ids, c2b_comm **out) {
+    C2B_API_BEGIN
+    if (n_dev < 1 || n_dev > 64 || !out) return fail(C2B_ERR_INVALID_ARGUMENT, "comm_init_all: bad arguments");
+    for (int i = 0; i < n_dev; ++i) out[i] = nullptr;
+    NEED_RCCL("comm_init_all");
+    int devs[64];
+    ncclComm_t comms[64];
+    for (int i = 0; i < n_dev; ++i) devs[i] = dev_ids ? dev_ids[i] : i;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    RCCL_TRY("comm_init_all", rccl().CommInitAll(comms, n_dev, devs));
+    (void)hipSetDevice(prev);
+    for (int i = 0; i < n_dev; ++i) {
+        out[i] = new c2b_comm;
+        out[i]->comm = comms[i]; out[i]->rank = i; out[i]->world = n_dev; out[i]->device = devs[i];
+    }
+    return C2B_OK;
+    C2B_API_END("comm_init_all")
+}
+
+int c2b_comm_info(const c2b_comm *c, int *rank, int *world, int *device) {
+    if (!c) return fail(C2B_ERR_INVALID_ARGUMENT, "comm_info: NULL communicator");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (device) *device = c->device;
+    return C2B_OK;
+}
+
+int c2b_comm_group_start(void) {
+    C2B_API_BEGIN
+    NEED_RCCL("comm_group_start");
+    RCCL_TRY("comm_group_start", rccl().GroupStart());
+    return C2B_OK;
+    C2B_API_END("comm_group_start")
+}
+
+int c2b_comm_group_end(void) {
+    C2B_API_BEGIN
+    NEED_RCCL("comm_group_end");
+    RCCL_TRY("comm_group_end", rccl().GroupEnd());
+    return C2B_OK;
+    C2B_API_END("comm_group_end")
+}
+
+int c2b_comm_all_reduce_sum_f64(c2b_comm *c, double *buf, int64_t n, void *stream) {
+    C2B_API_BEGIN
+    if (!c || !c->comm || n < 0 || (n && !buf)) return fail(C2B_ERR_INVALID_ARGUMENT, "comm_all_reduce_sum_f64: bad arguments");
+    if (!n) return C2B_OK;
+    RCCL_TRY("comm_all_reduce_sum_f64", rccl().AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c->comm, S(stream)));
+    return C2B_OK;
+    C2B_API_END("comm_all_reduce_sum_f64")
+}
+
+int c2b_comm_all_gather_f64(c2b_comm *c, const double *send, int64_t n_per_rank, double *recv, void *stream) {
+    C2B_API_BEGIN
+    if (!c || !c->comm || n_per_rank < 0 || (n_per_rank && (!send || !recv)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "comm_all_gather_f64: bad arguments");
+    if (!n_per_rank) return C2B_OK;
+    RCCL_TRY("comm_all_gather_f64", rccl().AllGather(send, recv, (size_t)n_per_rank, ncclDouble, c->comm, S(stream)));
+    return C2B_OK;
+    C2B_API_END("comm_all_gather_f64")
+}
+
+void c2b_comm_destroy(c2b_comm *c) {
+    if (!c) return;
+    if (c->comm && rccl().ok()) {
+        int prev = 0;
+        const bool sw = hipGetDevice(&prev) == hipSuccess && prev != c->device && hipSetDevice(c->device) == hipSuccess;
+        (void)rccl().CommDestroy(c->comm);
+        if (sw) (void)hipSetDevice(prev);
+    }
+    delete c;
+}
+
+// ---- host halves of the statistics over sharded cameras ------------------------------------
+// shares [world][20] = every rank's c2b_stats_partial_pass1 record in rank order.  mean: the shares summed in rank
+// order; origin: smallest distance, ties to the LARGER global index (fold1 with strict <, src/noise.rs:80-86).
+int c2b_stats_combine_shares(const double *shares, int world, double *stats) {
+    C2B_API_BEGIN
+    if (!shares || !stats || world < 1) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_combine_shares: bad arguments");
+    const double inf = std::numeric_limits<double>::infinity();
+    double mean[3] = {0, 0, 0}, mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+    const double *best = nullptr;
+    for (int r = 0; r < world; ++r) {
+        const double *p = shares + 20 * (size_t)r;
+        for (int k = 0; k < 3; ++k) {
+            mean[k] = mean[k] + p[k];
+            mn[k] = std::fmin(mn[k], p[6 + k]);
+            mx[k] = std::fmax(mx[k], p[9 + k]);
+        }
+        if (p[18] < 0) continue;
+        if (!best || p[19] < best[19] || (p[19] == best[19] && p[18] > best[18])) best = p;
+    }
+    if (!best) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: empty problem");
+    for (int k = 0; k < 20; ++k) stats[k] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        stats[k] = mean[k]; stats[6 + k] = mn[k]; stats[9 + k] = mx[k]; stats[12 + k] = mx[k] - mn[k];
+        stats[15 + k] = best[15 + k];
+    }
+    stats[18] = best[18];
+    stats[19] = best[19];
+    return C2B_OK;
+    C2B_API_END("stats_combine_shares")
+}
+
+// sumsq [world][3] = every rank's c2b_stats_partial_pass2 sums, rank order -> stats[3..5] = std, stats[19] = |std|
+int c2b_stats_finish_shares(const double *sumsq, int world, int64_t n_entities, double *stats) {
+    C2B_API_BEGIN
+    if (!sumsq || !stats || world < 1 || n_entities < 1) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_finish_shares: bad arguments");
+    double t[3] = {0, 0, 0};
+    for (int r = 0; r < world; ++r)
+        for (int k = 0; k < 3; ++k) t[k] = t[k] + sumsq[3 * (size_t)r + k];
+    const double num = (double)n_entities;
+    for (int k = 0; k < 3; ++k) stats[3 + k] = std::sqrt(t[k] / num);
+    stats[19] = std::sqrt((stats[3] * stats[3] + stats[4] * stats[4]) + stats[5] * stats[5]);
+    return C2B_OK;
+    C2B_API_END("stats_finish_shares")
+}
+
+// BAProblem::mean/std/extent/dimensions + add_drift's origin when cameras are sharded: this rank's camblk holds cameras
+// [cam_base, cam_base + n_cam) of n_cam_global, pts4 is the whole replicated table and rank r of W reduces its r-th
+// slice.  Two all-gathers (20 and 3 doubles per rank) through the communicator; sums in rank order on the host, so
+// every rank ends with the same bits.  Synchronous; `stats` (device, 20 doubles) is complete on return.
+int c2b_stats_sharded(c2b_comm *c, const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+                      const double *pts4, int64_t n_pts, void *workspace, double *stats, void *stream) {
+    C2B_API_BEGIN
+    if (!c || !c->comm || !workspace || !stats || n_cam < 0 || n_pts < 0 || cam_base < 0 || n_cam_global < cam_base + n_cam)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: bad arguments");
+    const int W = c->world, R = c->rank;
+    const int64_t lo = n_pts * R / W, hi = n_pts * (R + 1) / W, n_ent = n_cam_global + n_pts;
+    if (n_ent < 1) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: empty problem");
+    hipStream_t st = S(stream);
+    double *dev = nullptr;                                   // [20 mine | W x 20 | 3 mean | 3 mine | W x 3]
+    const size_t n_dev = 20 + 20 * (size_t)W + 3 + 3 + 3 * (size_t)W;
+    HIP_TRY(hipMalloc((void **)&dev, n_dev * sizeof(double)));
+    std::unique_ptr<double, void (*)(double *)> guard(dev, [](double *q) { (void)hipFree(q); });
+    double *d_mine = dev, *d_all = dev + 20, *d_mean = d_all + 20 * (size_t)W, *d_sq = d_mean + 3, *d_sqall = d_sq + 3;
+    std::vector<double> shares(20 * (size_t)W), sq(3 * (size_t)W);
+    double host_stats[20];
+    int rc = c2b_stats_partial_pass1(camblk, n_cam, cam_base, n_cam_global, pts4 + 4 * lo, hi - lo, lo, n_ent, workspace, d_mine, stream);
+    if (!rc) rc = c2b_comm_all_gather_f64(c, d_mine, 20, d_all, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(shares.data(), d_all, shares.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rc = c2b_stats_combine_shares(shares.data(), W, host_stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_mean, host_stats, 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = c2b_stats_partial_pass2(camblk, n_cam, pts4 + 4 * lo, hi - lo, d_mean, workspace, d_sq, stream);
+    if (!rc) rc = c2b_comm_all_gather_f64(c, d_sq, 3, d_sqall, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(sq.data(), d_sqall, sq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rc = c2b_stats_finish_shares(sq.data(), W, n_ent, host_stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stats, host_stats, sizeof host_stats, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return C2B_OK;
+    C2B_API_END("stats_sharded")
+}
+
 int c2b_add_drift_sharded(double *cam15, int64_t n_cam, int64_t cam_base, double *pts4, int64_t n_pts, const double *stats,
                           int normalized, double strength, double angle_strength, double std, double dir_x, double dir_y,
                           double dir_z, uint64_t seed, void *stream) {
@@ -2168,6 +2378,32 @@ int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *ou
     *out = std::pow(sum, 1.0 / norm);          // .powf(1. / norm), src/baproblem.rs:278
     return C2B_OK;
     C2B_API_END("problem_total_reprojection_error")
+}
+
+// The same for a problem that is one SHARD (a contiguous camera range) of a larger one: the local sum, one 8-byte
+// all-reduce through the communicator on the problem's stream, then .powf(1/norm) -- every rank returns the global
+// error (src/baproblem.rs:265-279 over all shards).  Collective: every rank of the communicator must call it.
+int c2b_problem_total_reprojection_error_sharded(c2b_problem *p, c2b_comm *comm, double norm, double *out) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_total_reprojection_error_sharded");
+    if (!out || !comm) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_error_sharded: NULL argument");
+    if (comm->device != p->device) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_error_sharded: communicator and problem live on different devices");
+    int rc = ensure_camblk(p);
+    if (!rc) rc = ensure_rows(p);
+    if (rc) return rc;
+    if (p->n_obs > 0)
+        rc = c2b_reprojection_error_sum_rows(p->camblk, p->pts4, p->rows_ptr, p->n_cam, p->rows_tiles, p->pt_idx, p->uv, p->n_obs,
+                                             norm, p->ws, p->scalar, p->stream);
+    else
+        HIP_TRY(hipMemsetAsync(p->scalar, 0, sizeof(double), p->stream));          // an empty shard still takes part
+    if (!rc) rc = c2b_comm_all_reduce_sum_f64(comm, p->scalar, 1, p->stream);
+    if (rc) return rc;
+    double sum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sum, p->scalar, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    *out = std::pow(sum, 1.0 / norm);
+    return C2B_OK;
+    C2B_API_END("problem_total_reprojection_error_sharded")
 }
 
 // Results leave in chunks of kJacChunk observations through a ring of kJacSlots device buffers: the kernel of chunk

@@ -76,30 +76,24 @@ def all_reduce_sum_(t, group=None):
 def combine_stats_partials(parts, n_entities):
     """parts [world][20] = every rank's c2b_stats_partial_pass1 record, in rank order -> (mean3, min3, max3,
     origin3, origin_global_index).  mean: the shares summed in rank order; origin: smallest distance, ties to the
-    larger global index (fold1 with strict <, src/noise.rs:80-86).  Pure numpy: the host half of the collective."""
-    parts = np.asarray(parts, dtype=np.float64).reshape(-1, 20)
-    mean = np.zeros(3)
-    for p in parts:
-        mean = mean + p[0:3]
-    mn, mx = parts[:, 6:9].min(axis=0), parts[:, 9:12].max(axis=0)
-    best = None
-    for p in parts:
-        if p[18] < 0:
-            continue
-        if best is None or p[19] < best[19] or (p[19] == best[19] and p[18] > best[18]):
-            best = p
-    if best is None:
-        raise L.City2baError(L.ERR_INVALID_ARGUMENT, "stats: empty problem")
-    return mean, mn, mx, best[15:18].copy(), int(best[18])
+    larger global index (fold1 with strict <, src/noise.rs:80-86).  The host half of the collective, computed by the
+    C ABI (c2b_stats_combine_shares) so that the Python and the C++ callers (c2b_stats_sharded) share one
+    implementation."""
+    parts = np.ascontiguousarray(parts, dtype=np.float64).reshape(-1, 20)
+    st = np.zeros(20)
+    L.check(L.lib().c2b_stats_combine_shares(parts.ctypes.data_as(C.c_void_p), len(parts), st.ctypes.data_as(C.c_void_p)))
+    return st[0:3].copy(), st[6:9].copy(), st[9:12].copy(), st[15:18].copy(), int(st[18])
 
 
 def finish_stats(mean, mn, mx, origin, origin_index, sumsq, n_entities):
-    """the 20-double statistics record of c2b_stats from the combined pieces (std = sqrt(sum of squares / n))"""
+    """the 20-double statistics record of c2b_stats from the combined pieces (std = sqrt(sum of squares / n));
+    sumsq = [world][3] per-rank sums in rank order, or one already summed row (c2b_stats_finish_shares)"""
     st = np.zeros(20)
-    st[0:3], st[6:9], st[9:12], st[12:15] = mean, mn, mx, mx - mn
-    st[3:6] = np.sqrt(np.asarray(sumsq, dtype=np.float64) / float(n_entities))
+    st[0:3], st[6:9], st[9:12], st[12:15] = mean, mn, mx, np.asarray(mx) - np.asarray(mn)
     st[15:18], st[18] = origin, float(origin_index)
-    st[19] = np.sqrt((st[3] * st[3] + st[4] * st[4]) + st[5] * st[5])
+    sq = np.ascontiguousarray(sumsq, dtype=np.float64).reshape(-1, 3)
+    L.check(L.lib().c2b_stats_finish_shares(sq.ctypes.data_as(C.c_void_p), len(sq), int(n_entities),
+                                            st.ctypes.data_as(C.c_void_p)))
     return st
 
 
@@ -135,10 +129,8 @@ def stats_sharded(camblk, cam_base, n_cam_global, pts4, ws, group=None):
     mean, mn, mx, origin, oidx = combine_stats_partials(parts, n_ent)
     mean_d = torch.from_numpy(mean).to(camblk.device)
     sq = D.stats_partial_pass2(camblk, pts4[lo:hi], mean_d, ws)
-    sumsq = np.zeros(3)
-    for row in _all_gather_rows(sq.cpu().numpy(), group):       # rank-ordered sum, identical on every rank
-        sumsq = sumsq + row
-    return torch.from_numpy(finish_stats(mean, mn, mx, origin, oidx, sumsq, n_ent)).to(camblk.device)
+    rows = _all_gather_rows(sq.cpu().numpy(), group)            # summed in rank order: identical on every rank
+    return torch.from_numpy(finish_stats(mean, mn, mx, origin, oidx, rows, n_ent)).to(camblk.device)
 
 
 def finish_error(total_sum, norm):

@@ -45,6 +45,7 @@ extern "C" {
 #define C2B_ERR_HIP                 -3
 #define C2B_ERR_OOM                 -4
 #define C2B_ERR_NO_DEVICE           -5
+#define C2B_ERR_RCCL                -6  /* a collective failed, or RCCL could not be loaded */
 
 #define C2B_CAMBLK_DOUBLES 32
 #define C2B_STATS_DOUBLES  20  /* mean[3] std[3] min[3] max[3] dim[3] origin[3] origin_idx |std| */
@@ -259,6 +260,52 @@ int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_bas
                             void *workspace, double *part, void *stream);
 int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
                             const double *mean3, void *workspace, double *sumsq3, void *stream);
+/* the host halves of the two steps above (plain CPU arithmetic; every rank computes the same bits from the same
+ * gathered rows): shares [world][20] in rank order -> stats[0..2] mean, [6..8] min, [9..11] max, [12..14] extent,
+ * [15..17] origin, [18] its global index, [19] its distance;  sumsq [world][3] in rank order -> stats[3..5] std,
+ * stats[19] |std| (overwriting the distance, like c2b_stats). */
+int c2b_stats_combine_shares(const double *shares, int world, double *stats);
+int c2b_stats_finish_shares(const double *sumsq, int world, int64_t n_entities_global, double *stats);
+
+/* ===================================================================================== *
+ * Collectives of the sharded path -- RCCL over xGMI behind this ABI.
+ * One process (or thread) per GPU holds one c2b_comm; rank k owns a contiguous camera range
+ * (c2b_partition_cameras), every point is replicated, outputs stay sharded.  What the ranks
+ * exchange: the 8-byte sum behind BAProblem::total_reprojection_error (src/baproblem.rs:265-279;
+ * the reference itself is single-process, rayon only: src/synthetic.rs:268-269) and the 20- /
+ * 3-double statistics shares above.  RCCL is loaded on first use (dlopen of librccl.so.1; the
+ * environment variable C2B_RCCL_LIB names another file), so single-GPU hosts never load it; a
+ * failure to load or any RCCL error is C2B_ERR_RCCL with the text in c2b_last_error().
+ * All collectives are asynchronous on `stream` and may be captured in a HIP graph.
+ * ===================================================================================== */
+#define C2B_COMM_ID_BYTES 128
+typedef struct c2b_comm c2b_comm;
+/* "RCCL 2.x.y (path)" or "unavailable: ..." */
+const char *c2b_comm_backend(void);
+/* Rank 0 makes the id and hands its C2B_COMM_ID_BYTES bytes to every rank through whatever channel the host has
+ * (a file, a pipe, MPI, the torch store); then EVERY rank calls c2b_comm_init_rank with it (collective; makes `device`
+ * the calling thread's current device). */
+int c2b_comm_unique_id(void *id128);
+int c2b_comm_init_rank(const void *id128, int rank, int world, int device, c2b_comm **out);
+/* One process driving n_dev GPUs (SURVEY 8(b)'s ctx_create(n_dev, dev_ids)): out[n_dev] communicators, rank i on
+ * device dev_ids[i] (NULL: devices 0..n_dev-1).  Collectives issued from ONE thread for several of them must sit
+ * between c2b_comm_group_start / _end. */
+int c2b_comm_init_all(int n_dev, const int *dev_ids, c2b_comm **out);
+int c2b_comm_group_start(void);
+int c2b_comm_group_end(void);
+int c2b_comm_info(const c2b_comm *c, int *rank, int *world, int *device);
+/* in place: buf[0..n) <- sum over ranks (device pointer) */
+int c2b_comm_all_reduce_sum_f64(c2b_comm *c, double *buf, int64_t n, void *stream);
+/* recv[world][n_per_rank] <- every rank's send[n_per_rank], rank order (device pointers) */
+int c2b_comm_all_gather_f64(c2b_comm *c, const double *send, int64_t n_per_rank, double *recv, void *stream);
+void c2b_comm_destroy(c2b_comm *c);
+/* BAProblem::mean/std/extent/dimensions + add_drift's origin over SHARDED cameras in one call: pass 1, all-gather,
+ * host combine, pass 2, all-gather, host finish.  camblk = this rank's cameras [cam_base, cam_base + n_cam) of
+ * n_cam_global, pts4 = the whole replicated table (rank r reduces its r-th slice).  Collective and synchronous;
+ * stats (DEVICE, C2B_STATS_DOUBLES) holds the same bits on every rank when it returns. */
+int c2b_stats_sharded(c2b_comm *c, const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+                      const double *pts4, int64_t n_pts, void *workspace, double *stats, void *stream);
+
 /* add_drift[_normalized] / add_noise on a shard: cam15 holds cameras [cam_base, cam_base + n_cam) and every draw
  * is keyed by the GLOBAL camera index, so the sharded result equals the unsharded one row for row; pts4 is the
  * whole replicated table (every rank perturbs it identically: same counters, no traffic).  stats = the GLOBAL
@@ -471,6 +518,9 @@ int c2b_problem_centers(c2b_problem *p, double *centers3);
 
 int c2b_problem_project(c2b_problem *p, double *uv_out);
 int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *out);
+/* ... when `p` is one shard (a contiguous camera range) of a larger problem: local sum, one 8-byte all-reduce through
+ * `comm` on the problem's stream, then powf(1/norm); every rank returns the global error.  Collective. */
+int c2b_problem_total_reprojection_error_sharded(c2b_problem *p, c2b_comm *comm, double norm, double *out);
 /* Jacobian columns refer to the uploaded 9-vector's w while cameras are unmodified since
  * c2b_problem_upload_bal, otherwise to w = to_rodrigues(R) (what to_vec would write).
  * r [n_obs][2], Jc [n_obs][18], Jp [n_obs][6] are HOST buffers: the results leave the device in chunks whose copies

@@ -42,12 +42,26 @@ def plain():
     return out
 
 
-def test_rccl_world_size_one_reproduces_the_plain_run(plain):
+@pytest.mark.parametrize("collective,graph", [("auto", "auto"), ("c2b", "off"), ("torch", "on"), ("torch", "off")])
+def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph):
+    """the multi-rank step as the driver's N-GPU run takes it (auto = RCCL through the C ABI, replayed from a HIP graph)
+    and its three other combinations: same reduced scalar, bit for bit, as the run without any collective"""
     env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
-    rc, out, err = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist"] + COMMON, env)
+    rc, out, err = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--collective", collective,
+                         "--graph", graph] + COMMON, env)
     assert rc == 0 and out is not None, err[-2000:]
     assert "Traceback" not in err, err[-2000:]
-    assert out["config"]["collective"].startswith("nccl")
+    cfg = out["config"]
+    assert cfg["collective_note"] is None, cfg["collective_note"]
+    if collective in ("auto", "c2b"):
+        assert cfg["collective"].startswith("c2b_comm_all_reduce_sum_f64 (RCCL "), cfg["collective"]
+    else:
+        assert cfg["collective"].startswith("nccl all_reduce"), cfg["collective"]
+    if graph in ("auto", "on"):
+        assert isinstance(cfg["hip_graph"], str) and cfg["hip_graph"].startswith("one graph launch per step"), cfg["hip_graph"]
+    else:
+        assert cfg["hip_graph"] is False
+    assert cfg["allreduce_us"] > 0 and cfg["kernel_us_rank0"] > 0
     assert out["config"]["n_observations"] == plain["config"]["n_observations"]
     assert out["config"]["observations_per_rank"] == [plain["config"]["n_observations"]]
     assert out["config"]["total_L2_error"] == plain["config"]["total_L2_error"]      # all_reduce over one rank: identity
@@ -70,3 +84,50 @@ def test_two_ranks_on_one_gpu_exit_cleanly_and_agree(plain):
     assert b[0] == 0 and b[-1] == plain["config"]["n_cameras"] and b[1] > 0
     rel = abs(out["config"]["total_L2_error"] - plain["config"]["total_L2_error"]) / plain["config"]["total_L2_error"]
     assert rel < 1e-12
+
+
+def test_comm_through_the_c_abi_at_world_size_one():
+    """c2b_comm_* directly (what a Rust host binds): RCCL loads, a one-rank communicator all-reduces / all-gathers the
+    identity, the sharded statistics through it equal c2b_stats bit for bit, and the Level-1 sharded error equals the
+    unsharded one."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as entry
+    entry.build()
+    import city2ba_amd as c2b
+    from city2ba_amd import _lib as L
+    from city2ba_amd import comm as Comm
+    from city2ba_amd import device as D
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _problems import random_problem
+    import ctypes as C
+
+    assert Comm.backend().startswith("RCCL "), Comm.backend()
+    dev = torch.device("cuda", 0)
+    c = Comm.Comm(Comm.unique_id(), 0, 1, 0)
+    r, w, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    assert L.lib().c2b_comm_info(c.handle, C.byref(r), C.byref(w), C.byref(d)) == L.OK and (r.value, w.value, d.value) == (0, 1, 0)
+    x = torch.tensor([1.25, -3.5e300, 7e-310], dtype=torch.float64, device=dev)
+    want = x.clone()
+    c.all_reduce_sum_(x)
+    g = c.all_gather(want)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want) and g.shape == (1, 3) and torch.equal(g[0], want)
+
+    P = random_problem(300, 4000, 12, seed=77, noise=1e-3)
+    camblk = D.cameras_prepare_state(torch.from_numpy(P["cams15"]).to(dev))
+    pts4 = D.points_pad(torch.from_numpy(P["pts"]).to(dev))
+    ws = D.workspace(len(P["pt_idx"]), dev)
+    st_plain = D.stats(camblk, pts4, ws).cpu().numpy()
+    st_comm = c.stats_sharded(camblk, 0, 300, pts4, ws).cpu().numpy()
+    assert np.array_equal(st_plain, st_comm), (st_plain, st_comm)
+
+    ba = c2b.BAProblem.from_visibility(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], device=0)
+    e = C.c_double(0.0)
+    L.check(L.lib().c2b_problem_total_reprojection_error_sharded(ba._h, c.handle, 2.0, C.byref(e)))
+    assert e.value == ba.total_reprojection_error(2.0)
+    # argument checks come back as statuses, never as aborts
+    assert L.lib().c2b_comm_all_reduce_sum_f64(None, None, 1, None) == L.ERR_INVALID_ARGUMENT
+    h = C.c_void_p()
+    assert L.lib().c2b_comm_init_rank(C.create_string_buffer(128), 3, 2, 0, C.byref(h)) == L.ERR_INVALID_ARGUMENT
+    c.destroy()
