@@ -339,26 +339,21 @@ C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32
     z1 = rad * s;
 }
 
-// The direction of normal_pair's pair, (z0, z1) / |(z0, z1)| = (cos, sin)(2 pi u2), without its radius.
-C2B_DEV void unit_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot, double &c, double &s) {
+// add_noise's observation draw (src/noise.rs:152-170: a uniformly distributed unit 2-vector times Normal(0, std)) from
+// ONE Philox block, counter = (observation, slot 0): words 0-1 -> the radius uniform u1 of the magnitude, word 3 -> its
+// angle, word 2 -> the direction (the normalised Gaussian pair of unit_random has a uniform direction and its radius
+// cancels, so only the direction is drawn).  The CPU restatement under tests/ reads the same bits of the block.  Rounds 1-2 spent
+// two blocks here, and the kernel was bound by exactly that: 20 rounds of two 32x32->64 multiplies per observation
+// are quarter-rate integer work, more than half of its ~340 vector instructions per wave.
+// c, s = the direction; returns the standard normal z.
+C2B_DEV double obs_noise_draw(uint64_t seed, uint64_t observation, double &c, double &s) {
     uint32_t o[4];
-    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), slot, stream, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), o);
-    const uint64_t b = ((uint64_t)o[3] << 32) | o[2];
-    const double u2 = (double)(b >> 11) * 0x1.0p-53;
-    sincospi(2.0 * u2, &s, &c);
-}
-
-// z0 of normal_pair alone.
-C2B_DEV double normal_first(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot) {
-    uint32_t o[4];
-    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), slot, stream, (uint32_t)seed,
+    philox4x32_10((uint32_t)observation, (uint32_t)(observation >> 32), 0u, kStreamNoiseObs, (uint32_t)seed,
                   (uint32_t)(seed >> 32), o);
     const uint64_t a = ((uint64_t)o[1] << 32) | o[0];
-    const uint64_t b = ((uint64_t)o[3] << 32) | o[2];
     const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   // (0,1]
-    const double u2 = (double)(b >> 11) * 0x1.0p-53;         // [0,1)
-    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    sincospi(2.0 * ((double)o[2] * 0x1.0p-32), &s, &c);
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * ((double)o[3] * 0x1.0p-32));
 }
 
 }  // namespace c2b

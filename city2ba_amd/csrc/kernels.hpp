@@ -24,6 +24,7 @@ constexpr int kBlock = 256;          // lanes per workgroup of the per-entity ke
 constexpr int kWaves = kBlock / 64;
 constexpr int kRedBlocks = 1024;     // grid of the entity reductions
 constexpr int kStatRec = 16;         // doubles per stats partial record
+constexpr int kStatBatch = 4;        // entities a thread of the statistics passes loads before it uses any
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -871,14 +872,13 @@ template <> struct V4<float> { typedef float4 type; };
 
 struct SrcBlk {                                  // f64: camblk centres + pts4
     const double *camblk; const double4 *pts; int64_t n_cam;
+    // branch-free: both kinds of entity are three consecutive doubles at a 16-byte aligned address, so the address is
+    // selected and the loads are unconditional -- a thread's batch of loads then issues back to back (with a branch per
+    // entity every arm ended in s_waitcnt vmcnt(0) and the batch was serial again)
     C2B_DEV void get(int64_t i, double &x, double &y, double &z) const {
-        if (i < n_cam) {
-            const double *c = camblk + i * kCamBlk + kCenter;
-            x = c[0]; y = c[1]; z = c[2];
-        } else {
-            const double4 p = pts[i - n_cam];
-            x = p.x; y = p.y; z = p.z;
-        }
+        const double *c = i < n_cam ? camblk + i * kCamBlk + kCenter : reinterpret_cast<const double *>(pts + (i - n_cam));
+        const double2 xy = *reinterpret_cast<const double2 *>(c);
+        x = xy.x; y = xy.y; z = c[2];
     }
 };
 struct SrcState32 {                              // f32: cam15 (float) + pts4 (float)
@@ -995,14 +995,28 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
     unsigned magic = 0u;
     if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
     StatRec a = stat_empty();
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        double x, y, z;
-        src.get(i, x, y, z);
-        a.s[0] += x / num; a.s[1] += y / num; a.s[2] += z / num;
-        a.mn[0] = fmin(a.mn[0], x); a.mn[1] = fmin(a.mn[1], y); a.mn[2] = fmin(a.mn[2], z);
-        a.mx[0] = fmax(a.mx[0], x); a.mx[1] = fmax(a.mx[1], y); a.mx[2] = fmax(a.mx[2], z);
-        const Best cand = {sqrt(dot3(x, y, z, x, y, z)), (double)i};
-        a.best = best_merge(a.best, cand);
+    // kStatBatch entities per thread and trip, all loads issued before the first use (indices past the end re-read the
+    // last entity and are not accumulated): a thread's ~10 entities cost ~3 memory latencies instead of ~10, which is
+    // what a pass over 2.6 M entities is made of (the bytes -- 148 MB -- take ~20 us).
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride * kStatBatch) {
+        double x[kStatBatch], y[kStatBatch], z[kStatBatch];
+#pragma unroll
+        for (int u = 0; u < kStatBatch; ++u) {
+            const int64_t j = i + u * stride;
+            src.get(j < n ? j : n - 1, x[u], y[u], z[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kStatBatch; ++u) {
+            const int64_t j = i + u * stride;
+            if (j < n) {
+                a.s[0] += x[u] / num; a.s[1] += y[u] / num; a.s[2] += z[u] / num;
+                a.mn[0] = fmin(a.mn[0], x[u]); a.mn[1] = fmin(a.mn[1], y[u]); a.mn[2] = fmin(a.mn[2], z[u]);
+                a.mx[0] = fmax(a.mx[0], x[u]); a.mx[1] = fmax(a.mx[1], y[u]); a.mx[2] = fmax(a.mx[2], z[u]);
+                const Best cand = {sqrt(dot3(x[u], y[u], z[u], x[u], y[u], z[u])), (double)j};
+                a.best = best_merge(a.best, cand);
+            }
+        }
     }
     a = stat_block_reduce(a, sh);
     if (threadIdx.x == 0) {
@@ -1051,10 +1065,20 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass2(Src src, int64_t n, cons
     if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
     const double m0 = mean3[0], m1 = mean3[1], m2 = mean3[2];
     double s0 = 0, s1 = 0, s2 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        double x, y, z;
-        src.get(i, x, y, z);
-        s0 += (x - m0) * (x - m0); s1 += (y - m1) * (y - m1); s2 += (z - m2) * (z - m2);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride * kStatBatch) {
+        double x[kStatBatch], y[kStatBatch], z[kStatBatch];
+#pragma unroll
+        for (int u = 0; u < kStatBatch; ++u) {
+            const int64_t j = i + u * stride;
+            src.get(j < n ? j : n - 1, x[u], y[u], z[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kStatBatch; ++u) {
+            if (i + u * stride < n) {
+                s0 += (x[u] - m0) * (x[u] - m0); s1 += (y[u] - m1) * (y[u] - m1); s2 += (z[u] - m2) * (z[u] - m2);
+            }
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto block_sum = [&](double &a, double &b, double &c) {          // -> thread 0
@@ -1205,13 +1229,11 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_observations(double2 *__re
                                                                   uint64_t seed) {
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (o >= n) return;
-    // Same draws as the CPU path: slot 0 = the Box-Muller pair (nx, ny), slot 1 = z.  The pair is only used as
-    // (nx, ny) / |(nx, ny)| = (cos, sin)(2 pi u2): its radius cancels, so the log / sqrt of slot 0 and the
-    // normalisation (sqrt + two divides) are not evaluated; slot 1 needs the cosine branch only.  The kernel is
-    // VALU-bound (two Philox blocks + transcendentals per 32 bytes), so the instructions are what it costs.
-    double c, s, z;
-    unit_pair(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 0, c, s);
-    z = normal_first(seed, kStreamNoiseObs, (uint64_t)(o + obs_base), 1);
+    // One Philox block per observation (camera_math.hpp: obs_noise_draw): the direction
+    // (cos, sin)(2 pi u) of unit_random's pair -- its radius cancels in the normalisation, so neither it nor the
+    // normalisation (sqrt + two divides) is evaluated -- and the Box-Muller magnitude.
+    double c, s;
+    const double z = obs_noise_draw(seed, (uint64_t)(o + obs_base), c, s);
     const double r = 0.0 + observations_std * z;
     double2 v = uv[o];
     v.x = v.x + c * r;

@@ -751,12 +751,24 @@ void orc_add_noise(double *cams15, int64_t n_cam, double *pts, int64_t n_pts, do
         for (int k = 0; k < 3; ++k) pts[3 * j + k] = pts[3 * j + k] + ax[k] * m;
     }
     for (int64_t o = 0; o < n_obs; ++o) {
-        double z0[2], z1[2];
-        orc_normal_pair(seed, ORC_STREAM_NOISE_OBS, obs_offset + (uint64_t)o, 0, z0);
-        orc_normal_pair(seed, ORC_STREAM_NOISE_OBS, obs_offset + (uint64_t)o, 1, z1);
-        double nx = z0[0], ny = z0[1];
+        /* ONE Philox block per observation (counter = observation, slot 0): words 0-1 -> the radius uniform of the
+         * magnitude draw, word 3 -> its angle, word 2 -> the direction.  unit_random::<Vector2>() normalises a pair
+         * of standard normals (src/noise.rs:35-45): its direction is uniform on the circle and its radius cancels,
+         * so the pair is drawn with radius 1, i.e. as (cos, sin) of a uniform angle, and normalised like the reference
+         * does; the magnitude is Normal(0, std) by Box-Muller (src/noise.rs:160-163). */
+        uint64_t ent = obs_offset + (uint64_t)o;
+        uint32_t ctr[4] = { (uint32_t)ent, (uint32_t)(ent >> 32), 0u, ORC_STREAM_NOISE_OBS };
+        uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+        uint32_t w[4];
+        orc_philox4x32_10(ctr, key, w);
+        uint64_t a = ((uint64_t)w[1] << 32) | w[0];
+        double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;                     /* (0,1] */
+        double dir = 6.283185307179586476925286766559 * ((double)w[2] * 0x1.0p-32);
+        double ang = 6.283185307179586476925286766559 * ((double)w[3] * 0x1.0p-32);
+        double z = sqrt(-2.0 * log(u1)) * cos(ang);
+        double nx = cos(dir), ny = sin(dir);
         double m = sqrt(nx * nx + ny * ny);       /* powf(2.0) == x*x exactly */
-        double r = 0.0 + observations_std * z1[0];
+        double r = 0.0 + observations_std * z;
         uv[2 * o] = uv[2 * o] + nx / m * r;
         uv[2 * o + 1] = uv[2 * o + 1] + ny / m * r;
     }

@@ -124,7 +124,7 @@ def test_jacobian_outputs_search_measures_and_keeps_the_best(env):
     n = 1_500_000
     out = D.JacobianOutputs(n, dev, max_attempts=3, fast_store_GBs=1e9)       # unreachable target: all three are tried
     assert len(out.log) == 3 and all(1000.0 < x < 8000.0 for x in out.log), out.log
-    assert out.log[out.chosen] == max(out.log)
+    assert out.log[out.chosen] * 1.02 >= max(out.log)      # a later set must beat the incumbent by 2 % to replace it
     D.calib_store_pattern(out.r, out.Jc, out.Jp)
     torch.cuda.synchronize()
     assert out.Jc[64 * 7 + 5, 0].item() in (float(v) for v in range(64))       # the pattern landed in the handle's memory
