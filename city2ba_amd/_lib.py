@@ -65,6 +65,7 @@ SIGNATURES = {
     "c2b_jacobian_outputs_log": (_int, [_vp, _vp, _int, C.POINTER(_int), C.POINTER(_int)]),
     "c2b_jacobian_outputs_free": (None, [_vp]),
     "c2b_calib_store_pattern": (_int, [_i64, _vp, _vp, _vp, _vp]),
+    "c2b_calib_store_pattern_map": (_int, [_i64, _vp, _vp, _vp, _int, _vp]),
     "c2b_calib_copy": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_visibility_dense_tiles": (_i64, [_i64]),

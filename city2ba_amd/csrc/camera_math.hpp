@@ -339,12 +339,70 @@ C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32
     z1 = rad * s;
 }
 
+// ---- lean transcendentals for the observation-noise kernel ---------------------------------------------------
+// k_add_noise_observations is bound by vector issue (SQ counters, profiles/r03d: ACTIVE_INST_VALU 85 % of the SIMDs'
+// cycles, 287 vector instructions per wave of 64 observations), and half of those instructions were the library's
+// log / sincospi / cospi, which carry double-double arithmetic and argument handling this kernel has no use for: its
+// log argument is a normal number in (0, 1], its angles are exact 32-bit fractions of a turn.  The forms below are the
+// classic fdlibm kernels (Sun, 1993: e_log.c, k_sin.c, k_cos.c; errors below 1 ulp on their intervals) on exactly
+// those domains, with explicit FMAs.  tests/test_gpu_parity.py pins them against libm to 1e-13 (the draws' tolerance
+// is 1e-9).
+
+// ln(x) for a normal x in (0, 1]
+C2B_DEV double log_unit(double x) {
+    int e = __builtin_amdgcn_frexp_exp(x);                   // x = m * 2^e, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    if (m < 0.70710678118654752440) { m = m + m; e -= 1; }   // m in [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0, d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);                      // 1 / d: hardware estimate + two Newton steps
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double q = f * r;
+    q = fma(fma(-d, q, f), r, q);                            // q = f / (2 + f)
+    const double z = q * q, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1, hfsq = 0.5 * f * f, de = (double)e;
+    return fma(de, 6.93147180369123816490e-01, -((hfsq - fma(q, hfsq + R, de * 1.90821492927058770002e-10)) - f));
+}
+
+// sin and cos of x in [-pi/4, pi/4] (fdlibm __kernel_sin / __kernel_cos without the tail argument)
+C2B_DEV void sincos_kernel(double x, double &sn, double &cs) {
+    const double z = x * x;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                  2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    sn = fma(x * z, ps, x);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                  -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                 -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+}
+
+// (cos, sin) of the angle w * 2^-32 turns: nearest quarter turn k, remainder in [-1/8, 1/8) turns exactly, the kernels
+// on 2 pi * remainder, then the quarter-turn rotation
+C2B_DEV void sincos_turns32(uint32_t w, double &sn, double &cs) {
+    const uint32_t k = (w + 0x20000000u) >> 30;                       // 0 .. 4
+    const int32_t rem = (int32_t)(w - (k << 30));                     // [-2^29, 2^29)
+    double s, c;
+    sincos_kernel((double)rem * (6.283185307179586476925286766559 * 0x1.0p-32), s, c);
+    const bool swap = (k & 1u) != 0;
+    const double a = swap ? s : c, b = swap ? c : s;                  // k odd: cos = -/+ sin, sin = +/- cos
+    cs = ((k + 1u) & 2u) ? -a : a;                                    // k = 1, 2: cos negated
+    sn = (k & 2u) ? -b : b;                                           // k = 2, 3: sin negated
+}
+C2B_DEV double cos_turns32(uint32_t w) {
+    double s, c;
+    sincos_turns32(w, s, c);
+    return c;
+}
+
 // add_noise's observation draw (src/noise.rs:152-170: a uniformly distributed unit 2-vector times Normal(0, std)) from
 // ONE Philox block, counter = (observation, slot 0): words 0-1 -> the radius uniform u1 of the magnitude, word 3 -> its
 // angle, word 2 -> the direction (the normalised Gaussian pair of unit_random has a uniform direction and its radius
-// cancels, so only the direction is drawn).  The CPU restatement under tests/ reads the same bits of the block.  Rounds 1-2 spent
-// two blocks here, and the kernel was bound by exactly that: 20 rounds of two 32x32->64 multiplies per observation
-// are quarter-rate integer work, more than half of its ~340 vector instructions per wave.
+// cancels, so only the direction is drawn).  The CPU restatement under tests/ reads the same bits of the block.
+// Rounds 1-2 spent two blocks here: 20 more quarter-rate 32x32->64 multiplies per observation.
 // c, s = the direction; returns the standard normal z.
 C2B_DEV double obs_noise_draw(uint64_t seed, uint64_t observation, double &c, double &s) {
     uint32_t o[4];
@@ -352,8 +410,8 @@ C2B_DEV double obs_noise_draw(uint64_t seed, uint64_t observation, double &c, do
                   (uint32_t)(seed >> 32), o);
     const uint64_t a = ((uint64_t)o[1] << 32) | o[0];
     const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   // (0,1]
-    sincospi(2.0 * ((double)o[2] * 0x1.0p-32), &s, &c);
-    return sqrt(-2.0 * log(u1)) * cospi(2.0 * ((double)o[3] * 0x1.0p-32));
+    sincos_turns32(o[2], s, c);
+    return sqrt(-2.0 * log_unit(u1)) * cos_turns32(o[3]);
 }
 
 }  // namespace c2b

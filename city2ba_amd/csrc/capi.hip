@@ -866,6 +866,19 @@ int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, vo
     C2B_API_END("calib_store_pattern")
 }
 
+int c2b_calib_store_pattern_map(int64_t n_obs, double *r, double *Jc, double *Jp, int tile_map, void *stream) {
+    C2B_API_BEGIN
+    if (n_obs < 0 || tile_map < 0 || (n_obs && (!r || !Jc || !Jp)) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "calib_store_pattern_map: bad arguments");
+    if (n_obs < 64) return C2B_OK;
+    const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
+    hipLaunchKernelGGL((k_store_pattern_map<true, 8>), dim3((unsigned)bt), dim3(512), 0, S(stream), n_obs, bt, tile_map,
+                       reinterpret_cast<double2 *>(r), Jc, Jp);
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("calib_store_pattern_map")
+}
+
 int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
     C2B_API_BEGIN
     if (bytes < 0 || (bytes && (!src || !dst)) || !aligned16(src) || !aligned16(dst) || (bytes & 15))

@@ -1549,6 +1549,37 @@ __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n
     for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
 }
 
+// The same store geometry under a selectable workgroup -> tile map (c2b_calib_store_pattern_map): 0 = every XCD streams
+// a contiguous eighth of the arrays (what the kernels do: 8 write fronts per array), 1 = launch order (the whole chip
+// writes inside one moving window), K >= 2 = XCD x takes K consecutive tiles of every group of 8K (xcd_tile_chunked).
+// A measurement aid for the question of section 3 of DESIGN.md: does the slow / fast allocation effect depend on how
+// the chip's concurrent write fronts are laid over the address space?
+template <bool NT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_store_pattern_map(int64_t n, int64_t n_btiles, int map, double2 *__restrict__ r_out,
+                                                               double *__restrict__ Jc, double *__restrict__ Jp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t bt = blockIdx.x;
+    if (map == 0) {
+        bt = xcd_tile(bt, n_btiles);
+    } else if (map >= 2) {
+        const int64_t K = map, whole = n_btiles / (8 * K) * (8 * K);
+        if (bt < whole) {
+            const int64_t xcd = bt & 7, k = bt >> 3;
+            bt = (k / K) * (8 * K) + xcd * K + (k % K);
+        }
+    }
+    const int64_t wave0 = (bt * WPB + wave) * 64;
+    if (wave0 + 64 > n) return;
+    const double2 v = make_double2((double)lane, (double)wave);
+    store16<NT>(reinterpret_cast<char *>(r_out + wave0 + lane), v);
+    char *dc = reinterpret_cast<char *>(Jc) + wave0 * 144;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) store16<NT>(dc + (k * 64 + lane) * 16, v);
+    char *dp = reinterpret_cast<char *>(Jp) + wave0 * 48;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
+}
+
 // 16 bytes per lane streaming copy, one element per thread (the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for)
 __global__ __launch_bounds__(256) void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n16) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -185,6 +185,11 @@ def calib_store_pattern(r, Jc, Jp):
     L.check(L.lib().c2b_calib_store_pattern(r.shape[0], _p(r), _p(Jc), _p(Jp), _stream()))
 
 
+def calib_store_pattern_map(r, Jc, Jp, tile_map):
+    """calib_store_pattern under another workgroup -> tile map (0 = XCD eighths, 1 = launch order, K >= 2 = chunked)"""
+    L.check(L.lib().c2b_calib_store_pattern_map(r.shape[0], _p(r), _p(Jc), _p(Jp), int(tile_map), _stream()))
+
+
 def calib_copy(src, dst):
     """Calibration: 16-bytes-per-lane streaming copy of src into dst (same byte size, multiple of 16)."""
     nbytes = src.numel() * src.element_size()

@@ -193,6 +193,9 @@ void c2b_jacobian_outputs_free(c2b_jacobian_outputs *h);
  * Jp [n][6] in exactly the residual+Jacobian kernel's store geometry with no loads and no arithmetic -- the time its
  * stores alone take; _copy is a 16-bytes-per-lane streaming copy (bytes % 16 == 0). */
 int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, void *stream);
+/* _store_pattern under another workgroup -> tile map: 0 = each XCD streams a contiguous eighth of the arrays (what the
+ * kernels and _store_pattern do), 1 = launch order, K >= 2 = XCD x takes K consecutive tiles of every group of 8K */
+int c2b_calib_store_pattern_map(int64_t n_obs, double *r, double *Jc, double *Jp, int tile_map, void *stream);
 int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream);
 
 /* visibility predicate of the generators (src/synthetic.rs:285-291, 368-375;

@@ -356,6 +356,30 @@ def test_add_noise_matches_oracle_and_inequality(c2b):
     assert abs(ba.total_reprojection_error(2.0) - e_cpu) / e_cpu < 1e-7
 
 
+def test_observation_noise_lean_transcendentals_track_libm_and_the_distribution(c2b):
+    """k_add_noise_observations evaluates its own log / sin / cos (camera_math.hpp: log_unit, sincos_turns32 -- the
+    fdlibm kernels on exactly the domains the draws need) instead of the library's; pinned here against the CPU
+    restatement's glibc to 1e-13 over 400 000 draws (std = 1 on a zero uv: the output IS the draw), far inside the
+    1e-9 the draws are compared at.  The draws themselves: direction uniform on the circle, magnitude N(0, 1)
+    (src/noise.rs:152-170: unit_random * Normal(0, std))."""
+    import torch
+    from city2ba_amd import device as D
+    n = 400_000
+    dev = torch.device("cuda", 0)
+    uv = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    D.add_noise_observations(uv, 12345, 1.0, seed=4242)
+    got = uv.cpu().numpy()
+    one_cam = np.array([[1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0]], dtype=np.float64)
+    _, _, want = O.add_noise(one_cam, np.ones((1, 3)), np.zeros((n, 2)), 0.0, 0.0, 0.0, 1.0, seed=4242, obs_offset=12345)
+    assert np.max(np.abs(got - want)) < 1e-13 * max(1.0, float(np.max(np.abs(want))))
+    r = np.hypot(got[:, 0], got[:, 1])                      # |z|: half-normal -> mean sqrt(2/pi), E r^2 = 1
+    assert abs(r.mean() - np.sqrt(2 / np.pi)) < 4e-3 and abs((r * r).mean() - 1.0) < 8e-3
+    ang = np.arctan2(got[:, 1], got[:, 0])                  # z's sign folds the direction: still uniform on the circle
+    assert abs(np.cos(ang).mean()) < 4e-3 and abs(np.sin(ang).mean()) < 4e-3 and abs(np.cos(2 * ang).mean()) < 4e-3
+    hist, _ = np.histogram(ang, bins=16, range=(-np.pi, np.pi))
+    assert hist.min() > 0.93 * n / 16 and hist.max() < 1.07 * n / 16
+
+
 def test_add_sin_noise_matches_oracle_and_inequality(c2b):
     P = _grid_problem()
     ba = _upload(c2b, P)

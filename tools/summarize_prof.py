@@ -48,6 +48,26 @@ def pmc_per_kernel(root, counter):
     return {k: (s[0] / s[1], s[1]) for k, s in acc.items()}
 
 
+def timed_region(root, steps):
+    """mean duration of the LAST `steps` dispatches of the residual + Jacobian kernel in a --kernel-trace run of
+    bench.py: the timed region (what comes before it -- the first-allocation timing, the warm-up -- runs the same kernel
+    in other allocations, so the whole-run average of --stats is not the number the bench line reports)"""
+    path = find(root, "*kernel_trace.csv")
+    if not path or not steps:
+        return None
+    rows = []
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            if "k_residual_jacobian" in row.get("Kernel_Name", ""):
+                rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+    rows.sort()
+    rows = rows[-int(steps):]
+    if not rows:
+        return None
+    d = [e - s for s, e in rows]
+    return {"calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
+
+
 def bench_line(log):
     try:
         for line in open(log):
@@ -104,10 +124,18 @@ def main():
                 "active_inst_valu_frac": round(sq_dom.get("SQ_ACTIVE_INST_VALU", 0) / wc, 4),
             }
     summary["bench_trace"] = bench_line(os.path.join(out, "trace.log"))
+    if summary["bench_trace"]:
+        tr = timed_region(os.path.join(out, "trace"), summary["bench_trace"].get("steps"))
+        summary["timed_region_in_kernel_trace"] = tr
+        if tr:
+            ev = summary["bench_trace"]["roofline"]["kernel_avg_us"]
+            summary["timed_region_vs_bench_events"] = {"rocprofv3_avg_us": round(tr["avg_ns"] / 1e3, 2), "bench_events_avg_us": ev,
+                                                        "ratio": round(tr["avg_ns"] / 1e3 / ev, 4)}
     summary["bench_pmc_fetch"] = bench_line(os.path.join(out, "pmc_fetch.log"))
     with open(os.path.join(out, "%s_summary.json" % tag), "w") as fh:
         json.dump(summary, fh, indent=1)
-    print(json.dumps({k: summary.get(k) for k in ("dominant_kernel", "traffic_bytes_per_launch", "sq_counters_dominant_kernel", "sq_derived")}, indent=1))
+    print(json.dumps({k: summary.get(k) for k in ("dominant_kernel", "timed_region_vs_bench_events", "traffic_bytes_per_launch",
+                                                  "sq_counters_dominant_kernel", "sq_derived")}, indent=1))
     for k in summary["kernels"][:8]:
         print("%-90s calls=%d avg=%.1f us  %.1f%%" % (k["name"][:90], k["calls"], k["avg_ns"] / 1e3, k["pct"]))
 
