@@ -260,6 +260,56 @@ def other_configs(dev):
     return res
 
 
+def light_kernels(sh, dev, ws):
+    """The other per-observation passes of the hot path on the headline grid, each timed two ways because the two differ
+    and both are real: back to back on the same problem (what a solver loop sees: the previous launch left the camera and
+    point tables in the 256 MB Infinity Cache) and cold (a 1-GiB read sweeps the caches before every launch: a single
+    call on a problem nobody has touched).  Fractions are algorithmic bytes (4-B point index + 16-B
+    result or observed uv per observation, every camera and point once) over the 8 TB/s peak."""
+    import torch
+    from city2ba_amd import device as D
+    n, n_cam, n_pts = sh["n_obs"], sh["n_cam_local"], sh["n_pts"]
+    uv_out = torch.empty_like(sh["uv"])
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    st = torch.empty(20, dtype=torch.float64, device=dev)
+    uv2 = sh["uv"].clone()
+    sweep = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
+    ent = n_cam * 72 + n_pts * 24
+    cases = {
+        "project_rows": (lambda: D.project_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], uv_out), n * 20 + ent),
+        "error_sum_rows_L2": (lambda: D.reprojection_error_sum_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], 2.0, ws, err), n * 20 + ent),
+        "visibility_rows": (lambda: D.visibility_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], 10.0, uv_out, keep), n * 21 + ent),
+        "add_noise_observations": (lambda: D.add_noise_observations(uv2, 0, 1e-9, 7), n * 32),
+        "stats": (lambda: D.stats(sh["camblk"], sh["pts4"], ws, st), n_cam * 24 + n_pts * 24),
+    }
+    out = {}
+    for name, (fn, alg) in cases.items():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        warm = s.elapsed_time(e) / 20 * 1e-3
+        cold = []
+        for _ in range(5):
+            sweep.sum()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            cold.append(s.elapsed_time(e) * 1e-3)
+        cold = sorted(cold)[2]
+        out[name] = {"us_back_to_back": round(warm * 1e6, 1), "frac_back_to_back": round(alg / warm / 1e9 / HBM_PEAK_GBS, 3),
+                     "us_cold": round(cold * 1e6, 1), "frac_cold": round(alg / cold / 1e9 / HBM_PEAK_GBS, 3)}
+    return out
+
+
 def adversarial_gather(sh, r, Jc, Jp, ws):
     """grid order is the friendly gather; uniformly random point indices are the adversarial
     one (every lane of a wave hits a different 128-B line of the 63 MB point table).  Timing only."""
@@ -658,6 +708,7 @@ def main():
         if world == 1 and args.blocks == 128 and not args.no_extras:
             out["other_configs"] = other_configs(dev)
             out["other_configs"]["blocks128_uniform_random_point_gather"] = adversarial_gather(sh, r, Jc, Jp, ws)
+            out["other_configs"]["blocks128_other_passes"] = light_kernels(sh, dev, ws)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

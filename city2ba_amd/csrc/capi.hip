@@ -418,16 +418,13 @@ inline int stats_grid(int64_t n) {
     return grid < 1 ? 1 : grid;
 }
 
-// mean / min / max / extent / origin, then std: two launches, each folded by its last workgroup (kernels.hpp)
+// mean / std / min / max / extent / origin in ONE launch folded by its last workgroup (kernels.hpp: Chan triples)
 template <typename Src>
 int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStream_t st) {
     double *rec = reinterpret_cast<double *>(workspace);
-    const int grid = stats_grid(n);
     const ShardMap whole{src.n_cam, 0, src.n_cam, 0};
-    hipLaunchKernelGGL(k_stats_pass1<Src>, dim3(grid), dim3(kBlock), 0, st, src, n, (double)n, rec, ws_ticket(workspace), whole, stats);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_stats_pass2<Src, false>), dim3(grid), dim3(kBlock), 0, st, src, n, (const double *)stats, rec,
-                       ws_ticket(workspace), stats);
+    hipLaunchKernelGGL((k_stats_pass1<Src, true>), dim3(stats_grid(n)), dim3(kBlock), 0, st, src, n, (double)n, rec,
+                       ws_ticket(workspace), whole, stats);
     LAUNCH_CHECK();
     return C2B_OK;
 }
@@ -1144,7 +1141,7 @@ int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_bas
     const int64_t n = n_cam + n_pts;
     double *rec = reinterpret_cast<double *>(workspace);
     const ShardMap map{n_cam, cam_base, n_cam_global, pt_base};
-    hipLaunchKernelGGL(k_stats_pass1<SrcBlk>, dim3(stats_grid(n)), dim3(kBlock), 0, S(stream), src, n, (double)n_entities_global, rec,
+    hipLaunchKernelGGL((k_stats_pass1<SrcBlk, false>), dim3(stats_grid(n)), dim3(kBlock), 0, S(stream), src, n, (double)n_entities_global, rec,
                        ws_ticket(workspace), map, part);
     LAUNCH_CHECK();
     return C2B_OK;

@@ -22,8 +22,8 @@ namespace c2b {
 
 constexpr int kBlock = 256;          // lanes per workgroup of the per-entity kernels (4 waves)
 constexpr int kWaves = kBlock / 64;
-constexpr int kRedBlocks = 1024;     // grid of the entity reductions
-constexpr int kStatRec = 16;         // doubles per stats partial record
+constexpr int kRedBlocks = 2048;     // largest grid of the entity reductions (one record per workgroup in the workspace)
+constexpr int kStatRec = 20;         // doubles per stats partial record (18 used)
 constexpr int kStatBatch = 4;        // entities a thread of the statistics passes loads before it uses any
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -922,72 +922,100 @@ C2B_DEV Best best_merge(Best a, Best b) {
     return r;
 }
 
-// Statistics in TWO launches (the mean must exist before the deviations are summed; src/baproblem.rs:282-337): each
-// pass leaves one record per workgroup, published like ticket_fold's partials (agent-scope write-through stores,
-// drained, then the arrival count in the workspace's ticket block), and the workgroup that arrives last folds the
-// records in a fixed order -- thread t takes records t, t + 256, ...; wave shuffle tree; waves in order -- and writes
-// the result.  Rounds 1-2 used two more single-workgroup launches for the folds (73 us in all at --blocks 128, most of
-// it launch gaps; the 1024-thread fold kernel also spilled: 128 VGPRs, 724-788 B of scratch).
+// Statistics (src/baproblem.rs:282-337, src/noise.rs:75-87).  Each pass leaves one record per workgroup, published like
+// ticket_fold's partials (agent-scope write-through stores, drained, then the arrival count in the workspace's ticket
+// block), and the workgroup that arrives last folds the records in a fixed order -- thread t takes records t, t + 256,
+// ...; wave shuffle tree; waves in order -- and writes the result.  Rounds 1-2 used two passes and two more
+// single-workgroup fold launches (73 us at --blocks 128; the 1024-thread fold kernel spilled: 128 VGPRs, 724-788 B of
+// scratch).  A pass over the 2.6 M entities of that problem is bound by its bytes (148 MB of 128-byte lines for 24 useful
+// bytes per camera: 26 us for the lightest possible pass, profiles/r03d), so the unsharded call now makes ONE pass:
+// the standard deviation comes from per-thread (count, mean, M2) triples merged pairwise by Chan's update
+//     delta = mean_b - mean_a;  mean = mean_a + delta n_b / n;  M2 = M2_a + M2_b + delta^2 n_a n_b / n
+// (Chan, Golub, LeVeque 1979) -- no subtraction of large sums anywhere, so it is as well conditioned as the reference's
+// second pass around the finished mean and agrees with it to rounding (tested at 1e-12).  The mean itself is still
+// accumulated the reference's way, element by element scaled by 1/num.  Sharded cameras keep the two-pass form: the
+// ranks exchange their shares between the passes anyway.
 struct StatRec {
     double s[3], mn[3], mx[3];
     Best best;
+    double cnt, mu[3], m2[3];                     // Chan triple per axis (shared count)
 };
 C2B_DEV StatRec stat_empty() {
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     StatRec r;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { r.s[k] = 0.0; r.mn[k] = inf; r.mx[k] = -inf; }
+    for (int k = 0; k < 3; ++k) { r.s[k] = 0.0; r.mn[k] = inf; r.mx[k] = -inf; r.mu[k] = 0.0; r.m2[k] = 0.0; }
     r.best.d = 0.0; r.best.i = -1.0;
+    r.cnt = 0.0;
     return r;
 }
+template <bool STD>
 C2B_DEV void stat_merge(StatRec &a, const StatRec &b) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { a.s[k] += b.s[k]; a.mn[k] = fmin(a.mn[k], b.mn[k]); a.mx[k] = fmax(a.mx[k], b.mx[k]); }
     a.best = best_merge(a.best, b.best);
+    if (STD) {
+        const double tot = a.cnt + b.cnt;
+        const double f = tot > 0.0 ? b.cnt / tot : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double delta = b.mu[k] - a.mu[k];
+            a.mu[k] = a.mu[k] + delta * f;
+            a.m2[k] = (a.m2[k] + b.m2[k]) + (delta * delta) * (a.cnt * f);
+        }
+        a.cnt = tot;
+    }
 }
 // all 64 lanes -> lane 0 (shuffle tree, fixed order)
+template <bool STD>
 C2B_DEV void stat_wave_reduce(StatRec &r) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { r.s[k] = wave_sum(r.s[k]); r.mn[k] = wave_min(r.mn[k]); r.mx[k] = wave_max(r.mx[k]); }
-#pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        Best o;
-        o.d = __shfl_down(r.best.d, off, 64);
-        o.i = __shfl_down(r.best.i, off, 64);
-        r.best = best_merge(r.best, o);
+        StatRec o;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o.s[k] = __shfl_down(r.s[k], off, 64); o.mn[k] = __shfl_down(r.mn[k], off, 64); o.mx[k] = __shfl_down(r.mx[k], off, 64);
+            if (STD) { o.mu[k] = __shfl_down(r.mu[k], off, 64); o.m2[k] = __shfl_down(r.m2[k], off, 64); }
+        }
+        o.best.d = __shfl_down(r.best.d, off, 64);
+        o.best.i = __shfl_down(r.best.i, off, 64);
+        o.cnt = STD ? __shfl_down(r.cnt, off, 64) : 0.0;
+        stat_merge<STD>(r, o);
     }
 }
 C2B_DEV void stat_to_lds(const StatRec &r, double *o) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { o[k] = r.s[k]; o[3 + k] = r.mn[k]; o[6 + k] = r.mx[k]; }
-    o[9] = r.best.d; o[10] = r.best.i;
+    for (int k = 0; k < 3; ++k) { o[k] = r.s[k]; o[3 + k] = r.mn[k]; o[6 + k] = r.mx[k]; o[12 + k] = r.mu[k]; o[15 + k] = r.m2[k]; }
+    o[9] = r.best.d; o[10] = r.best.i; o[11] = r.cnt;
 }
 C2B_DEV StatRec stat_from(const double *o) {
     StatRec r;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { r.s[k] = o[k]; r.mn[k] = o[3 + k]; r.mx[k] = o[6 + k]; }
-    r.best.d = o[9]; r.best.i = o[10];
+    for (int k = 0; k < 3; ++k) { r.s[k] = o[k]; r.mn[k] = o[3 + k]; r.mx[k] = o[6 + k]; r.mu[k] = o[12 + k]; r.m2[k] = o[15 + k]; }
+    r.best.d = o[9]; r.best.i = o[10]; r.cnt = o[11];
     return r;
 }
 
 // the workgroup's waves (one record each, on lane 0) -> one record on thread 0, waves in order
+template <bool STD>
 C2B_DEV StatRec stat_block_reduce(StatRec r, double (*sh)[kStatRec]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    stat_wave_reduce(r);
+    stat_wave_reduce<STD>(r);
     __syncthreads();
     if (lane == 0) stat_to_lds(r, sh[wave]);
     __syncthreads();
     if (threadIdx.x == 0) {
         r = stat_from(sh[0]);
-        for (int w = 1; w < kWaves; ++w) stat_merge(r, stat_from(sh[w]));
+        for (int w = 1; w < kWaves; ++w) stat_merge<STD>(r, stat_from(sh[w]));
     }
     return r;
 }
 
-// pass 1: stats[0..2]=mean, [6..8]=min, [9..11]=max, [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin's
-// GLOBAL index (map), [19]=its distance (sharded runs compare it across ranks; the unsharded pass 2 overwrites the slot
-// with |std|).  rec: gridDim.x records of kStatRec doubles in the workspace.
-template <typename Src>
+// stats[0..2]=mean, [6..8]=min, [9..11]=max, [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin's GLOBAL
+// index (map).  STD (the unsharded call): [3..5]=std, [19]=|std| from the Chan triples, all in this one launch.  !STD (a
+// shard's share, c2b_stats_partial_pass1): [19]=the origin's distance (compared across ranks), no moments.
+// rec: gridDim.x records of kStatRec doubles in the workspace.
+template <typename Src, bool STD>
 __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, double num, double *__restrict__ rec,
                                                        unsigned *__restrict__ ticket, ShardMap map,
                                                        double *__restrict__ stats) {
@@ -996,8 +1024,11 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
     if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
     StatRec a = stat_empty();
     // kStatBatch entities per thread and trip, all loads issued before the first use (indices past the end re-read the
-    // last entity and are not accumulated): a thread's ~10 entities cost ~3 memory latencies instead of ~10, which is
-    // what a pass over 2.6 M entities is made of (the bytes -- 148 MB -- take ~20 us).
+    // last entity and are not accumulated).
+    // mean(), src/baproblem.rs:282-289, folds `a + b / num` over the entities; here every element is scaled by the
+    // one reciprocal instead of divided (three IEEE divides per entity were a third of this pass's instructions).  The
+    // sums are tree-ordered already, so the last bits differ from the sequential fold either way (tested at 1e-12).
+    const double inv_num = 1.0 / num;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride * kStatBatch) {
         double x[kStatBatch], y[kStatBatch], z[kStatBatch];
@@ -1006,25 +1037,48 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
             const int64_t j = i + u * stride;
             src.get(j < n ? j : n - 1, x[u], y[u], z[u]);
         }
+        double c = 0.0, bs[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < kStatBatch; ++u) {
             const int64_t j = i + u * stride;
             if (j < n) {
-                a.s[0] += x[u] / num; a.s[1] += y[u] / num; a.s[2] += z[u] / num;
+                a.s[0] += x[u] * inv_num; a.s[1] += y[u] * inv_num; a.s[2] += z[u] * inv_num;
                 a.mn[0] = fmin(a.mn[0], x[u]); a.mn[1] = fmin(a.mn[1], y[u]); a.mn[2] = fmin(a.mn[2], z[u]);
                 a.mx[0] = fmax(a.mx[0], x[u]); a.mx[1] = fmax(a.mx[1], y[u]); a.mx[2] = fmax(a.mx[2], z[u]);
                 const Best cand = {sqrt(dot3(x[u], y[u], z[u], x[u], y[u], z[u])), (double)j};
                 a.best = best_merge(a.best, cand);
+                if (STD) { c += 1.0; bs[0] += x[u]; bs[1] += y[u]; bs[2] += z[u]; }
             }
         }
+        if (STD) {                                           // the batch's own triple (two passes over registers), then Chan
+            StatRec bt = stat_empty();
+            const double ic = 1.0 / c;                       // i < n: the batch holds at least one entity
+            bt.cnt = c;
+            bt.mu[0] = bs[0] * ic; bt.mu[1] = bs[1] * ic; bt.mu[2] = bs[2] * ic;
+#pragma unroll
+            for (int u = 0; u < kStatBatch; ++u) {
+                if (i + u * stride < n) {
+                    const double dx = x[u] - bt.mu[0], dy = y[u] - bt.mu[1], dz = z[u] - bt.mu[2];
+                    bt.m2[0] += dx * dx; bt.m2[1] += dy * dy; bt.m2[2] += dz * dz;
+                }
+            }
+            const double tot = a.cnt + c, f = c / tot;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double delta = bt.mu[k] - a.mu[k];
+                a.mu[k] = a.mu[k] + delta * f;
+                a.m2[k] = (a.m2[k] + bt.m2[k]) + (delta * delta) * (a.cnt * f);
+            }
+            a.cnt = tot;
+        }
     }
-    a = stat_block_reduce(a, sh);
+    a = stat_block_reduce<STD>(a, sh);
     if (threadIdx.x == 0) {
-        double t[11];
+        double t[kStatRec];
         stat_to_lds(a, t);
         double *o = rec + (int64_t)blockIdx.x * kStatRec;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) __hip_atomic_store(o + k, t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < (STD ? 18 : 11); ++k) __hip_atomic_store(o + k, t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_waitcnt(0);
         const bool last = ticket_arrive(ticket, magic);
         if (magic != kTicketMagic) {
@@ -1036,8 +1090,20 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
     __syncthreads();
     if (sh[kWaves][0] == 0.0) return;                  // workgroup-uniform
     StatRec f = stat_empty();
-    for (unsigned r = threadIdx.x; r < gridDim.x; r += kBlock) stat_merge(f, stat_from(rec + (int64_t)r * kStatRec));
-    f = stat_block_reduce(f, sh);
+    for (unsigned r = threadIdx.x; r < gridDim.x; r += kBlock) {
+        const double *q = rec + (int64_t)r * kStatRec;
+        StatRec g = stat_empty();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { g.s[k] = q[k]; g.mn[k] = q[3 + k]; g.mx[k] = q[6 + k]; }
+        g.best.d = q[9]; g.best.i = q[10];
+        if (STD) {
+            g.cnt = q[11];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { g.mu[k] = q[12 + k]; g.m2[k] = q[15 + k]; }
+        }
+        stat_merge<STD>(f, g);
+    }
+    f = stat_block_reduce<STD>(f, sh);
     if (threadIdx.x != 0) return;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double x = 0, y = 0, z = 0;
@@ -1051,11 +1117,18 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
     }
     stats[15] = x; stats[16] = y; stats[17] = z;
     stats[18] = f.best.i >= 0.0 ? map.global_index(f.best.i) : -1.0;
-    stats[19] = f.best.i >= 0.0 ? f.best.d : inf;
+    if (STD) {
+        const double sa = sqrt(f.m2[0] / num), sb = sqrt(f.m2[1] / num), sc = sqrt(f.m2[2] / num);
+        stats[3] = sa; stats[4] = sb; stats[5] = sc;
+        stats[19] = sqrt(dot3(sa, sb, sc, sa, sb, sc));      // |std()|  (InnerSpace::magnitude)
+    } else {
+        stats[19] = f.best.i >= 0.0 ? f.best.d : inf;
+    }
 }
 
-// pass 2: sums of squared deviations from mean3.  RAW: leave the three sums in out[0..2] (a shard's share; the ranks'
-// sums are all-reduced and finished on the host) instead of finishing std in out[3..5] and |std| in out[19].
+// pass 2 (sharded statistics only since r03): sums of squared deviations from mean3.  RAW: leave the three sums in
+// out[0..2] (a shard's share; the ranks' sums are gathered and finished on the host) instead of finishing std in
+// out[3..5] and |std| in out[19].
 template <typename Src, bool RAW>
 __global__ __launch_bounds__(kBlock) void k_stats_pass2(Src src, int64_t n, const double *__restrict__ mean3,
                                                        double *__restrict__ rec, unsigned *__restrict__ ticket,

@@ -88,8 +88,9 @@ def test_two_ranks_on_one_gpu_exit_cleanly_and_agree(plain):
 
 def test_comm_through_the_c_abi_at_world_size_one():
     """c2b_comm_* directly (what a Rust host binds): RCCL loads, a one-rank communicator all-reduces / all-gathers the
-    identity, the sharded statistics through it equal c2b_stats bit for bit, and the Level-1 sharded error equals the
-    unsharded one."""
+    identity, the sharded statistics through it equal c2b_stats (mean / min / max / origin bit for bit; std to rounding:
+    the unsharded call merges Chan triples in one pass, the sharded one sums squared deviations in a second pass), and
+    the Level-1 sharded error equals the unsharded one."""
     import numpy as np
     import torch
     import __graft_entry__ as entry
@@ -120,7 +121,9 @@ def test_comm_through_the_c_abi_at_world_size_one():
     ws = D.workspace(len(P["pt_idx"]), dev)
     st_plain = D.stats(camblk, pts4, ws).cpu().numpy()
     st_comm = c.stats_sharded(camblk, 0, 300, pts4, ws).cpu().numpy()
-    assert np.array_equal(st_plain, st_comm), (st_plain, st_comm)
+    exact = [0, 1, 2] + list(range(6, 19))
+    assert np.array_equal(st_plain[exact], st_comm[exact]), (st_plain, st_comm)
+    assert np.allclose(st_plain[[3, 4, 5, 19]], st_comm[[3, 4, 5, 19]], rtol=1e-13, atol=0.0), (st_plain, st_comm)
 
     ba = c2b.BAProblem.from_visibility(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], device=0)
     e = C.c_double(0.0)
