@@ -49,8 +49,16 @@ def parse():
                          "(c2b_comm_*; what a Rust host would call), torch = torch.distributed; auto = c2b over real "
                          "per-rank GPUs (nccl backend), torch in the shared-GPU gloo rehearsal")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay the step (kernel + all-reduce) from a HIP graph: auto = when N > 1 (one graph launch "
-                         "instead of a kernel launch and a collective enqueue per step)")
+                    help="replay the step (kernel + all-reduce) from a HIP graph (one graph launch instead of a kernel "
+                         "launch and a collective enqueue per step).  auto = off: measured at world size 1 on a rank's "
+                         "eighth of the problem the graph is 5 us per step SLOWER than eager launches with the C-ABI "
+                         "collective (100.2 vs 95.0 us, profiles/r03h_ab_step.txt); kept as an option")
+    ap.add_argument("--overlap", choices=("auto", "on", "off"), default="auto",
+                    help="N > 1: run the all-reduce of step k on its own stream so that it overlaps the kernel of step "
+                         "k + 1 (every step's scalar has its own slot; all collectives complete inside the timed "
+                         "region).  auto = off: at world size 1 the hand-off costs 5-8 us per step more than the in-line "
+                         "collective does (100.5 vs 95.0 us, profiles/r03h_ab_step.txt); whether it pays at N = 8, where the "
+                         "collective has a real latency to hide, can only be measured there")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group, balanced split, all-reduce) even with one rank: "
                          "how tests exercise the RCCL backend on a 1-GPU box")
@@ -518,22 +526,56 @@ def main():
                 if comm is not None:
                     comm.destroy()
                 comm, collective_note = None, "c2b communicator unavailable (%s): fell back to torch.distributed" % (why or "another rank failed")
-        collective = ("c2b_comm_all_reduce_sum_f64 (%s), 1 x f64 per step, same stream as the kernel" % Comm.backend()) if comm is not None \
-            else "%s all_reduce(sum, 1 x f64) per step via torch.distributed, same stream as the kernel" % backend
+        collective = ("c2b_comm_all_reduce_sum_f64 (%s), 1 x f64 per step" % Comm.backend()) if comm is not None \
+            else "%s all_reduce(sum, 1 x f64) per step via torch.distributed" % backend
 
-    def all_reduce():
+    def all_reduce(t=None):
+        t = err if t is None else t
         if comm is not None:
-            comm.all_reduce_sum_(err)
+            comm.all_reduce_sum_(t)
         else:
-            Dist.all_reduce_sum_(err)
+            Dist.all_reduce_sum_(t)
+
+    # N > 1.  The step is a ~90 us kernel (a rank's eighth of the problem) plus an 8-byte all-reduce whose cost is pure
+    # latency (tens of microseconds across 8 GPUs).  The steps are independent passes, so the collective of step k runs
+    # on its own stream next to the kernel of step k + 1: one event hand-off per step (kernel done -> collective may
+    # start), every step's scalar in its own slot so that nothing is ever waited for in the other direction, and every
+    # collective completes inside the timed region (the final synchronize covers both streams).  Round 1's side-stream
+    # arrangement lost (117 vs 96 us per step) because it double-buffered ONE scalar and paid three hand-offs per step.
+    overlap = dist_on and args.overlap == "on" and args.graph != "on"
+    comm_stream = torch.cuda.Stream(device=dev) if overlap else None
+    n_slots = args.steps + max(args.warmup, 1) + 64
+    err_ring = torch.zeros(n_slots if overlap else 1, dtype=torch.float64, device=dev)
+    handoff = [torch.cuda.Event() for _ in range(n_slots)] if overlap else None
+    slot = [0]
 
     def step(ev=None):
+        if overlap:
+            k = slot[0] % n_slots
+            slot[0] += 1
+            e = err_ring[k:k + 1]
+            if ev is not None:
+                ev[0].record()
+            D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, e)
+            if ev is not None:
+                ev[1].record()
+            handoff[k].record()
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(handoff[k])
+                if ev is not None:
+                    ev[3].record()
+                all_reduce(e)
+                if ev is not None:
+                    ev[2].record()
+            return
         if ev is not None:
             ev[0].record()
         D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
         if ev is not None:
             ev[1].record()
         if dist_on:
+            if ev is not None:
+                ev[3].record()
             all_reduce()
             if ev is not None:
                 ev[2].record()                       # after the collective
@@ -547,7 +589,11 @@ def main():
     # in-launch fold is replay-safe (its counters live in `ws` and every fold leaves them zero); RCCL collectives are
     # capturable.  If capture fails on ANY rank every rank runs eagerly (decision all-reduced).
     graph, graph_note = None, None
-    use_graph = args.graph == "on" or (args.graph == "auto" and dist_on and backend == "nccl")
+    use_graph = args.graph == "on"
+    # the collective rides in the graph when it is enqueued on the stream (RCCL, through the C ABI or torch); the gloo
+    # rehearsal stages its scalar through the host, so there only the kernel is captured and the all-reduce follows
+    # every replay eagerly
+    collective_in_graph = dist_on and (comm is not None or backend == "nccl")
     if use_graph:
         ok = 1
         try:
@@ -556,7 +602,10 @@ def main():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(g, stream=side):
-                    step()
+                    if collective_in_graph or not dist_on:
+                        step()
+                    else:
+                        D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
             torch.cuda.synchronize()
             graph = g
         except Exception as exc:                                      # noqa: BLE001
@@ -571,6 +620,8 @@ def main():
         if graph is not None:
             for _ in range(2):
                 graph.replay()
+                if dist_on and not collective_in_graph:
+                    all_reduce()
             torch.cuda.synchronize()
 
     if dist_on:
@@ -578,13 +629,23 @@ def main():
     torch.cuda.synchronize()
     events = None
     if rank == 0:                                   # per-kernel HIP events only where the roofline is reported
-        events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+        events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
+    # N > 1: no event records inside the timed loop.  A step there is ~90 us, and three event records per step cost
+    # ~13 us of it (measured at world size 1 on a rank's eighth of the problem: 102 -> 86 us per step without them;
+    # with the collective on a second stream they stall the kernel stream outright: 590 us per step).  The kernel /
+    # collective split of the N-rank step is measured right after the timed region instead, on the same buffers.
+    # N = 1 keeps its two records around the 700 us kernel: the roofline's kernel time is measured live in the region.
+    no_events = dist_on
+    if no_events:
+        events = None
     t0 = time.perf_counter()
     if graph is not None:
         for k in range(args.steps):
             if events is not None:
                 events[k][0].record()
             graph.replay()
+            if dist_on and not collective_in_graph:
+                all_reduce()
             if events is not None:
                 events[k][2].record()
     else:
@@ -599,19 +660,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # The kernel / collective split of the step when the timed loop carried no (or only outer) event records: a short
+    # instrumented pass right after the timed region, on the same buffers.  EVERY rank takes part (the step holds a
+    # collective); only rank 0 records.
     graph_step_us = None
-    if graph is not None:
-        # Events cannot be recorded inside a replayed graph, so the kernel / collective split of a step is measured
-        # right after the timed region on the same buffers, eagerly (every rank takes part: the step holds a collective).
-        if events is not None:
-            graph_step_us = sum(ev[0].elapsed_time(ev[2]) for ev in events) / len(events) * 1e3
-            events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(min(args.steps, 20))]
-        for k in range(min(args.steps, 20)):
+    if graph is not None and events is not None:
+        graph_step_us = sum(ev[0].elapsed_time(ev[2]) for ev in events) / len(events) * 1e3
+    if dist_on or graph is not None:
+        post = min(args.steps, 20)
+        events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(post)] if rank == 0 else None
+        for k in range(post):
             step(events[k] if events is not None else None)
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
-    total_err = Dist.finish_error(err.item(), 2.0)
+    total_err = Dist.finish_error((err_ring[(slot[0] - 1) % n_slots] if overlap else err).item(), 2.0)
     per_rank_obs = [n]
     if dist_on:
         per_rank_obs = [None] * world
@@ -622,9 +685,12 @@ def main():
         step_us = elapsed / args.steps * 1e6
         step_breakdown = {"kernel_us_rank0": round(sum(kern_ms) / len(kern_ms) * 1e3, 2)}
         if dist_on:
-            ar_us = sum(ev[1].elapsed_time(ev[2]) for ev in events) / len(events) * 1e3
+            ar_us = sum(ev[3].elapsed_time(ev[2]) for ev in events) / len(events) * 1e3
             step_breakdown["allreduce_us"] = round(ar_us, 2)
-            step_breakdown["step_overhead_us"] = round(step_us - step_breakdown["kernel_us_rank0"] - ar_us, 2)
+            # overlapped: the collective is off the kernel stream's critical path, so what a step costs beyond its kernel
+            # is launch gaps, the hand-off and waiting for the slowest rank; in line: kernel + collective + the rest
+            step_breakdown["step_overhead_us"] = round(step_us - step_breakdown["kernel_us_rank0"] - (0.0 if overlap else ar_us), 2)
+            step_breakdown["allreduce_overlaps_next_kernel"] = bool(overlap)
         else:
             step_breakdown["step_overhead_us"] = round(step_us - step_breakdown["kernel_us_rank0"], 2)
         kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
@@ -653,11 +719,12 @@ def main():
                 "camera_bounds": [int(x) for x in bounds] if bounds is not None else [0, sh["n_cam"]],
                 "total_L2_error": total_err,
                 "collective": collective, "collective_note": collective_note,
-                "hip_graph": ("one graph launch per step (kernel + all-reduce captured); step on the GPU %.2f us"
-                              % graph_step_us) if graph is not None else (graph_note or False),
-                "kernel_time_source": "HIP events around the launch inside the timed region" if graph is None else
-                                      "HIP events around %d eager steps right after the timed region (a replayed graph "
-                                      "takes no event records)" % min(args.steps, 20),
+                "hip_graph": ("one graph launch per step (%s captured)" % ("kernel + all-reduce" if collective_in_graph else "kernel")
+                              + ("; step on the GPU %.2f us" % graph_step_us if graph_step_us else ""))
+                if graph is not None else (graph_note or False),
+                "kernel_time_source": "HIP events around the launch inside the timed region" if not dist_on else
+                                      "HIP events around %d instrumented steps right after the timed region (event records "
+                                      "inside a ~90 us step would cost ~13 us of it)" % min(args.steps, 20),
                 # where rank 0's step goes (HIP events around the kernel and around the collective; the rest of the
                 # wall-clock step is launch gaps, host dispatch and waiting for the slowest rank)
                 **step_breakdown,
@@ -695,7 +762,7 @@ def main():
             cold = []
             for _ in range(5):
                 sweep.sum()
-                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
                 step(ev)                                     # events 0 -> 1 bracket the kernel, not the all-reduce
                 torch.cuda.synchronize()
                 cold.append(ev[0].elapsed_time(ev[1]))

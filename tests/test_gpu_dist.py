@@ -42,13 +42,15 @@ def plain():
     return out
 
 
-@pytest.mark.parametrize("collective,graph", [("auto", "auto"), ("c2b", "off"), ("torch", "on"), ("torch", "off")])
-def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph):
-    """the multi-rank step as the driver's N-GPU run takes it (auto = RCCL through the C ABI, replayed from a HIP graph)
-    and its three other combinations: same reduced scalar, bit for bit, as the run without any collective"""
+@pytest.mark.parametrize("collective,graph,overlap", [("auto", "auto", "auto"), ("c2b", "off", "off"), ("c2b", "on", "off"),
+                                                      ("torch", "on", "off"), ("torch", "off", "on")])
+def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph, overlap):
+    """the multi-rank step as the driver's N-GPU run takes it (auto = RCCL through the C ABI, in line behind the kernel,
+    eager launches) and four other combinations of who issues the collective, HIP-graph replay and overlap: same
+    reduced scalar, bit for bit, as the run without any collective"""
     env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
     rc, out, err = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--collective", collective,
-                         "--graph", graph] + COMMON, env)
+                         "--graph", graph, "--overlap", overlap] + COMMON, env)
     assert rc == 0 and out is not None, err[-2000:]
     assert "Traceback" not in err, err[-2000:]
     cfg = out["config"]
@@ -57,10 +59,11 @@ def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph):
         assert cfg["collective"].startswith("c2b_comm_all_reduce_sum_f64 (RCCL "), cfg["collective"]
     else:
         assert cfg["collective"].startswith("nccl all_reduce"), cfg["collective"]
-    if graph in ("auto", "on"):
+    if graph == "on":
         assert isinstance(cfg["hip_graph"], str) and cfg["hip_graph"].startswith("one graph launch per step"), cfg["hip_graph"]
     else:
         assert cfg["hip_graph"] is False
+    assert cfg["allreduce_overlaps_next_kernel"] is (overlap == "on" and graph != "on")      # auto = in line (A/B'd)
     assert cfg["allreduce_us"] > 0 and cfg["kernel_us_rank0"] > 0
     assert out["config"]["n_observations"] == plain["config"]["n_observations"]
     assert out["config"]["observations_per_rank"] == [plain["config"]["n_observations"]]
