@@ -137,3 +137,48 @@ def test_comm_through_the_c_abi_at_world_size_one():
     h = C.c_void_p()
     assert L.lib().c2b_comm_init_rank(C.create_string_buffer(128), 3, 2, 0, C.byref(h)) == L.ERR_INVALID_ARGUMENT
     c.destroy()
+
+
+def test_run_noise_flow_through_the_c_abi_matches_the_checker():
+    """INTEGRATION.md's multi-GPU run_noise (src/bin/city2ba.rs:280-357: add_drift_normalized -> add_noise -> error) as a
+    rank would run it -- statistics, drift, noise and the error all through Level 0 + the C-ABI communicator, world
+    size 1 -- against the CPU restatement's chain with the same seeds."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as entry
+    entry.build()
+    import oracle as O
+    from city2ba_amd import comm as Comm
+    from city2ba_amd import device as D
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _problems import random_problem
+
+    dev = torch.device("cuda", 0)
+    P = random_problem(260, 3000, 14, seed=314, noise=0.0)
+    n_cam = len(P["cams15"])
+    c = Comm.Comm(Comm.unique_id(), 0, 1, 0)
+    cam15 = torch.from_numpy(P["cams15"]).to(dev)
+    pts4 = D.points_pad(torch.from_numpy(P["pts"]).to(dev))
+    uv = torch.from_numpy(P["uv"]).to(dev)
+    rows = D.Rows(torch.from_numpy(P["row_ptr"].astype(np.int64)).to(dev))
+    pt_idx = torch.from_numpy(P["pt_idx"].astype(np.int64).astype(np.int32)).to(dev)
+    ws = D.workspace(rows.n_obs, dev)
+
+    st = c.stats_sharded(D.cameras_prepare_state(cam15), 0, n_cam, pts4, ws)
+    D.add_drift_sharded(cam15, 0, pts4, st, 0.05, 0.02, 0.1, 7)                     # normalized (direction None)
+    st = c.stats_sharded(D.cameras_prepare_state(cam15), 0, n_cam, pts4, ws)
+    D.add_noise_entities_sharded(cam15, 0, pts4, st, 0.05, 0.02, 0.03, 8)
+    D.add_noise_observations(uv, 0, 0.01, 8)
+    total = torch.zeros(1, dtype=torch.float64, device=dev)
+    D.reprojection_error_sum_rows(D.cameras_prepare_state(cam15), pts4, rows, pt_idx, uv, 2.0, ws, total)
+    c.all_reduce_sum_(total)
+    got = float(total.item()) ** 0.5
+
+    c0, p0 = O.add_drift_normalized(P["cams15"], P["pts"], 0.05, 0.02, 0.1, seed=7)
+    c0, p0, uv0 = O.add_noise(c0, p0, P["uv"], 0.05, 0.02, 0.03, 0.01, seed=8)
+    want = O.total_reprojection_error(c0, p0, P["row_ptr"], P["pt_idx"], uv0, 2.0)
+    assert np.max(np.abs(cam15.cpu().numpy() - c0)) < 1e-7
+    assert np.max(np.abs(pts4[:, :3].cpu().numpy() - p0)) < 1e-7
+    assert np.max(np.abs(uv.cpu().numpy() - uv0)) < 1e-9
+    assert abs(got - want) / want < 1e-7
+    c.destroy()
