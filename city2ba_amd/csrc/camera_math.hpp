@@ -295,12 +295,13 @@ C2B_DEV double abs_pow(double x, double norm) {
 // The same with the norm fixed at compile time (the launchers dispatch on the host-side value): kernels for the
 // reference's two norms carry no pow() code at all.  NORM_ANY = any other exponent.
 enum { NORM_ANY = 0, NORM_1 = 1, NORM_2 = 2 };
+C2B_DEV double pow_lean(double a, double y);      // below, with the other lean transcendentals
 template <int NK>
 C2B_DEV double abs_pow_k(double x, double norm) {
     const double a = fabs(x);
     if (NK == NORM_2) return a * a;
     if (NK == NORM_1) return a;
-    return pow(a, norm);
+    return pow_lean(a, norm);
 }
 
 // ---- Philox4x32-10 + Box-Muller (build-defined draw scheme) -------------
@@ -323,23 +324,7 @@ C2B_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot,
-                         double &z0, double &z1) {
-    uint32_t o[4];
-    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), slot, stream, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), o);
-    const uint64_t a = ((uint64_t)o[1] << 32) | o[0];
-    const uint64_t b = ((uint64_t)o[3] << 32) | o[2];
-    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   // (0,1]
-    const double u2 = (double)(b >> 11) * 0x1.0p-53;         // [0,1)
-    const double rad = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincos(6.283185307179586476925286766559 * u2, &s, &c);
-    z0 = rad * c;
-    z1 = rad * s;
-}
-
-// ---- lean transcendentals for the observation-noise kernel ---------------------------------------------------
+// ---- lean transcendentals for the noise draws ---------------------------------------------------------------------
 // k_add_noise_observations is bound by vector issue (SQ counters, profiles/r03d: ACTIVE_INST_VALU 85 % of the SIMDs'
 // cycles, 287 vector instructions per wave of 64 observations), and half of those instructions were the library's
 // log / sincospi / cospi, which carry double-double arithmetic and argument handling this kernel has no use for: its
@@ -348,7 +333,7 @@ C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32
 // those domains, with explicit FMAs.  tests/test_gpu_parity.py pins them against libm to 1e-13 (the draws' tolerance
 // is 1e-9).
 
-// ln(x) for a normal x in (0, 1]
+// ln(x) for a normal x > 0 (the noise draws call it on (0, 1], pow_lean on any finite positive number)
 C2B_DEV double log_unit(double x) {
     int e = __builtin_amdgcn_frexp_exp(x);                   // x = m * 2^e, m in [0.5, 1)
     double m = __builtin_amdgcn_frexp_mant(x);
@@ -366,6 +351,35 @@ C2B_DEV double log_unit(double x) {
     const double R = t2 + t1, hfsq = 0.5 * f * f, de = (double)e;
     return fma(de, 6.93147180369123816490e-01, -((hfsq - fma(q, hfsq + R, de * 1.90821492927058770002e-10)) - f));
 }
+
+// exp(x), fdlibm e_exp.c: k = nearest integer to x / ln 2, r = x - k ln 2 in two pieces, a degree-5 polynomial in r^2,
+// scaled by 2^k (v_ldexp_f64 saturates to 0 / inf by itself)
+C2B_DEV double exp_lean(double x) {
+    const double kf = rint(x * 1.44269504088896338700e+00);
+    const double hi = fma(-kf, 6.93147180369123816490e-01, x), lo = kf * 1.90821492927058770002e-10;
+    const double r = hi - lo, t = r * r;
+    const double c = r - t * fma(t, fma(t, fma(t, fma(t, 4.13813679705723846039e-08, -1.65339022054652515390e-06),
+                                                6.61375632143793436117e-05), -2.77777777770155933842e-03), 1.66666666666666019037e-01);
+    const double d = 2.0 - c;
+    double q = __builtin_amdgcn_rcp(d);
+    q = fma(fma(-d, q, 1.0), q, q);
+    q = fma(fma(-d, q, 1.0), q, q);
+    const double y = 1.0 - ((lo - (r * c) * q) - hi);
+    return ldexp(y, (int)kf);
+}
+
+// a^y for the error norms other than 1 and 2 (|residual|^norm, src/baproblem.rs:273-276): exp(y ln a) through the two
+// kernels above for finite a > 0 -- relative error ~ |y ln a| ulps (1e-14 at |y ln a| = 45), against a sum compared at
+// 1e-12 --, the library's pow for everything else (0, inf, NaN, subnormal results; a branch no sane residual takes).
+// The library's pow made the NORM_ANY error kernel 2.7 times slower than its L1 / L2 instances (r02: 0.22 of the peak).
+C2B_DEV double pow_lean(double a, double y) {
+    const double l = y * log_unit(a);
+    if (!(a > 0x1.0p-1000 && a < 0x1.0p+1000) || !(l > -600.0 && l < 600.0)) return pow(a, y);
+    return exp_lean(l);
+}
+
+C2B_DEV double pow_t(double a, double y) { return pow_lean(a, y); }      // add_drift's distance^1.2 (src/noise.rs:104)
+C2B_DEV float pow_t(float a, float y) { return powf(a, y); }
 
 // sin and cos of x in [-pi/4, pi/4] (fdlibm __kernel_sin / __kernel_cos without the tail argument)
 C2B_DEV void sincos_kernel(double x, double &sn, double &cs) {
@@ -396,6 +410,39 @@ C2B_DEV double cos_turns32(uint32_t w) {
     double s, c;
     sincos_turns32(w, s, c);
     return c;
+}
+
+// (sin, cos) of 2 pi u for u in [0, 1) given as a double (a 53-bit fraction of a turn): 4u, its nearest integer and the
+// remainder are all exact in double arithmetic, so the reduction to [-pi/4, pi/4] costs one rounding (the product with
+// pi/2), like sincos_turns32
+C2B_DEV void sincos_turns(double u, double &sn, double &cs) {
+    const double t = 4.0 * u, kf = rint(t);
+    const int k = (int)kf;                                            // 0 .. 4
+    double s, c;
+    sincos_kernel((t - kf) * 1.57079632679489661923, s, c);
+    const bool swap = (k & 1) != 0;
+    const double a = swap ? s : c, b = swap ? c : s;
+    cs = ((k + 1) & 2) ? -a : a;
+    sn = (k & 2) ? -b : b;
+}
+
+// two independent N(0, 1) for (seed; stream, entity, slot): Philox4x32-10 block -> u1 in (0, 1], u2 in [0, 1) ->
+// Box-Muller.  Same draws as rounds 1-2; since r03 through the lean log / sincos above (the library's carried
+// double-double arithmetic and argument handling these domains do not need; agreement with libm ~1e-15).
+C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot,
+                         double &z0, double &z1) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), slot, stream, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), o);
+    const uint64_t a = ((uint64_t)o[1] << 32) | o[0];
+    const uint64_t b = ((uint64_t)o[3] << 32) | o[2];
+    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   // (0,1]
+    const double u2 = (double)(b >> 11) * 0x1.0p-53;         // [0,1)
+    const double rad = sqrt(-2.0 * log_unit(u1));
+    double s, c;
+    sincos_turns(u2, s, c);
+    z0 = rad * c;
+    z1 = rad * s;
 }
 
 // add_noise's observation draw (src/noise.rs:152-170: a uniformly distributed unit 2-vector times Normal(0, std)) from

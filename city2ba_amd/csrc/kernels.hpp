@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(T *__restrict__ cam15, int
         normal_pair(seed, kStreamDriftCam, (uint64_t)(cam_base + i), 0, z0, z1);     // draws keyed by the GLOBAL camera index
         const T va = (T)(1.0 + std_d * z0);             // angle draw first (src/noise.rs:104-107)
         const T vt = (T)(1.0 + std_d * z1);
-        const T angle = angle_strength * va * pow(distance, (T)1.2);
+        const T angle = angle_strength * va * pow_t(distance, (T)1.2);
         T sn, cs;
         sincos_t(angle, &sn, &cs);
         dR[0] = 1; dR[1] = 0; dR[2] = 0; dR[3] = 0; dR[4] = cs; dR[5] = sn; dR[6] = 0; dR[7] = -sn; dR[8] = cs;

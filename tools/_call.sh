@@ -1,5 +1,8 @@
-mkdir -p gpurun_out/r03h
-(time python -m pytest tests/test_gpu_dist.py -m gpu -q) > gpurun_out/r03h/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r03h/pytest.log
-bash tools/ab_step.sh 45 > gpurun_out/r03h/ab_step_b45.txt 2>&1; cat gpurun_out/r03h/ab_step_b45.txt
-for n in 2 8; do bash tools/rehearse_n.sh $n 32 off; done > gpurun_out/r03h/rehearse.txt 2>&1; cat gpurun_out/r03h/rehearse.txt
-bash tools/rehearse_n.sh 4 32 on >> gpurun_out/r03h/rehearse.txt 2>&1; tail -3 gpurun_out/r03h/rehearse.txt
+mkdir -p gpurun_out/r03m
+(time python -m pytest tests -m gpu -q) > gpurun_out/r03m/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r03m/pytest.log
+python tools/bench_kernels.py > gpurun_out/r03m/per_kernel.json 2> gpurun_out/r03m/per_kernel.err; echo "kernels rc=$?"
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r03m/per_kernel.json'))
+for k,v in d['kernels'].items(): print("%-62s %8.1f us  frac %.3f"%(k,v['us'],v['frac_hbm_peak']))
+PY
