@@ -29,6 +29,7 @@ ap.add_argument("--variants", default="308,20308")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="", help="time only the modes whose name contains this")
+ap.add_argument("--cold", action="store_true", help="also time every mode with the caches swept by a 1-GiB read before each launch")
 ap.add_argument("--place", action="store_true", help="place the Jacobian outputs by measured store rate, as bench.py does")
 a = ap.parse_args()
 variants = [int(v) for v in a.variants.split(",")]
@@ -138,6 +139,20 @@ for _ in range(a.rounds):
         e.record()
         torch.cuda.synchronize()
         times[m].append(s.elapsed_time(e) / a.reps * 1e3)
+cold = {m: [] for m in modes}
+if a.cold:
+    sweep = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
+    for _ in range(max(a.rounds, 7)):
+        for m, (kind, fn) in modes.items():
+            sweep.sum()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            cold[m].append(s.elapsed_time(e) * 1e3)
 for m in modes:
     t = sorted(times[m])
-    print("%-58s: median %7.1f us  min %7.1f us  %6.1f Gobs/s" % (m, t[len(t) // 2], t[0], n / t[len(t) // 2] / 1e3))
+    c = sorted(cold[m])
+    print("%-58s: median %7.1f us  min %7.1f us  %6.1f Gobs/s%s" % (m, t[len(t) // 2], t[0], n / t[len(t) // 2] / 1e3,
+                                                                  ("   cold median %7.1f us" % c[len(c) // 2]) if c else ""))
