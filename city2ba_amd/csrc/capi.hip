@@ -721,8 +721,11 @@ int c2b_rows_pack(const uint64_t *row_ptr, int64_t n_cam, int64_t n_obs, void *t
     if (rc) return rc;
     if (!n_obs) return C2B_OK;
     const int64_t n_tiles = (n_obs + 63) / 64;
-    hipLaunchKernelGGL(k_rows_pack, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, S(stream), row_ptr, (int)n_cam, (int)n_obs,
+    hipStream_t st = S(stream);
+    hipLaunchKernelGGL(k_rows_pack_tiles, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, row_ptr, (int)n_cam, (int)n_obs,
                        reinterpret_cast<uint4 *>(tiles));
+    hipLaunchKernelGGL(k_rows_pack_marks, dim3((unsigned)((n_cam + 255) / 256)), dim3(256), 0, st, row_ptr, (int)n_cam, (int)n_obs,
+                       reinterpret_cast<uint32_t *>(tiles));
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("rows_pack")

@@ -255,20 +255,28 @@ C2B_DEV uint32_t csr_search(const uint64_t *__restrict__ row_ptr, int n_cam, uin
 // The row structure as the per-observation kernels read it (k_observations<..., CSR = true>): one 16-byte record per
 // 64 observations = { mask of the lanes whose observation opens a new camera's list (bit 0 unused), the camera of the
 // tile's first observation, 0 }.  Bit 31 of the camera marks a tile with an EMPTY list inside it (two boundaries on
-// one observation cannot be one mask bit); the kernels search row_ptr for those.  One wave per tile.
-__global__ __launch_bounds__(256) void k_rows_pack(const uint64_t *__restrict__ row_ptr, int n_cam, int n,
-                                                   uint4 *__restrict__ tiles) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if ((int64_t)tile * 64 >= n) return;                                 // wave-uniform
-    const int o = tile * 64 + lane;
-    const bool valid = o < n;
-    const uint32_t c = csr_search(row_ptr, n_cam, (uint64_t)(valid ? o : n - 1));
-    const uint32_t prev = __shfl_up(c, 1, 64);
-    const bool inner = valid && lane > 0;
-    const uint64_t first = __builtin_amdgcn_ballot_w64(inner && c != prev);
-    const uint64_t gap = __builtin_amdgcn_ballot_w64(inner && c - prev > 1u);
-    if (lane == 0) tiles[tile] = make_uint4((uint32_t)first, (uint32_t)(first >> 32), c | (gap ? 0x80000000u : 0u), 0u);
+// one observation cannot be one mask bit); the kernels search row_ptr for those.
+// Two launches (r03; one wave per tile with a binary search PER OBSERVATION took 218 us at 19.3 M observations):
+// k_rows_pack_tiles -- one thread per tile: the camera of its first observation (the only search), mask cleared;
+// k_rows_pack_marks -- one thread per camera: its list's first observation sets its lane's bit in its tile (unless that
+// is lane 0, whose camera the record already names), and flags the tile if the list before it is empty (then the step
+// from the previous observation's camera is larger than one, which the mask cannot say).
+__global__ __launch_bounds__(256) void k_rows_pack_tiles(const uint64_t *__restrict__ row_ptr, int n_cam, int n,
+                                                         uint4 *__restrict__ tiles) {
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)tile * 64 >= n) return;
+    tiles[tile] = make_uint4(0u, 0u, csr_search(row_ptr, n_cam, (uint64_t)tile * 64), 0u);
+}
+__global__ __launch_bounds__(256) void k_rows_pack_marks(const uint64_t *__restrict__ row_ptr, int n_cam, int n,
+                                                         uint32_t *__restrict__ tiles) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cam) return;
+    const uint64_t b = row_ptr[c], e = row_ptr[c + 1];
+    if (e <= b || b >= (uint64_t)n || (b & 63u) == 0) return;        // empty list, outside the list, or a tile's first lane
+    uint32_t *rec = tiles + 4 * (b >> 6);
+    const unsigned lane = (unsigned)(b & 63u);
+    atomicOr(rec + (lane >> 5), 1u << (lane & 31u));
+    if (c > 0 && row_ptr[c - 1] == b) atomicOr(rec + 2, 0x80000000u);  // the list before this one is empty
 }
 
 // The cameras of a wave's OPL tiles from the tile records (wave-uniform scalar loads): a lane's camera is the tile's
