@@ -537,11 +537,12 @@ def main():
             Dist.all_reduce_sum_(t)
 
     # N > 1.  The step is a ~90 us kernel (a rank's eighth of the problem) plus an 8-byte all-reduce whose cost is pure
-    # latency (tens of microseconds across 8 GPUs).  The steps are independent passes, so the collective of step k runs
-    # on its own stream next to the kernel of step k + 1: one event hand-off per step (kernel done -> collective may
-    # start), every step's scalar in its own slot so that nothing is ever waited for in the other direction, and every
-    # collective completes inside the timed region (the final synchronize covers both streams).  Round 1's side-stream
-    # arrangement lost (117 vs 96 us per step) because it double-buffered ONE scalar and paid three hand-offs per step.
+    # latency.  Shipped arrangement: the collective in line behind the kernel on the same stream, eager launches.
+    # --overlap on is the alternative that was built and measured: the collective of step k on its own stream next to the
+    # kernel of step k + 1 -- one event hand-off per step (kernel done -> collective may start), every step's scalar in
+    # its own slot so that nothing is ever waited for in the other direction, every collective complete inside the timed
+    # region (the final synchronize covers both streams).  At world size 1 it costs 5-8 us per step more than it saves
+    # (profiles/r03h_ab_step.txt); whether it pays at N = 8 can only be measured there.
     overlap = dist_on and args.overlap == "on" and args.graph != "on"
     comm_stream = torch.cuda.Stream(device=dev) if overlap else None
     n_slots = args.steps + max(args.warmup, 1) + 64
@@ -584,10 +585,10 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    # N > 1: the step is launch-bound on top of a ~90 us kernel (a rank's eighth of the problem), so it is replayed from
-    # a HIP graph -- ONE graph launch per step instead of a kernel launch plus a collective enqueue.  The kernel's
-    # in-launch fold is replay-safe (its counters live in `ws` and every fold leaves them zero); RCCL collectives are
-    # capturable.  If capture fails on ANY rank every rank runs eagerly (decision all-reduced).
+    # --graph on: the step replayed from a HIP graph -- ONE graph launch per step instead of a kernel launch plus a
+    # collective enqueue.  The kernel's in-launch fold is replay-safe (its counters live in `ws` and every fold leaves them
+    # zero); RCCL collectives are capturable.  If capture fails on ANY rank every rank runs eagerly (decision all-reduced).
+    # Not the default: at world size 1 a graph launch costs 5 us per step more than the two eager enqueues it replaces.
     graph, graph_note = None, None
     use_graph = args.graph == "on"
     # the collective rides in the graph when it is enqueued on the stream (RCCL, through the C ABI or torch); the gloo

@@ -132,6 +132,19 @@ def test_comm_through_the_c_abi_at_world_size_one():
     e = C.c_double(0.0)
     L.check(L.lib().c2b_problem_total_reprojection_error_sharded(ba._h, c.handle, 2.0, C.byref(e)))
     assert e.value == ba.total_reprojection_error(2.0)
+    # one process driving its GPUs itself (ctx_create(n_dev, dev_ids)): c2b_comm_init_all over the one device
+    # of this box, the collective bracketed by a group like NCCL asks of one thread issuing for several ranks
+    comms = (C.c_void_p * 1)()
+    ids = (C.c_int * 1)(0)
+    L.check(L.lib().c2b_comm_init_all(1, ids, comms))
+    y = torch.tensor([3.0, -4.5], dtype=torch.float64, device=dev)
+    L.check(L.lib().c2b_comm_group_start())
+    L.check(L.lib().c2b_comm_all_reduce_sum_f64(comms[0], C.c_void_p(y.data_ptr()), 2, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    L.check(L.lib().c2b_comm_group_end())
+    torch.cuda.synchronize()
+    assert y.tolist() == [3.0, -4.5]
+    L.lib().c2b_comm_destroy(comms[0])
+    assert L.lib().c2b_comm_init_all(0, None, comms) == L.ERR_INVALID_ARGUMENT
     # argument checks come back as statuses, never as aborts
     assert L.lib().c2b_comm_all_reduce_sum_f64(None, None, 1, None) == L.ERR_INVALID_ARGUMENT
     h = C.c_void_p()
