@@ -22,7 +22,7 @@ namespace c2b {
 
 constexpr int kBlock = 256;          // lanes per workgroup of the per-entity kernels (4 waves)
 constexpr int kWaves = kBlock / 64;
-constexpr int kRedBlocks = 2048;     // largest grid of the entity reductions (one record per workgroup in the workspace)
+constexpr int kRedBlocks = 512;      // largest grid of the entity reductions (one record per workgroup in the workspace): 2 per CU.  A/B at 2.6 M entities (r03): 256 / 512 / 768 / 1024 / 2048 / 4096 workgroups -> 35 / 37 / 38 / 40 / 49 / 68 us
 constexpr int kStatRec = 20;         // doubles per stats partial record (18 used)
 constexpr int kStatBatch = 4;        // entities a thread of the statistics passes loads before it uses any
 
@@ -974,21 +974,35 @@ C2B_DEV void stat_merge(StatRec &a, const StatRec &b) {
         a.cnt = tot;
     }
 }
-// all 64 lanes -> lane 0 (shuffle tree, fixed order)
+// all 64 lanes -> lane 0 (shuffle tree, fixed order).  Field by field, so that only one partner value is live at a time
+// (materialising the partner's whole record cost 149 VGPRs and two waves per SIMD of occupancy).
 template <bool STD>
 C2B_DEV void stat_wave_reduce(StatRec &r) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        StatRec o;
+    for (int k = 0; k < 3; ++k) { r.s[k] = wave_sum(r.s[k]); r.mn[k] = wave_min(r.mn[k]); r.mx[k] = wave_max(r.mx[k]); }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            o.s[k] = __shfl_down(r.s[k], off, 64); o.mn[k] = __shfl_down(r.mn[k], off, 64); o.mx[k] = __shfl_down(r.mx[k], off, 64);
-            if (STD) { o.mu[k] = __shfl_down(r.mu[k], off, 64); o.m2[k] = __shfl_down(r.m2[k], off, 64); }
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.d = __shfl_down(r.best.d, off, 64);
+        o.i = __shfl_down(r.best.i, off, 64);
+        r.best = best_merge(r.best, o);
+    }
+    if (STD) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {                    // Chan's update, exactly as stat_merge writes it
+            const double ocnt = __shfl_down(r.cnt, off, 64);
+            const double tot = r.cnt + ocnt;
+            const double f = tot > 0.0 ? ocnt / tot : 0.0;
+            const double w = r.cnt * f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double delta = __shfl_down(r.mu[k], off, 64) - r.mu[k];
+                const double om2 = __shfl_down(r.m2[k], off, 64);
+                r.mu[k] = r.mu[k] + delta * f;
+                r.m2[k] = (r.m2[k] + om2) + (delta * delta) * w;
+            }
+            r.cnt = tot;
         }
-        o.best.d = __shfl_down(r.best.d, off, 64);
-        o.best.i = __shfl_down(r.best.i, off, 64);
-        o.cnt = STD ? __shfl_down(r.cnt, off, 64) : 0.0;
-        stat_merge<STD>(r, o);
     }
 }
 C2B_DEV void stat_to_lds(const StatRec &r, double *o) {
