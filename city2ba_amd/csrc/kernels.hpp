@@ -148,53 +148,133 @@ __global__ __launch_bounds__(256) void k_workspace_init(unsigned *__restrict__ t
     for (unsigned i = threadIdx.x; i < kTicketWords; i += 256) ticket[i] = i == kTicketMagicAt ? kTicketMagic : 0u;
 }
 
-// ---- per-camera kernels ---------------------------------------------------------------------
-__global__ void k_cameras_from_bal(const double *__restrict__ bal9, int64_t n, double *__restrict__ cam15) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double *b = bal9 + 9 * i;
-    double R[9];
-    from_rodrigues(b[0], b[1], b[2], R);
-    double *o = cam15 + 15 * i;
+// ---- a wave's 64 consecutive records of an array-of-structures table, through LDS ---------------------------------
+// The per-camera kernels work on one record per lane (cam15: 15 scalars, bal9: 9).  Read or written straight from
+// registers, record field k of 64 lanes is one instruction touching ~60 different 128-byte lines (lane stride 120 B), W
+// instructions per record: ~900 line visits per wave for 60 lines of data.  These helpers move the wave's 64 records
+// between global memory and a wave-private slab with one scalar per lane per instruction -- consecutive addresses, four
+// whole lines per instruction for doubles -- and the lanes then pick their fields out of LDS (stride W scalars: at most
+// two lanes per bank).  n_rows < 64 only in a table's last wave.
+template <int W, typename T>
+C2B_DEV void wave_rows_load(const T *__restrict__ g, int n_rows, T *slab, int lane) {
+    const int total = n_rows * W;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[k] = R[k];
+    for (int it = 0; it < W; ++it) {
+        const int e = it * 64 + lane;
+        if (e < total) slab[e] = g[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int W, typename T>
+C2B_DEV void wave_rows_store(T *__restrict__ g, int n_rows, const T *slab, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int total = n_rows * W;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[9 + k] = b[3 + k];
+    for (int it = 0; it < W; ++it) {
+        const int e = it * 64 + lane;
+        if (e < total) g[e] = slab[e];
+    }
 }
 
-__global__ void k_cameras_to_bal(const double *__restrict__ cam15, int64_t n, double *__restrict__ bal9) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// ---- per-camera kernels ---------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cameras_from_bal(const double *__restrict__ bal9, int64_t n, double *__restrict__ cam15) {
+    __shared__ double sRows[kWaves][64 * 15];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+    if (wave0 >= n) return;                                              // wave-uniform; no workgroup barrier below
+    const int n_rows = n - wave0 < 64 ? (int)(n - wave0) : 64;
+    double *slab = sRows[wave];
+    const int64_t ic = wave0 + (lane < n_rows ? lane : n_rows - 1);
+    double b[9], R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) b[k] = bal9[9 * ic + k];               // strided reads re-use their lines in L1
+    from_rodrigues(b[0], b[1], b[2], R);
+    if (lane < n_rows) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) slab[15 * lane + k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) slab[15 * lane + 9 + k] = b[3 + k];
+    }
+    wave_rows_store<15>(cam15 + 15 * wave0, n_rows, slab, lane);
+}
+
+__global__ __launch_bounds__(kBlock) void k_cameras_to_bal(const double *__restrict__ cam15, int64_t n, double *__restrict__ bal9) {
+    __shared__ double sRows[kWaves][64 * 9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+    if (wave0 >= n) return;                                              // wave-uniform
+    const int n_rows = n - wave0 < 64 ? (int)(n - wave0) : 64;
+    double *slab = sRows[wave];
+    const int64_t ic = wave0 + (lane < n_rows ? lane : n_rows - 1);
     double c[15], w[3];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+    for (int k = 0; k < 15; ++k) c[k] = cam15[15 * ic + k];            // strided reads re-use their lines in L1 (A/B: no gain from LDS)
     to_rodrigues(c, w);
-    double *o = bal9 + 9 * i;
-    o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+    if (lane < n_rows) {
+        slab[9 * lane] = w[0]; slab[9 * lane + 1] = w[1]; slab[9 * lane + 2] = w[2];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[3 + k] = c[9 + k];
+        for (int k = 0; k < 6; ++k) slab[9 * lane + 3 + k] = c[9 + k];
+    }
+    wave_rows_store<9>(bal9 + 9 * wave0, n_rows, slab, lane);
 }
 
+// One camera per lane.  The 256-byte records leave through a wave-private LDS slab (two half-wave rounds of 32 records,
+// lane stride 33 doubles so that the 8-byte LDS writes spread over the banks) as 16-byte-per-lane stores of whole
+// lines: written straight from registers every one of the 32 store instructions touched 64 different lines (lane stride
+// 256 B) -- 2 048 line visits per wave for 128 lines of output (59 us for 660 480 cameras, r02).
 template <bool FROM_BAL>
-__global__ void k_cameras_prepare(const double *__restrict__ in, int64_t n, double *__restrict__ camblk) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(kBlock) void k_cameras_prepare(const double *__restrict__ in, int64_t n, double *__restrict__ camblk) {
+    constexpr int kStride = kCamBlk + 1;                                 // doubles per staged record
+    __shared__ __attribute__((aligned(16))) double sOut[kWaves][32 * kStride + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;  // this wave's first camera
+    if (wave0 >= n) return;                                              // wave-uniform; no workgroup barrier below
+    const int64_t i = wave0 + lane;
+    const bool valid = i < n;
+    const int64_t ic = valid ? i : n - 1;                                // lanes past the end recompute the last camera
     double c[15], w[3], blk[kCamBlk];
-    if (FROM_BAL) {
-        const double *b = in + 9 * i;
-        w[0] = b[0]; w[1] = b[1]; w[2] = b[2];
-        from_rodrigues(w[0], w[1], w[2], c);
+    double *slab = sOut[wave];
+    const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
+    constexpr int W = FROM_BAL ? 9 : 15;
+    {
+        const double *b = in + W * ic;                                   // strided reads re-use their lines in L1
+        if (FROM_BAL) {
+            w[0] = b[0]; w[1] = b[1]; w[2] = b[2];
+            from_rodrigues(w[0], w[1], w[2], c);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c[9 + k] = b[3 + k];
-    } else {
+            for (int k = 0; k < 6; ++k) c[9 + k] = b[3 + k];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 15; ++k) c[k] = in[15 * i + k];
-        to_rodrigues(c, w);
+            for (int k = 0; k < 15; ++k) c[k] = b[k];
+            to_rodrigues(c, w);
+        }
     }
     fill_camblk(c, w[0], w[1], w[2], blk);
-    double *o = camblk + (int64_t)kCamBlk * i;
 #pragma unroll
-    for (int k = 0; k < kCamBlk; ++k) o[k] = blk[k];
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+            double *o = slab + (lane & 31) * kStride;
+#pragma unroll
+            for (int k = 0; k < kCamBlk; ++k) o[k] = blk[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int nv = n_wave - h * 32;
+        nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
+        double *dst = camblk + (wave0 + h * 32) * kCamBlk;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                                 // 32 records x 16 chunks of 16 bytes = 512 chunks
+            const int ch = it * 64 + lane, rec = ch >> 4, part = ch & 15;
+            if (rec < nv) {
+                const double *q = slab + rec * kStride + 2 * part;
+                *reinterpret_cast<double2 *>(dst + rec * kCamBlk + 2 * part) = make_double2(q[0], q[1]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // Camera::from_position_direction, src/baproblem.rs:153-159: loc = -1.0 * dir.rotate_point(position)
@@ -1230,6 +1310,13 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(T *__restrict__ cam15, int
                                                      double angle_strength_d, double std_d, double dx_d, double dy_d,
                                                      double dz_d, const double *__restrict__ stats_norm,
                                                      uint64_t seed, int64_t cam_base) {
+    // waves that hold cameras only write their 64 records back through LDS (wave_rows_store: whole lines); the one wave
+    // that straddles the camera / point boundary stores per lane.  Reads stay per lane: a record's 15 strided loads re-use
+    // their lines in L1, and staging them through LDS measured slower (r03q)
+    __shared__ T sRows[kWaves][64 * 15];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const bool coop = wave0 + 64 <= n_cam;                                // wave-uniform
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
     if (stats_norm) {
@@ -1246,7 +1333,7 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(T *__restrict__ cam15, int
         T c[15], ctr[3], dR[9];
         double z0, z1;
 #pragma unroll
-        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];         // strided reads re-use their lines in L1
         cm_center(c, c[9], c[10], c[11], ctr);
         const T ex = ctr[0] - ox, ey = ctr[1] - oy, ez = ctr[2] - oz;
         const T distance = sqrt(dot3(ex, ey, ez, ex, ey, ez));
@@ -1259,8 +1346,14 @@ __global__ __launch_bounds__(kBlock) void k_add_drift(T *__restrict__ cam15, int
         dR[0] = 1; dR[1] = 0; dR[2] = 0; dR[3] = 0; dR[4] = cs; dR[5] = sn; dR[6] = 0; dR[7] = -sn; dR[8] = cs;
         transform_cam15(c, dR, dx * strength * vt * distance * distance,
                         dy * strength * vt * distance * distance, dz * strength * vt * distance * distance);
+        if (coop) {                                  // whole records (the three intrinsics unchanged) leave as whole lines
 #pragma unroll
-        for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+            for (int k = 0; k < 15; ++k) sRows[wave][15 * lane + k] = c[k];
+            wave_rows_store<15>(cam15 + 15 * wave0, 64, sRows[wave], lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+        }
     } else {
         const int64_t j = i - n_cam;
         typename V4<T>::type p = pts4[j];
@@ -1283,6 +1376,10 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ c
                                                               const double *__restrict__ stats,
                                                               double translation_std, double rotation_std,
                                                               double point_std, uint64_t seed, int64_t cam_base) {
+    __shared__ T sRows[kWaves][64 * 15];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const bool coop = wave0 + 64 <= n_cam;                                // wave-uniform (see k_add_drift)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
     if (i < n_cam) {
@@ -1290,7 +1387,7 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ c
         T c[15], dR[9];
         double a0, a1, a2, rot, b0, b1, b2, tr;
 #pragma unroll
-        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];         // strided reads re-use their lines in L1
         normal_pair(seed, kStreamNoiseCam, (uint64_t)(cam_base + i), 0, a0, a1);
         normal_pair(seed, kStreamNoiseCam, (uint64_t)(cam_base + i), 1, a2, rot);
         normal_pair(seed, kStreamNoiseCam, (uint64_t)(cam_base + i), 2, b0, b1);
@@ -1302,8 +1399,14 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ c
         const T t = (T)(0.0 + translation_std * tr);
         cm_from_axis_angle(A0 * ia, A1 * ia, A2 * ia, ang, dR);
         transform_cam15(c, dR, (B0 * ib) * bal_std * t, (B1 * ib) * bal_std * t, (B2 * ib) * bal_std * t);
+        if (coop) {                                  // whole records (the three intrinsics unchanged) leave as whole lines
 #pragma unroll
-        for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+            for (int k = 0; k < 15; ++k) sRows[wave][15 * lane + k] = c[k];
+            wave_rows_store<15>(cam15 + 15 * wave0, 64, sRows[wave], lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+        }
     } else {
         const int64_t j = i - n_cam;
         double a0, a1, a2, m;
@@ -1343,6 +1446,10 @@ __global__ __launch_bounds__(kBlock) void k_add_sin_noise(T *__restrict__ cam15,
                                                          const double *__restrict__ stats, double dx_d, double dy_d,
                                                          double dz_d, double nx_d, double ny_d, double nz_d,
                                                          double strength_d, double frequency_d) {
+    __shared__ T sRows[kWaves][64 * 15];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const bool coop = wave0 + 64 <= n_cam;                                // wave-uniform (see k_add_drift)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cam + n_pts) return;
     double e0 = stats[12], e1 = stats[13], e2 = stats[14];
@@ -1357,13 +1464,19 @@ __global__ __launch_bounds__(kBlock) void k_add_sin_noise(T *__restrict__ cam15,
     if (i < n_cam) {
         T c[15], ctr[3];
 #pragma unroll
-        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];
+        for (int k = 0; k < 15; ++k) c[k] = cam15[15 * i + k];         // strided reads re-use their lines in L1
         cm_center(c, c[9], c[10], c[11], ctr);
         const T s = sin(dot3(ctr[0] / d0, ctr[1] / d1, ctr[2] / d2, dx, dy, dz) * frequency * (T)kPi) * strength;
         const T I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         transform_cam15(c, I, nx * s, ny * s, nz * s);
+        if (coop) {                                  // whole records (the three intrinsics unchanged) leave as whole lines
 #pragma unroll
-        for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+            for (int k = 0; k < 15; ++k) sRows[wave][15 * lane + k] = c[k];
+            wave_rows_store<15>(cam15 + 15 * wave0, 64, sRows[wave], lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) cam15[15 * i + k] = c[k];
+        }
     } else {
         const int64_t j = i - n_cam;
         typename V4<T>::type p = pts4[j];
