@@ -246,7 +246,9 @@ int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uin
                              const void *tris, int64_t n_slots, uint8_t *keep, uint32_t *overflow, void *stream);
 
 /* BAProblem::mean/std/extent/dimensions (src/baproblem.rs:282-337) + add_drift's origin
- * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES]. */
+ * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES].  ONE launch: mean, min, max and
+ * the origin as the reference folds them, the standard deviation from per-thread (count, mean, M2) triples merged by
+ * Chan's pairwise update -- equal to the reference's second pass around the finished mean up to rounding. */
 int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
               void *workspace, double *stats, void *stream);
 
