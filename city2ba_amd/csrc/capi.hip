@@ -2559,13 +2559,29 @@ namespace {
 // device allocation that frees itself (the cull pipeline holds ~20 scratch arrays)
 struct DevBuf {
     void *ptr = nullptr;
+    bool owned = true;                         // false: a view into an arena (below), never freed or released by itself
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (ptr) (void)hipFree(ptr); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes ? bytes : 16); }
+    ~DevBuf() { if (ptr && owned) (void)hipFree(ptr); }
+    hipError_t alloc(size_t bytes) { owned = true; return hipMalloc(&ptr, bytes ? bytes : 16); }
+    void view(void *q) { ptr = q; owned = false; }
     template <typename T> T *as() const { return reinterpret_cast<T *>(ptr); }
     void *release() { void *q = ptr; ptr = nullptr; return q; }
+};
+
+// Temporaries of one call carved out of ONE allocation: a device malloc / free pair costs ~1 ms at these sizes (the free
+// synchronises), and cull used to make ~25 of each -- most of its 45 ms at --blocks 128 once its kernels took 10.
+struct DevArena {
+    DevBuf block;
+    size_t used = 0, cap = 0;
+    static size_t rounded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    hipError_t reserve(size_t bytes) { cap = bytes; return block.alloc(bytes); }
+    void *take(size_t bytes) {
+        void *q = static_cast<char *>(block.ptr) + used;
+        used += rounded(bytes ? bytes : 16);
+        return used <= cap ? q : nullptr;
+    }
 };
 
 unsigned blocks_of(int64_t n, int per) { return (unsigned)((n + per - 1) / per > 0 ? (n + per - 1) / per : 1); }
@@ -2600,15 +2616,23 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
     DevBuf parent, sets, size, keep_c, keep_p, keep_o, pos_c, pos_p, pos_o, tiles, best, total, deg, cnt;
     hipError_t e = hipSuccess;
     auto A = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
-    for (int k = 0; k < 2; ++k) {
-        A(cam[k], 4 * (size_t)no0); A(pt[k], 4 * (size_t)no0); A(eorig[k], 4 * (size_t)no0);
-        A(corig[k], 4 * (size_t)nc0); A(porig[k], 4 * (size_t)np0);
-    }
-    A(parent, 4 * (size_t)nodes0); A(sets, 4 * (size_t)nodes0); A(size, 4 * (size_t)nodes0);
-    A(keep_c, 4 * (size_t)nc0); A(keep_p, 4 * (size_t)np0); A(keep_o, 4 * (size_t)no0);
-    A(pos_c, 4 * (size_t)nc0); A(pos_p, 4 * (size_t)np0); A(pos_o, 4 * (size_t)no0);
-    A(tiles, 4 * (size_t)(big0 / kScanTile + 2)); A(best, 8); A(total, 4);
-    A(deg, 4 * (size_t)nc0); A(cnt, 4 * (size_t)np0);
+    // cam / pt are allocations of their own (one of each pair becomes the problem's index array); every other temporary
+    // is a view into one arena
+    for (int k = 0; k < 2; ++k) { A(cam[k], 4 * (size_t)no0); A(pt[k], 4 * (size_t)no0); }
+    DevArena arena;
+    struct Want { DevBuf *b; size_t bytes; };
+    const Want wants[] = {
+        {&eorig[0], 4 * (size_t)no0}, {&eorig[1], 4 * (size_t)no0}, {&corig[0], 4 * (size_t)nc0}, {&corig[1], 4 * (size_t)nc0},
+        {&porig[0], 4 * (size_t)np0}, {&porig[1], 4 * (size_t)np0},
+        {&parent, 4 * (size_t)nodes0}, {&sets, 4 * (size_t)nodes0}, {&size, 4 * (size_t)nodes0},
+        {&keep_c, 4 * (size_t)nc0}, {&keep_p, 4 * (size_t)np0}, {&keep_o, 4 * (size_t)no0},
+        {&pos_c, 4 * (size_t)nc0}, {&pos_p, 4 * (size_t)np0}, {&pos_o, 4 * (size_t)no0},
+        {&tiles, 4 * (size_t)(big0 / kScanTile + 2)}, {&best, 8}, {&total, 4}, {&deg, 4 * (size_t)nc0}, {&cnt, 4 * (size_t)np0}};
+    size_t arena_bytes = 0;
+    for (const Want &w : wants) arena_bytes += DevArena::rounded(w.bytes ? w.bytes : 16);
+    if (e == hipSuccess) e = arena.reserve(arena_bytes);
+    if (e == hipSuccess)
+        for (const Want &w : wants) w.b->view(arena.take(w.bytes));
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_cull: %s", hipGetErrorString(e));
 
     int cur = 0;

@@ -53,13 +53,26 @@ __global__ void k_uf_union(uint32_t *parent, const uint32_t *__restrict__ cam_id
     }
 }
 
-// sets[i] = root of i; size[root] += 1
+// sets[i] = root of i; size[root] += 1.  The counts are aggregated per wave first: a generator's graph is one giant
+// component, so one atomicAdd per element was 2.6 M adds to ONE word -- 30 ms of the 100-ms cull at --blocks 128
+// (profiles/r03r).  Lanes with the same root elect a leader (lowest lane) that adds their number once; a wave whose
+// lanes all share a root issues a single add.
 __global__ void k_uf_flatten(uint32_t *parent, int64_t n, uint32_t *__restrict__ sets, uint32_t *size) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r = uf_find(parent, (uint32_t)i);
-    sets[i] = r;
-    atomicAdd(&size[r], 1u);
+    const bool valid = i < n;
+    uint32_t r = 0;
+    if (valid) {
+        r = uf_find(parent, (uint32_t)i);
+        sets[i] = r;
+    }
+    const int lane = threadIdx.x & 63;
+    uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+    while (todo != 0) {                                                  // wave-uniform
+        const uint32_t lead = __builtin_amdgcn_readlane(r, (int)__builtin_ctzll(todo));
+        const uint64_t same = __builtin_amdgcn_ballot_w64(valid && ((todo >> lane) & 1ull) != 0 && r == lead);
+        if (lane == (int)__builtin_ctzll(same)) atomicAdd(&size[lead], (uint32_t)__builtin_popcountll(same));
+        todo &= ~same;
+    }
 }
 
 // best = max over roots of (size << 32 | ~root): the largest component, the smallest root among equals
@@ -92,9 +105,22 @@ __global__ void k_lcc_flags(const uint32_t *__restrict__ sets, const unsigned lo
 __global__ void k_degree(const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx, int64_t n_obs,
                          uint32_t *deg_cam, uint32_t *cnt_pt) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_obs) return;
-    atomicAdd(&deg_cam[cam_idx[e]], 1u);
-    atomicAdd(&cnt_pt[pt_idx[e]], 1u);
+    const bool valid = e < n_obs;
+    uint32_t c = 0;
+    if (valid) {
+        c = cam_idx[e];
+        atomicAdd(&cnt_pt[pt_idx[e]], 1u);
+    }
+    // the list is camera-major: a wave's 64 observations belong to 3-4 cameras, so the camera degrees are added once
+    // per camera and wave (see k_uf_flatten) instead of once per observation
+    const int lane = threadIdx.x & 63;
+    uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+    while (todo != 0) {                                                  // wave-uniform
+        const uint32_t lead = __builtin_amdgcn_readlane(c, (int)__builtin_ctzll(todo));
+        const uint64_t same = __builtin_amdgcn_ballot_w64(valid && ((todo >> lane) & 1ull) != 0 && c == lead);
+        if (lane == (int)__builtin_ctzll(same)) atomicAdd(&deg_cam[lead], (uint32_t)__builtin_popcountll(same));
+        todo &= ~same;
+    }
 }
 
 // remove_singletons (src/baproblem.rs:426-453): cameras need > 3 observations, points > 1
