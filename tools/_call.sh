@@ -1,5 +1,10 @@
-mkdir -p gpurun_out/r03t /tmp/c2bcli
-for b in 32 128; do echo "\$ city2ba synthetic /tmp/c2bcli/g$b.bbal --blocks $b"; ( time C2B_TIMING=1 city2ba_amd/cli/city2ba synthetic /tmp/c2bcli/g$b.bbal --blocks $b ) 2>&1 | grep -v "^$\|user\|sys"; done > gpurun_out/r03t/cli_times.txt 2>&1
-echo "\$ city2ba noise g128.bbal n128.bbal --drift-strength 1e-5 --rotation-std 0.01 --observation-std 0.001 --seed 1" >> gpurun_out/r03t/cli_times.txt
-( time C2B_TIMING=1 city2ba_amd/cli/city2ba noise /tmp/c2bcli/g128.bbal /tmp/c2bcli/n128.bbal --drift-strength 1e-5 --rotation-std 0.01 --observation-std 0.001 --seed 1 ) 2>&1 | grep -v "^$\|user\|sys" >> gpurun_out/r03t/cli_times.txt
-cat gpurun_out/r03t/cli_times.txt
+mkdir -p gpurun_out/r03v
+(time python -m pytest tests -m gpu -q) > gpurun_out/r03v/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r03v/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > gpurun_out/r03v/bench.json 2> gpurun_out/r03v/bench.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+b=json.loads(open('gpurun_out/r03v/bench.json').read().strip().split('\n')[-1]); r=b['roofline']
+print(b['value'], b['ms_per_step'], r['frac'], r['kernel_avg_us'], r['kernel_us_first_allocation'], r['frac_first_allocation'], r['output_placement']['store_GBs_per_attempt'])
+for k,v in b['other_configs']['blocks128_other_passes'].items(): print(k, v)
+PY
