@@ -746,7 +746,7 @@ def main():
                 "frac_first_allocation": round(alg / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if first_us else None,
                 "output_placement": {"store_GBs_per_attempt": placement_log, "attempts": max(1, len(placement_log)),
                                      "note": "c2b_jacobian_outputs_alloc (C ABI): r/Jc/Jp allocations tried until the "
-                                             "store pattern streams >= 6.8 TB/s, at most --placement-attempts; untimed "
+                                             "store pattern streams >= 7.0 TB/s, at most --placement-attempts; untimed "
                                              "set-up; `achieved` / `frac` / `value` are measured in the set it kept"},
                 "input_placement": input_placement,
             },

@@ -930,7 +930,7 @@ int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_stor
     *out = nullptr;
     if (max_attempts < 1) max_attempts = 1;
     if (max_attempts > 8) max_attempts = 8;
-    if (!(fast_store_GBs > 0.0)) fast_store_GBs = 6800.0;
+    if (!(fast_store_GBs > 0.0)) fast_store_GBs = 7000.0;
     hipStream_t st = S(stream);
     std::unique_ptr<c2b_jacobian_outputs> h(new c2b_jacobian_outputs);
     HIP_TRY(hipGetDevice(&h->device));

@@ -173,7 +173,7 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
  * as device allocations CHOSEN FOR STREAMING-STORE SPEED.  On MI355X the very same launch runs ~20 % faster or slower
  * depending only on which allocation its outputs live in; nothing visible from user space
  * predicts it, so this entry allocates a set, times the kernel's own store pattern into it (~4 ms), keeps it if it
- * streams at fast_store_GBs (<= 0: 6800) or better and otherwise holds it and tries again, at most max_attempts
+ * streams at fast_store_GBs (<= 0: 7000) or better and otherwise holds it and tries again, at most max_attempts
  * (clamped to 1..8) times; the best set wins, the others are freed before it returns.  max_attempts = 1, or n_obs
  * < 10^6, allocates without measuring.  An attempt that runs out of memory ends the search with the best set so far.
  * Synchronises `stream`.  The handle owns the memory until c2b_jacobian_outputs_free.
