@@ -128,3 +128,35 @@ def test_jacobian_outputs_search_measures_and_keeps_the_best(env):
     D.calib_store_pattern(out.r, out.Jc, out.Jp)
     torch.cuda.synchronize()
     assert out.Jc[64 * 7 + 5, 0].item() in (float(v) for v in range(64))       # the pattern landed in the handle's memory
+
+
+def test_two_problems_driven_from_two_threads_do_not_disturb_each_other(env):
+    """ADVICE r02's scenario for the old shared counter pool: two c2b_problem objects (each with its own stream and, since
+    r03, its own workspace-held counters) used concurrently from two host threads.  ctypes drops the GIL inside the C
+    calls, so the launches really interleave; every result must equal the problem's own single-threaded value."""
+    import threading
+    import city2ba_amd as c2b
+    probs, want = [], []
+    for seed, (n_cam, n_pts, opc) in ((21, (900, 6000, 25)), (22, (300, 2500, 40))):
+        P = random_problem(n_cam, n_pts, opc, seed=seed, noise=1e-3)
+        ba = c2b.BAProblem.from_visibility(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], device=0)
+        probs.append(ba)
+        want.append((ba.total_reprojection_error(2.0), ba.total_reprojection_error(1.0), ba._stats().copy()))
+    bad = []
+
+    def hammer(k):
+        ba, (e2, e1, st) = probs[k], want[k]
+        for _ in range(150):
+            if ba.total_reprojection_error(2.0) != e2 or ba.total_reprojection_error(1.0) != e1:
+                bad.append(("error", k))
+                return
+            if not np.array_equal(ba._stats(), st):
+                bad.append(("stats", k))
+                return
+
+    threads = [threading.Thread(target=hammer, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad

@@ -1,6 +1,1 @@
-python bench.py --no-extras --no-cpu-baseline --steps 30 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        b=json.loads(l); r=b['roofline']
-        print('DEVICE value %.0f frac %.4f kernel %.1f first %.1f frac_first %.4f attempts %s' % (b['value'], r['frac'], r['kernel_avg_us'], r['kernel_us_first_allocation'], r['frac_first_allocation'], r['output_placement']['store_GBs_per_attempt']))"
+python -m pytest tests/test_gpu_workspace.py -m gpu -q 2>&1 | tail -5
