@@ -171,6 +171,11 @@ SIGNATURES = {
     "c2b_problem_add_drift_normalized": (_int, [_vp, _d, _d, _d, _u64]),
     "c2b_problem_add_noise": (_int, [_vp, _d, _d, _d, _d, _u64]),
     "c2b_problem_add_sin_noise": (_int, [_vp, _vp, _vp, _d, _d]),
+    "c2b_problem_set_shard": (_int, [_vp, _i64, _i64, _i64]),
+    "c2b_problem_stats_sharded": (_int, [_vp, _vp, _vp]),
+    "c2b_problem_add_drift_sharded": (_int, [_vp, _vp, _d, _d, _d, _vp, _u64]),
+    "c2b_problem_add_noise_sharded": (_int, [_vp, _vp, _d, _d, _d, _d, _u64]),
+    "c2b_problem_add_sin_noise_sharded": (_int, [_vp, _vp, _vp, _vp, _d, _d]),
 }
 
 

@@ -9,7 +9,7 @@
 //   city2ba noise IN OUT [--rotation-std X --translation-std X --point-std X --observation-std X
 //                         --drift-std X --drift-strength X --fixed-drift --drift-angle X
 //                         --sin-strength X --sin-frequency X --mismatch-chance X --drop-features X
-//                         --split-landmarks X --join-landmarks X] [--seed N]
+//                         --split-landmarks X --join-landmarks X] [--seed N] [--gpus N | --devices a,b,...]
 //
 //   city2ba generate FILE OUT [--cameras N --intrinsics-start x,y,z --intrinsics-end x,y,z --points N --max-dist X
 //                              --ground X --height X --no-lcc --move-to-origin --path NAME --step-size X] [--seed N]
@@ -218,11 +218,155 @@ int run_synthetic_line(int argc, char **argv) {
     return 0;
 }
 
+// `noise --gpus N` (or --devices a,b,...): run_noise (src/bin/city2ba.rs:280-357) with the problem sharded over N GPUs of
+// this node, driven from ONE process -- SURVEY 8(b)'s ctx_create(n_dev, dev_ids).  The index-corruption passes and their
+// culls run on the host arrays as in the single-GPU path; then cameras are cut into N contiguous ranges holding equal
+// numbers of observations (c2b_partition_cameras), every GPU gets its range, that range's observations and ALL points
+// (one c2b_problem each, marked with c2b_problem_set_shard), and one host thread per GPU runs the same sequence of
+// collective Level-1 calls (c2b_problem_*_sharded: statistics and errors go through RCCL, c2b_comm_init_all).  Draws
+// are keyed by global indices, so the written file does not depend on N (statistics differ from the one-GPU path in
+// their last bits only: two passes with gathered shares instead of one pass).
+int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts, int64_t n_obs, std::vector<double> &bal9,
+                      std::vector<double> &pts, size_t pts_cap, std::vector<double> &uv, std::vector<uint64_t> &row_ptr,
+                      std::vector<uint64_t> &pt_idx) {
+    std::vector<int> devs;
+    if (a.has("devices")) {
+        const std::string &sv = a.opt.at("devices");
+        size_t pos = 0;
+        while (pos <= sv.size()) {
+            const size_t comma = std::min(sv.find(',', pos), sv.size());
+            const std::string tok = sv.substr(pos, comma - pos);
+            char *end = nullptr;
+            const long v = std::strtol(tok.c_str(), &end, 10);
+            if (tok.empty() || *end || v < 0) die("Invalid value for '--devices <devices>': expected a,b,c");
+            devs.push_back((int)v);
+            pos = comma + 1;
+        }
+    } else {
+        for (int64_t k = 0; k < a.i("gpus", 1); ++k) devs.push_back((int)k);
+    }
+    const int N = (int)devs.size();
+    if (N < 1 || N > 64) die("Invalid value for '--gpus <gpus>': expected 1..64");
+    int visible = 0;
+    ck(c2b_device_count(&visible));
+    for (int d : devs) if (d >= visible) die("--gpus / --devices: device " + std::to_string(d) + " is not visible (" + std::to_string(visible) + " devices)");
+
+    std::vector<c2b_comm *> comms((size_t)N, nullptr);
+    ck(c2b_comm_init_all(N, devs.data(), comms.data()));
+    double err[4] = {0, 0, 0, 0};                                         // initial L1, L2, final L1, L2 (written by rank 0)
+    std::vector<double> pts_out;
+
+    // One pass over the GPUs: cut the cameras, give every GPU its shard, run the collective sequence on one host thread
+    // per GPU.  with_initial: evaluate the error of the problem as uploaded; with_noise: drift, sine, Gaussian noise, final
+    // error, download.
+    auto pass = [&](bool with_initial, bool with_noise) {
+        std::vector<int64_t> bounds((size_t)N + 1);
+        ck(c2b_partition_cameras(row_ptr.data(), n_cam, N, bounds.data()));
+        if (with_noise) {
+            std::fprintf(stderr, "noise on %d GPU%s through %s; observations per GPU:", N, N == 1 ? "" : "s", c2b_comm_backend());
+            for (int k = 0; k < N; ++k)
+                std::fprintf(stderr, " %llu", (unsigned long long)(row_ptr[(size_t)bounds[(size_t)k + 1]] - row_ptr[(size_t)bounds[(size_t)k]]));
+            std::fprintf(stderr, "\n");
+            pts_out.assign((size_t)n_pts * 3 + 1, 0.0);
+        }
+        std::vector<std::thread> workers;
+        for (int k = 0; k < N; ++k) {
+            workers.emplace_back([&, k]() {
+                const int64_t lo = bounds[(size_t)k], hi = bounds[(size_t)k + 1], nc = hi - lo;
+                const uint64_t o0 = row_ptr[(size_t)lo];
+                std::vector<uint64_t> rp((size_t)nc + 1);
+                for (int64_t c = 0; c <= nc; ++c) rp[(size_t)c] = row_ptr[(size_t)(lo + c)] - o0;
+                c2b_problem *p = nullptr;
+                ck(c2b_problem_create(devs[(size_t)k], &p));
+                ck(c2b_problem_upload_bal(p, nc, bal9.data() + 9 * lo, n_pts, pts.data(), rp.data(), pt_idx.data() + o0, uv.data() + 2 * o0));
+                ck(c2b_problem_set_shard(p, lo, n_cam, (int64_t)o0));
+                c2b_comm *comm = comms[(size_t)k];
+                double l1, l2;
+                if (with_initial) {
+                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 1.0, &l1));
+                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 2.0, &l2));
+                    if (k == 0) { err[0] = l1; err[1] = l2; }
+                }
+                if (with_noise) {
+                    // src/bin/city2ba.rs:305-316: drift is ALWAYS applied, even with zero strength
+                    if (a.has("fixed-drift")) {
+                        double stats[C2B_STATS_DOUBLES];
+                        ck(c2b_problem_stats_sharded(p, comm, stats));
+                        ck(c2b_problem_add_drift_sharded(p, comm, a.f("drift-strength", 0), a.f("drift-angle", 0), a.f("drift-std", 0), stats + 3, seed));
+                    } else {
+                        ck(c2b_problem_add_drift_sharded(p, comm, a.f("drift-strength", 0), a.f("drift-angle", 0), a.f("drift-std", 0), nullptr, seed));
+                    }
+                    if (a.f("sin-strength", 0) > 0.0) {        // :318-333
+                        const double dx[3] = {1, 0, 0}, dz[3] = {0, 0, 1}, up[3] = {0, 1, 0};
+                        ck(c2b_problem_add_sin_noise_sharded(p, comm, dx, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
+                        ck(c2b_problem_add_sin_noise_sharded(p, comm, dz, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
+                    }
+                    ck(c2b_problem_add_noise_sharded(p, comm, a.f("translation-std", 0), a.f("rotation-std", 0), a.f("point-std", 0),
+                                                     a.f("observation-std", 0), seed + 1));      // :334-340, always
+                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 1.0, &l1));
+                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 2.0, &l2));
+                    if (k == 0) { err[2] = l1; err[3] = l2; }
+                    // every shard's cameras and observations go back to their rows of the host arrays; the points
+                    // (identical on every GPU) come from rank 0
+                    ck(c2b_problem_download(p, nullptr, k == 0 ? pts_out.data() : nullptr, uv.data() + 2 * o0));
+                    ck(c2b_problem_download_bal(p, bal9.data() + 9 * lo));
+                }
+                c2b_problem_destroy(p);
+            });
+        }
+        for (auto &w : workers) w.join();
+    };
+
+    // host-side index corruption + cull, exactly as in the single-GPU path (src/bin/city2ba.rs:288-303): the reference
+    // prints the initial error BEFORE these passes, so when any of them is requested the problem visits the GPUs twice
+    const double split = a.f("split-landmarks", 0.0);
+    const bool reshapes = a.f("drop-features", 1.0) < 1.0 || a.f("join-landmarks", 0.0) > 0.0 || split > 0.0;
+    if (reshapes) pass(true, false);
+    auto cull = [&]() {
+        ck(c2b_cull(&n_cam, bal9.data(), 9, &n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data(), 1));
+        n_obs = (int64_t)row_ptr[(size_t)n_cam];
+    };
+    if (a.f("drop-features", 1.0) < 1.0) {
+        ck(c2b_drop_features(n_cam, row_ptr.data(), pt_idx.data(), uv.data(), a.f("drop-features", 1.0), seed + 2));
+        cull();
+    }
+    if (a.f("join-landmarks", 0.0) > 0.0) {
+        ck(c2b_join_landmarks(n_pts, pts.data(), (int64_t)row_ptr[(size_t)n_cam], pt_idx.data(), split, seed + 3));
+        cull();
+    }
+    if (split > 0.0) {
+        ck(c2b_split_landmarks(&n_pts, pts.data(), (int64_t)pts_cap, (int64_t)row_ptr[(size_t)n_cam], pt_idx.data(), split, seed + 4));
+        cull();
+    }
+    if (n_cam == 0 || n_pts == 0) die("EmptyProblem: nothing remains after culling");
+    pass(!reshapes, true);
+    for (c2b_comm *c : comms) c2b_comm_destroy(c);
+    std::copy(pts_out.begin(), pts_out.begin() + (size_t)n_pts * 3, pts.begin());
+    std::printf("Initial error: %s (L1) %s (L2)\n", sci2(err[0]).c_str(), sci2(err[1]).c_str());
+    if (a.f("mismatch-chance", 0.0) > 0.0)                               // :341, on the noised image positions (host arrays)
+        ck(c2b_add_incorrect_correspondences(n_cam, row_ptr.data(), pt_idx.data(), uv.data(), a.f("mismatch-chance", 0.0), seed + 5));
+    std::printf("BA Problem with %lld cameras, %lld points, %lld correspondences\n", (long long)n_cam, (long long)n_pts,
+                (long long)n_obs);
+    if (a.f("mismatch-chance", 0.0) > 0.0) {
+        // the reference reports the error AFTER the correspondences were scrambled: one more sharded pass would need a
+        // re-upload; the single-GPU evaluation of the final arrays gives the same number
+        c2b_problem *p = nullptr;
+        ck(c2b_problem_create(devs[0], &p));
+        ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+        ck(c2b_problem_total_reprojection_error(p, 1.0, &err[2]));
+        ck(c2b_problem_total_reprojection_error(p, 2.0, &err[3]));
+        c2b_problem_destroy(p);
+    }
+    std::printf("Final error: %s (L1) %s (L2)\n", sci2(err[2]).c_str(), sci2(err[3]).c_str());
+    ck(c2b_bal_write(a.positional[1].c_str(), n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+    return 0;
+}
+
 int run_noise(int argc, char **argv) {
     const Args a = parse(argc, argv, 2, {"fixed-drift"},
                          {"rotation-std", "translation-std", "point-std", "observation-std", "drift-std", "drift-strength",
                           "drift-angle", "mismatch-chance", "drop-features", "split-landmarks", "join-landmarks",
-                          "sin-strength", "sin-frequency", "seed", "device"});
+                          "sin-strength", "sin-frequency", "seed", "device", "gpus", "devices"});
     if (a.positional.size() != 2) die("The following required arguments were not provided:\n    <FILE> <OUT>");
     uint64_t seed;
     if (a.has("seed")) seed = (uint64_t)a.i("seed", 0);
@@ -239,6 +383,9 @@ int run_noise(int argc, char **argv) {
     std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs + 1);
     ck(c2b_bal_copy(f, bal9.data(), pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
     c2b_bal_close(f);
+
+    if (a.has("gpus") || a.has("devices"))
+        return run_noise_sharded(a, seed, n_cam, n_pts, n_obs, bal9, pts, pts_cap, uv, row_ptr, pt_idx);
 
     c2b_problem *p = nullptr;
     ck(c2b_problem_create((int)a.i("device", 0), &p));
@@ -498,7 +645,9 @@ const char *subcommand_help(const std::string &sub) {
                "    --drift-strength <X> --drift-angle <X> --drift-std <X> [--fixed-drift]            drift [0]\n"
                "    --sin-strength <X> [0]  --sin-frequency <X> [1]                                  sine displacement\n"
                "    --mismatch-chance <X> [0]  --drop-features <X> [1]  --split-landmarks <X> [0]  --join-landmarks <X> [0]\n"
-               "    --seed <N>                every random draw is seeded (default: std::random_device)\n";
+               "    --seed <N>                every random draw is seeded (default: std::random_device)\n"
+               "    --gpus <N> | --devices <a,b,...>   shard the problem over N GPUs of this node (contiguous camera ranges,\n"
+               "                              points replicated, statistics and errors through RCCL); same file for every N\n";
     if (sub == "generate")
         return "city2ba generate <FILE.obj> <OUT>\n"
                "    --cameras <N> [100]   --points <N> [1000]   --max-dist <X> [100]\n"

@@ -2071,6 +2071,9 @@ struct c2b_problem {
     uint32_t *cam_idx = nullptr, *pt_idx = nullptr;
     void *ws = nullptr;
     double *stats = nullptr, *scalar = nullptr;
+    // this problem as ONE SHARD of a larger one (c2b_problem_set_shard): its cameras are [shard_cam_base, + n_cam) of
+    // shard_n_cam_global (< 0: not a shard), its first observation is observation shard_obs_base of the whole list
+    int64_t shard_cam_base = 0, shard_n_cam_global = -1, shard_obs_base = 0;
     bool bal_valid = false;     // bal9 still describes the cameras (no mutation since upload_bal)
     bool blk_valid = false;     // camblk matches cam15 (and bal_valid mode)
     // the row structure of the observation list for the *_rows launchers, rebuilt on demand after the list changed
@@ -3102,6 +3105,97 @@ int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double 
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
     C2B_API_END("problem_add_sin_noise")
+}
+
+// ---- Level 1 for a problem that is ONE SHARD of a larger one -------------------------------
+// One c2b_problem per GPU holds a contiguous camera range (c2b_partition_cameras), its slice of the observation list
+// and the WHOLE point table.  After c2b_problem_set_shard the *_sharded entries below give, shard by shard, exactly what
+// the unsharded calls give on the whole problem: draws are keyed by global indices, the statistics go through the
+// communicator (c2b_stats_sharded), every rank perturbs the replicated points identically.  All are collective (every
+// rank of the communicator calls them in the same order) and synchronous.
+int c2b_problem_set_shard(c2b_problem *p, int64_t cam_base, int64_t n_cam_global, int64_t obs_base) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_set_shard");
+    if (cam_base < 0 || obs_base < 0 || n_cam_global < cam_base + p->n_cam)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_set_shard: the shard [%lld, %lld) does not fit %lld cameras",
+                    (long long)cam_base, (long long)(cam_base + p->n_cam), (long long)n_cam_global);
+    p->shard_cam_base = cam_base; p->shard_n_cam_global = n_cam_global; p->shard_obs_base = obs_base;
+    return C2B_OK;
+    C2B_API_END("problem_set_shard")
+}
+
+#define NEED_SHARD(p, comm, who)                                                                          \
+    NEED_UPLOADED(p, who);                                                                                \
+    if (!(comm)) return fail(C2B_ERR_INVALID_ARGUMENT, who ": communicator is NULL");                     \
+    if ((p)->shard_n_cam_global < 0) return fail(C2B_ERR_INVALID_ARGUMENT, who ": c2b_problem_set_shard first"); \
+    if ((comm)->device != (p)->device) return fail(C2B_ERR_INVALID_ARGUMENT, who ": communicator and problem live on different devices")
+
+static int sharded_stats(c2b_problem *p, c2b_comm *comm) {
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    return c2b_stats_sharded(comm, p->camblk, p->n_cam, p->shard_cam_base, p->shard_n_cam_global, p->pts4, p->n_pts, p->ws,
+                             p->stats, p->stream);
+}
+
+int c2b_problem_stats_sharded(c2b_problem *p, c2b_comm *comm, double *stats) {
+    C2B_API_BEGIN
+    NEED_SHARD(p, comm, "problem_stats_sharded");
+    if (!stats) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_stats_sharded: stats is NULL");
+    const int rc = sharded_stats(p, comm);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stats, p->stats, sizeof(double) * C2B_STATS_DOUBLES, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+    C2B_API_END("problem_stats_sharded")
+}
+
+// dir == NULL: add_drift_normalized (direction and scale from the global std, src/noise.rs:47-56)
+int c2b_problem_add_drift_sharded(c2b_problem *p, c2b_comm *comm, double strength, double angle_strength, double std,
+                                  const double *dir, uint64_t seed) {
+    C2B_API_BEGIN
+    NEED_SHARD(p, comm, "problem_add_drift_sharded");
+    int rc = sharded_stats(p, comm);
+    if (rc) return rc;
+    rc = c2b_add_drift_sharded(p->cam15, p->n_cam, p->shard_cam_base, p->pts4, p->n_pts, p->stats, dir ? 0 : 1, strength,
+                               angle_strength, std, dir ? dir[0] : 0.0, dir ? dir[1] : 0.0, dir ? dir[2] : 0.0, seed, p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+    C2B_API_END("problem_add_drift_sharded")
+}
+
+int c2b_problem_add_noise_sharded(c2b_problem *p, c2b_comm *comm, double translation_std, double rotation_std,
+                                  double point_std, double observations_std, uint64_t seed) {
+    C2B_API_BEGIN
+    NEED_SHARD(p, comm, "problem_add_noise_sharded");
+    int rc = sharded_stats(p, comm);
+    if (rc) return rc;
+    rc = c2b_add_noise_entities_sharded(p->cam15, p->n_cam, p->shard_cam_base, p->pts4, p->n_pts, p->stats, translation_std,
+                                        rotation_std, point_std, seed, p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    rc = c2b_add_noise_observations(p->uv, p->n_obs, p->shard_obs_base, observations_std, seed, p->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+    C2B_API_END("problem_add_noise_sharded")
+}
+
+int c2b_problem_add_sin_noise_sharded(c2b_problem *p, c2b_comm *comm, const double dir[3], const double noise_dir[3],
+                                      double strength, double frequency) {
+    C2B_API_BEGIN
+    NEED_SHARD(p, comm, "problem_add_sin_noise_sharded");
+    if (!dir || !noise_dir) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_add_sin_noise_sharded: NULL direction");
+    int rc = sharded_stats(p, comm);                        // the extent of the WHOLE problem scales the phase
+    if (rc) return rc;
+    rc = c2b_add_sin_noise(p->cam15, p->n_cam, p->pts4, p->n_pts, p->stats, dir[0], dir[1], dir[2], noise_dir[0],
+                           noise_dir[1], noise_dir[2], strength, frequency, p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return C2B_OK;
+    C2B_API_END("problem_add_sin_noise_sharded")
 }
 
 }  // extern "C"

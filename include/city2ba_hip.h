@@ -573,6 +573,24 @@ int c2b_problem_add_noise(c2b_problem *p, double translation_std, double rotatio
 int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double noise_dir[3],
                               double strength, double frequency);
 
+/* ---- a problem that is ONE SHARD of a larger one (multi-GPU at Level 1) ----
+ * One c2b_problem per GPU: a contiguous camera range [cam_base, cam_base + n_cam) of n_cam_global cameras
+ * (c2b_partition_cameras), that range's observations (row_ptr rebased to 0; obs_base = the global index of its first
+ * observation) and the WHOLE point table with global point indices.  c2b_problem_set_shard records the three numbers;
+ * the *_sharded entries then do, shard by shard, exactly what the unsharded calls do on the whole problem (the noise
+ * functions of src/noise.rs:47-177, 388-416 and run_noise, src/bin/city2ba.rs:280-357): noise draws are keyed by global
+ * indices, the statistics go through `comm`, every rank perturbs the replicated points identically.  All are
+ * collective -- every rank calls them, in the same order -- and synchronous.  dir == NULL in _add_drift_sharded means
+ * add_drift_normalized.  (c2b_problem_total_reprojection_error_sharded, above, completes the set.) */
+int c2b_problem_set_shard(c2b_problem *p, int64_t cam_base, int64_t n_cam_global, int64_t obs_base);
+int c2b_problem_stats_sharded(c2b_problem *p, c2b_comm *comm, double *stats);
+int c2b_problem_add_drift_sharded(c2b_problem *p, c2b_comm *comm, double strength, double angle_strength, double std,
+                                  const double *dir, uint64_t seed);
+int c2b_problem_add_noise_sharded(c2b_problem *p, c2b_comm *comm, double translation_std, double rotation_std,
+                                  double point_std, double observations_std, uint64_t seed);
+int c2b_problem_add_sin_noise_sharded(c2b_problem *p, c2b_comm *comm, const double dir[3], const double noise_dir[3],
+                                      double strength, double frequency);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,3 +195,50 @@ def test_run_noise_flow_through_the_c_abi_matches_the_checker():
     assert np.max(np.abs(uv.cpu().numpy() - uv0)) < 1e-9
     assert abs(got - want) / want < 1e-7
     c.destroy()
+
+
+def test_level1_sharded_entries_equal_the_unsharded_calls_at_world_size_one():
+    """c2b_problem_set_shard + c2b_problem_{stats,add_drift,add_sin_noise,add_noise,total_reprojection_error}_sharded on
+    a one-rank communicator against the plain Level-1 calls on an identical problem: same draws (global indices = local
+    ones here), statistics through the communicator's two-pass form -> results equal to rounding."""
+    import ctypes as C
+    import numpy as np
+    import __graft_entry__ as entry
+    entry.build()
+    import city2ba_amd as c2b
+    from city2ba_amd import _lib as L
+    from city2ba_amd import comm as Comm
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _problems import random_problem
+
+    P = random_problem(310, 2600, 16, seed=99, noise=1e-4)
+    mk = lambda: c2b.BAProblem.from_visibility(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"], device=0)
+    plain, shard = mk(), mk()
+    c = Comm.Comm(Comm.unique_id(), 0, 1, 0)
+    lib = L.lib()
+    h = shard._h
+    # before set_shard the sharded entries refuse
+    st = np.zeros(20)
+    assert lib.c2b_problem_stats_sharded(h, c.handle, st.ctypes.data_as(C.c_void_p)) == L.ERR_INVALID_ARGUMENT
+    assert lib.c2b_problem_set_shard(h, 5, 300, 0) == L.ERR_INVALID_ARGUMENT          # 5 + 310 cameras do not fit 300
+    L.check(lib.c2b_problem_set_shard(h, 0, 310, 0))
+    L.check(lib.c2b_problem_stats_sharded(h, c.handle, st.ctypes.data_as(C.c_void_p)))
+    assert np.allclose(st, plain._stats(), rtol=1e-13, atol=0)
+    d3 = (C.c_double * 3)(0.3, -0.5, 0.8)
+    L.check(lib.c2b_problem_add_drift_sharded(h, c.handle, 0.01, 0.02, 0.1, None, 3))            # normalized
+    L.check(lib.c2b_problem_add_drift_sharded(h, c.handle, 0.01, 0.02, 0.1, d3, 4))
+    dx, up = (C.c_double * 3)(1, 0, 0), (C.c_double * 3)(0, 1, 0)
+    L.check(lib.c2b_problem_add_sin_noise_sharded(h, c.handle, dx, up, 0.1, 2.0))
+    L.check(lib.c2b_problem_add_noise_sharded(h, c.handle, 0.02, 0.01, 0.03, 0.004, 5))
+    L.check(lib.c2b_problem_add_drift_normalized(plain._h, 0.01, 0.02, 0.1, 3))
+    L.check(lib.c2b_problem_add_drift(plain._h, 0.01, 0.02, 0.1, d3, 4))
+    L.check(lib.c2b_problem_add_sin_noise(plain._h, dx, up, 0.1, 2.0))
+    L.check(lib.c2b_problem_add_noise(plain._h, 0.02, 0.01, 0.03, 0.004, 5))
+    scale = max(1.0, float(np.max(np.abs(plain.points()))))        # the drift (strength * d^2) moves things out to ~1e5
+    assert np.max(np.abs(shard.cameras() - plain.cameras())) <= 1e-13 * scale
+    assert np.max(np.abs(shard.points() - plain.points())) <= 1e-13 * scale
+    assert np.array_equal(shard.observations(), plain.observations())       # same draws, same kernel, nothing statistical in between
+    e = C.c_double(0.0)
+    L.check(lib.c2b_problem_total_reprojection_error_sharded(h, c.handle, 2.0, C.byref(e)))
+    assert abs(e.value - plain.total_reprojection_error(2.0)) <= 1e-9 * e.value
+    c.destroy()

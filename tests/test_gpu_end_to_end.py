@@ -229,6 +229,46 @@ def test_cli_noise_index_corruption_flags(c2b, cli, tmp_path):
     assert np.array_equal(b.points(), got.points()) and np.array_equal(b.observations(), got.observations())
 
 
+def test_cli_noise_sharded_over_gpus_writes_the_same_file(c2b, cli, tmp_path):
+    """`noise --gpus N`: run_noise with the problem sharded over GPUs from one process (c2b_comm_init_all, one
+    c2b_problem per GPU marked with c2b_problem_set_shard, one host thread per GPU, the Level-1 *_sharded entries).  On
+    this one-GPU box N = 1 still takes that whole path -- RCCL communicator, sharded statistics, all-reduced errors --
+    and must write what the classic single-GPU path writes: same indices, points / cameras / observations equal to
+    rounding (the sharded statistics make two passes with gathered shares, the classic call one pass)."""
+    src = tmp_path / "g.bbal"
+    assert _run(cli, "synthetic", src, "--blocks", "4").returncode == 0
+    flags = ["--drift-strength", "0.001", "--drift-angle", "0.002", "--drift-std", "0.1", "--rotation-std", "0.01",
+             "--translation-std", "0.02", "--point-std", "0.03", "--observation-std", "0.004", "--sin-strength", "0.1",
+             "--sin-frequency", "2", "--seed", "5"]
+    a, b = tmp_path / "classic.bbal", tmp_path / "sharded.bbal"
+    ra = _run(cli, "noise", src, a, *flags)
+    rb = _run(cli, "noise", src, b, *flags, "--gpus", "1")
+    assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr, rb.stderr)
+    assert "noise on 1 GPU through RCCL" in rb.stderr
+
+    def report(r):                                                 # RCCL prints its own banner on stdout when it starts
+        return [ln for ln in r.stdout.splitlines() if ln.startswith(("Initial error", "BA Problem", "Final error"))]
+    assert len(report(ra)) == 3 and report(ra) == report(rb)       # same Initial / Final error lines (2 decimals)
+    pa, pb = c2b.BAProblem.from_file(a), c2b.BAProblem.from_file(b)
+    assert np.array_equal(pa.row_ptr, pb.row_ptr) and np.array_equal(pa.pt_idx, pb.pt_idx)
+    scale = max(1.0, float(np.max(np.abs(pa.points()))))
+    assert np.max(np.abs(pa.points() - pb.points())) <= 1e-13 * scale
+    assert np.max(np.abs(pa.cameras_bal() - pb.cameras_bal())) <= 1e-12 * scale
+    assert np.array_equal(pa.observations(), pb.observations())
+    assert not np.array_equal(pa.points(), c2b.BAProblem.from_file(src).points())      # the noise really happened
+    # the index-corruption flags go through the two-pass form (initial error before the host passes)
+    rc = _run(cli, "noise", src, tmp_path / "c.bbal", "--drop-features", "0.8", "--mismatch-chance", "0.01", "--seed", "7", "--devices", "0")
+    rd = _run(cli, "noise", src, tmp_path / "d.bbal", "--drop-features", "0.8", "--mismatch-chance", "0.01", "--seed", "7")
+    assert rc.returncode == 0 and rd.returncode == 0, (rc.stderr, rd.stderr)
+    assert len(report(rc)) == 3 and report(rc) == report(rd)
+    pc, pd = c2b.BAProblem.from_file(tmp_path / "c.bbal"), c2b.BAProblem.from_file(tmp_path / "d.bbal")
+    assert np.array_equal(pc.row_ptr, pd.row_ptr) and np.array_equal(pc.pt_idx, pd.pt_idx)
+    assert np.array_equal(pc.observations(), pd.observations())
+    # a device that does not exist is an error message, not a crash
+    re_ = _run(cli, "noise", src, tmp_path / "e.bbal", "--gpus", "9")
+    assert re_.returncode != 0 and "not visible" in re_.stderr
+
+
 def test_cli_synthetic_line_and_errors(cli, tmp_path):
     r = _run(cli, "synthetic-line", tmp_path / "l.bal", "--cameras", "30", "--points", "40", "--length", "10")
     assert r.returncode == 0 and "Bundle Adjustment Problem with" in r.stdout
