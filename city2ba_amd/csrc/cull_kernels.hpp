@@ -21,13 +21,18 @@ constexpr int kScanBlock = 256;                 // threads
 constexpr int kScanPer = 4;                     // elements per thread
 constexpr int kScanTile = kScanBlock * kScanPer;
 
+// Every link points at a SMALLER index (k_uf_union hooks the larger root under the smaller), so a walk always terminates,
+// a component's root is its smallest member, and a stale view of `parent` is harmless: a node that looked like a root
+// once is still in the right component, and the hook itself is a compare-and-swap that only succeeds on a current root.
+// FRESH = false walks with ordinary cached loads (L2 hits); FRESH = true with agent-scope atomic loads (global_load ...
+// sc1: past the per-XCD L2, which other XCDs' hooks do not update) -- ~4x the latency per hop, used only to retry after
+// a failed hook, where a stale cached line could otherwise be re-read for ever.
+template <bool FRESH>
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
-    // other lanes hook roots while this one walks: agent-scope atomic loads (global_load ... sc1; a volatile pointer
-    // compiled to system-scope FLAT loads)
     while (true) {
-        const uint32_t p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t p = FRESH ? __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : parent[x];
         if (p == x) return x;
-        const uint32_t gp = __hip_atomic_load(parent + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t gp = FRESH ? __hip_atomic_load(parent + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : parent[p];
         if (gp != p) parent[x] = gp;            // path halving; a stale write still points at an ancestor
         x = p;
     }
@@ -44,12 +49,14 @@ __global__ void k_uf_union(uint32_t *parent, const uint32_t *__restrict__ cam_id
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_obs) return;
     uint32_t a = cam_idx[e], b = n_cam + pt_idx[e];
+    bool fresh = false;
     while (true) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        a = fresh ? uf_find<true>(parent, a) : uf_find<false>(parent, a);
+        b = fresh ? uf_find<true>(parent, b) : uf_find<false>(parent, b);
         if (a == b) break;
         if (a < b) { const uint32_t t = a; a = b; b = t; }          // a > b: hook the larger root under the smaller
         if (atomicCAS(&parent[a], a, b) == a) break;
+        fresh = true;                                               // the view was stale: look again past the L2
     }
 }
 
@@ -62,7 +69,7 @@ __global__ void k_uf_flatten(uint32_t *parent, int64_t n, uint32_t *__restrict__
     const bool valid = i < n;
     uint32_t r = 0;
     if (valid) {
-        r = uf_find(parent, (uint32_t)i);
+        r = uf_find<false>(parent, (uint32_t)i);                     // the unions are complete (previous launch): cached loads
         sets[i] = r;
     }
     const int lane = threadIdx.x & 63;

@@ -1,1 +1,3 @@
-python -m pytest tests/test_gpu_dist.py tests/test_gpu_end_to_end.py -m gpu -q -k "level1_sharded or noise_sharded" 2>&1 | grep -v "^$" | tail -30 | cut -c1-250
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03z/cull2 -- python3 $GRAFT_REPO_ROOT/tools/probe_cull.py > /dev/null 2>&1
+f=$(find $GRAFT_REPO_ROOT/gpurun_out/r03z/cull2 -name "*kernel_stats.csv" | head -1); grep "k_uf_" "$f" | cut -c1-160
