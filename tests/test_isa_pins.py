@@ -69,3 +69,14 @@ def test_fold_publish_and_acquire_instruction_order(isa):
         assert loads_after, r["name"]
         # counters are reset with sc1 stores by whoever completes them
         assert len([t for t in body if re.match(r"global_store_dword .* sc1$", t)]) >= 2, r["name"]
+
+
+def test_other_offload_targets_are_refused_at_compile_time(tmp_path):
+    """the publish of the in-kernel folds is validated for gfx942 / gfx950 only (kernels.hpp): building for anything else
+    must stop with that message instead of producing a library whose sums may be stale"""
+    import subprocess
+    src = os.path.join(ROOT, "city2ba_amd", "csrc", "capi.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "--offload-arch=gfx90a", "-ffp-contract=off", "-fPIC", "-std=c++17", "-c", src,
+                        "-o", str(tmp_path / "x.o")], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "validated on gfx942 / gfx950 only" in r.stderr
