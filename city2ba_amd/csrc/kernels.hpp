@@ -1486,6 +1486,12 @@ __global__ __launch_bounds__(kBlock) void k_add_sin_noise(T *__restrict__ cam15,
     }
 }
 
+// device indices are u32, the host ABI speaks usize (u64): widened on the device so that a download is one copy
+__global__ void k_widen_u32(const uint32_t *__restrict__ a, int64_t n, uint64_t *__restrict__ b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+
 // f64 <-> f32 state conversion for the config-5 extension (element-wise, n scalars)
 __global__ void k_f64_to_f32(const double *__restrict__ a, int64_t n, float *__restrict__ b) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
