@@ -56,9 +56,13 @@ def parse():
     ap.add_argument("--overlap", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: run the all-reduce of step k on its own stream so that it overlaps the kernel of step "
                          "k + 1 (every step's scalar has its own slot; all collectives complete inside the timed "
-                         "region).  auto = off: at world size 1 the hand-off costs 5-8 us per step more than the in-line "
-                         "collective does (100.5 vs 95.0 us, profiles/r03h_ab_step.txt); whether it pays at N = 8, where the "
-                         "collective has a real latency to hide, can only be measured there")
+                         "region).  auto = on when N > 1 and the collective is enqueued on a stream: the hand-off costs 4.5 us "
+                         "per step and hides a collective of any length up to the kernel's (measured with an emulated "
+                         "collective of 0-45 us, profiles/r03z_ab_step_emulated_allreduce.txt); in line at world size 1")
+    ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
+                    help="diagnostic (1-GPU boxes): replace the collective by a kernel that spins this many microseconds on "
+                         "the collective's stream -- what an N-rank all-reduce of that latency would cost the step in line "
+                         "and overlapped (tools/ab_step.sh)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group, balanced split, all-reduce) even with one rank: "
                          "how tests exercise the RCCL backend on a 1-GPU box")
@@ -529,8 +533,13 @@ def main():
         collective = ("c2b_comm_all_reduce_sum_f64 (%s), 1 x f64 per step" % Comm.backend()) if comm is not None \
             else "%s all_reduce(sum, 1 x f64) per step via torch.distributed" % backend
 
+    spin_cycles = int(args.emulate_allreduce_us * 2340.0)         # torch.cuda._sleep(100 000) spins 42.8 us on MI355X
+
     def all_reduce(t=None):
         t = err if t is None else t
+        if spin_cycles:
+            torch.cuda._sleep(spin_cycles)
+            return
         if comm is not None:
             comm.all_reduce_sum_(t)
         else:
@@ -543,15 +552,21 @@ def main():
     # its own slot so that nothing is ever waited for in the other direction, every collective complete inside the timed
     # region (the final synchronize covers both streams).  At world size 1 it costs 5-8 us per step more than it saves
     # (profiles/r03h_ab_step.txt); whether it pays at N = 8 can only be measured there.
-    overlap = dist_on and args.overlap == "on" and args.graph != "on"
+    # auto: overlapped whenever there is a real collective to hide (more than one rank, enqueued on a stream).  Measured
+    # with the collective replaced by a kernel that spins X us (--emulate-allreduce-us, a rank's eighth of the problem,
+    # profiles/r03z_ab_step_emulated_allreduce.txt): in line the step is 88.5 + X us, overlapped it is 93 us for every X
+    # from 0 to 45 -- the hand-off costs 4.5 us and hides the rest, so it pays from X = 5 us on, and an 8-GPU all-reduce
+    # of 8 bytes is several times that.  At world size 1 (the rehearsal of this path on a 1-GPU box) it stays in line.
+    on_stream = dist_on and (comm is not None or backend == "nccl")
+    overlap = dist_on and args.graph != "on" and (args.overlap == "on" or (args.overlap == "auto" and on_stream and world > 1))
     comm_stream = torch.cuda.Stream(device=dev) if overlap else None
     n_slots = args.steps + max(args.warmup, 1) + 64
     err_ring = torch.zeros(n_slots if overlap else 1, dtype=torch.float64, device=dev)
     handoff = [torch.cuda.Event() for _ in range(n_slots)] if overlap else None
     slot = [0]
 
-    def step(ev=None):
-        if overlap:
+    def step(ev=None, in_line=False):
+        if overlap and not in_line:
             k = slot[0] % n_slots
             slot[0] += 1
             e = err_ring[k:k + 1]
@@ -670,12 +685,14 @@ def main():
     if dist_on or graph is not None:
         post = min(args.steps, 20)
         events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(post)] if rank == 0 else None
-        for k in range(post):
-            step(events[k] if events is not None else None)
+        for k in range(post):                       # in line even when the timed loop overlapped: a clean kernel / collective split
+            step(events[k] if events is not None else None, in_line=True)
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
-    total_err = Dist.finish_error((err_ring[(slot[0] - 1) % n_slots] if overlap else err).item(), 2.0)
+    total_err = Dist.finish_error(err.item(), 2.0)          # the instrumented pass above ran in line and left the scalar in `err`
+    # every overlapped step reduced the same data: each of its slots must hold exactly the in-line sum
+    ring_ok = bool((err_ring[:min(slot[0], n_slots)] == err).all().item()) if overlap else None
     per_rank_obs = [n]
     if dist_on:
         per_rank_obs = [None] * world
@@ -692,6 +709,8 @@ def main():
             # is launch gaps, the hand-off and waiting for the slowest rank; in line: kernel + collective + the rest
             step_breakdown["step_overhead_us"] = round(step_us - step_breakdown["kernel_us_rank0"] - (0.0 if overlap else ar_us), 2)
             step_breakdown["allreduce_overlaps_next_kernel"] = bool(overlap)
+            if overlap:
+                step_breakdown["overlapped_sums_equal_the_in_line_sum"] = ring_ok
         else:
             step_breakdown["step_overhead_us"] = round(step_us - step_breakdown["kernel_us_rank0"], 2)
         kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3

@@ -63,7 +63,9 @@ def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph, 
         assert isinstance(cfg["hip_graph"], str) and cfg["hip_graph"].startswith("one graph launch per step"), cfg["hip_graph"]
     else:
         assert cfg["hip_graph"] is False
-    assert cfg["allreduce_overlaps_next_kernel"] is (overlap == "on" and graph != "on")      # auto = in line (A/B'd)
+    assert cfg["allreduce_overlaps_next_kernel"] is (overlap == "on" and graph != "on")      # auto = in line at world size 1
+    if cfg["allreduce_overlaps_next_kernel"]:
+        assert cfg["overlapped_sums_equal_the_in_line_sum"] is True
     assert cfg["allreduce_us"] > 0 and cfg["kernel_us_rank0"] > 0
     assert out["config"]["n_observations"] == plain["config"]["n_observations"]
     assert out["config"]["observations_per_rank"] == [plain["config"]["n_observations"]]
