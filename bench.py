@@ -8,8 +8,8 @@
 
 One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian_rows (residual, Jc, Jp and
 the folded sum of squared residuals, ONE launch; the observation list addressed through its row structure, the
-reference's one list per camera) on every rank's shard, then ONE 1-element RCCL all-reduce
-(N > 1; queued behind the kernel on the same stream, completed inside the timed region).
+reference's one list per camera) on every rank's shard, then ONE 1-element RCCL all-reduce through this library's C ABI
+(N > 1; on its own stream, overlapping the next step's kernel; every collective completes inside the timed region).
 Inputs are resident in HBM before the timed region.  Strong scaling: the same `--blocks 128` problem is sharded
 over the ranks by contiguous camera ranges cut on the observation prefix sum (BASELINE.json configs[3]); at
 N = 1 one GPU holds all of it.

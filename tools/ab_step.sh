@@ -15,3 +15,15 @@ for l in sys.stdin:
         j=json.loads(l); c=j['config']
         print('collective=%-5s graph=%-3s overlap=%-3s  step %.2f us (timed loop, no event records)  | instrumented afterwards: kernel %.2f  allreduce %.2f' % ('$C', '$G', '$O', j['ms_per_step']*1e3, c['kernel_us_rank0'], c['allreduce_us']))"
 done
+# the same shard with the collective EMULATED by a kernel that spins X us on the collective's stream: what an N-rank
+# all-reduce of that latency costs the step in line and overlapped
+for us in 10 20 30 45; do for O in off on; do
+  RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$((29800 + RANDOM % 100)) \
+  python bench.py --gpus 1 --force-dist --collective c2b --overlap $O --emulate-allreduce-us $us --blocks $B --steps 300 --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null \
+  | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); c=j['config']
+        print('emulated collective %2d us  overlap=%-3s  step %.2f us  | overlapped sums ok: %s' % ($us, '$O', j['ms_per_step']*1e3, c.get('overlapped_sums_equal_the_in_line_sum')))"
+done; done
