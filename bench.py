@@ -92,7 +92,7 @@ def build_shard(args, rank, world, dev, bounds=None):
     camblk = D.cameras_prepare_state(cam15)
     centers = camblk[:, 24:27].contiguous().cpu().numpy()
 
-    threads = max(1, (os.cpu_count() or 8) // max(1, min(world, 8)))
+    threads = max(1, usable_cores()[0] // max(1, min(world, 8)))     # the cgroup quota, not the 256 logical CPUs the box shows
     ci, pi = S.candidate_pairs(centers, pts, max_dist, occlusion=True, block_length=L, block_inset=inset,
                                n_threads=threads)
     n_cand = len(ci)
