@@ -52,6 +52,8 @@ SIGNATURES = {
     "c2b_project_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "c2b_reprojection_error_sum_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_visibility_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
+    "c2b_reprojection_error_sums2_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "c2b_add_noise_observations_error_sums2_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _u64, _vp, _vp, _vp]),
     "c2b_jacobian_stream_policy": (_int, [_i64, _i64, _i64]),
     "c2b_jacobian_tiles_per_wave": (_int, [_i64]),
     "c2b_residual_jacobian_rows": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
@@ -153,6 +155,10 @@ SIGNATURES = {
     "c2b_problem_project": (_int, [_vp, _vp]),
     "c2b_problem_total_reprojection_error": (_int, [_vp, _d, C.POINTER(_d)]),
     "c2b_problem_total_reprojection_error_sharded": (_int, [_vp, _vp, _d, C.POINTER(_d)]),
+    "c2b_problem_total_reprojection_errors_l1_l2": (_int, [_vp, C.POINTER(_d), C.POINTER(_d)]),
+    "c2b_problem_total_reprojection_errors_l1_l2_sharded": (_int, [_vp, _vp, C.POINTER(_d), C.POINTER(_d)]),
+    "c2b_problem_add_noise_errors_l1_l2": (_int, [_vp, _d, _d, _d, _d, _u64, C.POINTER(_d), C.POINTER(_d)]),
+    "c2b_problem_add_noise_errors_l1_l2_sharded": (_int, [_vp, _vp, _d, _d, _d, _d, _u64, C.POINTER(_d), C.POINTER(_d)]),
     "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_stats": (_int, [_vp, _vp]),
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),

@@ -156,6 +156,13 @@ class BAProblem:
         L.check(L.lib().c2b_problem_total_reprojection_error(self._h, float(norm), C.byref(out)))
         return out.value
 
+    def total_reprojection_errors_l1_l2(self):
+        """(total_reprojection_error(1.), total_reprojection_error(2.)) from ONE pass over the observations -- the pair
+        run_noise prints before and after the noise (src/bin/city2ba.rs:283-287, 350-354)"""
+        l1, l2 = C.c_double(), C.c_double()
+        L.check(L.lib().c2b_problem_total_reprojection_errors_l1_l2(self._h, C.byref(l1), C.byref(l2)))
+        return l1.value, l2.value
+
     def residual_jacobian(self, out=None, pinned=False):
         """r [n,2], Jc [n,2,9] (w t f k1 k2 columns), Jp [n,2,3].  Build-defined: the reference has no Jacobian.
         out = (r, Jc, Jp) reuses the caller's arrays; pinned=True returns arrays in page-locked memory

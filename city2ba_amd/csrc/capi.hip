@@ -185,13 +185,14 @@ template <int MODE, int OPL, int WPB, int MINW = 1, bool FAKECI = false, bool CS
 void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
-                  const uint64_t *row_ptr = nullptr, int64_t n_cam = 0) {
+                  const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0, uint64_t seed = 0) {
+    static_assert(WPB * OPL >= 8, "two partials per workgroup must fit block_part_slots (one per 4 tiles)");
     const int tiles = (int)(((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
     hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, FAKECI, CSR, NTS, NTL>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,    \
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                               \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n, tiles, norm, max_dist,                       \
-                       reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum, row_ptr, (int)n_cam)
+                       reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum, row_ptr, (int)n_cam, obs_base, seed)
     if constexpr (MODE != MODE_ERROR) { C2B_GO(NORM_2); }
     else if (norm == 2.0) C2B_GO(NORM_2);
     else if (norm == 1.0) C2B_GO(NORM_1);
@@ -204,7 +205,8 @@ void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_
 template <int MODE>
 int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-               void *workspace, double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0) {
+               void *workspace, double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0,
+               int64_t obs_base = 0, uint64_t seed = 0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
     unsigned *ticket = ws_ticket(workspace);
     // Cache policy of the streams (A/B in profiles/r02i_ab_cache_policy.txt): results leave through non-temporal stores
@@ -212,9 +214,10 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
     // gathers from -- points, cameras -- keep the L2 / Infinity Cache; the 4-byte point index stays cached where the
     // camera footprint is small (project, error: tables + indices of the --blocks 128 problem fit the 256 MB cache and
     // the next call finds them there) and is non-temporal where it is not (visibility, Jacobian: 256 B per camera).
-    constexpr int kNTL = MODE == MODE_ERROR ? 2 : (MODE == MODE_VISIBILITY ? 1 : 0);
+    // (the fused observation noise reads and rewrites uv exactly once: both directions bypass the caches)
+    constexpr int kNTL = (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) ? 2 : (MODE == MODE_VISIBILITY ? 1 : 0);
     if (row_ptr) {          // the *_rows entry points: cam_idx = the tile records of c2b_rows_pack
-#define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st, row_ptr, n_cam
+#define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base, seed
 #ifdef C2B_TUNE
         switch (g_obs_variant) {
             case 20308: launch_obs_v<MODE, 3, 8, 1, false, true, false, 0>(C2B_ROWS_ARGS); return C2B_OK;   // everything cached (r02h)
@@ -764,6 +767,52 @@ int c2b_reprojection_error_sum_rows(const double *camblk, const double *pts4, co
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("reprojection_error_sum_rows")
+}
+
+// L1 and L2 in one pass: out_sums[0] = sum |du| + |dv|, out_sums[1] = sum du^2 + dv^2 -- each bit-identical to what
+// c2b_reprojection_error_sum_rows returns for that norm (same grid, same fold order per sum, one arrival count).
+int c2b_reprojection_error_sums2_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                                      const void *tiles, const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                                      void *workspace, double *out_sums, void *stream) {
+    C2B_API_BEGIN
+    int rc = check_obs_args("reprojection_error_sums2_rows", camblk, pts4, tiles, pt_idx, n_obs);
+    if (!rc) rc = check_rows_args("reprojection_error_sums2_rows", row_ptr, n_cam, tiles, n_obs);
+    if (rc) return rc;
+    if (!out_sums) return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sums2_rows: out_sums is NULL");
+    if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sums, 0, 2 * sizeof(double), S(stream))); return C2B_OK; }
+    if (!uv_obs || !aligned16(uv_obs) || !workspace)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "reprojection_error_sums2_rows: uv_obs/workspace NULL or misaligned");
+    rc = launch_obs<MODE_ERROR12>(camblk, pts4, reinterpret_cast<const uint32_t *>(tiles), pt_idx, uv_obs, n_obs, 0.0, 0.0, nullptr,
+                                  nullptr, workspace, out_sums, S(stream), row_ptr, n_cam);
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("reprojection_error_sums2_rows")
+}
+
+// add_noise's observation pass (src/noise.rs:152-170) and the two error sums run_noise evaluates right after it
+// (src/bin/city2ba.rs:350-354) in ONE pass over the list: uv is perturbed in place exactly as
+// c2b_add_noise_observations would (same draws: counter = obs_base + i), and out_sums = the L1 / L2 sums of the
+// PERTURBED observations against the cameras and points as they are now (entity noise first, then this).
+int c2b_add_noise_observations_error_sums2_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                                                const void *tiles, const uint32_t *pt_idx, double *uv, int64_t n_obs,
+                                                int64_t obs_base, double observations_std, uint64_t seed, void *workspace,
+                                                double *out_sums, void *stream) {
+    C2B_API_BEGIN
+    int rc = check_obs_args("add_noise_observations_error_sums2_rows", camblk, pts4, tiles, pt_idx, n_obs);
+    if (!rc) rc = check_rows_args("add_noise_observations_error_sums2_rows", row_ptr, n_cam, tiles, n_obs);
+    if (rc) return rc;
+    if (!out_sums || obs_base < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_observations_error_sums2_rows: bad arguments");
+    if (!(observations_std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise: standard deviations must be >= 0");
+    if (!n_obs) { HIP_TRY(hipMemsetAsync(out_sums, 0, 2 * sizeof(double), S(stream))); return C2B_OK; }
+    if (!uv || !aligned16(uv) || !workspace)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_observations_error_sums2_rows: uv/workspace NULL or misaligned");
+    rc = launch_obs<MODE_NOISE_ERROR12>(camblk, pts4, reinterpret_cast<const uint32_t *>(tiles), pt_idx, nullptr, n_obs, observations_std,
+                                        0.0, uv, nullptr, workspace, out_sums, S(stream), row_ptr, n_cam, obs_base, seed);
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("add_noise_observations_error_sums2_rows")
 }
 
 int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam, const void *tiles,
@@ -2424,6 +2473,43 @@ int c2b_problem_total_reprojection_error_sharded(c2b_problem *p, c2b_comm *comm,
     C2B_API_END("problem_total_reprojection_error_sharded")
 }
 
+// Both norms run_noise prints (src/bin/city2ba.rs:283-287, 350-354) from ONE pass over the observations.
+static int errors_l1_l2_impl(c2b_problem *p, c2b_comm *comm, double *l1, double *l2) {
+    int rc = ensure_camblk(p);
+    if (!rc) rc = ensure_rows(p);
+    if (rc) return rc;
+    if (p->n_obs > 0)
+        rc = c2b_reprojection_error_sums2_rows(p->camblk, p->pts4, p->rows_ptr, p->n_cam, p->rows_tiles, p->pt_idx, p->uv, p->n_obs,
+                                               p->ws, p->scalar, p->stream);
+    else
+        HIP_TRY(hipMemsetAsync(p->scalar, 0, 2 * sizeof(double), p->stream));      // an empty shard still takes part
+    if (!rc && comm) rc = c2b_comm_all_reduce_sum_f64(comm, p->scalar, 2, p->stream);   // ONE 2-element all-reduce
+    if (rc) return rc;
+    double sums[2] = {0.0, 0.0};
+    HIP_TRY(hipMemcpyAsync(sums, p->scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    *l1 = std::pow(sums[0], 1.0 / 1.0);        // .powf(1. / norm), src/baproblem.rs:278
+    *l2 = std::pow(sums[1], 1.0 / 2.0);
+    return C2B_OK;
+}
+
+int c2b_problem_total_reprojection_errors_l1_l2(c2b_problem *p, double *l1, double *l2) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_total_reprojection_errors_l1_l2");
+    if (!l1 || !l2) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_errors_l1_l2: NULL output");
+    return errors_l1_l2_impl(p, nullptr, l1, l2);
+    C2B_API_END("problem_total_reprojection_errors_l1_l2")
+}
+
+int c2b_problem_total_reprojection_errors_l1_l2_sharded(c2b_problem *p, c2b_comm *comm, double *l1, double *l2) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_total_reprojection_errors_l1_l2_sharded");
+    if (!l1 || !l2 || !comm) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_errors_l1_l2_sharded: NULL argument");
+    if (comm->device != p->device) return fail(C2B_ERR_INVALID_ARGUMENT, "total_reprojection_errors_l1_l2_sharded: communicator and problem live on different devices");
+    return errors_l1_l2_impl(p, comm, l1, l2);
+    C2B_API_END("problem_total_reprojection_errors_l1_l2_sharded")
+}
+
 // Results leave in chunks of kJacChunk observations through a ring of kJacSlots device buffers: the kernel of chunk
 // k + 1 is queued before the copies of chunk k start, copies run on their own stream, so PCIe and the kernel overlap
 // and the device never holds more than the ring (159 MB) whatever the problem size.  Host buffers from
@@ -3094,6 +3180,48 @@ int c2b_problem_add_noise(c2b_problem *p, double translation_std, double rotatio
     C2B_API_END("problem_add_noise")
 }
 
+// add_noise followed by the L1 / L2 errors of the result -- run_noise's tail (src/bin/city2ba.rs:334-354) -- with the
+// observation pass and both error sums in one launch.  comm != NULL: the problem is a shard (statistics and the
+// 2-element sum go through the communicator).
+static int sharded_stats(c2b_problem *p, c2b_comm *comm);
+static int add_noise_errors_impl(c2b_problem *p, c2b_comm *comm, double translation_std, double rotation_std, double point_std,
+                                 double observations_std, uint64_t seed, double *l1, double *l2) {
+    int rc = comm ? sharded_stats(p, comm) : compute_stats(p);
+    if (rc) return rc;
+    rc = comm ? c2b_add_noise_entities_sharded(p->cam15, p->n_cam, p->shard_cam_base, p->pts4, p->n_pts, p->stats, translation_std,
+                                               rotation_std, point_std, seed, p->stream)
+              : c2b_add_noise_entities(p->cam15, p->n_cam, p->pts4, p->n_pts, p->stats, translation_std, rotation_std, point_std,
+                                       seed, p->stream);
+    if (rc) return rc;
+    cameras_mutated(p);
+    rc = ensure_camblk(p);                                 // the perturbed cameras' records
+    if (!rc) rc = ensure_rows(p);
+    if (rc) return rc;
+    if (p->n_obs > 0)
+        rc = c2b_add_noise_observations_error_sums2_rows(p->camblk, p->pts4, p->rows_ptr, p->n_cam, p->rows_tiles, p->pt_idx, p->uv,
+                                                         p->n_obs, comm ? p->shard_obs_base : 0, observations_std, seed, p->ws,
+                                                         p->scalar, p->stream);
+    else
+        HIP_TRY(hipMemsetAsync(p->scalar, 0, 2 * sizeof(double), p->stream));
+    if (!rc && comm) rc = c2b_comm_all_reduce_sum_f64(comm, p->scalar, 2, p->stream);
+    if (rc) return rc;
+    double sums[2] = {0.0, 0.0};
+    HIP_TRY(hipMemcpyAsync(sums, p->scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    *l1 = std::pow(sums[0], 1.0 / 1.0);
+    *l2 = std::pow(sums[1], 1.0 / 2.0);
+    return C2B_OK;
+}
+
+int c2b_problem_add_noise_errors_l1_l2(c2b_problem *p, double translation_std, double rotation_std, double point_std,
+                                       double observations_std, uint64_t seed, double *l1, double *l2) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_add_noise_errors_l1_l2");
+    if (!l1 || !l2) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_add_noise_errors_l1_l2: NULL output");
+    return add_noise_errors_impl(p, nullptr, translation_std, rotation_std, point_std, observations_std, seed, l1, l2);
+    C2B_API_END("problem_add_noise_errors_l1_l2")
+}
+
 int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double noise_dir[3], double strength,
                               double frequency) {
     C2B_API_BEGIN
@@ -3183,6 +3311,15 @@ int c2b_problem_add_noise_sharded(c2b_problem *p, c2b_comm *comm, double transla
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
     C2B_API_END("problem_add_noise_sharded")
+}
+
+int c2b_problem_add_noise_errors_l1_l2_sharded(c2b_problem *p, c2b_comm *comm, double translation_std, double rotation_std,
+                                               double point_std, double observations_std, uint64_t seed, double *l1, double *l2) {
+    C2B_API_BEGIN
+    NEED_SHARD(p, comm, "problem_add_noise_errors_l1_l2_sharded");
+    if (!l1 || !l2) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_add_noise_errors_l1_l2_sharded: NULL output");
+    return add_noise_errors_impl(p, comm, translation_std, rotation_std, point_std, observations_std, seed, l1, l2);
+    C2B_API_END("problem_add_noise_errors_l1_l2_sharded")
 }
 
 int c2b_problem_add_sin_noise_sharded(c2b_problem *p, c2b_comm *comm, const double dir[3], const double noise_dir[3],

@@ -106,41 +106,64 @@ C2B_DEV bool ticket_arrive(unsigned *__restrict__ ticket, unsigned magic) {
     return last;
 }
 
-C2B_DEV void ticket_fold(double wave_value, double *sRed, double *__restrict__ block_part,
-                         unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
+// N sums through ONE arrival count (N = 2: the L1 and L2 errors run_noise prints back to back, src/bin/city2ba.rs:283-287,
+// 350-354).  wave_value[k] is valid on lane 0; set k's partials live at block_part[k * gridDim.x ...]; out_sum[k] gets
+// set k's total.  Each set is folded exactly like the single sum (same thread -> partial map, same trees), so out_sum[k]
+// carries the bits a one-sum launch of the same grid would produce.  sRed: >= N * blockDim.x/64 + 1 doubles of LDS.
+template <int N>
+C2B_DEV void ticket_fold_n(const double (&wave_value)[N], double *sRed, double *__restrict__ block_part,
+                           unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     unsigned magic = 0u;
     if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];          // in flight across the barriers below
     __syncthreads();                                   // sRed may alias LDS other waves were still using
-    if (lane == 0) sRed[wave] = wave_value;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) sRed[k * n_waves + wave] = wave_value[k];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double b = 0.0;
-        for (int w = 0; w < n_waves; ++w) b += sRed[w];
-        __hip_atomic_store(block_part + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double b = 0.0;
+            for (int w = 0; w < n_waves; ++w) b += sRed[k * n_waves + w];
+            __hip_atomic_store(block_part + (size_t)k * gridDim.x + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_s_waitcnt(0);                 // (a builtin, not inline asm: asm would halve the VGPR budget)
         const bool last = ticket_arrive(ticket, magic);
-        if (magic != kTicketMagic) out_sum[0] = __longlong_as_double(0x7ff8000000000000LL);
-        sRed[n_waves] = last ? 1.0 : 0.0;
+        if (magic != kTicketMagic) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) out_sum[k] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        sRed[N * n_waves] = last ? 1.0 : 0.0;
     }
     __syncthreads();
-    if (sRed[n_waves] == 0.0) return;                  // workgroup-uniform
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // four independent chains keep the loads in flight
+    if (sRed[N * n_waves] == 0.0) return;              // workgroup-uniform
     const unsigned n = gridDim.x, step = blockDim.x;
-    unsigned k = threadIdx.x;
-    for (; k + 3 * step < n; k += 4 * step) {
-        a0 += block_part[k]; a1 += block_part[k + step]; a2 += block_part[k + 2 * step]; a3 += block_part[k + 3 * step];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        const double *part = block_part + (size_t)s * n;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains keep the loads in flight
+        unsigned k = threadIdx.x;
+        for (; k + 3 * step < n; k += 4 * step) {
+            a0 += part[k]; a1 += part[k + step]; a2 += part[k + 2 * step]; a3 += part[k + 3 * step];
+        }
+        for (; k < n; k += step) a0 += part[k];
+        const double w = wave_sum((a0 + a1) + (a2 + a3));
+        __syncthreads();
+        if (lane == 0) sRed[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < n_waves; ++i) t += sRed[i];
+            out_sum[s] = t;
+        }
     }
-    for (; k < n; k += step) a0 += block_part[k];
-    const double w = wave_sum((a0 + a1) + (a2 + a3));
-    __syncthreads();
-    if (lane == 0) sRed[wave] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < n_waves; ++i) t += sRed[i];
-        out_sum[0] = t;
-    }
+}
+C2B_DEV void ticket_fold(double wave_value, double *sRed, double *__restrict__ block_part,
+                         unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
+    const double v[1] = {wave_value};
+    ticket_fold_n<1>(v, sRed, block_part, ticket, out_sum);
 }
 
 // c2b_workspace_init: zero the arrival counters, write the magic (one workgroup)
@@ -421,7 +444,10 @@ C2B_DEV void store16(char *dst, const double2 v) {
 
 // ---- project / error / visibility: the light per-observation kernels ----------------------------
 // Wave-centric like the Jacobian kernel; they need R, t, intrinsics only (15 doubles, staged as 16).
-enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2 };
+// MODE_ERROR12: the L1 and the L2 error sum in one pass (run_noise evaluates them back to back on the same data,
+// src/bin/city2ba.rs:283-287, 350-354); MODE_NOISE_ERROR12: add_noise's observation pass (src/noise.rs:152-170) -- draw,
+// perturb and store uv -- fused with the two error sums of the perturbed observations that follow it in run_noise.
+enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2, MODE_ERROR12 = 3, MODE_NOISE_ERROR12 = 4 };
 constexpr int kObsWPB = 8;                     // waves per workgroup
 constexpr int kCamLight = 16;
 
@@ -491,7 +517,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
     const double2 *__restrict__ uv_obs, int n, int n_btiles, double norm, double max_dist,
     double2 *__restrict__ uv_out, uint8_t *__restrict__ keep, double *__restrict__ block_part,
-    unsigned *__restrict__ ticket, double *__restrict__ out_sum, const uint64_t *__restrict__ row_ptr, int n_cam) {
+    unsigned *__restrict__ ticket, double *__restrict__ out_sum, const uint64_t *__restrict__ row_ptr, int n_cam,
+    int64_t obs_base, uint64_t seed) {
+    // MODE_NOISE_ERROR12: `norm` carries observations_std, uv_out is the observation array (read, perturbed, written
+    // back), obs_base the global index of this launch's first observation (the draws' counter), uv_obs is unused
     // per staged camera: R, t, intrinsics (16 doubles) and, for the visibility predicate, the centre (camblk 24..27)
     constexpr int HOT = MODE == MODE_VISIBILITY ? 20 : kCamLight;
     constexpr int CH = HOT / 2;                                           // 16-byte chunks per camera
@@ -500,7 +529,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
-    double eacc = 0.0;
+    double eacc = 0.0, eacc1 = 0.0;                                      // MODE_*ERROR12: eacc1 = the L1 sum, eacc = the L2 sum
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];
         double4 X[OPL];
@@ -541,12 +570,13 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             // the observed uv of THIS tile is requested only now: holding all OPL of them from the start costs 12
             // VGPRs and the eighth wave per SIMD (measured: 119 us held, 111 us requested per tile)
             double2 ob = make_double2(0.0, 0.0);
-            if (MODE == MODE_ERROR) {
+            if (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) {
+                const double2 *src = (MODE == MODE_NOISE_ERROR12 ? uv_out : uv_obs) + (valid ? o : n - 1);
                 if (NTL & 2) {
-                    const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(uv_obs + (valid ? o : n - 1)));
+                    const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(src));
                     ob = make_double2(t2.x, t2.y);
                 } else {
-                    ob = uv_obs[valid ? o : n - 1];
+                    ob = *src;
                 }
             }
             // First pass, unmasked: every lane projects through a staged camera -- its own if that is staged, camera 0
@@ -598,12 +628,29 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 }
             } else if (MODE == MODE_PROJECT) {
                 if (valid) store16<NTS>(reinterpret_cast<char *>(uv_out + o), make_double2(p.u, p.v));
-            } else {
+            } else if (MODE == MODE_ERROR) {
                 eacc += valid ? abs_pow_k<NK>(p.u - ob.x, norm) + abs_pow_k<NK>(p.v - ob.y, norm) : 0.0;
+            } else {
+                if (MODE == MODE_NOISE_ERROR12) {
+                    // k_add_noise_observations' arithmetic, operation for operation (the stored uv is bit-identical)
+                    double c, s;
+                    const double z = obs_noise_draw(seed, (uint64_t)(obs_base + (valid ? o : n - 1)), c, s);
+                    const double r = 0.0 + norm * z;
+                    ob.x = ob.x + c * r;
+                    ob.y = ob.y + s * r;
+                    if (valid) store16<NTS>(reinterpret_cast<char *>(uv_out + o), ob);
+                }
+                const double du = p.u - ob.x, dv = p.v - ob.y;
+                eacc1 += valid ? abs_pow_k<NORM_1>(du, 1.0) + abs_pow_k<NORM_1>(dv, 1.0) : 0.0;
+                eacc += valid ? abs_pow_k<NORM_2>(du, 2.0) + abs_pow_k<NORM_2>(dv, 2.0) : 0.0;
             }
         }
     }
     if (MODE == MODE_ERROR) ticket_fold(wave_sum(eacc), sCamAll, block_part, ticket, out_sum);
+    if (MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) {
+        const double w[2] = {wave_sum(eacc1), wave_sum(eacc)};            // out_sum[0] = L1, out_sum[1] = L2
+        ticket_fold_n<2>(w, sCamAll, block_part, ticket, out_sum);
+    }
 }
 
 // ---- residual + Jacobian, wave-centric form -------------------------------------------------------

@@ -141,6 +141,24 @@ def reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, norm, ws, out_su
     return out_sum
 
 
+def reprojection_error_sums2_rows(camblk, pts4, rows, pt_idx, uv, ws, out_sums):
+    """out_sums[0] = the L1 sum, out_sums[1] = the L2 sum, ONE pass (what run_noise evaluates back to back,
+    src/bin/city2ba.rs:283-287, 350-354); each bit-identical to reprojection_error_sum_rows with that norm"""
+    L.check(L.lib().c2b_reprojection_error_sums2_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(rows.tiles),
+                                                      _p(pt_idx), _p(uv), rows.n_obs, _p(ws), _p(out_sums), _stream()))
+    return out_sums
+
+
+def add_noise_observations_error_sums2_rows(camblk, pts4, rows, pt_idx, uv, obs_base, observations_std, seed, ws, out_sums):
+    """add_noise's observation pass (src/noise.rs:152-170) fused with the L1 / L2 error sums of the perturbed
+    observations (src/bin/city2ba.rs:350-354): uv is perturbed in place exactly as add_noise_observations would"""
+    L.check(L.lib().c2b_add_noise_observations_error_sums2_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam,
+                                                                _p(rows.tiles), _p(pt_idx), _p(uv), rows.n_obs, int(obs_base),
+                                                                float(observations_std), int(seed), _p(ws), _p(out_sums),
+                                                                _stream()))
+    return out_sums
+
+
 def visibility_rows(camblk, pts4, rows, pt_idx, max_dist, uv_out, keep):
     L.check(L.lib().c2b_visibility_rows(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(rows.tiles), _p(pt_idx),
                                         rows.n_obs, float(max_dist), _p(uv_out), _p(keep), _stream()))

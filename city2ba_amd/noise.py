@@ -33,6 +33,16 @@ def add_noise(bal, translation_std, rotation_std, point_std, observations_std, s
     return bal
 
 
+def add_noise_with_errors(bal, translation_std, rotation_std, point_std, observations_std, seed=0):
+    """add_noise followed by the L1 / L2 reprojection errors of the result -- run_noise's tail
+    (src/bin/city2ba.rs:334-354) -- with the observation pass and both error sums in one launch.
+    Returns (bal, l1, l2); the resident state is what add_noise alone leaves, bit for bit."""
+    l1, l2 = C.c_double(), C.c_double()
+    L.check(L.lib().c2b_problem_add_noise_errors_l1_l2(bal._h, float(translation_std), float(rotation_std), float(point_std),
+                                                       float(observations_std), int(seed), C.byref(l1), C.byref(l2)))
+    return bal, l1.value, l2.value
+
+
 # ---- index-corruption functions (src/noise.rs:179-378): host-side reshuffles of the visibility graph ------------
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)

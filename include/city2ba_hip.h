@@ -135,6 +135,21 @@ int c2b_reprojection_error_sum_rows(const double *camblk, const double *pts4, co
 int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
                         const void *tiles, const uint32_t *pt_idx, int64_t n_pairs, double max_dist,
                         double *uv_out, uint8_t *keep, void *stream);
+/* total_reprojection_error's numerators for norm 1 AND norm 2 from ONE pass -- run_noise evaluates exactly this pair,
+ * back to back on the same data, before and after the noise (src/bin/city2ba.rs:283-287, 350-354):
+ * out_sums[0] = sum |du| + |dv|, out_sums[1] = sum du^2 + dv^2 (device pointer, 2 doubles).  Each is bit-identical to
+ * c2b_reprojection_error_sum_rows with that norm (same grid, same fold order per sum, one arrival count). */
+int c2b_reprojection_error_sums2_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                                      const void *tiles, const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                                      void *workspace, double *out_sums, void *stream);
+/* noise::add_noise's observation pass (src/noise.rs:152-170) fused with the two error sums run_noise evaluates right
+ * after it (src/bin/city2ba.rs:350-354): uv [n_obs][2] is perturbed in place exactly as c2b_add_noise_observations
+ * would (same draws, counter = obs_base + i; the stored bits are identical) and out_sums = the L1 / L2 sums of the
+ * PERTURBED observations against camblk / pts4 as passed (run c2b_add_noise_entities and re-derive camblk first). */
+int c2b_add_noise_observations_error_sums2_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr,
+                                                int64_t n_cam, const void *tiles, const uint32_t *pt_idx, double *uv,
+                                                int64_t n_obs, int64_t obs_base, double observations_std, uint64_t seed,
+                                                void *workspace, double *out_sums, void *stream);
 /* c2b_residual_jacobian / _sum in the row-structure form, for the whole list (obs_base = 0) or a slice of it: tiles,
  * pt_idx, uv_obs, r, Jc, Jp all point at observation obs_base (a multiple of 64) of the list row_ptr describes and
  * n_obs observations are processed.  workspace == NULL: no error sum.  Otherwise sum |r|^norm goes to out_sum[0]
@@ -526,6 +541,10 @@ int c2b_problem_total_reprojection_error(c2b_problem *p, double norm, double *ou
 /* ... when `p` is one shard (a contiguous camera range) of a larger problem: local sum, one 8-byte all-reduce through
  * `comm` on the problem's stream, then powf(1/norm); every rank returns the global error.  Collective. */
 int c2b_problem_total_reprojection_error_sharded(c2b_problem *p, c2b_comm *comm, double norm, double *out);
+/* Both norms run_noise prints (src/bin/city2ba.rs:283-287, 350-354) from one pass over the observations:
+ * *l1 = total_reprojection_error(1.), *l2 = total_reprojection_error(2.).  _sharded: ONE 2-element all-reduce. */
+int c2b_problem_total_reprojection_errors_l1_l2(c2b_problem *p, double *l1, double *l2);
+int c2b_problem_total_reprojection_errors_l1_l2_sharded(c2b_problem *p, c2b_comm *comm, double *l1, double *l2);
 /* Jacobian columns refer to the uploaded 9-vector's w while cameras are unmodified since
  * c2b_problem_upload_bal, otherwise to w = to_rodrigues(R) (what to_vec would write).
  * r [n_obs][2], Jc [n_obs][18], Jp [n_obs][6] are HOST buffers: the results leave the device in chunks whose copies
@@ -572,6 +591,11 @@ int c2b_problem_add_noise(c2b_problem *p, double translation_std, double rotatio
                           double point_std, double observations_std, uint64_t seed);
 int c2b_problem_add_sin_noise(c2b_problem *p, const double dir[3], const double noise_dir[3],
                               double strength, double frequency);
+/* c2b_problem_add_noise followed by c2b_problem_total_reprojection_errors_l1_l2 -- the tail of run_noise
+ * (src/bin/city2ba.rs:334-354) -- with the observation pass and both error sums in one launch: same resident state
+ * afterwards (bit for bit), same two numbers. */
+int c2b_problem_add_noise_errors_l1_l2(c2b_problem *p, double translation_std, double rotation_std, double point_std,
+                                       double observations_std, uint64_t seed, double *l1, double *l2);
 
 /* ---- a problem that is ONE SHARD of a larger one (multi-GPU at Level 1) ----
  * One c2b_problem per GPU: a contiguous camera range [cam_base, cam_base + n_cam) of n_cam_global cameras
@@ -590,6 +614,9 @@ int c2b_problem_add_noise_sharded(c2b_problem *p, c2b_comm *comm, double transla
                                   double point_std, double observations_std, uint64_t seed);
 int c2b_problem_add_sin_noise_sharded(c2b_problem *p, c2b_comm *comm, const double dir[3], const double noise_dir[3],
                                       double strength, double frequency);
+int c2b_problem_add_noise_errors_l1_l2_sharded(c2b_problem *p, c2b_comm *comm, double translation_std, double rotation_std,
+                                               double point_std, double observations_std, uint64_t seed, double *l1,
+                                               double *l2);
 
 #ifdef __cplusplus
 }

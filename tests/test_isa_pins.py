@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # the one kernel allowed to use scratch: its per-lane traversal stack (64 node ids) is indexed dynamically
 SCRATCH_ALLOWED = {"k_occlusion_bvh": 272}
-FOLDING = ("k_observations<1,", "k_residual_jacobian_l<0, true", "k_residual_jacobian_l<1, true",
+FOLDING = ("k_observations<1,", "k_observations<3,", "k_observations<4,", "k_residual_jacobian_l<0, true", "k_residual_jacobian_l<1, true",
            "k_residual_jacobian_l<2, true", "k_stats_pass1<", "k_stats_pass2<")
 
 

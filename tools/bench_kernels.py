@@ -94,6 +94,19 @@ for norm in (2.0, 1.0, 1.5):
     if norm == 2.0:
         t = timed_cold(lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pt_idx, uv, norm, ws, err))
         report("error_sum_rows(norm=2), caches flushed before every launch", t, n, n * (4 + 16) + entity_bytes, "obs")
+# the pair run_noise evaluates back to back (src/bin/city2ba.rs:283-287, 350-354), as ONE pass
+err2 = torch.zeros(2, dtype=torch.float64, device=dev)
+t = timed(lambda: D.reprojection_error_sums2_rows(camblk, pts4, rows, pt_idx, uv, ws, err2))
+report("error_sums2_rows(L1+L2, one launch)", t, n, n * (4 + 16) + entity_bytes, "obs")
+t = timed_cold(lambda: D.reprojection_error_sums2_rows(camblk, pts4, rows, pt_idx, uv, ws, err2))
+report("error_sums2_rows(L1+L2, one launch), caches flushed before every launch", t, n, n * (4 + 16) + entity_bytes, "obs")
+# add_noise's observation pass fused with that pair (src/noise.rs:152-170 -> src/bin/city2ba.rs:350-354): uv read + written once
+uv3 = uv.clone()
+t = timed(lambda: D.add_noise_observations_error_sums2_rows(camblk, pts4, rows, pt_idx, uv3, 0, 1e-6, 7, ws, err2))
+report("add_noise_observations+error_sums2_rows (one launch)", t, n, n * (4 + 32) + entity_bytes, "obs")
+t = timed_cold(lambda: D.add_noise_observations_error_sums2_rows(camblk, pts4, rows, pt_idx, uv3, 0, 1e-6, 7, ws, err2))
+report("add_noise_observations+error_sums2_rows, caches flushed before every launch", t, n, n * (4 + 32) + entity_bytes, "obs")
+del uv3
 r = torch.empty((n, 2), dtype=torch.float64, device=dev)
 Jc = torch.empty((n, 18), dtype=torch.float64, device=dev)
 Jp = torch.empty((n, 6), dtype=torch.float64, device=dev)
