@@ -170,6 +170,7 @@ SIGNATURES = {
     "c2b_problem_adopt_visibility": (_int, [_vp]),
     "c2b_problem_download_graph": (_int, [_vp, _vp, _vp]),
     "c2b_problem_visibility_pairs_compact": (_int, [_vp, _i64, _vp, _vp, _d, _vp]),
+    "c2b_problem_visibility_within_distance": (_int, [_vp, _d, _int, _d, _d, _vp]),
     "c2b_problem_visibility_dense": (_int, [_vp, _d, _vp]),
     "c2b_problem_visibility_dense_fetch": (_int, [_vp, _vp, _vp]),
     "c2b_problem_visibility_dense_occlude": (_int, [_vp, _vp, _i64, _vp]),

@@ -340,6 +340,22 @@ class BAProblem:
                                                      _ptr(uv), _ptr(keep)))
         return uv, keep
 
+    def visibility_within_distance(self, max_dist, occlusion=False, block_length=20.0, block_inset=1.0, fetch=True):
+        """the synthetic generators' whole visibility loop on the device (src/synthetic.rs:268-297, :353-378): candidates
+        within max_dist of each camera centre (a cell list in place of rstar's locate_within_distance), hits_building when
+        `occlusion`, the predicate, kept lists per camera in ascending point index.  Returns (row_ptr, pt_idx, uv), or
+        the row pointer only with fetch=False (the lists stay on the device for adopt_visibility)."""
+        row_ptr = np.zeros(self.num_cameras() + 1, dtype=np.uint64)
+        L.check(L.lib().c2b_problem_visibility_within_distance(self._h, float(max_dist), int(bool(occlusion)), float(block_length),
+                                                               float(block_inset), _ptr(row_ptr)))
+        if not fetch:
+            return row_ptr
+        n = int(row_ptr[-1])
+        kept = np.empty(n, dtype=np.uint64)
+        uv = np.empty((n, 2))
+        L.check(L.lib().c2b_problem_visibility_dense_fetch(self._h, _ptr(kept), _ptr(uv)))
+        return row_ptr, kept, uv
+
     def visibility_pairs_compact(self, cam_idx, pt_idx, max_dist, fetch=True):
         """the same predicate with the kept pairs compacted on the device (cam_idx non-decreasing): returns the CSR
         graph (row_ptr u64, pt_idx u64, uv) of the survivors in candidate order; fetch=False leaves the lists on the

@@ -142,34 +142,41 @@ void download_problem(c2b_problem *p, HostProblem &hp) {
     hp.pt_idx.resize((size_t)n_obs);
 }
 
-// shared tail of synthetic_grid / synthetic_line: visibility predicate, then cull, both on the device
+// shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:268-299, :353-380): the whole visibility loop --
+// candidates within max_dist, hits_building, the predicate -- then cull, all on the device.  C2B_HOST_CANDIDATES=1 takes
+// rounds 1-3's route (candidate search on the host, 47.5 M pairs uploaded at --blocks 128) for comparison.
 HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, const std::vector<double> &dir,
                                 const std::vector<double> &pts, double max_dist, bool occlusion, double L, double inset) {
     const int64_t n_cam = (int64_t)pos.size() / 3, n_pts = (int64_t)pts.size() / 3;
     HostProblem hp;
     PhaseTimer timer;
-    hp.n_cam = n_cam; hp.n_pts = n_pts; hp.pts = pts;
-    hp.cams15.resize((size_t)n_cam * 15);
-    ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), hp.cams15.data()));
-    std::vector<uint64_t> empty_rows((size_t)n_cam + 1, 0);
-    ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), n_pts, pts.data(), empty_rows.data(), nullptr, nullptr));
-    std::vector<double> centers((size_t)n_cam * 3);
-    ck(c2b_problem_centers(p, centers.data()));
-    timer.mark("from_position_direction + upload + centres");
-    c2b_pairs *pairs = nullptr;
-    const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    ck(c2b_candidate_pairs(centers.data(), n_cam, pts.data(), n_pts, max_dist, 0, n_cam, occlusion ? 1 : 0, L, inset, threads, &pairs));
-    timer.mark("candidate pairs (host, threaded)");
-    const int64_t n_pairs = c2b_pairs_count(pairs);
-    // predicate + stable compaction on the device; the kept pairs become the problem's vis_graph there
-    std::vector<uint64_t> rows((size_t)n_cam + 1, 0);
-    ck(c2b_problem_visibility_pairs_compact(p, n_pairs, c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, rows.data()));
-    c2b_pairs_free(pairs);
+    hp.n_cam = n_cam; hp.n_pts = n_pts;
+    {
+        std::vector<double> cams15((size_t)n_cam * 15);
+        ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), cams15.data()));
+        std::vector<uint64_t> empty_rows((size_t)n_cam + 1, 0);
+        ck(c2b_problem_upload(p, n_cam, cams15.data(), n_pts, pts.data(), empty_rows.data(), nullptr, nullptr));
+    }
+    timer.mark("from_position_direction + upload");
+    if (std::getenv("C2B_HOST_CANDIDATES")) {
+        std::vector<double> centers((size_t)n_cam * 3);
+        ck(c2b_problem_centers(p, centers.data()));
+        c2b_pairs *pairs = nullptr;
+        const int threads = (int)std::max(1u, std::thread::hardware_concurrency());
+        ck(c2b_candidate_pairs(centers.data(), n_cam, pts.data(), n_pts, max_dist, 0, n_cam, occlusion ? 1 : 0, L, inset, threads, &pairs));
+        timer.mark("centres + candidate pairs (host, threaded)");
+        std::vector<uint64_t> rows((size_t)n_cam + 1, 0);
+        ck(c2b_problem_visibility_pairs_compact(p, c2b_pairs_count(pairs), c2b_pairs_cam_idx(pairs), c2b_pairs_pt_idx(pairs), max_dist, rows.data()));
+        c2b_pairs_free(pairs);
+        timer.mark("visibility predicate + compaction (device)");
+    } else {
+        ck(c2b_problem_visibility_within_distance(p, max_dist, occlusion ? 1 : 0, L, inset, nullptr));
+        timer.mark("candidates + hits_building + predicate (device)");
+    }
     ck(c2b_problem_adopt_visibility(p));
-    timer.mark("visibility predicate + compaction (device)");
     // .cull(), src/synthetic.rs:299 -- on the device
     ck(c2b_problem_cull(p, 1));
-    timer.mark("cull (device)");
+    timer.mark("adopt + cull (device)");
     download_problem(p, hp);
     timer.mark("download");
     return hp;
@@ -282,9 +289,8 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
                 ck(c2b_problem_set_shard(p, lo, n_cam, (int64_t)o0));
                 c2b_comm *comm = comms[(size_t)k];
                 double l1, l2;
-                if (with_initial) {
-                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 1.0, &l1));
-                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 2.0, &l2));
+                if (with_initial) {           // both norms from one pass, ONE 2-element all-reduce (src/bin/city2ba.rs:283-287)
+                    ck(c2b_problem_total_reprojection_errors_l1_l2_sharded(p, comm, &l1, &l2));
                     if (k == 0) { err[0] = l1; err[1] = l2; }
                 }
                 if (with_noise) {
@@ -301,10 +307,9 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
                         ck(c2b_problem_add_sin_noise_sharded(p, comm, dx, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
                         ck(c2b_problem_add_sin_noise_sharded(p, comm, dz, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
                     }
-                    ck(c2b_problem_add_noise_sharded(p, comm, a.f("translation-std", 0), a.f("rotation-std", 0), a.f("point-std", 0),
-                                                     a.f("observation-std", 0), seed + 1));      // :334-340, always
-                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 1.0, &l1));
-                    ck(c2b_problem_total_reprojection_error_sharded(p, comm, 2.0, &l2));
+                    // :334-340 (always) and :350-354: the observation pass and both final errors in one launch per shard
+                    ck(c2b_problem_add_noise_errors_l1_l2_sharded(p, comm, a.f("translation-std", 0), a.f("rotation-std", 0),
+                                                                  a.f("point-std", 0), a.f("observation-std", 0), seed + 1, &l1, &l2));
                     if (k == 0) { err[2] = l1; err[3] = l2; }
                     // every shard's cameras and observations go back to their rows of the host arrays; the points
                     // (identical on every GPU) come from rank 0
@@ -353,8 +358,7 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
         c2b_problem *p = nullptr;
         ck(c2b_problem_create(devs[0], &p));
         ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
-        ck(c2b_problem_total_reprojection_error(p, 1.0, &err[2]));
-        ck(c2b_problem_total_reprojection_error(p, 2.0, &err[3]));
+        ck(c2b_problem_total_reprojection_errors_l1_l2(p, &err[2], &err[3]));
         c2b_problem_destroy(p);
     }
     std::printf("Final error: %s (L1) %s (L2)\n", sci2(err[2]).c_str(), sci2(err[3]).c_str());
@@ -391,8 +395,7 @@ int run_noise(int argc, char **argv) {
     ck(c2b_problem_create((int)a.i("device", 0), &p));
     ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
     double l1, l2;
-    ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
-    ck(c2b_problem_total_reprojection_error(p, 2.0, &l2));
+    ck(c2b_problem_total_reprojection_errors_l1_l2(p, &l1, &l2));        // src/bin/city2ba.rs:283-287: both norms, one pass
     std::printf("Initial error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
 
     // index-corruption passes on the host arrays, each followed by cull() (src/bin/city2ba.rs:288-303); camera rows
@@ -434,19 +437,20 @@ int run_noise(int argc, char **argv) {
         ck(c2b_problem_add_sin_noise(p, dx, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
         ck(c2b_problem_add_sin_noise(p, dz, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
     }
-    ck(c2b_problem_add_noise(p, a.f("translation-std", 0), a.f("rotation-std", 0), a.f("point-std", 0),
-                             a.f("observation-std", 0), seed + 1));      // :334-340, always
+    // :334-340 (always) fused with the final errors of :350-354: the observation pass draws, perturbs, stores, projects
+    // and folds both norms in one launch.  With --mismatch-chance the errors are re-evaluated after the scramble below.
+    ck(c2b_problem_add_noise_errors_l1_l2(p, a.f("translation-std", 0), a.f("rotation-std", 0), a.f("point-std", 0),
+                                          a.f("observation-std", 0), seed + 1, &l1, &l2));
     ck(c2b_problem_download(p, nullptr, pts.data(), uv.data()));
     if (a.f("mismatch-chance", 0.0) > 0.0) {                             // :341, on the noised image positions
         std::vector<double> cams15((size_t)n_cam * 15 + 1);
         ck(c2b_problem_download(p, cams15.data(), nullptr, nullptr));
         ck(c2b_add_incorrect_correspondences(n_cam, row_ptr.data(), pt_idx.data(), uv.data(), a.f("mismatch-chance", 0.0), seed + 5));
         ck(c2b_problem_upload(p, n_cam, cams15.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
+        ck(c2b_problem_total_reprojection_errors_l1_l2(p, &l1, &l2));
     }
     std::printf("BA Problem with %lld cameras, %lld points, %lld correspondences\n", (long long)n_cam, (long long)n_pts,
                 (long long)n_obs);
-    ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
-    ck(c2b_problem_total_reprojection_error(p, 2.0, &l2));
     std::printf("Final error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
     ck(c2b_problem_download_bal(p, bal9.data()));
     ck(c2b_bal_write(a.positional[1].c_str(), n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));

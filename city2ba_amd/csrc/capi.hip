@@ -27,6 +27,7 @@
 #include "obs_pipeline.hpp"      // persistent pipelined variants: measured slower, tuning library only
 #endif
 #include "cull_kernels.hpp"
+#include "cell_kernels.hpp"
 #include "comm_rccl.hpp"
 
 using namespace c2b;
@@ -2983,6 +2984,137 @@ int c2b_problem_visibility_pairs_compact(c2b_problem *p, int64_t n_pairs, const 
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_pairs_compact: %s", hipGetErrorString(e));
     return C2B_OK;
     C2B_API_END("problem_visibility_pairs_compact")
+}
+
+// The generators' whole visibility loop (src/synthetic.rs:268-297, :353-378) on the device: candidates by a cell list
+// (rstar's locate_within_distance), the sight line against the buildings (hits_building), the predicate, and the kept
+// (point, uv) lists compacted per camera in ascending point index -- csrc/cell_kernels.hpp.  The result becomes the
+// pending visibility result like c2b_problem_visibility_pairs_compact's (adopt / fetch it the same way); row_ptr (host,
+// n_cam + 1) may be NULL.
+int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int occlusion, double block_length, double block_inset,
+                                           uint64_t *row_ptr) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_visibility_within_distance");
+    if (!(max_dist >= 0.0) || (occlusion && !(block_length > 0.0)))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_within_distance: max_dist must be >= 0 (and block_length > 0 with occlusion)");
+    const int64_t n_cam = p->n_cam, n_pts = p->n_pts;
+    if (n_pts >= ((int64_t)1 << 32) || n_cam >= ((int64_t)1 << 31))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_within_distance: too many cameras or points");
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    free_dense(p);
+    hipStream_t st = p->stream;
+    if (n_cam == 0 || n_pts == 0) {                                      // nothing can be seen: an empty graph
+        DevBuf row0, pt0, uv0;
+        hipError_t e0 = row0.alloc(sizeof(uint64_t) * (size_t)(n_cam + 1));
+        if (e0 == hipSuccess) e0 = pt0.alloc(4);
+        if (e0 == hipSuccess) e0 = uv0.alloc(16);
+        if (e0 == hipSuccess) e0 = hipMemsetAsync(row0.ptr, 0, sizeof(uint64_t) * (size_t)(n_cam + 1), st);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
+        if (e0 != hipSuccess) return fail(C2B_ERR_HIP, "problem_visibility_within_distance: %s", hipGetErrorString(e0));
+        if (row_ptr) std::fill(row_ptr, row_ptr + n_cam + 1, (uint64_t)0);
+        p->dense_row = (uint64_t *)row0.release(); p->dense_pt = (uint32_t *)pt0.release(); p->dense_uv = (double *)uv0.release();
+        p->dense_n = 0;
+        return C2B_OK;
+    }
+    // extent of cameras and points -> the cell grid.  Cells are a hair wider than max_dist so that rounding in the cell
+    // arithmetic can never separate a camera from a point within max_dist by more than one cell.
+    double stats[C2B_STATS_DOUBLES];
+    rc = compute_stats(p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stats, p->stats, sizeof stats, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    CellGrid g;
+    g.x0 = stats[6]; g.z0 = stats[8];
+    const double ex = stats[9] - stats[6], ez = stats[11] - stats[8];
+    double cs = (max_dist > 0.0 ? max_dist : 1.0) * (1.0 + 0x1.0p-20);
+    if (!(ex >= 0.0) || !(ez >= 0.0) || !std::isfinite(ex) || !std::isfinite(ez) || !std::isfinite(cs))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_within_distance: non-finite coordinates");
+    auto cells = [&](double c) { return (std::floor(ex / c) + 1.0) * (std::floor(ez / c) + 1.0); };
+    while (cells(cs) > (double)(1 << 24)) cs *= 2.0;                     // wider cells stay correct, only slower
+    g.inv_cs = 1.0 / cs;
+    g.ncx = (int)std::floor(ex / cs) + 1; g.ncz = (int)std::floor(ez / cs) + 1;
+    const int64_t n_cells = (int64_t)g.ncx * g.ncz;
+
+    DevArena arena;
+    DevBuf cell_of, counts, cursor, sorted, tiles, total, cam_count, pos, sum64, row64;
+    struct Want { DevBuf *b; size_t bytes; };
+    const int64_t big = std::max(n_cells + 1, n_cam + 1);
+    const Want wants[] = {{&cell_of, 4 * (size_t)n_pts}, {&counts, 4 * (size_t)(n_cells + 1)}, {&cursor, 4 * (size_t)(n_cells + 1)},
+                          {&sorted, 4 * (size_t)n_pts}, {&tiles, 4 * (size_t)(big / kScanTile + 2)}, {&total, 4},
+                          {&cam_count, 4 * (size_t)(n_cam + 1)}, {&pos, 4 * (size_t)(n_cam + 1)}, {&sum64, 8}};
+    size_t arena_bytes = 0;
+    for (const Want &w : wants) arena_bytes += DevArena::rounded(w.bytes ? w.bytes : 16);
+    hipError_t e = arena.reserve(arena_bytes);
+    if (e == hipSuccess) e = row64.alloc(sizeof(uint64_t) * (size_t)(n_cam + 1));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_within_distance: %s", hipGetErrorString(e));
+    for (const Want &w : wants) w.b->view(arena.take(w.bytes));
+
+    // cell list: count, exclusive scan (start[n_cells] = n_pts), fill
+    HIP_TRY(hipMemsetAsync(counts.ptr, 0, 4 * (size_t)(n_cells + 1), st));
+    HIP_TRY(hipMemsetAsync(cursor.ptr, 0, 4 * (size_t)(n_cells + 1), st));
+    HIP_TRY(hipMemsetAsync(cam_count.ptr, 0, 4 * (size_t)(n_cam + 1), st));
+    HIP_TRY(hipMemsetAsync(sum64.ptr, 0, 8, st));
+    if (n_pts) hipLaunchKernelGGL(k_cells_assign, dim3(blocks_of(n_pts, 256)), dim3(256), 0, st, reinterpret_cast<const double4 *>(p->pts4), n_pts,
+                                  g, cell_of.as<uint32_t>(), counts.as<uint32_t>());
+    uint32_t n_sorted = 0, n_kept32 = 0;
+    uint32_t *start = cursor.as<uint32_t>();                             // scanned counts; the fill's cursors live in `counts` afterwards
+    e = scan_flags(st, counts.as<uint32_t>(), n_cells + 1, start, tiles.as<uint32_t>(), total.as<uint32_t>(), &n_sorted);
+    if (e == hipSuccess && (int64_t)n_sorted != n_pts) return fail(C2B_ERR_HIP, "problem_visibility_within_distance: cell counts do not add up");
+    if (e == hipSuccess) e = hipMemsetAsync(counts.ptr, 0, 4 * (size_t)(n_cells + 1), st);
+    if (e == hipSuccess && n_pts)
+        hipLaunchKernelGGL(k_cells_fill, dim3(blocks_of(n_pts, 256)), dim3(256), 0, st, (const uint32_t *)cell_of.as<uint32_t>(), n_pts,
+                           (const uint32_t *)start, counts.as<uint32_t>(), sorted.as<uint32_t>());
+    // pass 1: survivors per camera; scan; total
+    const unsigned cam_blocks = blocks_of(n_cam, kCellWPB);
+    if (e == hipSuccess && n_cam && n_pts) {
+        hipLaunchKernelGGL((k_cells_visibility<false>), dim3(cam_blocks), dim3(kCellWPB * 64), 0, st, (const double *)p->camblk, n_cam,
+                           reinterpret_cast<const double4 *>(p->pts4), g, (const uint32_t *)start, (const uint32_t *)sorted.as<uint32_t>(),
+                           max_dist, occlusion ? 1 : 0, block_length, block_inset, cam_count.as<uint32_t>(), (const uint64_t *)nullptr,
+                           (uint32_t *)nullptr, (double2 *)nullptr);
+        hipLaunchKernelGGL(k_sum_u32_u64, dim3(256), dim3(256), 0, st, (const uint32_t *)cam_count.as<uint32_t>(), n_cam,
+                           sum64.as<unsigned long long>());
+    }
+    if (e == hipSuccess) e = scan_flags(st, cam_count.as<uint32_t>(), n_cam + 1, pos.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &n_kept32);
+    unsigned long long n_kept = 0;
+    if (e == hipSuccess) e = hipMemcpy(&n_kept, sum64.ptr, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_kept != (unsigned long long)n_kept32)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_within_distance: more than 2^32 observations");
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_widen_u32, dim3(blocks_for(n_cam + 1)), dim3(kBlock), 0, st, (const uint32_t *)pos.as<uint32_t>(), n_cam + 1,
+                           row64.as<uint64_t>());
+        e = launch_error();
+    }
+    // pass 2: fill in meeting order, then every row into ascending point index
+    DevBuf tmp_pt, tmp_uv, out_pt, out_uv;
+    const size_t w = (size_t)n_kept;
+    if (e == hipSuccess) e = tmp_pt.alloc(4 * w);
+    if (e == hipSuccess) e = tmp_uv.alloc(16 * w);
+    if (e == hipSuccess) e = out_pt.alloc(4 * w);
+    if (e == hipSuccess) e = out_uv.alloc(16 * w);
+    if (e == hipSuccess && w) {
+        hipLaunchKernelGGL((k_cells_visibility<true>), dim3(cam_blocks), dim3(kCellWPB * 64), 0, st, (const double *)p->camblk, n_cam,
+                           reinterpret_cast<const double4 *>(p->pts4), g, (const uint32_t *)start, (const uint32_t *)sorted.as<uint32_t>(),
+                           max_dist, occlusion ? 1 : 0, block_length, block_inset, (uint32_t *)nullptr, (const uint64_t *)row64.as<uint64_t>(),
+                           tmp_pt.as<uint32_t>(), tmp_uv.as<double2>());
+        hipLaunchKernelGGL(k_rows_rank_sort, dim3(cam_blocks), dim3(kCellWPB * 64), 0, st, (const uint64_t *)row64.as<uint64_t>(), n_cam,
+                           (const uint32_t *)tmp_pt.as<uint32_t>(), (const double2 *)tmp_uv.as<double2>(), out_pt.as<uint32_t>(),
+                           out_uv.as<double2>());
+        e = launch_error();
+    }
+    if (e == hipSuccess && row_ptr)
+        e = hipMemcpyAsync(row_ptr, row64.ptr, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_within_distance: %s", hipGetErrorString(e));
+    }
+    p->dense_row = (uint64_t *)row64.release();
+    p->dense_pt = (uint32_t *)out_pt.release();
+    p->dense_uv = (double *)out_uv.release();
+    p->dense_n = (int64_t)n_kept;
+    return C2B_OK;
+    C2B_API_END("problem_visibility_within_distance")
 }
 
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr) {

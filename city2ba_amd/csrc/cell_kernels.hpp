@@ -1,0 +1,190 @@
+// cell_kernels.hpp -- the generators' visibility loop on the device, candidates included (included by capi.hip only).
+//
+// synthetic_grid / synthetic_line (src/synthetic.rs:268-297, :353-378) run, per camera (rayon par_iter over cameras):
+//     for p in rtree.locate_within_distance(camera.center(), max_dist * max_dist)       -- rstar: squared distance <= r2
+//         if !hits_building(camera.center(), p)                                           -- grid only (:52-124)
+//             if (camera.center() - p).magnitude() < max_dist && project_world(p).z <= 0 && -1 <= u, v <= 1  -> push
+// Rounds 1-3 did the R-tree query and hits_building on the host (290 ms of a 1.2 s `synthetic --blocks 128`) and shipped
+// 47.5 M candidate pairs to the device for the predicate.  Here the whole loop runs on the device:
+//   * the R-tree is replaced by a uniform cell list over the (x, z) plane with cells at least max_dist wide: every point
+//     within max_dist of a camera lies in the 3 x 3 cells around the camera's cell, and the three cells of one column
+//     are one contiguous range of the cell-sorted point list;
+//   * one wave per camera walks those three ranges 64 points at a time: squared distance, projection + predicate, then
+//     (grid) the sight line against the buildings -- the cheap tests first, the result is their conjunction;
+//   * two passes (count, scan, fill) like the dense sweep; the fill writes a camera's survivors in the order the wave met
+//     them and k_rows_rank_sort puts every row into ASCENDING POINT INDEX, the canonical in-camera order of this build
+//     (rstar's traversal order is not reproducible, host_synthetic.hpp) -- so the result does not depend on the order the
+//     atomics of the cell fill happened to produce.
+// Everything the reference computes in f64 (distances, the intersection arithmetic of hits_building, the projection) is
+// evaluated in the same operation order as csrc/host_synthetic.hpp and camera_math.hpp: kept indices are bit-equal to the
+// host path's.
+#pragma once
+#include "camera_math.hpp"
+
+namespace c2b {
+
+struct CellGrid {
+    double x0, z0, inv_cs;       // cell (i, k) covers x0 + [i, i + 1) cs, z0 + [k, k + 1) cs
+    int ncx, ncz;
+};
+
+C2B_DEV int cell_coord(double v, double v0, double inv_cs, int n) {
+    const double f = floor((v - v0) * inv_cs);
+    return f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f);       // clamped (NaN -> last cell): conservative, the distance test decides
+}
+
+// cell of every point + points per cell (integer atomics: the counts do not depend on their order)
+__global__ __launch_bounds__(256) void k_cells_assign(const double4 *__restrict__ pts4, int64_t n, CellGrid g,
+                                                     uint32_t *__restrict__ cell_of, uint32_t *__restrict__ counts) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const double4 p = pts4[j];
+    const uint32_t c = (uint32_t)(cell_coord(p.x, g.x0, g.inv_cs, g.ncx) * g.ncz + cell_coord(p.z, g.z0, g.inv_cs, g.ncz));
+    cell_of[j] = c;
+    atomicAdd(counts + c, 1u);
+}
+
+// the cell-sorted point list (order inside a cell = arrival order of the atomics; k_rows_rank_sort makes the result
+// independent of it)
+__global__ __launch_bounds__(256) void k_cells_fill(const uint32_t *__restrict__ cell_of, int64_t n, const uint32_t *__restrict__ start,
+                                                   uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t c = cell_of[j];
+    sorted[start[c] + atomicAdd(cursor + c, 1u)] = (uint32_t)j;
+}
+
+// ---- hits_building, src/synthetic.rs:52-124, as csrc/host_synthetic.hpp restates it (same operations, same order) ----
+// unique intersection of segments (p0, p1) and (q0, q1): line_intersection 0.4.0's relate().unique_intersection()
+C2B_DEV bool seg_unique_intersection(double p0x, double p0y, double p1x, double p1y, double q0x, double q0y, double q1x,
+                                     double q1y, double &ix, double &iy) {
+    const double rx = p1x - p0x, ry = p1y - p0y;
+    const double sx = q1x - q0x, sy = q1y - q0y;
+    const double r_cross_s = rx * sy - ry * sx;
+    if (r_cross_s == 0.0) return false;                      // parallel or collinear
+    const double qpx = q0x - p0x, qpy = q0y - p0y;
+    const double t = qpx * (sy / r_cross_s) - qpy * (sx / r_cross_s);
+    const double u = qpx * (ry / r_cross_s) - qpy * (rx / r_cross_s);
+    if (!(0.0 <= t && t <= 1.0 && 0.0 <= u && u <= 1.0)) return false;
+    ix = p0x + t * rx;
+    iy = p0y + t * ry;
+    return true;
+}
+
+C2B_DEV bool hits_in_block_dev(double sx, double sy, double ex, double ey, int64_t bix, int64_t biy, double L, double inset) {
+    const double block_end = L - inset;
+    const double ox = (double)bix * L, oy = (double)biy * L;
+    const double lo_x = ox + inset, lo_y = oy + inset, hi_x = ox + block_end, hi_y = oy + block_end;
+    // the four sides in the reference's order (:72-89); any hit ends the test, so the order only matters for speed
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double ax = k == 2 ? hi_x : lo_x, ay = k == 3 ? hi_y : lo_y;
+        const double bx = k == 0 ? lo_x : hi_x, by = k == 1 ? lo_y : hi_y;
+        double px, py;
+        if (seg_unique_intersection(sx, sy, ex, ey, ax, ay, bx, by, px, py)) {
+            // reference quirk kept (src/synthetic.rs:93): the y term is NOT squared, so the radicand can be negative
+            // -> sqrt = NaN -> comparison false -> "no hit"
+            const double dx = ex - px;
+            if (sqrt(dx * dx + (ey - py)) > 1e-8) return true;
+        }
+    }
+    return false;
+}
+
+C2B_DEV bool hits_building_dev(double cx, double cz, double px, double pz, double L, double inset) {
+    // block index by truncation (:104-105), wrong for negative coordinates like the reference
+    const int64_t cbx = (int64_t)trunc(cx / L), cby = (int64_t)trunc(cz / L);
+    const int64_t pbx = (int64_t)trunc(px / L), pby = (int64_t)trunc(pz / L);
+    const int64_t x0 = cbx < pbx ? cbx : pbx, x1 = cbx < pbx ? pbx : cbx;
+    const int64_t y0 = cby < pby ? cby : pby, y1 = cby < pby ? pby : cby;
+    for (int64_t bx = x0; bx <= x1; ++bx)
+        for (int64_t by = y0; by <= y1; ++by)
+            if (hits_in_block_dev(cx, cz, px, pz, bx, by, L, inset)) return true;
+    return false;
+}
+
+// One wave per camera.  FILL = false: cam_count[c] = survivors of camera c.  FILL = true: survivors (point index, uv)
+// at row_ptr[c] ..., in the order the wave meets them.
+constexpr int kCellWPB = 4;
+template <bool FILL>
+__global__ __launch_bounds__(kCellWPB * 64) void k_cells_visibility(
+    const double *__restrict__ camblk, int64_t n_cam, const double4 *__restrict__ pts4, CellGrid g,
+    const uint32_t *__restrict__ start, const uint32_t *__restrict__ sorted, double max_dist, int occlusion, double L,
+    double inset, uint32_t *__restrict__ cam_count, const uint64_t *__restrict__ row_ptr, uint32_t *__restrict__ pt_out,
+    double2 *__restrict__ uv_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * kCellWPB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (c >= n_cam) return;                                              // wave-uniform; no workgroup barrier below
+    const double *cam = camblk + c * kCamBlk;                            // wave-uniform address: scalar loads
+    const double gx = cam[kCenter], gy = cam[kCenter + 1], gz = cam[kCenter + 2];
+    const int ccx = cell_coord(gx, g.x0, g.inv_cs, g.ncx), ccz = cell_coord(gz, g.z0, g.inv_cs, g.ncz);
+    const double r2 = max_dist * max_dist;
+    uint64_t dst = FILL ? row_ptr[c] : 0;
+    uint32_t count = 0;
+    const int ix0 = ccx > 0 ? ccx - 1 : 0, ix1 = ccx + 1 < g.ncx ? ccx + 1 : g.ncx - 1;
+    const int iz0 = ccz > 0 ? ccz - 1 : 0, iz1 = ccz + 1 < g.ncz ? ccz + 1 : g.ncz - 1;
+    for (int ix = ix0; ix <= ix1; ++ix) {
+        const uint32_t b = start[ix * g.ncz + iz0], e = start[ix * g.ncz + iz1 + 1];      // three cells, one range
+        for (uint32_t k0 = b; k0 < e; k0 += 64) {                                          // wave-uniform trip count
+            const uint32_t k = k0 + lane;
+            const bool valid = k < e;
+            const uint32_t j = sorted[valid ? k : e - 1];
+            const double4 X = pts4[j];
+            // rstar's locate_within_distance: squared distance <= max_dist^2, accumulated in dimension order
+            const double dx = gx - X.x, dy = gy - X.y, dz = gz - X.z;
+            const double d2 = dot3(dx, dy, dz, dx, dy, dz);
+            bool keep = valid && d2 <= r2;
+            double u = 0.0, v = 0.0;
+            if (keep) {
+                // (center - p).magnitude() < max_dist && q.z <= 0 && -1 <= u, v <= 1   (src/synthetic.rs:285-291, :368-375)
+                const Proj p = project_obs(cam, X.x, X.y, X.z);
+                u = p.u; v = p.v;
+                keep = sqrt(d2) < max_dist && p.qz <= 0.0 && u >= -1.0 && u <= 1.0 && v >= -1.0 && v <= 1.0;
+            }
+            if (keep && occlusion) keep = !hits_building_dev(gx, gz, X.x, X.z, L, inset);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            if (FILL && keep) {
+                const uint64_t at = dst + (uint64_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                pt_out[at] = j;
+                uv_out[at] = make_double2(u, v);
+            }
+            const uint32_t got = (uint32_t)__builtin_popcountll(m);
+            count += got;
+            dst += got;
+        }
+    }
+    if (!FILL && lane == 0) cam_count[c] = count;
+}
+
+// Every row into ascending point index: entry i goes to position #{entries of its row with a smaller index} (indices are
+// distinct inside a row).  One wave per camera; rows are a few dozen entries (the grid: 29 on average), all in L1.
+__global__ __launch_bounds__(kCellWPB * 64) void k_rows_rank_sort(const uint64_t *__restrict__ row_ptr, int64_t n_cam,
+                                                                const uint32_t *__restrict__ pt_in, const double2 *__restrict__ uv_in,
+                                                                uint32_t *__restrict__ pt_out, double2 *__restrict__ uv_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * kCellWPB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (c >= n_cam) return;
+    const uint64_t b = row_ptr[c], e = row_ptr[c + 1];
+    for (uint64_t i0 = b; i0 < e; i0 += 64) {                            // wave-uniform trip count
+        const uint64_t i = i0 + lane;
+        const bool valid = i < e;
+        const uint32_t mine = pt_in[valid ? i : e - 1];
+        uint32_t rank = 0;
+        for (uint64_t j = b; j < e; ++j) rank += pt_in[j] < mine ? 1u : 0u;
+        if (valid) {
+            pt_out[b + rank] = mine;
+            uv_out[b + rank] = uv_in[i];
+        }
+    }
+}
+
+// sum of n u32 counts in 64 bits (the scans run in 32 bits: this catches a total that does not fit them)
+__global__ __launch_bounds__(256) void k_sum_u32_u64(const uint32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+}  // namespace c2b

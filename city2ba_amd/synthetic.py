@@ -1,6 +1,7 @@
-"""Host-side mirror of synthetic.rs over the C ABI: layout and candidate search run in the native
-host code (csrc/host_synthetic.hpp), from_position_direction and the visibility predicate
-(src/synthetic.rs:285-291) on the GPU, cull() (src/synthetic.rs:299) in the native host code again."""
+"""Host-side mirror of synthetic.rs over the C ABI: the layout runs in the native host code (csrc/host_synthetic.hpp);
+from_position_direction, the whole visibility loop (src/synthetic.rs:268-297: candidates within max_dist, hits_building,
+the predicate -- csrc/cell_kernels.hpp) and cull() (src/synthetic.rs:299) on the GPU.  The host candidate search
+(candidate_pairs) stays as the second implementation the device path is tested against."""
 import ctypes as C
 import os
 
@@ -62,8 +63,10 @@ def candidate_pairs(centers, pts, max_dist, cam_lo=0, cam_hi=None, occlusion=Fal
     return ci, pi
 
 
-def _visibility_problem(pos, dirs, pts, max_dist, occlusion, block_length, block_inset, cull, device):
-    """Shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:260-299, 346-380)."""
+def _visibility_problem(pos, dirs, pts, max_dist, occlusion, block_length, block_inset, cull, device, host_candidates=False):
+    """Shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:260-299, 346-380).  host_candidates = True takes
+    rounds 1-3's route (candidate search and hits_building on the host, predicate + compaction on the device): the same
+    graph, index for index -- kept for the tests that compare the two."""
     from .baproblem import BAProblem
     n_cam = len(pos)
     empty_rows = np.zeros(n_cam + 1, dtype=np.uint64)
@@ -71,25 +74,28 @@ def _visibility_problem(pos, dirs, pts, max_dist, occlusion, block_length, block
     stage = BAProblem(device)
     cam15 = stage._cameras_from_position_direction(pos, dirs)
     ba = BAProblem.from_visibility(cam15, pts, empty_rows, [], np.zeros((0, 2)), device)
-    s = ba._camera_centers()
-    ci, pi = candidate_pairs(s, pts, max_dist, occlusion=occlusion, block_length=block_length,
-                             block_inset=block_inset)
-    ba.visibility_pairs_compact(ci, pi, max_dist, fetch=False)             # survivors compacted on the device ...
+    if host_candidates:
+        s = ba._camera_centers()
+        ci, pi = candidate_pairs(s, pts, max_dist, occlusion=occlusion, block_length=block_length,
+                                 block_inset=block_inset)
+        ba.visibility_pairs_compact(ci, pi, max_dist, fetch=False)         # survivors compacted on the device ...
+    else:
+        ba.visibility_within_distance(max_dist, occlusion, block_length, block_inset, fetch=False)
     ba.adopt_visibility()                                                  # ... where they become the vis_graph
     return ba.cull() if cull else ba
 
 
 def synthetic_grid(num_cameras_per_block, num_points_per_block, num_blocks, block_length, block_inset,
-                   camera_height, point_height, max_dist, verbose=False, cull=True, device=0):
+                   camera_height, point_height, max_dist, verbose=False, cull=True, device=0, host_candidates=False):
     """synthetic_grid (src/synthetic.rs:163-300), same argument order.  In-camera observation order is
     ascending point index (the reference's is rstar's traversal order)."""
     pos, dirs, pts = grid_layout(num_blocks, num_cameras_per_block, num_points_per_block, block_length,
                                  block_inset, camera_height, point_height)
-    return _visibility_problem(pos, dirs, pts, max_dist, True, block_length, block_inset, cull, device)
+    return _visibility_problem(pos, dirs, pts, max_dist, True, block_length, block_inset, cull, device, host_candidates)
 
 
 def synthetic_line(num_cameras, num_points, length, point_offset, camera_height, point_height, max_dist,
-                   verbose=False, cull=True, device=0):
+                   verbose=False, cull=True, device=0, host_candidates=False):
     """synthetic_line (src/synthetic.rs:313-381)"""
     pos, dirs, pts = line_layout(num_cameras, num_points, length, point_offset, camera_height, point_height)
-    return _visibility_problem(pos, dirs, pts, max_dist, False, 1.0, 0.0, cull, device)
+    return _visibility_problem(pos, dirs, pts, max_dist, False, 1.0, 0.0, cull, device, host_candidates)

@@ -575,6 +575,16 @@ int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t
  * survivors cross PCIe. */
 int c2b_problem_visibility_pairs_compact(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx,
                                          const uint32_t *pt_idx, double max_dist, uint64_t *row_ptr);
+/* The synthetic generators' WHOLE visibility loop on the device (src/synthetic.rs:268-297 grid, :353-378 line), the
+ * candidate search included: for every camera the points within max_dist of its centre (rstar's
+ * locate_within_distance(center, max_dist^2): squared distance <= max_dist^2, here a cell list), minus those whose
+ * sight line hits a building when `occlusion` != 0 (hits_building, :52-124, with block_length / block_inset), filtered
+ * by the predicate ((center - p).magnitude() < max_dist, z <= 0, |u|, |v| <= 1), kept per camera in ascending point
+ * index.  Same result, index for index and bit for bit, as c2b_candidate_pairs + c2b_problem_visibility_pairs_compact;
+ * nothing but row_ptr [n_cam + 1] (may be NULL) crosses PCIe.  The kept lists become the pending visibility result
+ * (c2b_problem_adopt_visibility / c2b_problem_visibility_dense_fetch). */
+int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int occlusion, double block_length,
+                                           double block_inset, uint64_t *row_ptr);
 /* dense sweep (src/generate.rs:446-469, no occlusion) over the problem's cameras and points: writes
  * row_ptr[n_cam + 1] and keeps the survivors on the device; _fetch copies pt_idx[row_ptr[n_cam]] and
  * uv[row_ptr[n_cam]][2] out (either may be NULL). */
