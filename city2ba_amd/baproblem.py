@@ -318,8 +318,9 @@ class BAProblem:
         return cls.from_file(path, device, "binary")
 
     def write(self, path, fmt=None):
-        """BAProblem::write (src/baproblem.rs:768-785)"""
-        write_bal(path, self.cameras_bal(), self.points(), self._row_ptr, self._pt_idx, self.observations(), fmt)
+        """BAProblem::write (src/baproblem.rs:768-785) straight from the resident problem: a .bbal image is assembled on
+        the device (to_vec, counts, byte order) and only its bytes cross PCIe; .bal text is formatted by the host"""
+        L.check(L.lib().c2b_problem_write(self._h, str(path).encode(), _FORMATS[fmt]))
 
     def write_text(self, path):                     # src/baproblem.rs:709-733
         self.write(path, "text")

@@ -142,15 +142,28 @@ void download_problem(c2b_problem *p, HostProblem &hp) {
     hp.pt_idx.resize((size_t)n_obs);
 }
 
-// shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:268-299, :353-380): the whole visibility loop --
-// candidates within max_dist, hits_building, the predicate -- then cull, all on the device.  C2B_HOST_CANDIDATES=1 takes
-// rounds 1-3's route (candidate search on the host, 47.5 M pairs uploaded at --blocks 128) for comparison.
-HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, const std::vector<double> &dir,
-                                const std::vector<double> &pts, double max_dist, bool occlusion, double L, double inset) {
-    const int64_t n_cam = (int64_t)pos.size() / 3, n_pts = (int64_t)pts.size() / 3;
-    HostProblem hp;
+void display_and_write(c2b_problem *p, const HostProblem &hp, const std::string &out) {
     PhaseTimer timer;
-    hp.n_cam = n_cam; hp.n_pts = n_pts;
+    std::printf("Bundle Adjustment Problem with %lld cameras, %lld points, and %lld observations\n", (long long)hp.n_cam,
+                (long long)hp.n_pts, (long long)hp.pt_idx.size());
+    std::vector<double> bal9((size_t)hp.n_cam * 9);
+    ck(c2b_problem_download_bal(p, bal9.data()));
+    timer.mark("to_vec + download");
+    ck(c2b_bal_write(out.c_str(), hp.n_cam, bal9.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+    timer.mark("write");
+}
+
+// shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:268-299, :353-380) and of their subcommands
+// (src/bin/city2ba.rs:447-478): the whole visibility loop -- candidates within max_dist, hits_building, the predicate --
+// then cull, the Display line and the file, all from the resident problem: nothing but the file's bytes leaves the
+// device.  C2B_HOST_CANDIDATES=1 takes rounds 1-3's route (candidate search on the host, 47.5 M pairs uploaded at
+// --blocks 128, the arrays downloaded and serialised by the host) for comparison; it writes the same file.
+void visibility_cull_write(c2b_problem *p, const std::vector<double> &pos, const std::vector<double> &dir,
+                           const std::vector<double> &pts, double max_dist, bool occlusion, double L, double inset,
+                           const std::string &out) {
+    const int64_t n_cam = (int64_t)pos.size() / 3, n_pts = (int64_t)pts.size() / 3;
+    PhaseTimer timer;
+    const bool host_route = std::getenv("C2B_HOST_CANDIDATES") != nullptr;
     {
         std::vector<double> cams15((size_t)n_cam * 15);
         ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), cams15.data()));
@@ -158,7 +171,7 @@ HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, 
         ck(c2b_problem_upload(p, n_cam, cams15.data(), n_pts, pts.data(), empty_rows.data(), nullptr, nullptr));
     }
     timer.mark("from_position_direction + upload");
-    if (std::getenv("C2B_HOST_CANDIDATES")) {
+    if (host_route) {
         std::vector<double> centers((size_t)n_cam * 3);
         ck(c2b_problem_centers(p, centers.data()));
         c2b_pairs *pairs = nullptr;
@@ -177,17 +190,18 @@ HostProblem visibility_and_cull(c2b_problem *p, const std::vector<double> &pos, 
     // .cull(), src/synthetic.rs:299 -- on the device
     ck(c2b_problem_cull(p, 1));
     timer.mark("adopt + cull (device)");
-    download_problem(p, hp);
-    timer.mark("download");
-    return hp;
-}
-
-void display_and_write(c2b_problem *p, const HostProblem &hp, const std::string &out) {
-    std::printf("Bundle Adjustment Problem with %lld cameras, %lld points, and %lld observations\n", (long long)hp.n_cam,
-                (long long)hp.n_pts, (long long)hp.pt_idx.size());
-    std::vector<double> bal9((size_t)hp.n_cam * 9);
-    ck(c2b_problem_download_bal(p, bal9.data()));
-    ck(c2b_bal_write(out.c_str(), hp.n_cam, bal9.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+    if (host_route) {
+        HostProblem hp;
+        download_problem(p, hp);
+        timer.mark("download");
+        display_and_write(p, hp, out);
+        return;
+    }
+    int64_t nc = 0, np = 0, no = 0;
+    ck(c2b_problem_sizes(p, &nc, &np, &no));
+    std::printf("Bundle Adjustment Problem with %lld cameras, %lld points, and %lld observations\n", (long long)nc, (long long)np, (long long)no);
+    ck(c2b_problem_write(p, out.c_str(), -1));
+    timer.mark("write (file image built on the device for .bbal)");
 }
 
 int run_synthetic(int argc, char **argv) {
@@ -198,13 +212,15 @@ int run_synthetic(int argc, char **argv) {
     const double max_dist = a.f("max-dist", 10), cam_h = a.f("camera-height", 1), pt_h = a.f("point-height", 1);
     const double inset = a.f("block-inset", 1), L = a.f("block-length", 20);
     int64_t n_cam, n_pts;
+    PhaseTimer timer;
     ck(c2b_synthetic_grid_sizes(cpb, ppb, B, &n_cam, &n_pts));
     std::vector<double> pos((size_t)n_cam * 3), dir((size_t)n_cam * 9), pts((size_t)n_pts * 3);
     ck(c2b_synthetic_grid_layout(cpb, ppb, B, L, inset, cam_h, pt_h, pos.data(), dir.data(), pts.data()));
+    timer.mark("layout (host)");
     c2b_problem *p = nullptr;
     ck(c2b_problem_create((int)a.i("device", 0), &p));
-    const HostProblem hp = visibility_and_cull(p, pos, dir, pts, max_dist, true, L, inset);
-    display_and_write(p, hp, a.positional[0]);
+    timer.mark("problem_create (HIP runtime start)");
+    visibility_cull_write(p, pos, dir, pts, max_dist, true, L, inset, a.positional[0]);
     c2b_problem_destroy(p);
     return 0;
 }
@@ -219,8 +235,7 @@ int run_synthetic_line(int argc, char **argv) {
                                  a.f("point-height", 1), pos.data(), dir.data(), pts.data()));
     c2b_problem *p = nullptr;
     ck(c2b_problem_create((int)a.i("device", 0), &p));
-    const HostProblem hp = visibility_and_cull(p, pos, dir, pts, a.f("max-dist", 10), false, 1.0, 0.0);
-    display_and_write(p, hp, a.positional[0]);
+    visibility_cull_write(p, pos, dir, pts, a.f("max-dist", 10), false, 1.0, 0.0, a.positional[0]);
     c2b_problem_destroy(p);
     return 0;
 }

@@ -15,7 +15,11 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "host_baproblem.hpp"
 #include "host_bvh.hpp"
@@ -3115,6 +3119,95 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
     p->dense_n = (int64_t)n_kept;
     return C2B_OK;
     C2B_API_END("problem_visibility_within_distance")
+}
+
+// BAProblem::write (src/baproblem.rs:768-785) of the RESIDENT problem.  `.bbal` (format 1): the file image is assembled
+// on the device (cell_kernels.hpp: k_bbal_*: to_vec of every camera, the per-camera counts, the byte order) and leaves
+// through a few host threads, each copying its chunks into a pinned buffer and pwrite()-ing them -- the host touches no
+// observation.  `.bal` (format 0): the text writer of csrc/host_baproblem.hpp over a download (shortest round-trip
+// decimals are host work).  format -1: by extension, like the reference.
+int c2b_problem_write(c2b_problem *p, const char *path, int format) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_write");
+    if (!path) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_write: path is NULL");
+    bool binary = false;
+    int rc = bal_format(path, format, &binary);
+    if (rc) return rc;
+    const int64_t n_cam = p->n_cam, n_pts = p->n_pts, n_obs = p->n_obs;
+    if (!p->bal_valid) {                                     // to_vec (src/baproblem.rs:189-202) of the current state
+        rc = c2b_cameras_to_bal(p->cam15, n_cam, p->bal9, p->stream);
+        if (rc) return rc;
+    }
+    if (!binary) {
+        std::vector<double> bal9((size_t)n_cam * 9 + 1), pts((size_t)n_pts * 3 + 1), uv((size_t)n_obs * 2 + 1);
+        std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs + 1);
+        if (n_cam) HIP_TRY(hipMemcpyAsync(bal9.data(), p->bal9, sizeof(double) * 9 * (size_t)n_cam, hipMemcpyDeviceToHost, p->stream));
+        rc = c2b_problem_download(p, nullptr, pts.data(), uv.data());
+        if (!rc) rc = c2b_problem_download_graph(p, row_ptr.data(), pt_idx.data());
+        if (rc) return rc;
+        return c2b_bal_write_as(path, 0, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data());
+    }
+    rc = ensure_rows(p);
+    if (rc) return rc;
+    const size_t words = 3 + (size_t)n_cam + 3 * (size_t)n_obs + 9 * (size_t)n_cam + 3 * (size_t)n_pts, bytes = words * 8;
+    DevBuf img;
+    hipError_t e = img.alloc(bytes);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_write: %s", hipGetErrorString(e));
+    uint64_t *w = img.as<uint64_t>();
+    hipStream_t st = p->stream;
+    // (no observations: no row structure exists and every count is zero)
+    hipLaunchKernelGGL(k_bbal_rows, dim3(blocks_of(n_cam, 256)), dim3(256), 0, st, (const uint64_t *)(n_obs ? p->rows_ptr : nullptr),
+                       n_cam, n_pts, n_obs, w);
+    if (n_obs) hipLaunchKernelGGL(k_bbal_observations, dim3(blocks_of(n_obs, 256)), dim3(256), 0, st, (const uint32_t *)p->cam_idx,
+                                  (const uint32_t *)p->pt_idx, reinterpret_cast<const double2 *>(p->uv), n_obs, w);
+    uint64_t *wc = w + 3 + n_cam + 3 * (size_t)n_obs, *wp = wc + 9 * (size_t)n_cam;
+    if (n_cam) hipLaunchKernelGGL(k_bbal_rows_f64, dim3(blocks_of(9 * n_cam, 256)), dim3(256), 0, st, (const double *)p->bal9, n_cam, 9, 9, wc);
+    if (n_pts) hipLaunchKernelGGL(k_bbal_rows_f64, dim3(blocks_of(3 * n_pts, 256)), dim3(256), 0, st, (const double *)p->pts4, n_pts, 3, 4, wp);
+    e = launch_error();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_write: %s", hipGetErrorString(e));
+
+    const int fd = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "cannot create %s", path);
+    if (::ftruncate(fd, (off_t)bytes) != 0) { ::close(fd); return fail(C2B_ERR_INVALID_ARGUMENT, "write failed: %s", path); }
+    constexpr size_t kChunk = (size_t)16 << 20;
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    int n_threads = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), n_chunks);
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    const int device = p->device;
+    auto worker = [&]() {
+        void *pin = nullptr;
+        hipStream_t cs = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin, kChunk, hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
+            failed = 1;
+        } else {
+            for (size_t k = next++; k < n_chunks && !failed; k = next++) {
+                const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+                if (hipMemcpyAsync(pin, reinterpret_cast<const char *>(img.ptr) + off, len, hipMemcpyDeviceToHost, cs) != hipSuccess ||
+                    hipStreamSynchronize(cs) != hipSuccess) { failed = 1; break; }
+                size_t done = 0;
+                while (done < len) {
+                    const ssize_t r = ::pwrite(fd, static_cast<const char *>(pin) + done, len - done, (off_t)(off + done));
+                    if (r <= 0) { failed = 2; break; }
+                    done += (size_t)r;
+                }
+            }
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+        if (pin) (void)hipHostFree(pin);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker);
+    worker();
+    for (auto &x : th) x.join();
+    const bool closed = ::close(fd) == 0;
+    (void)hipSetDevice(p->device);
+    if (failed == 1) return fail(C2B_ERR_HIP, "problem_write: device-to-host copy failed");
+    if (failed || !closed) return fail(C2B_ERR_INVALID_ARGUMENT, "write failed: %s", path);
+    return C2B_OK;
+    C2B_API_END("problem_write")
 }
 
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr) {

@@ -187,4 +187,38 @@ __global__ __launch_bounds__(256) void k_sum_u32_u64(const uint32_t *__restrict_
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
+// ---- BAProblem::write_binary (src/baproblem.rs:736-764) assembled on the device -------------------------------------
+// The .bbal image: header (3 big-endian u64: cameras, points, observations) | per camera: BE u64 count, then count x
+// (BE u64 point, BE f64 u, BE f64 v) | 9 BE f64 per camera (to_vec order) | 3 BE f64 per point.  Every word is 8-byte
+// aligned in the file, so the image is an array of u64 and each kernel below writes byte-swapped words into it; the host
+// only moves bytes (pinned chunks -> pwrite).  463 MB of a 564 MB file at --blocks 128 are observation records.
+C2B_DEV uint64_t bswap64(uint64_t v) { return __builtin_bswap64(v); }
+
+__global__ __launch_bounds__(256) void k_bbal_rows(const uint64_t *__restrict__ row_ptr, int64_t n_cam, int64_t n_pts, int64_t n_obs,
+                                                  uint64_t *__restrict__ img) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c == 0) { img[0] = bswap64((uint64_t)n_cam); img[1] = bswap64((uint64_t)n_pts); img[2] = bswap64((uint64_t)n_obs); }
+    if (c >= n_cam) return;
+    const uint64_t b = row_ptr ? row_ptr[c] : 0, e = row_ptr ? row_ptr[c + 1] : 0;     // no row structure: no observations
+    img[3 + c + 3 * b] = bswap64(e - b);                                 // its count sits in front of its records
+}
+__global__ __launch_bounds__(256) void k_bbal_observations(const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
+                                                          const double2 *__restrict__ uv, int64_t n_obs, uint64_t *__restrict__ img) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_obs) return;
+    const double2 q = uv[o];
+    uint64_t *w = img + 3 + ((uint64_t)cam_idx[o] + 1) + 3 * (uint64_t)o;   // header | one count per camera up to and including its own
+    w[0] = bswap64((uint64_t)pt_idx[o]);
+    w[1] = bswap64((uint64_t)__double_as_longlong(q.x));
+    w[2] = bswap64((uint64_t)__double_as_longlong(q.y));
+}
+// n rows of `width` doubles out of rows `stride` doubles apart (cameras: 9 of 9; points: 3 of the padded 4)
+__global__ __launch_bounds__(256) void k_bbal_rows_f64(const double *__restrict__ in, int64_t n, int width, int stride,
+                                                      uint64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * width) return;
+    const int64_t r = i / width, k = i % width;
+    out[i] = bswap64((uint64_t)__double_as_longlong(in[r * stride + k]));
+}
+
 }  // namespace c2b

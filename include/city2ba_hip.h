@@ -528,6 +528,11 @@ int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int6
 /* any of the outputs may be NULL */
 int c2b_problem_download(c2b_problem *p, double *cams15, double *pts3, double *uv);
 int c2b_problem_download_bal(c2b_problem *p, double *bal9);
+/* BAProblem::write / write_text / write_binary (src/baproblem.rs:709-785) of the RESIDENT problem: format -1 = by
+ * extension (.bal text, .bbal binary, anything else an error, like the reference), 0 = text, 1 = binary.  The binary
+ * image -- to_vec of every camera, per-camera counts, big-endian words -- is assembled on the device and leaves through
+ * pinned chunks written by a few host threads; the bytes equal c2b_bal_write's on the downloaded arrays. */
+int c2b_problem_write(c2b_problem *p, const char *path, int format);
 
 /* Camera::from_position_direction (src/baproblem.rs:153-159) for n cameras on p's device:
  * pos3 [n][3], dir9 [n][9] col-major -> cams15 [n][15].  Does not change the problem. */
