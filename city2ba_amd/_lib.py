@@ -147,6 +147,8 @@ SIGNATURES = {
     "c2b_problem_destroy": (None, [_vp]),
     "c2b_problem_upload": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "c2b_problem_upload_bal": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_problem_synthetic_grid_layout": (_int, [_vp, _i64, _i64, _i64, _d, _d, _d, _d]),
+    "c2b_problem_synthetic_line_layout": (_int, [_vp, _i64, _i64, _d, _d, _d, _d]),
     "c2b_problem_sizes": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "c2b_problem_download": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_download_bal": (_int, [_vp, _vp]),

@@ -153,25 +153,31 @@ void display_and_write(c2b_problem *p, const HostProblem &hp, const std::string 
     timer.mark("write");
 }
 
-// shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:268-299, :353-380) and of their subcommands
-// (src/bin/city2ba.rs:447-478): the whole visibility loop -- candidates within max_dist, hits_building, the predicate --
-// then cull, the Display line and the file, all from the resident problem: nothing but the file's bytes leaves the
-// device.  C2B_HOST_CANDIDATES=1 takes rounds 1-3's route (candidate search on the host, 47.5 M pairs uploaded at
-// --blocks 128, the arrays downloaded and serialised by the host) for comparison; it writes the same file.
-void visibility_cull_write(c2b_problem *p, const std::vector<double> &pos, const std::vector<double> &dir,
-                           const std::vector<double> &pts, double max_dist, bool occlusion, double L, double inset,
-                           const std::string &out) {
-    const int64_t n_cam = (int64_t)pos.size() / 3, n_pts = (int64_t)pts.size() / 3;
-    PhaseTimer timer;
+// synthetic_grid / synthetic_line (src/synthetic.rs:163-300, :313-381) and the tail of their subcommands
+// (src/bin/city2ba.rs:447-478), everything on the resident problem: the layout loops, the visibility loop -- candidates
+// within max_dist, hits_building, the predicate --, cull, the Display line, and the file image.  Only the file's bytes
+// leave the device.  C2B_HOST_CANDIDATES=1 takes rounds 1-3's route (layout and candidate search on the host, 47.5 M
+// pairs uploaded at --blocks 128, the arrays downloaded and serialised by the host) for comparison; same file.
+struct Layout {
+    bool grid = true;
+    int64_t cpb = 0, ppb = 0, blocks = 0, n_cam = 0, n_pts = 0;              // grid: per block; line: totals in n_cam / n_pts
+    double L = 0, inset = 0, cam_h = 0, pt_h = 0, length = 0, point_offset = 0;
+};
+
+void generate_cull_write(c2b_problem *p, const Layout &lay, double max_dist, const std::string &out, PhaseTimer &timer) {
     const bool host_route = std::getenv("C2B_HOST_CANDIDATES") != nullptr;
-    {
-        std::vector<double> cams15((size_t)n_cam * 15);
+    const bool occlusion = lay.grid;
+    const double L = lay.grid ? lay.L : 1.0, inset = lay.grid ? lay.inset : 0.0;
+    if (host_route) {
+        int64_t n_cam = lay.n_cam, n_pts = lay.n_pts;
+        if (lay.grid) ck(c2b_synthetic_grid_sizes(lay.cpb, lay.ppb, lay.blocks, &n_cam, &n_pts));
+        std::vector<double> pos((size_t)n_cam * 3), dir((size_t)n_cam * 9), pts((size_t)n_pts * 3), cams15((size_t)n_cam * 15);
+        if (lay.grid) ck(c2b_synthetic_grid_layout(lay.cpb, lay.ppb, lay.blocks, lay.L, lay.inset, lay.cam_h, lay.pt_h, pos.data(), dir.data(), pts.data()));
+        else ck(c2b_synthetic_line_layout(n_cam, n_pts, lay.length, lay.point_offset, lay.cam_h, lay.pt_h, pos.data(), dir.data(), pts.data()));
         ck(c2b_problem_from_position_direction(p, n_cam, pos.data(), dir.data(), cams15.data()));
         std::vector<uint64_t> empty_rows((size_t)n_cam + 1, 0);
         ck(c2b_problem_upload(p, n_cam, cams15.data(), n_pts, pts.data(), empty_rows.data(), nullptr, nullptr));
-    }
-    timer.mark("from_position_direction + upload");
-    if (host_route) {
+        timer.mark("layout (host) + from_position_direction + upload");
         std::vector<double> centers((size_t)n_cam * 3);
         ck(c2b_problem_centers(p, centers.data()));
         c2b_pairs *pairs = nullptr;
@@ -183,6 +189,9 @@ void visibility_cull_write(c2b_problem *p, const std::vector<double> &pos, const
         c2b_pairs_free(pairs);
         timer.mark("visibility predicate + compaction (device)");
     } else {
+        if (lay.grid) ck(c2b_problem_synthetic_grid_layout(p, lay.cpb, lay.ppb, lay.blocks, lay.L, lay.inset, lay.cam_h, lay.pt_h));
+        else ck(c2b_problem_synthetic_line_layout(p, lay.n_cam, lay.n_pts, lay.length, lay.point_offset, lay.cam_h, lay.pt_h));
+        timer.mark("layout (device)");
         ck(c2b_problem_visibility_within_distance(p, max_dist, occlusion ? 1 : 0, L, inset, nullptr));
         timer.mark("candidates + hits_building + predicate (device)");
     }
@@ -208,19 +217,15 @@ int run_synthetic(int argc, char **argv) {
     const Args a = parse(argc, argv, 2, {}, {"cameras-per-block", "points-per-block", "max-dist", "camera-height",
                                              "point-height", "block-inset", "block-length", "blocks", "device"});
     if (a.positional.size() != 1) die("The following required arguments were not provided:\n    <OUTPUT>");
-    const int64_t cpb = a.i("cameras-per-block", 10), ppb = a.i("points-per-block", 10), B = a.i("blocks", 5);
-    const double max_dist = a.f("max-dist", 10), cam_h = a.f("camera-height", 1), pt_h = a.f("point-height", 1);
-    const double inset = a.f("block-inset", 1), L = a.f("block-length", 20);
-    int64_t n_cam, n_pts;
+    Layout lay;
+    lay.cpb = a.i("cameras-per-block", 10); lay.ppb = a.i("points-per-block", 10); lay.blocks = a.i("blocks", 5);
+    lay.cam_h = a.f("camera-height", 1); lay.pt_h = a.f("point-height", 1);
+    lay.inset = a.f("block-inset", 1); lay.L = a.f("block-length", 20);
     PhaseTimer timer;
-    ck(c2b_synthetic_grid_sizes(cpb, ppb, B, &n_cam, &n_pts));
-    std::vector<double> pos((size_t)n_cam * 3), dir((size_t)n_cam * 9), pts((size_t)n_pts * 3);
-    ck(c2b_synthetic_grid_layout(cpb, ppb, B, L, inset, cam_h, pt_h, pos.data(), dir.data(), pts.data()));
-    timer.mark("layout (host)");
     c2b_problem *p = nullptr;
     ck(c2b_problem_create((int)a.i("device", 0), &p));
     timer.mark("problem_create (HIP runtime start)");
-    visibility_cull_write(p, pos, dir, pts, max_dist, true, L, inset, a.positional[0]);
+    generate_cull_write(p, lay, a.f("max-dist", 10), a.positional[0], timer);
     c2b_problem_destroy(p);
     return 0;
 }
@@ -229,13 +234,16 @@ int run_synthetic_line(int argc, char **argv) {
     const Args a = parse(argc, argv, 2, {}, {"cameras", "points", "max-dist", "camera-height", "point-height",
                                              "point-offset", "length", "device"});
     if (a.positional.size() != 1) die("The following required arguments were not provided:\n    <OUTPUT>");
-    const int64_t n_cam = a.i("cameras", 10), n_pts = a.i("points", 10);
-    std::vector<double> pos((size_t)n_cam * 3), dir((size_t)n_cam * 9), pts((size_t)n_pts * 3);
-    ck(c2b_synthetic_line_layout(n_cam, n_pts, a.f("length", 20), a.f("point-offset", 1), a.f("camera-height", 1),
-                                 a.f("point-height", 1), pos.data(), dir.data(), pts.data()));
+    Layout lay;
+    lay.grid = false;
+    lay.n_cam = a.i("cameras", 10); lay.n_pts = a.i("points", 10);
+    lay.length = a.f("length", 20); lay.point_offset = a.f("point-offset", 1);
+    lay.cam_h = a.f("camera-height", 1); lay.pt_h = a.f("point-height", 1);
+    PhaseTimer timer;
     c2b_problem *p = nullptr;
     ck(c2b_problem_create((int)a.i("device", 0), &p));
-    visibility_cull_write(p, pos, dir, pts, a.f("max-dist", 10), false, 1.0, 0.0, a.positional[0]);
+    timer.mark("problem_create (HIP runtime start)");
+    generate_cull_write(p, lay, a.f("max-dist", 10), a.positional[0], timer);
     c2b_problem_destroy(p);
     return 0;
 }

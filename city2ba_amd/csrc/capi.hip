@@ -2214,6 +2214,26 @@ static int ensure_camblk(c2b_problem *p) {
     return C2B_OK;
 }
 
+// the resident arrays of a problem with these sizes (whatever it held before is freed); contents undefined
+static int alloc_problem(c2b_problem *p, int64_t n_cam, int64_t n_pts, int64_t n_obs) {
+    HIP_TRY(hipSetDevice(p->device));
+    free_buffers(p);
+    auto dalloc = [&](void **q, size_t bytes) -> hipError_t { return hipMalloc(q, bytes ? bytes : 16); };
+    HIP_TRY(dalloc((void **)&p->cam15, sizeof(double) * 15 * n_cam));
+    HIP_TRY(dalloc((void **)&p->bal9, sizeof(double) * 9 * n_cam));
+    HIP_TRY(dalloc((void **)&p->camblk, sizeof(double) * kCamBlk * n_cam));
+    HIP_TRY(dalloc((void **)&p->pts4, sizeof(double) * 4 * n_pts));
+    HIP_TRY(dalloc((void **)&p->uv, sizeof(double) * 2 * n_obs));
+    HIP_TRY(dalloc((void **)&p->cam_idx, sizeof(uint32_t) * n_obs));
+    HIP_TRY(dalloc((void **)&p->pt_idx, sizeof(uint32_t) * n_obs));
+    HIP_TRY(dalloc(&p->ws, (size_t)c2b_workspace_bytes(n_obs)));
+    if (int rc = c2b_workspace_init(p->ws, p->stream)) return rc;
+    HIP_TRY(dalloc((void **)&p->stats, sizeof(double) * C2B_STATS_DOUBLES));
+    HIP_TRY(dalloc((void **)&p->scalar, sizeof(double) * 2));
+    p->n_cam = n_cam; p->n_pts = n_pts; p->n_obs = n_obs;
+    return C2B_OK;
+}
+
 static int upload_common(c2b_problem *p, int64_t n_cam, const double *cams, bool is_bal, int64_t n_pts,
                          const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv) {
     if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_upload: problem is NULL");
@@ -2235,21 +2255,8 @@ static int upload_common(c2b_problem *p, int64_t n_cam, const double *cams, bool
                         (long long)o, (unsigned long long)pt_idx[o], (long long)n_pts);
         pi32[(size_t)o] = (uint32_t)pt_idx[o];
     }
-    HIP_TRY(hipSetDevice(p->device));
-    free_buffers(p);
+    if (int rc = alloc_problem(p, n_cam, n_pts, n_obs)) return rc;
     auto dalloc = [&](void **q, size_t bytes) -> hipError_t { return hipMalloc(q, bytes ? bytes : 16); };
-    HIP_TRY(dalloc((void **)&p->cam15, sizeof(double) * 15 * n_cam));
-    HIP_TRY(dalloc((void **)&p->bal9, sizeof(double) * 9 * n_cam));
-    HIP_TRY(dalloc((void **)&p->camblk, sizeof(double) * kCamBlk * n_cam));
-    HIP_TRY(dalloc((void **)&p->pts4, sizeof(double) * 4 * n_pts));
-    HIP_TRY(dalloc((void **)&p->uv, sizeof(double) * 2 * n_obs));
-    HIP_TRY(dalloc((void **)&p->cam_idx, sizeof(uint32_t) * n_obs));
-    HIP_TRY(dalloc((void **)&p->pt_idx, sizeof(uint32_t) * n_obs));
-    HIP_TRY(dalloc(&p->ws, (size_t)c2b_workspace_bytes(n_obs)));
-    if (int rc = c2b_workspace_init(p->ws, p->stream)) return rc;
-    HIP_TRY(dalloc((void **)&p->stats, sizeof(double) * C2B_STATS_DOUBLES));
-    HIP_TRY(dalloc((void **)&p->scalar, sizeof(double) * 2));
-    p->n_cam = n_cam; p->n_pts = n_pts; p->n_obs = n_obs;
 
     // staging through temporary device buffers (row_ptr, packed points)
     uint64_t *d_row = nullptr;
@@ -2297,6 +2304,66 @@ int c2b_problem_upload_bal(c2b_problem *p, int64_t n_cam, const double *bal9, in
     C2B_API_BEGIN
     return upload_common(p, n_cam, bal9, true, n_pts, pts3, row_ptr, pt_idx, uv);
     C2B_API_END("problem_upload_bal")
+}
+
+// synthetic_grid's / synthetic_line's layout loops (src/synthetic.rs:178-258, :323-344) straight into the resident problem:
+// cameras by Camera::from_position_direction, points, no observations yet (the visibility loop adds them).  Entity for
+// entity and bit for bit what c2b_synthetic_grid_layout + c2b_problem_from_position_direction + c2b_problem_upload give,
+// without 2 x 112 MB crossing PCIe.  The orientations' sines and cosines come from the host's libm like the host
+// layout's (Basis3::from_angle_y(Deg(..)), :191-205).
+static GridDirs layout_dirs() {
+    GridDirs d;
+    c2b_host::basis_from_angle_y_deg(-90.0, d.m[0]);
+    c2b_host::basis_from_angle_y_deg(90.0, d.m[1]);
+    c2b_host::basis_from_angle_y_deg(180.0, d.m[2]);
+    const double one[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::copy(one, one + 9, d.m[3]);
+    return d;
+}
+
+int c2b_problem_synthetic_grid_layout(c2b_problem *p, int64_t cpb, int64_t ppb, int64_t blocks, double block_length,
+                                      double block_inset, double camera_height, double point_height) {
+    C2B_API_BEGIN
+    if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_synthetic_grid_layout: problem is NULL");
+    if (cpb < 0 || ppb < 0 || blocks < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_synthetic_grid_layout: bad arguments");
+    // assert!(block_inset * 2. < block_length, ...), src/synthetic.rs:177
+    if (!(block_inset * 2.0 < block_length))
+        return fail(C2B_ERR_INVALID_ARGUMENT,
+                    "Block inset (%g) must be less than half the block length (%g), to not violate physical constraints.",
+                    block_inset, block_length);
+    int64_t n_cam = 0, n_pts = 0;
+    c2b_host::grid_sizes(cpb, ppb, blocks, &n_cam, &n_pts);
+    if (n_cam >= ((int64_t)1 << 32) || n_pts >= ((int64_t)1 << 32))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_synthetic_grid_layout: device indices are 32-bit");
+    int rc = alloc_problem(p, n_cam, n_pts, 0);
+    if (rc) return rc;
+    if (n_cam) hipLaunchKernelGGL(k_grid_cameras, dim3(blocks_for(n_cam, 256)), dim3(256), 0, p->stream, n_cam, cpb, blocks, block_length,
+                                  camera_height, layout_dirs(), p->cam15);
+    if (n_pts) hipLaunchKernelGGL(k_grid_points, dim3(blocks_for(n_pts, 256)), dim3(256), 0, p->stream, n_pts, ppb, blocks, block_length,
+                                  block_inset, point_height, reinterpret_cast<double4 *>(p->pts4));
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->bal_valid = false; p->blk_valid = false;
+    return C2B_OK;
+    C2B_API_END("problem_synthetic_grid_layout")
+}
+
+int c2b_problem_synthetic_line_layout(c2b_problem *p, int64_t n_cam, int64_t n_pts, double length, double point_offset,
+                                      double camera_height, double point_height) {
+    C2B_API_BEGIN
+    if (!p) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_synthetic_line_layout: problem is NULL");
+    if (n_cam < 0 || n_pts < 0 || n_cam >= ((int64_t)1 << 32) || n_pts >= ((int64_t)1 << 32))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_synthetic_line_layout: bad arguments");
+    int rc = alloc_problem(p, n_cam, n_pts, 0);
+    if (rc) return rc;
+    const int64_t n = std::max(n_cam, n_pts);
+    if (n) hipLaunchKernelGGL(k_line_layout, dim3(blocks_for(n, 256)), dim3(256), 0, p->stream, n_cam, n_pts, length, point_offset,
+                              camera_height, point_height, layout_dirs(), p->cam15, reinterpret_cast<double4 *>(p->pts4));
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->bal_valid = false; p->blk_valid = false;
+    return C2B_OK;
+    C2B_API_END("problem_synthetic_line_layout")
 }
 
 int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs) {

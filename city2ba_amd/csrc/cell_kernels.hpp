@@ -187,6 +187,102 @@ __global__ __launch_bounds__(256) void k_sum_u32_u64(const uint32_t *__restrict_
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
+// ---- the layout loops of synthetic_grid / synthetic_line (src/synthetic.rs:178-258, :323-344) on the device ---------
+// One thread per camera / point: the loop nest's push order is inverted in closed form (block column bx, block row by,
+// slot i, which of the block's entities) and every coordinate is evaluated with the reference's operations in its order
+// (`offset + i as f64 / n as f64 * L`, `(L - inset * 2.) / n`, ...), so positions are bit-equal to the host loops of
+// csrc/host_synthetic.hpp.  The four camera orientations (Basis3::from_angle_y of -90, 90, 180 degrees and the identity,
+// :191-205) are evaluated by the host's libm once and passed in; cameras are finished here like
+// Camera::from_position_direction (src/baproblem.rs:153-159).
+struct GridDirs { double m[4][9]; };          // column-major: from_angle_y(-90), (90), (180), one
+
+// entity n of a loop nest that pushes `per` entities per slot for each of the two street directions:
+// for bx in 0..=B { for by in 0..=B { for i in 0..slots { if bx != B { per x } if by != B { per x } } } }
+C2B_DEV void grid_slot(int64_t n, int64_t B, int64_t slots, int per, int64_t &bx, int64_t &by, int64_t &i, int &k, bool &along_x) {
+    const int64_t row_full = slots * per * (2 * B + 1);                  // a column bx < B: B blocks of 2 per, one of per
+    if (n < B * row_full) {
+        bx = n / row_full;
+        const int64_t r = n % row_full;
+        if (r < 2 * per * slots * B) {
+            by = r / (2 * per * slots);
+            const int64_t r2 = r % (2 * per * slots);
+            i = r2 / (2 * per);
+            const int kk = (int)(r2 % (2 * per));
+            along_x = kk < per; k = kk % per;
+        } else {
+            by = B;
+            const int64_t r2 = r - 2 * per * slots * B;
+            i = r2 / per; k = (int)(r2 % per); along_x = true;
+        }
+    } else {                                                              // the last column: only the streets along z
+        bx = B;
+        const int64_t r = n - B * row_full;
+        by = r / (per * slots);
+        const int64_t r2 = r % (per * slots);
+        i = r2 / per; k = (int)(r2 % per); along_x = false;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grid_cameras(int64_t n_cam, int64_t cpb, int64_t B, double L, double cam_h, GridDirs d,
+                                                     double *__restrict__ cam15) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_cam) return;
+    int64_t bx, by, i;
+    int k;
+    bool along_x;
+    grid_slot(n, B, cpb, 2, bx, by, i, k, along_x);
+    const double offset_x = L * (double)bx, offset_z = L * (double)by;
+    const double t = (double)i / (double)cpb * L;
+    const double px = along_x ? offset_x + t : offset_x, pz = along_x ? offset_z : offset_z + t;
+    const double *R = d.m[(along_x ? 0 : 2) + k];
+    double v[3];
+    cm_mat_vec(R, px, cam_h, pz, v);
+    double *o = cam15 + 15 * n;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) o[q] = R[q];
+    o[9] = -1.0 * v[0]; o[10] = -1.0 * v[1]; o[11] = -1.0 * v[2];
+    o[12] = 1.0; o[13] = 0.0; o[14] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_grid_points(int64_t n_pts, int64_t ppb, int64_t B, double L, double inset, double pt_h,
+                                                    double4 *__restrict__ pts4) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_pts) return;
+    int64_t bx, by, i;
+    int k;
+    bool along_x;
+    grid_slot(n, B, ppb, 6, bx, by, i, k, along_x);
+    const double offset_x = L * (double)bx, offset_z = L * (double)by;
+    const double step = (L - inset * 2.0) / (double)ppb;
+    // the six points of a slot (:219-253): two at point_height on either side of the street, four on the ground
+    const double loc = (along_x ? offset_x : offset_z) + inset + (double)i * step;
+    const double a = k < 2 ? loc : loc + step / 2.0;                      // along the street
+    const double o = along_x ? offset_z : offset_x;                       // across it
+    const double half = inset / 2.0;
+    const double c = k == 0 || k == 2 ? o - inset : (k == 1 || k == 3 ? o + inset : (k == 4 ? o - half : o + half));
+    const double y = k < 2 ? pt_h : 0.0;
+    pts4[n] = along_x ? make_double4(a, y, c, 0.0) : make_double4(c, y, a, 0.0);
+}
+
+__global__ __launch_bounds__(256) void k_line_layout(int64_t n_cam, int64_t n_pts, double length, double point_offset, double cam_h,
+                                                    double pt_h, GridDirs d, double *__restrict__ cam15, double4 *__restrict__ pts4) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n < n_cam) {
+        const double *R = d.m[2];                                        // from_angle_y(Deg(180)), :330
+        double v[3];
+        cm_mat_vec(R, 0.0, cam_h, (double)n * length / (double)(n_cam - 1), v);
+        double *o = cam15 + 15 * n;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[q] = R[q];
+        o[9] = -1.0 * v[0]; o[10] = -1.0 * v[1]; o[11] = -1.0 * v[2];
+        o[12] = 1.0; o[13] = 0.0; o[14] = 0.0;
+    }
+    if (n < n_pts) {
+        const double z = (double)(n / 2) * length / (double)(n_pts / 2 - 1);
+        pts4[n] = make_double4((n % 2 == 0) ? -point_offset : point_offset, pt_h, z, 0.0);
+    }
+}
+
 // ---- BAProblem::write_binary (src/baproblem.rs:736-764) assembled on the device -------------------------------------
 // The .bbal image: header (3 big-endian u64: cameras, points, observations) | per camera: BE u64 count, then count x
 // (BE u64 point, BE f64 u, BE f64 v) | 9 BE f64 per camera (to_vec order) | 3 BE f64 per point.  Every word is 8-byte

@@ -63,23 +63,29 @@ def candidate_pairs(centers, pts, max_dist, cam_lo=0, cam_hi=None, occlusion=Fal
     return ci, pi
 
 
-def _visibility_problem(pos, dirs, pts, max_dist, occlusion, block_length, block_inset, cull, device, host_candidates=False):
-    """Shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:260-299, 346-380).  host_candidates = True takes
-    rounds 1-3's route (candidate search and hits_building on the host, predicate + compaction on the device): the same
-    graph, index for index -- kept for the tests that compare the two."""
+def _visibility_problem(layout, max_dist, occlusion, block_length, block_inset, cull, device, host_candidates=False):
+    """Shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:260-299, 346-380).  `layout` = ("grid", cpb, ppb,
+    blocks, L, inset, cam_h, pt_h) or ("line", n_cam, n_pts, length, point_offset, cam_h, pt_h).  By default everything
+    -- the layout loops, the candidate search, hits_building, the predicate, cull -- runs on the resident problem;
+    host_candidates = True takes rounds 1-3's route (layout, candidate search and hits_building on the host, predicate +
+    compaction on the device): the same problem, element for element -- kept for the tests that compare the two."""
     from .baproblem import BAProblem
-    n_cam = len(pos)
-    empty_rows = np.zeros(n_cam + 1, dtype=np.uint64)
-    # from_position_direction on the device; cameras only, no observations yet
-    stage = BAProblem(device)
-    cam15 = stage._cameras_from_position_direction(pos, dirs)
-    ba = BAProblem.from_visibility(cam15, pts, empty_rows, [], np.zeros((0, 2)), device)
+    ba = BAProblem(device)
     if host_candidates:
+        pos, dirs, pts = grid_layout(*layout[3:4], *layout[1:3], *layout[4:]) if layout[0] == "grid" else line_layout(*layout[1:])
+        cam15 = ba._cameras_from_position_direction(pos, dirs)
+        ba._upload(cam15, False, pts, np.zeros(len(pos) + 1, dtype=np.uint64), [], np.zeros((0, 2)))
         s = ba._camera_centers()
         ci, pi = candidate_pairs(s, pts, max_dist, occlusion=occlusion, block_length=block_length,
                                  block_inset=block_inset)
         ba.visibility_pairs_compact(ci, pi, max_dist, fetch=False)         # survivors compacted on the device ...
     else:
+        if layout[0] == "grid":
+            L.check(L.lib().c2b_problem_synthetic_grid_layout(ba._h, *[int(v) for v in layout[1:4]], *[float(v) for v in layout[4:]]))
+        else:
+            L.check(L.lib().c2b_problem_synthetic_line_layout(ba._h, int(layout[1]), int(layout[2]), *[float(v) for v in layout[3:]]))
+        ba._row_ptr = np.zeros(ba._sizes()[0] + 1, dtype=np.uint64)
+        ba._pt_idx = np.zeros(0, dtype=np.uint64)
         ba.visibility_within_distance(max_dist, occlusion, block_length, block_inset, fetch=False)
     ba.adopt_visibility()                                                  # ... where they become the vis_graph
     return ba.cull() if cull else ba
@@ -89,13 +95,12 @@ def synthetic_grid(num_cameras_per_block, num_points_per_block, num_blocks, bloc
                    camera_height, point_height, max_dist, verbose=False, cull=True, device=0, host_candidates=False):
     """synthetic_grid (src/synthetic.rs:163-300), same argument order.  In-camera observation order is
     ascending point index (the reference's is rstar's traversal order)."""
-    pos, dirs, pts = grid_layout(num_blocks, num_cameras_per_block, num_points_per_block, block_length,
-                                 block_inset, camera_height, point_height)
-    return _visibility_problem(pos, dirs, pts, max_dist, True, block_length, block_inset, cull, device, host_candidates)
+    layout = ("grid", num_cameras_per_block, num_points_per_block, num_blocks, block_length, block_inset, camera_height, point_height)
+    return _visibility_problem(layout, max_dist, True, block_length, block_inset, cull, device, host_candidates)
 
 
 def synthetic_line(num_cameras, num_points, length, point_offset, camera_height, point_height, max_dist,
                    verbose=False, cull=True, device=0, host_candidates=False):
     """synthetic_line (src/synthetic.rs:313-381)"""
-    pos, dirs, pts = line_layout(num_cameras, num_points, length, point_offset, camera_height, point_height)
-    return _visibility_problem(pos, dirs, pts, max_dist, False, 1.0, 0.0, cull, device, host_candidates)
+    layout = ("line", num_cameras, num_points, length, point_offset, camera_height, point_height)
+    return _visibility_problem(layout, max_dist, False, 1.0, 0.0, cull, device, host_candidates)

@@ -524,6 +524,14 @@ int c2b_problem_upload(c2b_problem *p, int64_t n_cam, const double *cams15, int6
 int c2b_problem_upload_bal(c2b_problem *p, int64_t n_cam, const double *bal9, int64_t n_pts,
                            const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx,
                            const double *uv);
+/* The layout loops of synthetic_grid / synthetic_line (src/synthetic.rs:178-258, :323-344) evaluated on the device,
+ * straight into the resident problem: cameras through Camera::from_position_direction (src/baproblem.rs:153-159),
+ * points, an empty vis_graph (c2b_problem_visibility_within_distance fills it).  Entity for entity and bit for bit what
+ * c2b_synthetic_*_layout + c2b_problem_from_position_direction + c2b_problem_upload produce; nothing crosses PCIe. */
+int c2b_problem_synthetic_grid_layout(c2b_problem *p, int64_t cameras_per_block, int64_t points_per_block, int64_t blocks,
+                                      double block_length, double block_inset, double camera_height, double point_height);
+int c2b_problem_synthetic_line_layout(c2b_problem *p, int64_t n_cam, int64_t n_pts, double length, double point_offset,
+                                      double camera_height, double point_height);
 int c2b_problem_sizes(const c2b_problem *p, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs);
 /* any of the outputs may be NULL */
 int c2b_problem_download(c2b_problem *p, double *cams15, double *pts3, double *uv);

@@ -125,3 +125,36 @@ def test_full_size_grids_observation_counts_and_the_host_route(c2b, blocks, n_ex
     ba.adopt_visibility()
     assert ba.total_reprojection_error(2.0) == 0.0
     ba.close()
+
+
+@pytest.mark.parametrize("cpb,ppb,blocks,L,inset", [(10, 10, 4, 20.0, 1.0), (10, 20, 3, 5.0, 1.0), (3, 7, 1, 9.5, 0.75), (1, 1, 6, 20.0, 1.0),
+                                                     (4, 5, 0, 20.0, 1.0), (7, 3, 11, 13.25, 2.5)])
+def test_layout_loops_on_the_device_equal_the_host_loops(c2b, cpb, ppb, blocks, L, inset):
+    """c2b_problem_synthetic_grid_layout (one thread per entity, the loop nest's push order inverted in closed form)
+    against the host loops of src/synthetic.rs:178-258 (c2b_synthetic_grid_layout) + from_position_direction: every
+    camera record and every point, bit for bit"""
+    from city2ba_amd import _lib as Lb
+    from city2ba_amd import synthetic as S
+    pos, dirs, pts = S.grid_layout(blocks, cpb, ppb, L, inset, 1.25, 0.5)
+    ba = c2b.BAProblem(0)
+    want_cams = ba._cameras_from_position_direction(pos, dirs) if len(pos) else np.zeros((0, 15))
+    Lb.check(Lb.lib().c2b_problem_synthetic_grid_layout(ba._h, cpb, ppb, blocks, L, inset, 1.25, 0.5))
+    assert ba._sizes() == (len(pos), len(pts), 0)
+    assert np.array_equal(ba.cameras().view(np.uint64), want_cams.view(np.uint64))
+    assert np.array_equal(ba.points().view(np.uint64), pts.view(np.uint64))
+    # the reference's assert (src/synthetic.rs:177) as a status
+    assert Lb.lib().c2b_problem_synthetic_grid_layout(ba._h, cpb, ppb, blocks, 2.0, 1.0, 1.0, 1.0) == Lb.ERR_INVALID_ARGUMENT
+    ba.close()
+
+
+def test_line_layout_on_the_device_equals_the_host_loop(c2b):
+    from city2ba_amd import _lib as Lb
+    from city2ba_amd import synthetic as S
+    for n_cam, n_pts in ((40, 60), (10, 10), (3, 200), (129, 4)):
+        pos, dirs, pts = S.line_layout(n_cam, n_pts, 20.0, 1.5, 1.0, 0.75)
+        ba = c2b.BAProblem(0)
+        want = ba._cameras_from_position_direction(pos, dirs)
+        Lb.check(Lb.lib().c2b_problem_synthetic_line_layout(ba._h, n_cam, n_pts, 20.0, 1.5, 1.0, 0.75))
+        assert np.array_equal(ba.cameras().view(np.uint64), want.view(np.uint64))
+        assert np.array_equal(ba.points().view(np.uint64), pts.view(np.uint64))
+        ba.close()
