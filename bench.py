@@ -9,7 +9,8 @@
 One "step" = one pass of the hot path over the whole grid: c2b_residual_jacobian_rows (residual, Jc, Jp and
 the folded sum of squared residuals, ONE launch; the observation list addressed through its row structure, the
 reference's one list per camera) on every rank's shard, then ONE 1-element RCCL all-reduce through this library's C ABI
-(N > 1; on its own stream, overlapping the next step's kernel; every collective completes inside the timed region).
+(N > 1; in line behind the kernel or on its own stream next to the next step's kernel -- both are timed during warm-up
+and the faster one runs the timed region, the other is timed right after it; every collective completes inside its loop).
 Inputs are resident in HBM before the timed region.  Strong scaling: the same `--blocks 128` problem is sharded
 over the ranks by contiguous camera ranges cut on the observation prefix sum (BASELINE.json configs[3]); at
 N = 1 one GPU holds all of it.
@@ -28,6 +29,38 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 KERNEL_FMT = "k_residual_jacobian_l<2, true, 8, true, %d, 1, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; OPL = c2b_jacobian_tiles_per_wave, NTL = c2b_jacobian_stream_policy of the launch
 KERNEL_NAME = KERNEL_FMT % (2, 3)     # the launch the roofline object describes (set in main() from the shard's sizes)
+
+
+class Watchdog:
+    """N > 1: every phase of the run that can block on another rank -- communicator init, the A/B loops, the timed
+    region's final synchronize -- calls beat(what) when it starts; a daemon thread checks once a second, and if the last
+    beat is older than the limit it prints the rank, what it was waiting for and for how long, then ends the process with
+    status 3 (os._exit: a fresh exit, never a re-exec; torch.distributed.run then takes the other ranks down).  The GPU
+    calls the main thread blocks in (synchronize, barrier) release the GIL, so the thread runs."""
+
+    def __init__(self, rank, seconds):
+        import threading
+        self.rank, self.seconds, self.what, self.t = rank, float(seconds), "start", time.monotonic()
+        self._stop = threading.Event()
+        self._thread = None
+        if self.seconds > 0:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def beat(self, what):
+        self.what, self.t = what, time.monotonic()
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        while not self._stop.wait(1.0):
+            idle = time.monotonic() - self.t
+            if idle > self.seconds:
+                sys.stderr.write("bench.py watchdog: rank %d made no progress for %.0f s in: %s -- exiting with status 3\n"
+                                 % (self.rank, idle, self.what))
+                sys.stderr.flush()
+                os._exit(3)
 
 
 def parse():
@@ -56,9 +89,11 @@ def parse():
     ap.add_argument("--overlap", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: run the all-reduce of step k on its own stream so that it overlaps the kernel of step "
                          "k + 1 (every step's scalar has its own slot; all collectives complete inside the timed "
-                         "region).  auto = on when N > 1 and the collective is enqueued on a stream: the hand-off costs 4.5 us "
-                         "per step and hides a collective of any length up to the kernel's (measured with an emulated "
-                         "collective of 0-45 us, profiles/r03z_ab_step_emulated_allreduce.txt); in line at world size 1")
+                         "region).  auto = time both arrangements during warm-up and run the timed region with the faster "
+                         "one (the decision is taken on times all-reduced over the ranks); the line reports both")
+    ap.add_argument("--watchdog-seconds", type=float, default=60.0,
+                    help="N > 1: a rank that makes no progress for this long (a collective that never completes, a peer that "
+                         "died) prints where it was and exits with status 3 instead of hanging the job; 0 disables")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="diagnostic (1-GPU boxes): replace the collective by a kernel that spins this many microseconds on "
                          "the collective's stream -- what an N-rank all-reduce of that latency would cost the step in line "
@@ -502,28 +537,41 @@ def main():
         first, _ = D.alloc_jacobian_outputs(n, dev, max_attempts=1)
         first_us = kernel_us_in(first)
         del first
-    (r, Jc, Jp), placement_log = D.alloc_jacobian_outputs(n, dev, max_attempts=args.placement_attempts)
+    outs = D.JacobianOutputs(n, dev, max_attempts=args.placement_attempts)
+    (r, Jc, Jp), placement_log, placement_chosen = (outs.r, outs.Jc, outs.Jp), outs.log, outs.chosen
     input_placement = place_inputs(sh, r, Jc, Jp, ws, err) if args.place_inputs else {}
 
-    # One launch per step: residual + Jacobian + the folded L2 error sum (in-kernel ticket fold) -> err, then (N > 1)
-    # the 8-byte all-reduce on the SAME stream.  Measured on one rank holding an eighth of the problem
-    # (tools/probe_host_overhead.py: kernel alone 90 us/step): all-reduce queued behind the kernel on the same stream
-    # 96 us/step; round 1's arrangement -- all-reduce on a side stream overlapping the next kernel, double-buffered
-    # scalar, three cross-stream event hand-offs per step -- 117 us/step.  The hand-offs cost more than they hide.
-    comm, collective, collective_note = None, None, None
+    # ---- the step -------------------------------------------------------------------------------------------------
+    # One launch per step: residual + Jacobian + the folded L2 error sum (in-kernel ticket fold) -> a scalar, then (N > 1)
+    # ONE 8-byte all-reduce (src/baproblem.rs:265-279's sum over all cameras).  Two arrangements of the collective exist:
+    #   in line      queued behind the kernel on the same stream;
+    #   overlapped   on its own stream next to the kernel of the NEXT step -- one event hand-off per step, every step's
+    #                scalar in its own slot, every collective complete inside the timed region.
+    # Which one is faster depends on what the collective costs next to a CU-saturating kernel on the other ranks, and that
+    # cannot be known before it runs on N real GPUs (at world size 1 in line wins by 5 us per step; a spin kernel standing
+    # in for a 10-45 us collective says overlapped wins, profiles/r03h, r03z).  So `--overlap auto` MEASURES: both
+    # arrangements are timed during warm-up (barrier-bracketed, max over ranks, the decision identical on every rank
+    # because it is taken on all-reduced times), the faster one runs the timed region, and the other one is timed again
+    # right after it -- the line carries both (config.ms_per_step_in_line / _overlapped) and says which one `value` is.
+    dog = Watchdog(rank, args.watchdog_seconds if dist_on else 0.0)
+    comm, collective, collective_note, comm_init_ms, rccl_ranks = None, None, None, None, None
     if dist_on:
         want = args.collective
         if want == "auto":
             want = "c2b" if backend == "nccl" else "torch"
         if want == "c2b":
-            # RCCL through the C ABI.  The id travels over the process group that already exists; if ANY rank cannot
-            # join, every rank falls back to torch's collective together (the decision is all-reduced).
+            # RCCL through the C ABI.  The id travels over the process group that already exists; from_process_group
+            # raises on EVERY rank together if any rank cannot load RCCL or rank 0 cannot make an id; a rank whose init
+            # fails on its own is caught by the gathered flag below (and a rank stuck inside it by the watchdog).
             from city2ba_amd import comm as Comm
             ok, why = 1, ""
+            dog.beat("c2b_comm_init_rank (RCCL communicator over %d ranks)" % world)
+            t_init = time.perf_counter()
             try:
                 comm = Comm.Comm.from_process_group(dev_index)
             except Exception as exc:                                  # noqa: BLE001 -- reported in the line
                 ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+            comm_init_ms = (time.perf_counter() - t_init) * 1e3
             flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
@@ -532,11 +580,14 @@ def main():
                 comm, collective_note = None, "c2b communicator unavailable (%s): fell back to torch.distributed" % (why or "another rank failed")
         collective = ("c2b_comm_all_reduce_sum_f64 (%s), 1 x f64 per step" % Comm.backend()) if comm is not None \
             else "%s all_reduce(sum, 1 x f64) per step via torch.distributed" % backend
+        # how many ranks the communicator itself says it spans, from every rank (must all equal n_gpus)
+        mine = comm.info()[1] if comm is not None else dist.get_world_size()
+        rccl_ranks = [None] * world
+        dist.all_gather_object(rccl_ranks, int(mine))
 
     spin_cycles = int(args.emulate_allreduce_us * 2340.0)         # torch.cuda._sleep(100 000) spins 42.8 us on MI355X
 
-    def all_reduce(t=None):
-        t = err if t is None else t
+    def all_reduce(t):
         if spin_cycles:
             torch.cuda._sleep(spin_cycles)
             return
@@ -545,59 +596,66 @@ def main():
         else:
             Dist.all_reduce_sum_(t)
 
-    # N > 1.  The step is a ~90 us kernel (a rank's eighth of the problem) plus an 8-byte all-reduce whose cost is pure
-    # latency.  Shipped arrangement: the collective in line behind the kernel on the same stream, eager launches.
-    # --overlap on is the alternative that was built and measured: the collective of step k on its own stream next to the
-    # kernel of step k + 1 -- one event hand-off per step (kernel done -> collective may start), every step's scalar in
-    # its own slot so that nothing is ever waited for in the other direction, every collective complete inside the timed
-    # region (the final synchronize covers both streams).  At world size 1 it costs 5-8 us per step more than it saves
-    # (profiles/r03h_ab_step.txt); whether it pays at N = 8 can only be measured there.
-    # auto: overlapped whenever there is a real collective to hide (more than one rank, enqueued on a stream).  Measured
-    # with the collective replaced by a kernel that spins X us (--emulate-allreduce-us, a rank's eighth of the problem,
-    # profiles/r03z_ab_step_emulated_allreduce.txt): in line the step is 88.5 + X us, overlapped it is 93 us for every X
-    # from 0 to 45 -- the hand-off costs 4.5 us and hides the rest, so it pays from X = 5 us on, and an 8-GPU all-reduce
-    # of 8 bytes is several times that.  At world size 1 (the rehearsal of this path on a 1-GPU box) it stays in line.
-    on_stream = dist_on and (comm is not None or backend == "nccl")
-    overlap = dist_on and args.graph != "on" and (args.overlap == "on" or (args.overlap == "auto" and on_stream and world > 1))
-    comm_stream = torch.cuda.Stream(device=dev) if overlap else None
-    n_slots = args.steps + max(args.warmup, 1) + 64
-    err_ring = torch.zeros(n_slots if overlap else 1, dtype=torch.float64, device=dev)
-    handoff = [torch.cuda.Event() for _ in range(n_slots)] if overlap else None
+    on_stream = dist_on and (comm is not None or backend == "nccl")       # gloo stages the scalar through the host
+    can_overlap = dist_on and on_stream and args.graph != "on"
+    comm_stream = torch.cuda.Stream(device=dev) if can_overlap else None
+    n_ab = max(5, min(20, args.steps)) if dist_on else 0
+    n_slots = 2 * args.steps + 2 * n_ab + max(args.warmup, 1) + 64
+    err_ring = torch.zeros(n_slots if can_overlap else 1, dtype=torch.float64, device=dev)
+    handoff = [torch.cuda.Event() for _ in range(n_slots)] if can_overlap else None
     slot = [0]
 
-    def step(ev=None, in_line=False):
-        if overlap and not in_line:
-            k = slot[0] % n_slots
-            slot[0] += 1
-            e = err_ring[k:k + 1]
-            if ev is not None:
-                ev[0].record()
-            D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, e)
-            if ev is not None:
-                ev[1].record()
-            handoff[k].record()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(handoff[k])
-                if ev is not None:
-                    ev[3].record()
-                all_reduce(e)
-                if ev is not None:
-                    ev[2].record()
-            return
+    def kernel(e):
+        D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, e)
+
+    def step_in_line(ev=None):
         if ev is not None:
             ev[0].record()
-        D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
+        kernel(err)
         if ev is not None:
             ev[1].record()
         if dist_on:
-            if ev is not None:
-                ev[3].record()
-            all_reduce()
+            all_reduce(err)
             if ev is not None:
                 ev[2].record()                       # after the collective
 
+    def step_overlapped():
+        k = slot[0] % n_slots
+        slot[0] += 1
+        e = err_ring[k:k + 1]
+        kernel(e)
+        handoff[k].record()
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(handoff[k])
+            all_reduce(e)
+
+    def timed_loop(fn, count, what):
+        """`count` steps of one arrangement, bracketed like the timed region (barrier + synchronize on both sides);
+        returns the MAX over ranks of the wall time in seconds"""
+        dog.beat("%s: barrier before %d steps" % (what, count))
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(count):
+            if dist_on and (k & 15) == 0:
+                dog.beat("%s: enqueueing step %d of %d" % (what, k, count))
+            fn()
+        dog.beat("%s: waiting for %d enqueued steps (their collectives included) to complete" % (what, count))
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    dog.beat("warm-up")
     for _ in range(max(args.warmup, 1) if dist_on else args.warmup):     # the first collective must not be captured
-        step()
+        step_in_line()
     torch.cuda.synchronize()
 
     # --graph on: the step replayed from a HIP graph -- ONE graph launch per step instead of a kernel launch plus a
@@ -609,7 +667,7 @@ def main():
     # the collective rides in the graph when it is enqueued on the stream (RCCL, through the C ABI or torch); the gloo
     # rehearsal stages its scalar through the host, so there only the kernel is captured and the all-reduce follows
     # every replay eagerly
-    collective_in_graph = dist_on and (comm is not None or backend == "nccl")
+    collective_in_graph = on_stream
     if use_graph:
         ok = 1
         try:
@@ -619,9 +677,9 @@ def main():
             with torch.cuda.stream(side):
                 with torch.cuda.graph(g, stream=side):
                     if collective_in_graph or not dist_on:
-                        step()
+                        step_in_line()
                     else:
-                        D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, err)
+                        kernel(err)
             torch.cuda.synchronize()
             graph = g
         except Exception as exc:                                      # noqa: BLE001
@@ -637,36 +695,53 @@ def main():
             for _ in range(2):
                 graph.replay()
                 if dist_on and not collective_in_graph:
-                    all_reduce()
+                    all_reduce(err)
             torch.cuda.synchronize()
 
+    def step_graph():
+        graph.replay()
+        if dist_on and not collective_in_graph:
+            all_reduce(err)
+
+    # which arrangement runs the timed region
+    ab = None
+    if graph is not None:
+        shipped = "hip_graph"
+    elif not can_overlap or args.overlap == "off":
+        shipped = "in_line"
+    elif args.overlap == "on":
+        shipped = "overlapped"
+    else:                                                         # auto: measure both, keep the faster (same decision on every rank)
+        t_a = timed_loop(step_in_line, n_ab, "A/B in line")
+        t_b = timed_loop(step_overlapped, n_ab, "A/B overlapped")
+        ab = {"steps_each": n_ab, "us_per_step_in_line": round(t_a / n_ab * 1e6, 2), "us_per_step_overlapped": round(t_b / n_ab * 1e6, 2)}
+        shipped = "overlapped" if t_b < t_a else "in_line"
+    step_of = {"in_line": step_in_line, "overlapped": step_overlapped, "hip_graph": step_graph if graph is not None else None}
+
+    # ---- the timed region: EXACTLY args.steps steps of the shipped arrangement -------------------------------------
+    dog.beat("timed region: barrier")
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     events = None
-    if rank == 0:                                   # per-kernel HIP events only where the roofline is reported
-        events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
-    # N > 1: no event records inside the timed loop.  A step there is ~90 us, and three event records per step cost
-    # ~13 us of it (measured at world size 1 on a rank's eighth of the problem: 102 -> 86 us per step without them;
-    # with the collective on a second stream they stall the kernel stream outright: 590 us per step).  The kernel /
-    # collective split of the N-rank step is measured right after the timed region instead, on the same buffers.
-    # N = 1 keeps its two records around the 700 us kernel: the roofline's kernel time is measured live in the region.
-    no_events = dist_on
-    if no_events:
-        events = None
+    # N = 1: two HIP event records around the ~700 us kernel of every step (the roofline's kernel time is measured live in
+    # the region).  N > 1: none -- three records cost ~13 us of a ~90 us step and stall a two-stream arrangement outright
+    # (r03); the per-rank kernel / collective split is measured right after the region instead, on every rank.
+    if rank == 0 and not dist_on:
+        events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    if graph is not None:
+    if shipped == "in_line":
         for k in range(args.steps):
-            if events is not None:
-                events[k][0].record()
-            graph.replay()
-            if dist_on and not collective_in_graph:
-                all_reduce()
-            if events is not None:
-                events[k][2].record()
+            if dist_on and (k & 15) == 0:
+                dog.beat("timed region (%s): enqueueing step %d of %d" % (shipped, k, args.steps))
+            step_in_line(events[k] if events is not None else None)
     else:
+        fn = step_of[shipped]
         for k in range(args.steps):
-            step(events[k] if events is not None else None)
+            if dist_on and (k & 15) == 0:
+                dog.beat("timed region (%s): enqueueing step %d of %d" % (shipped, k, args.steps))
+            fn()
+    dog.beat("timed region (%s): waiting for %d enqueued steps (their collectives included) to complete" % (shipped, args.steps))
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -676,41 +751,77 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # The kernel / collective split of the step when the timed loop carried no (or only outer) event records: a short
-    # instrumented pass right after the timed region, on the same buffers.  EVERY rank takes part (the step holds a
-    # collective); only rank 0 records.
-    graph_step_us = None
-    if graph is not None and events is not None:
-        graph_step_us = sum(ev[0].elapsed_time(ev[2]) for ev in events) / len(events) * 1e3
+
+    # ---- after the region --------------------------------------------------------------------------------------------
+    # (1) the OTHER arrangement, the same number of un-instrumented steps, bracketed the same way
+    other = {}
+    if dist_on and graph is None:
+        other["in_line"] = elapsed if shipped == "in_line" else timed_loop(step_in_line, args.steps, "in-line loop after the region")
+        if can_overlap:
+            other["overlapped"] = elapsed if shipped == "overlapped" else timed_loop(step_overlapped, args.steps, "overlapped loop after the region")
+    # (2) the kernel / collective split on EVERY rank: instrumented in-line steps (events would distort the timed loops)
+    kernel_us_mine, allreduce_us_mine, graph_step_us = None, None, None
     if dist_on or graph is not None:
         post = min(args.steps, 20)
-        events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(post)] if rank == 0 else None
-        for k in range(post):                       # in line even when the timed loop overlapped: a clean kernel / collective split
-            step(events[k] if events is not None else None, in_line=True)
+        dog.beat("instrumented pass: %d in-line steps with HIP events on every rank" % post)
+        pev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(post)]
+        for k in range(post):
+            step_in_line(pev[k])
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
-    total_err = Dist.finish_error(err.item(), 2.0)          # the instrumented pass above ran in line and left the scalar in `err`
-    # every overlapped step reduced the same data: each of its slots must hold exactly the in-line sum
-    ring_ok = bool((err_ring[:min(slot[0], n_slots)] == err).all().item()) if overlap else None
-    per_rank_obs = [n]
+        kernel_us_mine = sum(ev[0].elapsed_time(ev[1]) for ev in pev) / post * 1e3
+        if dist_on:
+            allreduce_us_mine = sum(ev[1].elapsed_time(ev[2]) for ev in pev) / post * 1e3
+        if rank == 0:
+            events = pev
+    else:
+        step_in_line()                                            # N = 1: leave the scalar of one more launch in `err`
+        torch.cuda.synchronize()
+    total_err = Dist.finish_error(err.item(), 2.0)          # every arrangement reduced the same data: `err` holds the in-line sum
+    # every overlapped step's slot must hold exactly that sum, bit for bit
+    ring_ok = bool((err_ring[:min(slot[0], n_slots)] == err).all().item()) if (can_overlap and slot[0]) else None
+    per_rank = [{"n_obs": n, "kernel_us": kernel_us_mine, "allreduce_us": allreduce_us_mine,
+                 "store_GBs_kept": (placement_log[placement_chosen] if placement_log and 0 <= placement_chosen < len(placement_log) else None),
+                 "ring_ok": ring_ok}]
     if dist_on:
-        per_rank_obs = [None] * world
-        dist.all_gather_object(per_rank_obs, n)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"n_obs": n, "kernel_us": kernel_us_mine, "allreduce_us": allreduce_us_mine,
+                                          "store_GBs_kept": (placement_log[placement_chosen] if placement_log and 0 <= placement_chosen < len(placement_log) else None),
+                                          "ring_ok": ring_ok})
+    per_rank_obs = [q["n_obs"] for q in per_rank]
+    dog.stop()
 
     if rank == 0:
         kern_ms = sorted(ev[0].elapsed_time(ev[1]) for ev in events)
         step_us = elapsed / args.steps * 1e6
         step_breakdown = {"kernel_us_rank0": round(sum(kern_ms) / len(kern_ms) * 1e3, 2)}
         if dist_on:
-            ar_us = sum(ev[3].elapsed_time(ev[2]) for ev in events) / len(events) * 1e3
+            ar_us = per_rank[0]["allreduce_us"]
             step_breakdown["allreduce_us"] = round(ar_us, 2)
+            # every rank's own figures (instrumented in-line steps right after the region): a slow device among the N --
+            # one whose outputs stream at 5.7 instead of 7 TB/s paces every step -- is named here
+            step_breakdown["kernel_us_per_rank"] = [round(q["kernel_us"], 2) for q in per_rank]
+            step_breakdown["allreduce_us_per_rank"] = [round(q["allreduce_us"], 2) for q in per_rank]
+            step_breakdown["store_GBs_kept_per_rank"] = [q["store_GBs_kept"] for q in per_rank]
+            step_breakdown["rccl_ranks"] = rccl_ranks
+            step_breakdown["comm_init_ms"] = round(comm_init_ms, 1) if comm_init_ms is not None else None
+            step_breakdown["arrangement"] = shipped
+            step_breakdown["arrangement_chosen_by"] = ("--graph on" if shipped == "hip_graph" else
+                                                        "--overlap %s" % args.overlap if (args.overlap != "auto" or not can_overlap) else
+                                                        "A/B during warm-up (the faster of the two, decided on times all-reduced over the ranks)")
+            step_breakdown["ab_during_warmup"] = ab
+            for name, secs in other.items():
+                step_breakdown["ms_per_step_" + name] = round(secs / args.steps * 1e3, 5)
             # overlapped: the collective is off the kernel stream's critical path, so what a step costs beyond its kernel
             # is launch gaps, the hand-off and waiting for the slowest rank; in line: kernel + collective + the rest
-            step_breakdown["step_overhead_us"] = round(step_us - step_breakdown["kernel_us_rank0"] - (0.0 if overlap else ar_us), 2)
-            step_breakdown["allreduce_overlaps_next_kernel"] = bool(overlap)
-            if overlap:
-                step_breakdown["overlapped_sums_equal_the_in_line_sum"] = ring_ok
+            slowest = max(q["kernel_us"] for q in per_rank)
+            step_breakdown["step_overhead_us"] = round(step_us - slowest - (0.0 if shipped == "overlapped" else ar_us), 2)
+            step_breakdown["allreduce_overlaps_next_kernel"] = shipped == "overlapped"
+            if can_overlap:
+                oks = [q["ring_ok"] for q in per_rank]
+                step_breakdown["overlapped_sums_equal_the_in_line_sum"] = (all(o for o in oks if o is not None) if any(o is not None for o in oks) else None)
+            step_breakdown["watchdog_seconds"] = args.watchdog_seconds
         else:
             step_breakdown["step_overhead_us"] = round(step_us - step_breakdown["kernel_us_rank0"], 2)
         kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
@@ -743,8 +854,8 @@ def main():
                               + ("; step on the GPU %.2f us" % graph_step_us if graph_step_us else ""))
                 if graph is not None else (graph_note or False),
                 "kernel_time_source": "HIP events around the launch inside the timed region" if not dist_on else
-                                      "HIP events around %d instrumented steps right after the timed region (event records "
-                                      "inside a ~90 us step would cost ~13 us of it)" % min(args.steps, 20),
+                                      "HIP events around %d instrumented in-line steps right after the timed region, on every "
+                                      "rank (event records inside a ~90 us step would cost ~13 us of it)" % min(args.steps, 20),
                 # where rank 0's step goes (HIP events around the kernel and around the collective; the rest of the
                 # wall-clock step is launch gaps, host dispatch and waiting for the slowest rank)
                 **step_breakdown,
@@ -782,8 +893,8 @@ def main():
             cold = []
             for _ in range(5):
                 sweep.sum()
-                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
-                step(ev)                                     # events 0 -> 1 bracket the kernel, not the all-reduce
+                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                step_in_line(ev)                             # events 0 -> 1 bracket the kernel
                 torch.cuda.synchronize()
                 cold.append(ev[0].elapsed_time(ev[1]))
             del sweep

@@ -29,13 +29,56 @@ class Comm:
     @classmethod
     def from_process_group(cls, device, group=None):
         """every rank of an initialised torch.distributed group joins one communicator: rank 0 makes the id, the
-        group's object broadcast carries it"""
+        group's object broadcast carries it.  No rank can be left waiting in a collective the others never enter:
+        (1) every rank probes the backend (RCCL loadable?) and the answers are gathered BEFORE anyone makes an id or calls
+        init_rank -- one rank without RCCL and every rank raises together; (2) rank 0 broadcasts either the id or the
+        text of its failure, so a failing c2b_comm_unique_id reaches every rank as an exception instead of a hang;
+        (3) the outcome of c2b_comm_init_rank is gathered, so a rank whose init failed takes every rank down with it."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [unique_id() if rank == 0 else None]
+
+        def everyone(ok, why):
+            """gather (ok, why) from every rank; raise on all of them if any failed"""
+            if world == 1:
+                answers = [(ok, why)]
+            else:
+                answers = [None] * world
+                dist.all_gather_object(answers, (bool(ok), str(why)), group=group)
+            bad = ["rank %d: %s" % (r, w) for r, (o, w) in enumerate(answers) if not o]
+            if bad:
+                raise L.City2baError(L.ERR_RCCL, "communicator unavailable -- " + "; ".join(bad))
+
+        name = backend()
+        everyone(name.startswith("RCCL"), "c2b_comm_backend() = %r" % name)
+        box = [None]
+        if rank == 0:
+            try:
+                box = [("id", unique_id())]
+            except Exception as exc:                                  # noqa: BLE001 -- travels to every rank
+                box = [("error", "%s: %s" % (type(exc).__name__, exc))]
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        return cls(box[0], rank, world, device)
+        kind, payload = box[0]
+        if kind != "id":
+            raise L.City2baError(L.ERR_RCCL, "rank 0 could not make a communicator id -- " + payload)
+        self, why = None, ""
+        try:
+            self = cls(payload, rank, world, device)
+        except Exception as exc:                                      # noqa: BLE001
+            why = "%s: %s" % (type(exc).__name__, exc)
+        try:
+            everyone(self is not None, why)
+        except Exception:
+            if self is not None:
+                self.destroy()
+            raise
+        return self
+
+    def info(self):
+        """(rank, world, device) as the communicator itself reports them (c2b_comm_info)"""
+        r, w, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        L.check(L.lib().c2b_comm_info(self._h, C.byref(r), C.byref(w), C.byref(d)))
+        return r.value, w.value, d.value
 
     @property
     def handle(self):

@@ -2,6 +2,7 @@
 offsets, and the single sum all-reduce behind total_reprojection_error.  The per-shard sums come from the
 CPU oracle here (no GPU in this container); on the GPU box the same code path runs with nccl/RCCL in bench.py."""
 import os
+import subprocess
 import socket
 import sys
 
@@ -115,3 +116,19 @@ def test_single_process_helpers():
     assert oidx == 9 and list(origin) == [0, 1, 0]
     st = D.finish_stats(mean, mn, mx, origin, oidx, [10.0, 40.0, 90.0], 10)
     assert np.allclose(st[3:6], [1, 2, 3]) and abs(st[19] - 14 ** 0.5) < 1e-15 and list(st[12:15]) == [1, 1, 1]
+
+
+def test_watchdog_ends_a_rank_that_stops_making_progress():
+    """bench.Watchdog: no beat for longer than the limit -> the rank says where it was and exits with status 3 (a fresh
+    exit); a rank that keeps beating, or a stopped watchdog, is left alone"""
+    code = ("import bench, time\n"
+            "d = bench.Watchdog(5, 1.0)\n"
+            "for k in range(3):\n"
+            "    d.beat('loop %d' % k); time.sleep(0.6)\n"
+            "d.beat('all-reduce of step 17'); time.sleep(30)\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert p.returncode == 3, (p.returncode, p.stderr)
+    assert "rank 5 made no progress" in p.stderr and "all-reduce of step 17" in p.stderr
+    code = "import bench, time\nd = bench.Watchdog(0, 1.0); d.stop(); time.sleep(2.5); print('alive')\n"
+    p = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert p.returncode == 0 and "alive" in p.stdout

@@ -45,9 +45,11 @@ def plain():
 @pytest.mark.parametrize("collective,graph,overlap", [("auto", "auto", "auto"), ("c2b", "off", "off"), ("c2b", "on", "off"),
                                                       ("torch", "on", "off"), ("torch", "off", "on")])
 def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph, overlap):
-    """the multi-rank step as the driver's N-GPU run takes it (auto = RCCL through the C ABI, in line behind the kernel,
-    eager launches) and four other combinations of who issues the collective, HIP-graph replay and overlap: same
-    reduced scalar, bit for bit, as the run without any collective"""
+    """the multi-rank step as the driver's N-GPU run takes it (auto = RCCL through the C ABI, eager launches, the
+    arrangement of the collective chosen by an A/B during warm-up) and four other combinations of who issues the
+    collective, HIP-graph replay and overlap: same reduced scalar, bit for bit, as the run without any collective; and
+    the line explains itself -- per-rank kernel / collective times, the store rate of every rank's kept output set, how
+    many ranks the communicator spans, both arrangements timed in the same run"""
     env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
     rc, out, err = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--collective", collective,
                          "--graph", graph, "--overlap", overlap] + COMMON, env)
@@ -63,10 +65,28 @@ def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph, 
         assert isinstance(cfg["hip_graph"], str) and cfg["hip_graph"].startswith("one graph launch per step"), cfg["hip_graph"]
     else:
         assert cfg["hip_graph"] is False
-    assert cfg["allreduce_overlaps_next_kernel"] is (overlap == "on" and graph != "on")      # auto = in line at world size 1
-    if cfg["allreduce_overlaps_next_kernel"]:
+    if graph == "on":
+        assert cfg["arrangement"] == "hip_graph" and cfg["allreduce_overlaps_next_kernel"] is False
+    elif overlap == "auto":                                       # measured, not assumed: both arrangements timed during warm-up
+        ab = cfg["ab_during_warmup"]
+        assert ab["us_per_step_in_line"] > 0 and ab["us_per_step_overlapped"] > 0 and ab["steps_each"] >= 5
+        assert cfg["arrangement"] == ("overlapped" if ab["us_per_step_overlapped"] < ab["us_per_step_in_line"] else "in_line")
+        assert cfg["arrangement_chosen_by"].startswith("A/B during warm-up")
+    else:
+        assert cfg["arrangement"] == ("overlapped" if overlap == "on" else "in_line") and cfg["ab_during_warmup"] is None
+    assert cfg["allreduce_overlaps_next_kernel"] is (cfg["arrangement"] == "overlapped")
+    if graph != "on":
+        # the OTHER arrangement was timed in the same run, and every overlapped step's slot equals the in-line sum bit for bit
+        assert cfg["ms_per_step_in_line"] > 0 and cfg["ms_per_step_overlapped"] > 0
+        assert out["ms_per_step"] == cfg["ms_per_step_" + cfg["arrangement"]]
         assert cfg["overlapped_sums_equal_the_in_line_sum"] is True
     assert cfg["allreduce_us"] > 0 and cfg["kernel_us_rank0"] > 0
+    assert cfg["rccl_ranks"] == [1]
+    assert len(cfg["kernel_us_per_rank"]) == 1 and cfg["kernel_us_per_rank"][0] > 0 and cfg["allreduce_us_per_rank"][0] > 0
+    assert len(cfg["store_GBs_kept_per_rank"]) == 1 and cfg["store_GBs_kept_per_rank"][0] > 1000.0      # 1.2 M observations: measured
+    if collective in ("auto", "c2b"):
+        assert cfg["comm_init_ms"] > 0
+    assert cfg["watchdog_seconds"] == 60.0
     assert out["config"]["n_observations"] == plain["config"]["n_observations"]
     assert out["config"]["observations_per_rank"] == [plain["config"]["n_observations"]]
     assert out["config"]["total_L2_error"] == plain["config"]["total_L2_error"]      # all_reduce over one rank: identity
@@ -89,6 +109,10 @@ def test_two_ranks_on_one_gpu_exit_cleanly_and_agree(plain):
     assert b[0] == 0 and b[-1] == plain["config"]["n_cameras"] and b[1] > 0
     rel = abs(out["config"]["total_L2_error"] - plain["config"]["total_L2_error"]) / plain["config"]["total_L2_error"]
     assert rel < 1e-12
+    cfg = out["config"]
+    assert cfg["rccl_ranks"] == [2, 2] and cfg["arrangement"] == "in_line"          # gloo stages the scalar through the host
+    assert len(cfg["kernel_us_per_rank"]) == 2 and min(cfg["kernel_us_per_rank"]) > 0 and min(cfg["allreduce_us_per_rank"]) > 0
+    assert out["ms_per_step"] == cfg["ms_per_step_in_line"] and "ms_per_step_overlapped" not in cfg
 
 
 def test_comm_through_the_c_abi_at_world_size_one():

@@ -11,6 +11,6 @@ C2B_DIST_BACKEND=gloo C2B_SHARE_GPU=1 timeout 600 python -m torch.distributed.ru
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); c=j['config']; print('N=%d value %.0f obs/rank %s err %.15g graph=%s overlap=%s (sums ok: %s) kernel_us=%s allreduce_us=%s overhead_us=%s' % (j['n_gpus'], j['value'], c['observations_per_rank'], c['total_L2_error'], c['hip_graph'], c.get('allreduce_overlaps_next_kernel'), c.get('overlapped_sums_equal_the_in_line_sum'), c.get('kernel_us_rank0'), c.get('allreduce_us'), c.get('step_overhead_us')))"
+        j=json.loads(l); c=j['config']; print('N=%d value %.0f ms/step %s obs/rank %s err %.15g graph=%s arrangement=%s (%s) A/B=%s in_line=%s overlapped=%s (sums ok: %s) kernel_us/rank=%s allreduce_us/rank=%s store_GBs_kept/rank=%s rccl_ranks=%s comm_init_ms=%s overhead_us=%s' % (j['n_gpus'], j['value'], j['ms_per_step'], c['observations_per_rank'], c['total_L2_error'], c['hip_graph'], c.get('arrangement'), c.get('arrangement_chosen_by'), c.get('ab_during_warmup'), c.get('ms_per_step_in_line'), c.get('ms_per_step_overlapped'), c.get('overlapped_sums_equal_the_in_line_sum'), c.get('kernel_us_per_rank'), c.get('allreduce_us_per_rank'), c.get('store_GBs_kept_per_rank'), c.get('rccl_ranks'), c.get('comm_init_ms'), c.get('step_overhead_us')))"
 rc=$?
 echo "rc=$rc"; grep -c Traceback /tmp/rehearse_$N.err
