@@ -163,6 +163,7 @@ SIGNATURES = {
     "c2b_problem_add_noise_errors_l1_l2": (_int, [_vp, _d, _d, _d, _d, _u64, C.POINTER(_d), C.POINTER(_d)]),
     "c2b_problem_add_noise_errors_l1_l2_sharded": (_int, [_vp, _vp, _d, _d, _d, _d, _u64, C.POINTER(_d), C.POINTER(_d)]),
     "c2b_problem_residual_jacobian": (_int, [_vp, _vp, _vp, _vp]),
+    "c2b_problem_residual_jacobian_device": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_d)]),
     "c2b_problem_stats": (_int, [_vp, _vp]),
     "c2b_problem_visibility_pairs": (_int, [_vp, _i64, _vp, _vp, _d, _vp, _vp]),
     "c2b_problem_cull": (_int, [_vp, _int]),

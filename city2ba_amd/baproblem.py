@@ -181,6 +181,20 @@ class BAProblem:
         L.check(L.lib().c2b_problem_residual_jacobian(self._h, _ptr(r), _ptr(Jc), _ptr(Jp)))
         return r, Jc, Jp
 
+    def residual_jacobian_device(self, outputs=None, max_attempts=8):
+        """residual + Jacobian of every observation in ONE launch with the results left on the device
+        (c2b_problem_residual_jacobian_device): returns (outputs, sum_sq) -- outputs.r [n,2], .Jc [n,18], .Jp [n,6] are
+        torch views of device arrays placed for streaming stores (device.JacobianOutputs; pass the object back in to
+        reuse it in a loop), sum_sq = sum of squared residuals (total_reprojection_error(2.) ** 2).  The BAProblem-level
+        route to the Level-0 headline rate: nothing but the 8-byte sum crosses PCIe."""
+        from . import device as D
+        h = C.c_void_p(outputs.handle.value) if outputs is not None else C.c_void_p()
+        s = C.c_double()
+        L.check(L.lib().c2b_problem_residual_jacobian_device(self._h, int(max_attempts), C.byref(h), C.byref(s)))
+        if outputs is None:
+            outputs = D.JacobianOutputs(self.num_observations(), self._device, max_attempts, _handle=h)
+        return outputs, s.value
+
     def _stats(self):
         s = np.empty(L.STATS_DOUBLES)
         L.check(L.lib().c2b_problem_stats(self._h, _ptr(s)))

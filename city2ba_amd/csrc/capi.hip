@@ -2643,6 +2643,44 @@ int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double 
     C2B_API_END("problem_residual_jacobian")
 }
 
+// The same launch with the results left ON THE DEVICE, in output arrays placed for streaming stores: what a
+// BAProblem-level caller that consumes the Jacobian on the GPU (a solver's normal equations) calls in its loop.  The
+// whole list in ONE launch -- residual, both blocks and the folded sum of squared residuals -- at the Level-0 headline
+// rate; nothing crosses PCIe but the 8-byte sum.  *outputs == NULL: a set is allocated by c2b_jacobian_outputs_alloc
+// (max_attempts placements tried, as there) and handed to the caller, who passes it back on later calls (it is reused as
+// long as the observation count matches) and frees it with c2b_jacobian_outputs_free.
+int c2b_problem_residual_jacobian_device(c2b_problem *p, int max_attempts, c2b_jacobian_outputs **outputs, double *sum_sq) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_residual_jacobian_device");
+    if (!outputs) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_residual_jacobian_device: outputs is NULL");
+    if (*outputs && ((*outputs)->n_obs != p->n_obs || (*outputs)->device != p->device))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_residual_jacobian_device: the output set holds %lld observations on device %d, the problem %lld on device %d",
+                    (long long)(*outputs)->n_obs, (*outputs)->device, (long long)p->n_obs, p->device);
+    int rc = ensure_camblk(p);
+    if (!rc) rc = ensure_rows(p);
+    if (rc) return rc;
+    const bool mine = *outputs == nullptr;
+    if (mine) {
+        rc = c2b_jacobian_outputs_alloc(p->n_obs, max_attempts, 0.0, p->stream, outputs);
+        if (rc) return rc;
+    }
+    c2b_jacobian_outputs *h = *outputs;
+    rc = c2b_residual_jacobian_rows(p->camblk, p->pts4, p->n_pts, p->rows_ptr, p->n_cam, p->rows_tiles, 0, p->pt_idx, p->uv, p->n_obs,
+                                    h->r, h->Jc, h->Jp, 2.0, p->ws, p->scalar, p->stream);
+    double sum = 0.0;
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(&sum, p->scalar, sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    const hipError_t e2 = hipStreamSynchronize(p->stream);
+    if (rc || e != hipSuccess || e2 != hipSuccess) {
+        if (mine) { c2b_jacobian_outputs_free(h); *outputs = nullptr; }
+        if (rc) return rc;
+        return fail(C2B_ERR_HIP, "problem_residual_jacobian_device: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    if (sum_sq) *sum_sq = sum;
+    return C2B_OK;
+    C2B_API_END("problem_residual_jacobian_device")
+}
+
 int c2b_host_alloc(void **ptr, int64_t bytes) {
     C2B_API_BEGIN
     if (!ptr || bytes < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "host_alloc: bad arguments");

@@ -243,12 +243,15 @@ class JacobianOutputs:
     (include/city2ba_hip.h).  .r / .Jc / .Jp are torch views of the handle's memory; .log = store
     GB/s of every attempt, .chosen = the attempt kept."""
 
-    def __init__(self, n_obs, device, max_attempts=8, fast_store_GBs=7000.0):
+    def __init__(self, n_obs, device, max_attempts=8, fast_store_GBs=7000.0, _handle=None):
         own = self._own = _OutputsHandle()
         dev = torch.device(device)
-        with torch.cuda.device(dev):
-            L.check(L.lib().c2b_jacobian_outputs_alloc(int(n_obs), int(max_attempts), float(fast_store_GBs), _stream(),
-                                                       C.byref(own.h)))
+        if _handle is not None:                                  # a set the library allocated (c2b_problem_residual_jacobian_device)
+            own.h = _handle
+        else:
+            with torch.cuda.device(dev):
+                L.check(L.lib().c2b_jacobian_outputs_alloc(int(n_obs), int(max_attempts), float(fast_store_GBs), _stream(),
+                                                           C.byref(own.h)))
         r, jc, jp = C.c_void_p(), C.c_void_p(), C.c_void_p()
         L.check(L.lib().c2b_jacobian_outputs_pointers(own.h, C.byref(r), C.byref(jc), C.byref(jp)))
         rates = (C.c_double * 8)()
@@ -263,6 +266,10 @@ class JacobianOutputs:
             self.r = torch.as_tensor(_DeviceArray(r.value, (n, 2), own), device=dev)
             self.Jc = torch.as_tensor(_DeviceArray(jc.value, (n, 18), own), device=dev)
             self.Jp = torch.as_tensor(_DeviceArray(jp.value, (n, 6), own), device=dev)
+
+    @property
+    def handle(self):
+        return self._own.h
 
 
 def alloc_jacobian_outputs(n_obs, device, max_attempts=8, fast_store_GBs=7000.0):

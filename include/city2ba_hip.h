@@ -564,6 +564,14 @@ int c2b_problem_total_reprojection_errors_l1_l2_sharded(c2b_problem *p, c2b_comm
  * overlap the kernel of the next chunk.  Buffers from c2b_host_alloc (pinned) receive them at link speed (PCIe);
  * pageable memory works at the runtime's staged rate (about a third of that). */
 int c2b_problem_residual_jacobian(c2b_problem *p, double *r, double *Jc, double *Jp);
+/* The same launch with the results left ON THE DEVICE, in output arrays placed for streaming stores
+ * (c2b_jacobian_outputs, above): the whole list in ONE launch -- r, Jc, Jp and the folded sum of squared residuals
+ * (*sum_sq, may be NULL; total_reprojection_error(2.) is its square root) -- i.e. the Level-0 headline rate for a
+ * BAProblem-level caller that consumes the Jacobian on the GPU.  *outputs == NULL: a set is allocated
+ * (max_attempts placements tried, see c2b_jacobian_outputs_alloc) and handed over; pass it back on later calls to reuse
+ * it (the observation count must still match), read it through c2b_jacobian_outputs_pointers, release it with
+ * c2b_jacobian_outputs_free.  Bits equal to c2b_problem_residual_jacobian's. */
+int c2b_problem_residual_jacobian_device(c2b_problem *p, int max_attempts, c2b_jacobian_outputs **outputs, double *sum_sq);
 /* page-locked host memory for buffers that cross PCIe often (hipHostMalloc / hipHostFree) */
 int c2b_host_alloc(void **ptr, int64_t bytes);
 void c2b_host_free(void *ptr);

@@ -263,3 +263,46 @@ def test_one_launch_step_is_graph_capturable_and_replays_cleanly():
         assert got == err_e.item() and got > 0
         seen.add(got)
     assert len(seen) == 6
+
+
+def test_level1_jacobian_left_on_the_device_equals_the_host_output_entry():
+    """c2b_problem_residual_jacobian_device (VERDICT r03 "Missing" 5): the BAProblem-level caller's route to the placed
+    output arrays -- bits equal to c2b_problem_residual_jacobian's host arrays, the folded sum equal to
+    total_reprojection_error(2.)^2, the set reusable across calls and refused when the problem changed size"""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import city2ba_amd as c2b
+    from city2ba_amd import _lib as L
+    from _problems import random_problem
+    P = random_problem(140, 1800, 13, seed=31, noise=1e-3, empty_every=7)
+    ba = c2b.BAProblem.from_bal(P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    r, Jc, Jp = ba.residual_jacobian()
+    outs, s = ba.residual_jacobian_device()
+    torch.cuda.synchronize()
+    assert np.array_equal(outs.r.cpu().numpy().view(np.uint64), np.asarray(r).view(np.uint64))
+    assert np.array_equal(outs.Jc.cpu().numpy().view(np.uint64), np.asarray(Jc).reshape(-1, 18).view(np.uint64))
+    assert np.array_equal(outs.Jp.cpu().numpy().view(np.uint64), np.asarray(Jp).reshape(-1, 6).view(np.uint64))
+    e2 = ba.total_reprojection_error(2.0)
+    assert abs(s - e2 * e2) <= 1e-12 * s and abs(s - float((np.asarray(r) ** 2).sum())) <= 1e-12 * s
+    # the loop of a solver: perturb, re-evaluate into the SAME set
+    c2b.noise.add_noise(ba, 0.01, 0.01, 0.01, 0.001, seed=3)
+    ptr = outs.Jc.data_ptr()
+    outs2, s2 = ba.residual_jacobian_device(outs)
+    assert outs2 is outs and outs.Jc.data_ptr() == ptr and s2 != s
+    r2, Jc2, _ = ba.residual_jacobian()
+    torch.cuda.synchronize()
+    assert np.array_equal(outs.r.cpu().numpy().view(np.uint64), np.asarray(r2).view(np.uint64))
+    assert np.array_equal(outs.Jc.cpu().numpy().view(np.uint64), np.asarray(Jc2).reshape(-1, 18).view(np.uint64))
+    # a set of the wrong size is refused, not overrun
+    ba.cull(False)
+    assert ba.num_observations() < len(r)
+    h = C.c_void_p(outs.handle.value)
+    assert L.lib().c2b_problem_residual_jacobian_device(ba._h, 1, C.byref(h), None) == L.ERR_INVALID_ARGUMENT
+    assert L.lib().c2b_problem_residual_jacobian_device(ba._h, 1, None, None) == L.ERR_INVALID_ARGUMENT
+    # an empty list: an empty set, a zero sum
+    e = c2b.BAProblem.from_visibility(P["cams15"][:3], P["pts"], np.zeros(4, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros((0, 2)))
+    o0, s0 = e.residual_jacobian_device()
+    assert s0 == 0.0 and o0.r.shape == (0, 2)
+    for b in (ba, e):
+        b.close()
