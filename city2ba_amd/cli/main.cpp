@@ -29,6 +29,7 @@
 #include <cstring>
 #include <map>
 #include <random>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -254,8 +255,8 @@ int run_synthetic_line(int argc, char **argv) {
 // numbers of observations (c2b_partition_cameras), every GPU gets its range, that range's observations and ALL points
 // (one c2b_problem each, marked with c2b_problem_set_shard), and one host thread per GPU runs the same sequence of
 // collective Level-1 calls (c2b_problem_*_sharded: statistics and errors go through RCCL, c2b_comm_init_all).  Draws
-// are keyed by global indices, so the written file does not depend on N (statistics differ from the one-GPU path in
-// their last bits only: two passes with gathered shares instead of one pass).
+// are keyed by global indices, so the written file is the same for every N up to rounding: the statistics that scale
+// the perturbations (mean, std) are sums of per-rank shares, whose last bits depend on how the cameras were cut.
 int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts, int64_t n_obs, std::vector<double> &bal9,
                       std::vector<double> &pts, size_t pts_cap, std::vector<double> &uv, std::vector<uint64_t> &row_ptr,
                       std::vector<uint64_t> &pt_idx) {
@@ -292,6 +293,12 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
     auto pass = [&](bool with_initial, bool with_noise) {
         std::vector<int64_t> bounds((size_t)N + 1);
         ck(c2b_partition_cameras(row_ptr.data(), n_cam, N, bounds.data()));
+        int nonempty = 0;
+        for (int k = 0; k < N; ++k) nonempty += bounds[(size_t)k + 1] > bounds[(size_t)k];
+        if (nonempty < N)
+            die("--gpus " + std::to_string(N) + ": the problem's " + std::to_string(n_cam) + " cameras (" + std::to_string(n_obs) +
+                " observations) cut into only " + std::to_string(nonempty) + " non-empty ranges; use --gpus " + std::to_string(std::max(1, nonempty)));
+        std::vector<std::string> failures((size_t)N);
         if (with_noise) {
             std::fprintf(stderr, "noise on %d GPU%s through %s; observations per GPU:", N, N == 1 ? "" : "s", c2b_comm_backend());
             for (int k = 0; k < N; ++k)
@@ -302,6 +309,11 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
         std::vector<std::thread> workers;
         for (int k = 0; k < N; ++k) {
             workers.emplace_back([&, k]() {
+                // a failing call ends THIS worker with its message (reported after the join; std::exit from a worker thread
+                // would run static destructors under the other workers' feet).  A rank that fails between two collectives
+                // leaves its peers waiting in the next one -- the same as a rank of an MPI job dying
+                auto ck = [&](int rc) { if (rc != C2B_OK) throw std::runtime_error(c2b_last_error()); };
+                try {
                 const int64_t lo = bounds[(size_t)k], hi = bounds[(size_t)k + 1], nc = hi - lo;
                 const uint64_t o0 = row_ptr[(size_t)lo];
                 std::vector<uint64_t> rp((size_t)nc + 1);
@@ -340,9 +352,12 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
                     ck(c2b_problem_download_bal(p, bal9.data() + 9 * lo));
                 }
                 c2b_problem_destroy(p);
+                } catch (const std::exception &e) { failures[(size_t)k] = e.what(); }
             });
         }
         for (auto &w : workers) w.join();
+        for (int k = 0; k < N; ++k)
+            if (!failures[(size_t)k].empty()) die("GPU " + std::to_string(devs[(size_t)k]) + " (rank " + std::to_string(k) + "): " + failures[(size_t)k]);
     };
 
     // host-side index corruption + cull, exactly as in the single-GPU path (src/bin/city2ba.rs:288-303): the reference
@@ -674,7 +689,7 @@ const char *subcommand_help(const std::string &sub) {
                "    --mismatch-chance <X> [0]  --drop-features <X> [1]  --split-landmarks <X> [0]  --join-landmarks <X> [0]\n"
                "    --seed <N>                every random draw is seeded (default: std::random_device)\n"
                "    --gpus <N> | --devices <a,b,...>   shard the problem over N GPUs of this node (contiguous camera ranges,\n"
-               "                              points replicated, statistics and errors through RCCL); same file for every N\n";
+               "                              points replicated, statistics and errors through RCCL); the same file for every N up to rounding\n";
     if (sub == "generate")
         return "city2ba generate <FILE.obj> <OUT>\n"
                "    --cameras <N> [100]   --points <N> [1000]   --max-dist <X> [100]\n"

@@ -1184,6 +1184,7 @@ int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n
     if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: bad arguments");
     if (n_cam + n_pts == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: empty problem (the reference's fold1().unwrap() panics)");
     if ((n_cam && !camblk) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: NULL input");
+    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: camblk/pts4 must be 16-byte aligned");
     const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
     return stats_impl(src, n_cam + n_pts, workspace, stats, S(stream));
     C2B_API_END("stats")
@@ -1196,6 +1197,7 @@ int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_bas
     if (n_cam < 0 || n_pts < 0 || cam_base < 0 || pt_base < 0 || n_cam_global < cam_base + n_cam || n_entities_global < 1 ||
         !part || !workspace || (n_cam && !camblk) || (n_pts && !pts4))
         return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass1: bad arguments");
+    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass1: camblk/pts4 must be 16-byte aligned");
     const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
     const int64_t n = n_cam + n_pts;
     double *rec = reinterpret_cast<double *>(workspace);
@@ -1212,6 +1214,7 @@ int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *p
     C2B_API_BEGIN
     if (n_cam < 0 || n_pts < 0 || !mean3 || !sumsq3 || !workspace || (n_cam && !camblk) || (n_pts && !pts4))
         return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass2: bad arguments");
+    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass2: camblk/pts4 must be 16-byte aligned");
     const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
     const int64_t n = n_cam + n_pts;
     double *rec = reinterpret_cast<double *>(workspace);
@@ -1280,11 +1283,24 @@ int c2b_comm_init_all(int n_dev, const int *dev_ids, c2b_comm **out) {
     for (int i = 0; i < n_dev; ++i) devs[i] = dev_ids ? dev_ids[i] : i;
     int prev = 0;
     HIP_TRY(hipGetDevice(&prev));
-    RCCL_TRY("comm_init_all", rccl().CommInitAll(comms, n_dev, devs));
+    const ncclResult_t r = rccl().CommInitAll(comms, n_dev, devs);      // switches the current device as it goes
     (void)hipSetDevice(prev);
-    for (int i = 0; i < n_dev; ++i) {
-        out[i] = new c2b_comm;
-        out[i]->comm = comms[i]; out[i]->rank = i; out[i]->world = n_dev; out[i]->device = devs[i];
+    if (r != ncclSuccess) return fail(C2B_ERR_RCCL, "comm_init_all: ncclCommInitAll: %s", rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+    int made = 0;
+    for (; made < n_dev; ++made) {
+        out[made] = new (std::nothrow) c2b_comm;
+        if (!out[made]) break;
+        out[made]->comm = comms[made]; out[made]->rank = made; out[made]->world = n_dev; out[made]->device = devs[made];
+    }
+    if (made < n_dev) {                                       // out of host memory half way: give every communicator back
+        for (int i = 0; i < made; ++i) { c2b_comm_destroy(out[i]); out[i] = nullptr; }
+        for (int i = made; i < n_dev; ++i) {
+            const bool sw = hipSetDevice(devs[i]) == hipSuccess;
+            (void)rccl().CommDestroy(comms[i]);
+            if (sw) (void)hipSetDevice(prev);
+        }
+        (void)hipSetDevice(prev);
+        return fail(C2B_ERR_OOM, "comm_init_all: out of host memory");
     }
     return C2B_OK;
     C2B_API_END("comm_init_all")
@@ -1398,32 +1414,45 @@ int c2b_stats_sharded(c2b_comm *c, const double *camblk, int64_t n_cam, int64_t 
     C2B_API_BEGIN
     if (!c || !c->comm || !workspace || !stats || n_cam < 0 || n_pts < 0 || cam_base < 0 || n_cam_global < cam_base + n_cam)
         return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: bad arguments");
+    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: camblk/pts4 must be 16-byte aligned");
     const int W = c->world, R = c->rank;
     const int64_t lo = n_pts * R / W, hi = n_pts * (R + 1) / W, n_ent = n_cam_global + n_pts;
     if (n_ent < 1) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: empty problem");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: the current device (%d) is not the communicator's (%d)", cur, c->device);
     hipStream_t st = S(stream);
-    double *dev = nullptr;                                   // [20 mine | W x 20 | 3 mean | 3 mine | W x 3]
+    // scratch [20 mine | W x 20 | 3 mean | 3 mine | W x 3] carved out of the workspace's partial slots, which the
+    // statistics kernels do not use (they keep their records in front of them): no device allocation per call -- a
+    // hipMalloc / hipFree pair synchronises the device, ~1 ms each, while the peers' collectives are in flight
     const size_t n_dev = 20 + 20 * (size_t)W + 3 + 3 + 3 * (size_t)W;
-    HIP_TRY(hipMalloc((void **)&dev, n_dev * sizeof(double)));
-    std::unique_ptr<double, void (*)(double *)> guard(dev, [](double *q) { (void)hipFree(q); });
+    if ((int64_t)n_dev > block_part_slots(0)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: more than %d ranks", 150);
+    double *dev = reinterpret_cast<double *>(workspace) + kWsBlockPart;
     double *d_mine = dev, *d_all = dev + 20, *d_mean = d_all + 20 * (size_t)W, *d_sq = d_mean + 3, *d_sqall = d_sq + 3;
     std::vector<double> shares(20 * (size_t)W), sq(3 * (size_t)W);
     double host_stats[20];
-    int rc = c2b_stats_partial_pass1(camblk, n_cam, cam_base, n_cam_global, pts4 + 4 * lo, hi - lo, lo, n_ent, workspace, d_mine, stream);
-    if (!rc) rc = c2b_comm_all_gather_f64(c, d_mine, 20, d_all, stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(shares.data(), d_all, shares.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    rc = c2b_stats_combine_shares(shares.data(), W, host_stats);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_mean, host_stats, 3 * sizeof(double), hipMemcpyHostToDevice, st));
-    rc = c2b_stats_partial_pass2(camblk, n_cam, pts4 + 4 * lo, hi - lo, d_mean, workspace, d_sq, stream);
-    if (!rc) rc = c2b_comm_all_gather_f64(c, d_sq, 3, d_sqall, stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(sq.data(), d_sqall, sq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    rc = c2b_stats_finish_shares(sq.data(), W, n_ent, host_stats);
-    if (rc) return rc;
+    for (double &v : host_stats) v = std::numeric_limits<double>::quiet_NaN();
+    // A rank that fails locally keeps taking part in BOTH all-gathers (its peers are already waiting in them) and
+    // reports its first error afterwards: `first` carries it.
+    int first = C2B_OK;
+    char first_msg[sizeof g_err] = "";
+    auto note = [&](int rc) { if (rc && !first) { first = rc; std::snprintf(first_msg, sizeof first_msg, "%s", g_err); } return rc; };
+    auto hip = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess) note(fail(C2B_ERR_HIP, "stats_sharded: %s: %s", what, hipGetErrorString(e)));
+        return e == hipSuccess;
+    };
+    note(c2b_stats_partial_pass1(camblk, n_cam, cam_base, n_cam_global, pts4 + 4 * lo, hi - lo, lo, n_ent, workspace, d_mine, stream));
+    note(c2b_comm_all_gather_f64(c, d_mine, 20, d_all, stream));
+    if (hip(hipMemcpyAsync(shares.data(), d_all, shares.size() * sizeof(double), hipMemcpyDeviceToHost, st), "copy of the shares") &&
+        hip(hipStreamSynchronize(st), "synchronize") && !first)
+        note(c2b_stats_combine_shares(shares.data(), W, host_stats));
+    hip(hipMemcpyAsync(d_mean, host_stats, 3 * sizeof(double), hipMemcpyHostToDevice, st), "upload of the mean");
+    if (!first) note(c2b_stats_partial_pass2(camblk, n_cam, pts4 + 4 * lo, hi - lo, d_mean, workspace, d_sq, stream));
+    note(c2b_comm_all_gather_f64(c, d_sq, 3, d_sqall, stream));
+    if (hip(hipMemcpyAsync(sq.data(), d_sqall, sq.size() * sizeof(double), hipMemcpyDeviceToHost, st), "copy of the squared sums") &&
+        hip(hipStreamSynchronize(st), "synchronize") && !first)
+        note(c2b_stats_finish_shares(sq.data(), W, n_ent, host_stats));
+    if (first) { std::snprintf(g_err, sizeof g_err, "%s", first_msg); return first; }
     HIP_TRY(hipMemcpyAsync(stats, host_stats, sizeof host_stats, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return C2B_OK;
