@@ -1,0 +1,102 @@
+"""INTEGRATION.md shows the Rust `extern "C"` blocks a maintainer of the reference would add.  No Rust toolchain exists
+in the image, so nothing compiles them; this test pins them to include/city2ba_hip.h instead: every
+declared function exists in the header, with the same arity, and every parameter and the return value agree under the
+Rust <-> C type map (`*const f64` <-> `const double *`, `i64` <-> `int64_t`, `c_int` <-> `int`, opaque structs by name)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+C_BASE = {"double": "f64", "float": "f32", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8",
+          "int": "c_int", "char": "c_char", "void": "c_void"}
+
+
+def _opaque(c_name):
+    """c2b_jacobian_outputs -> C2bJacobianOutputs"""
+    return "".join(w.capitalize() for w in c_name.split("_"))
+
+
+def c_type(text):
+    """(base in Rust spelling, pointer levels, innermost pointee is const) of one C parameter / return type"""
+    s = text.strip()
+    array = bool(re.search(r"\[\d*\]\s*$", s))
+    s = re.sub(r"\[\d*\]\s*$", "", s)
+    m = re.match(r"^(?P<const>const\s+)?(?P<base>\w+)\s*(?P<stars>(?:\*\s*)*)(?P<name>\w+)?$", s)
+    assert m, text
+    base = m.group("base")
+    stars = m.group("stars").count("*") + (1 if array else 0)
+    rust = C_BASE.get(base) or (_opaque(base) if base.startswith("c2b_") else None)
+    assert rust, "unmapped C type %r" % text
+    return rust, stars, bool(m.group("const")) and stars > 0
+
+
+def rust_type(text):
+    s = text.strip()
+    quals = []
+    while True:
+        m = re.match(r"^\*(const|mut)\s+", s)
+        if not m:
+            break
+        quals.append(m.group(1))
+        s = s[m.end():]
+    return s, len(quals), bool(quals) and quals[-1] == "const"
+
+
+def header_prototypes():
+    text = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(?m)^\s*((?:const\s+)?\w+\s*\**)\s*(c2b_\w+)\s*\(([^;{]*)\)\s*;", text):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        params = " ".join(params.split())
+        plist = [] if params in ("", "void") else [c_type(q) for q in params.split(",")]
+        r = ret.strip()
+        protos[name] = (None if r == "void" else c_type(r + " x"), plist)
+    return protos
+
+
+def rust_declarations():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    decls = []
+    for block in re.findall(r'extern "C" \{(.*?)\n\}', text, flags=re.S):
+        block = re.sub(r"//[^\n]*", "", block)
+        for m in re.finditer(r"pub fn (c2b_\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+            name, params, ret = m.group(1), " ".join(m.group(2).split()), m.group(3)
+            plist = []
+            for q in [x for x in params.split(",") if x.strip()]:
+                pname, ptype = q.split(":", 1)
+                plist.append(rust_type(ptype))
+            decls.append((name, rust_type(ret) if ret else None, plist))
+    return decls
+
+
+def test_every_rust_declaration_matches_the_header():
+    protos = header_prototypes()
+    assert len(protos) >= 150 and "c2b_problem_write" in protos and "c2b_comm_init_rank" in protos
+    decls = rust_declarations()
+    assert len(decls) >= 50, len(decls)
+    seen = set()
+    for name, ret, params in decls:
+        assert name in protos, "INTEGRATION.md declares %s, which include/city2ba_hip.h does not" % name
+        c_ret, c_params = protos[name]
+        assert ret == c_ret, (name, "return", ret, c_ret)
+        assert len(params) == len(c_params), (name, "arity", len(params), len(c_params))
+        for k, (a, b) in enumerate(zip(params, c_params)):
+            assert a == b, (name, "parameter %d" % k, a, b)
+        seen.add(name)
+    # what the text promises is really declared: both levels, the communicator, round 4's fused and device-resident calls
+    for must in ("c2b_problem_upload", "c2b_problem_total_reprojection_error", "c2b_problem_residual_jacobian_device",
+                 "c2b_problem_add_noise_errors_l1_l2_sharded", "c2b_problem_visibility_within_distance", "c2b_problem_write",
+                 "c2b_comm_all_reduce_sum_f64", "c2b_stats_sharded", "c2b_add_noise_observations_error_sums2_rows"):
+        assert must in seen, must
+
+
+def test_the_type_parsers_themselves():
+    assert c_type("const double *camblk") == ("f64", 1, True)
+    assert c_type("c2b_problem **out") == ("C2bProblem", 2, False)
+    assert c_type("const double dir[3]") == ("f64", 1, True)
+    assert c_type("uint64_t seed") == ("u64", 0, False)
+    assert c_type("void *stream") == ("c_void", 1, False)
+    assert rust_type("*mut *mut C2bProblem") == ("C2bProblem", 2, False)
+    assert rust_type("*const f64") == ("f64", 1, True)
+    assert rust_type("c_int") == ("c_int", 0, False)
