@@ -153,6 +153,7 @@ SIGNATURES = {
     "c2b_problem_download": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_problem_download_bal": (_int, [_vp, _vp]),
     "c2b_problem_write": (_int, [_vp, C.c_char_p, _int]),
+    "c2b_problem_read": (_int, [_vp, C.c_char_p, _int]),
     "c2b_problem_from_position_direction": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "c2b_problem_centers": (_int, [_vp, _vp]),
     "c2b_problem_project": (_int, [_vp, _vp]),

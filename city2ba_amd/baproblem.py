@@ -319,9 +319,12 @@ class BAProblem:
 
     @classmethod
     def from_file(cls, path, device=0, fmt=None):
-        """BAProblem::from_file (src/baproblem.rs:697-706): .bal text or .bbal binary by extension."""
-        bal9, pts, row_ptr, pt_idx, uv = read_bal(path, fmt)
-        return cls.from_bal(bal9, pts, row_ptr, pt_idx, uv, device)
+        """BAProblem::from_file (src/baproblem.rs:697-706) straight into the resident problem (c2b_problem_read): a .bbal is
+        streamed to the device and decoded there (byte order, index / uv split, range checks, from_vec); .bal text is
+        parsed by the host.  fmt None = by extension, "text", "binary"."""
+        self = cls(device)
+        L.check(L.lib().c2b_problem_read(self._h, str(path).encode(), _FORMATS[fmt]))
+        return self._refresh_graph()
 
     @classmethod
     def from_file_text(cls, path, device=0):        # src/baproblem.rs:580-630

@@ -414,6 +414,46 @@ int run_noise(int argc, char **argv) {
     if (a.has("seed")) seed = (uint64_t)a.i("seed", 0);
     else { std::random_device rd; seed = ((uint64_t)rd() << 32) ^ rd(); }   // the reference: unseeded thread_rng()
 
+    // The common case -- no index-corruption pass (src/bin/city2ba.rs:288-303, :341), one GPU -- never leaves the device:
+    // the file is decoded into the resident problem (c2b_problem_read), the whole chain of src/bin/city2ba.rs:280-357 runs
+    // on it, and the output file's image is assembled there (c2b_problem_write).  Both error pairs cost one pass each, the
+    // second one fused with add_noise's observation pass.
+    const bool reshapes_any = a.f("drop-features", 1.0) < 1.0 || a.f("join-landmarks", 0.0) > 0.0 || a.f("split-landmarks", 0.0) > 0.0;
+    if (!reshapes_any && !(a.f("mismatch-chance", 0.0) > 0.0) && !a.has("gpus") && !a.has("devices") && !std::getenv("C2B_HOST_IO")) {
+        PhaseTimer timer;
+        c2b_problem *p = nullptr;
+        ck(c2b_problem_create((int)a.i("device", 0), &p));
+        timer.mark("problem_create (HIP runtime start)");
+        ck(c2b_problem_read(p, a.positional[0].c_str(), -1));
+        timer.mark("read (decoded on the device for .bbal)");
+        double l1, l2;
+        ck(c2b_problem_total_reprojection_errors_l1_l2(p, &l1, &l2));
+        std::printf("Initial error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
+        if (a.has("fixed-drift")) {                                      // :305-316: drift is ALWAYS applied
+            double stats[C2B_STATS_DOUBLES];
+            ck(c2b_problem_stats(p, stats));
+            ck(c2b_problem_add_drift(p, a.f("drift-strength", 0), a.f("drift-angle", 0), a.f("drift-std", 0), stats + 3, seed));
+        } else {
+            ck(c2b_problem_add_drift_normalized(p, a.f("drift-strength", 0), a.f("drift-angle", 0), a.f("drift-std", 0), seed));
+        }
+        if (a.f("sin-strength", 0) > 0.0) {                              // :318-333
+            const double dx[3] = {1, 0, 0}, dz[3] = {0, 0, 1}, up[3] = {0, 1, 0};
+            ck(c2b_problem_add_sin_noise(p, dx, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
+            ck(c2b_problem_add_sin_noise(p, dz, up, a.f("sin-strength", 0), a.f("sin-frequency", 1)));
+        }
+        ck(c2b_problem_add_noise_errors_l1_l2(p, a.f("translation-std", 0), a.f("rotation-std", 0), a.f("point-std", 0),
+                                              a.f("observation-std", 0), seed + 1, &l1, &l2));      // :334-340 + :350-354
+        int64_t nc = 0, np = 0, no = 0;
+        ck(c2b_problem_sizes(p, &nc, &np, &no));
+        std::printf("BA Problem with %lld cameras, %lld points, %lld correspondences\n", (long long)nc, (long long)np, (long long)no);
+        std::printf("Final error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
+        timer.mark("errors + drift + noise (device)");
+        ck(c2b_problem_write(p, a.positional[1].c_str(), -1));
+        timer.mark("write (file image built on the device for .bbal)");
+        c2b_problem_destroy(p);
+        return 0;
+    }
+
     c2b_balfile *f = nullptr;
     ck(c2b_bal_read(a.positional[0].c_str(), &f));
     int64_t n_cam, n_pts, n_obs;

@@ -3368,6 +3368,140 @@ int c2b_problem_write(c2b_problem *p, const char *path, int format) {
     C2B_API_END("problem_write")
 }
 
+// BAProblem::from_file (src/baproblem.rs:697-706) into the resident problem.  `.bbal`: a reader thread streams the file
+// through a ring of pinned slots, this thread sends every slot to the device as it arrives and walks the per-camera
+// counts (the only part of the format that must be read in order); the per-observation decoding -- byte order, index
+// range checks, the split into index and uv arrays -- and from_vec of every camera run on the device.  `.bal`: the host
+// parser (decimal text is host work), then an ordinary upload.  format: -1 by extension, 0 text, 1 binary.
+int c2b_problem_read(c2b_problem *p, const char *path, int format) {
+    C2B_API_BEGIN
+    if (!p || !path) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_read: NULL argument");
+    bool binary = false;
+    int rc = bal_format(path, format, &binary);
+    if (rc) return rc;
+    if (!binary) {
+        c2b_balfile *f = nullptr;
+        rc = c2b_bal_read_as(path, 0, &f);
+        if (rc) return rc;
+        std::unique_ptr<c2b_balfile> own(f);
+        const c2b_host::Graph &g = f->g;
+        return upload_common(p, g.n_cam, g.cams.data(), true, g.n_pts, g.pts.data(), g.row_ptr.data(), g.pt_idx.data(), g.uv.data());
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "cannot open %s", path);
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    const off_t end = ::lseek(fd, 0, SEEK_END);
+    if (end < 24) return fail(C2B_ERR_INVALID_ARGUMENT, "Binary parse error");
+    const size_t bytes = (size_t)end & ~(size_t)7;                       // whole words (the format has nothing else)
+    DevBuf raw;
+    hipError_t e = raw.alloc(bytes);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+    constexpr size_t kChunk = (size_t)8 << 20;
+    constexpr int kSlots = 4;
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    char *pin = nullptr;
+    if (hipHostMalloc((void **)&pin, kChunk * kSlots, hipHostMallocDefault) != hipSuccess) return fail(C2B_ERR_OOM, "problem_read: no pinned staging memory");
+    struct PinFree { char *q; ~PinFree() { (void)hipHostFree(q); } } pin_free{pin};
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t filled = 0, drained = 0;                          // chunks read into / sent out of the ring
+    int failed = 0;
+    std::thread reader([&]() {
+        for (size_t k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return k < drained + kSlots || failed; });
+                if (failed) return;
+            }
+            const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+            char *dst = pin + (k % kSlots) * kChunk;
+            size_t done = 0;
+            while (done < len) {
+                const ssize_t r = ::pread(fd, dst + done, len - done, (off_t)(off + done));
+                if (r <= 0) break;
+                done += (size_t)r;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (done < len) failed = 2;
+            filled = k + 1;
+            cv.notify_all();
+            if (failed) return;
+        }
+    });
+    auto be64 = [](const char *q) { uint64_t v; std::memcpy(&v, q, 8); return __builtin_bswap64(v); };
+    uint64_t n_cam = 0, n_pts = 0, cam = 0, next_hdr = 24, n_obs = 0;
+    std::vector<uint64_t> row_ptr;
+    bool parse_error = false;
+    for (size_t k = 0; k < n_chunks; ++k) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return filled > k || failed; });
+            if (failed) break;
+        }
+        const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+        const char *src = pin + (k % kSlots) * kChunk;
+        if (k == 0) {
+            n_cam = be64(src); n_pts = be64(src + 8);        // the third word (the observation count) is not used by the reference either
+            // untrusted header: a camera costs 8 + 72 bytes, a point 24 -- reject counts the file cannot hold
+            if (n_cam > (bytes - 24) / 80 || n_pts > (bytes - 24) / 24 || n_cam >= ((uint64_t)1 << 32) || n_pts >= ((uint64_t)1 << 32)) parse_error = true;
+            else { row_ptr.assign((size_t)n_cam + 1, 0); }
+        }
+        while (!parse_error && cam < n_cam && next_hdr < off + len) {      // the counts whose word lies in this chunk
+            const uint64_t cnt = be64(src + (next_hdr - off));
+            if (cnt > (bytes - next_hdr) / 24) { parse_error = true; break; }
+            n_obs += cnt;
+            row_ptr[(size_t)++cam] = n_obs;
+            next_hdr += 8 + 24 * cnt;
+        }
+        const hipError_t ce = hipMemcpy(raw.as<char>() + off, src, len, hipMemcpyHostToDevice);
+        std::lock_guard<std::mutex> lk(mu);
+        if (ce != hipSuccess) failed = 1;
+        if (parse_error) failed = 3;
+        drained = k + 1;
+        cv.notify_all();
+        if (failed) break;
+    }
+    reader.join();
+    if (failed == 1) return fail(C2B_ERR_HIP, "problem_read: host-to-device copy failed");
+    if (failed == 2) return fail(C2B_ERR_INVALID_ARGUMENT, "cannot read %s", path);
+    if (failed == 3 || cam < n_cam || next_hdr + 72 * n_cam + 24 * n_pts > bytes || n_obs >= ((uint64_t)1 << 32))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "Binary parse error");
+
+    rc = alloc_problem(p, (int64_t)n_cam, (int64_t)n_pts, (int64_t)n_obs);
+    if (rc) return rc;
+    hipStream_t st = p->stream;
+    DevBuf d_row, d_bad;
+    e = d_row.alloc(sizeof(uint64_t) * (size_t)(n_cam + 1));
+    if (e == hipSuccess) e = d_bad.alloc(4);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad.ptr, 0, 4, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_row.ptr, row_ptr.data(), sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+    rc = c2b_expand_rows(d_row.as<uint64_t>(), (int64_t)n_cam, 0, (int64_t)n_obs, p->cam_idx, st);
+    if (rc) return rc;
+    const uint64_t *w = raw.as<uint64_t>();
+    if (n_obs) hipLaunchKernelGGL(k_bbal_read_observations, dim3(blocks_of((int64_t)n_obs, 256)), dim3(256), 0, st, w, (const uint32_t *)p->cam_idx,
+                                  (int64_t)n_obs, n_pts, p->pt_idx, reinterpret_cast<double2 *>(p->uv), d_bad.as<uint32_t>());
+    const uint64_t *wc = w + next_hdr / 8, *wp = wc + 9 * n_cam;
+    if (n_cam) hipLaunchKernelGGL(k_bbal_read_rows_f64, dim3(blocks_of(9 * (int64_t)n_cam, 256)), dim3(256), 0, st, wc, (int64_t)n_cam, 9, 9, p->bal9);
+    if (n_pts) hipLaunchKernelGGL(k_bbal_read_rows_f64, dim3(blocks_of(4 * (int64_t)n_pts, 256)), dim3(256), 0, st, wp, (int64_t)n_pts, 3, 4, p->pts4);
+    e = launch_error();
+    if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+    rc = c2b_cameras_from_bal(p->bal9, (int64_t)n_cam, p->cam15, st);      // SnavelyCamera::from_vec, src/baproblem.rs:180-186
+    if (rc) return rc;
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad.ptr, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad) {
+        free_buffers(p);
+        return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "Binary parse error: point index out of range");
+    }
+    p->bal_valid = true;
+    p->blk_valid = false;
+    return C2B_OK;
+    C2B_API_END("problem_read")
+}
+
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr) {
     C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_visibility_dense");

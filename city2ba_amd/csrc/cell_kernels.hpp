@@ -317,4 +317,27 @@ __global__ __launch_bounds__(256) void k_bbal_rows_f64(const double *__restrict_
     out[i] = bswap64((uint64_t)__double_as_longlong(in[r * stride + k]));
 }
 
+// ---- BAProblem::from_file_binary (src/baproblem.rs:632-695) decoded on the device ------------------------------------
+// `raw` = the file's bytes as u64 words; the host has walked the per-camera counts (each sits in front of its records, so
+// finding them is a pointer chase through the file) and uploaded row_ptr; everything per observation happens here.
+__global__ __launch_bounds__(256) void k_bbal_read_observations(const uint64_t *__restrict__ raw, const uint32_t *__restrict__ cam_idx,
+                                                               int64_t n_obs, uint64_t n_pts, uint32_t *__restrict__ pt_idx,
+                                                               double2 *__restrict__ uv, uint32_t *__restrict__ bad) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_obs) return;
+    const uint64_t *w = raw + 3 + ((uint64_t)cam_idx[o] + 1) + 3 * (uint64_t)o;
+    const uint64_t pt = bswap64(w[0]);
+    if (pt >= n_pts) atomicOr(bad, 1u);                                  // assert!(ci < &points.len()), src/baproblem.rs:368
+    pt_idx[o] = (uint32_t)pt;
+    uv[o] = make_double2(__longlong_as_double((long long)bswap64(w[1])), __longlong_as_double((long long)bswap64(w[2])));
+}
+// n rows of `width` big-endian doubles -> rows `stride` doubles apart (cameras 9 -> 9, points 3 -> the padded 4)
+__global__ __launch_bounds__(256) void k_bbal_read_rows_f64(const uint64_t *__restrict__ in, int64_t n, int width, int stride,
+                                                           double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * stride) return;
+    const int64_t r = i / stride, k = i % stride;
+    out[i] = k < width ? __longlong_as_double((long long)bswap64(in[r * width + k])) : 0.0;
+}
+
 }  // namespace c2b

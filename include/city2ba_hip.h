@@ -541,6 +541,11 @@ int c2b_problem_download_bal(c2b_problem *p, double *bal9);
  * image -- to_vec of every camera, per-camera counts, big-endian words -- is assembled on the device and leaves through
  * pinned chunks written by a few host threads; the bytes equal c2b_bal_write's on the downloaded arrays. */
 int c2b_problem_write(c2b_problem *p, const char *path, int format);
+/* BAProblem::from_file / from_file_text / from_file_binary (src/baproblem.rs:580-706) INTO the resident problem (what
+ * it held is dropped): format as above.  A `.bbal` is streamed to the device through pinned chunks while the host walks
+ * the per-camera counts; byte order, the index / uv split, the point-index range check (C2B_ERR_INDEX_OUT_OF_RANGE) and
+ * SnavelyCamera::from_vec run on the device.  Same resident state as c2b_bal_read + c2b_problem_upload_bal. */
+int c2b_problem_read(c2b_problem *p, const char *path, int format);
 
 /* Camera::from_position_direction (src/baproblem.rs:153-159) for n cameras on p's device:
  * pos3 [n][3], dir9 [n][9] col-major -> cams15 [n][15].  Does not change the problem. */

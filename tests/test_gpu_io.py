@@ -62,3 +62,57 @@ def test_resident_write_without_observations_and_across_chunks(c2b, tmp_path):
     g.write(str(a))
     assert open(a, "rb").read() == _host_file(c2b, g, str(b), None)
     g.close()
+
+
+def test_resident_read_equals_the_host_reader_plus_upload(c2b, tmp_path):
+    """c2b_problem_read (a .bbal decoded on the device; .bal through the host parser): the resident state equals
+    read_bal + from_bal's, bit for bit -- cameras (from_vec), points, graph, observations -- for both formats, with empty
+    camera lists, and across chunk boundaries; malformed files come back as statuses"""
+    from city2ba_amd.baproblem import read_bal, write_bal
+    from city2ba_amd import _lib as L
+    P = random_problem(61, 700, 9, seed=12, noise=1e-3, empty_every=5)
+    for ext in ("bbal", "bal"):
+        path = str(tmp_path / ("in." + ext))
+        write_bal(path, P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+        a = c2b.BAProblem.from_file(path)
+        b = c2b.BAProblem.from_bal(*read_bal(path))
+        assert np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.pt_idx, b.pt_idx)
+        for x, y in ((a.cameras(), b.cameras()), (a.cameras_bal(), b.cameras_bal()), (a.points(), b.points()), (a.observations(), b.observations())):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+        if ext == "bbal":
+            assert np.array_equal(a.cameras_bal(), P["bal9"]) and np.array_equal(a.observations(), P["uv"])
+        assert a.total_reprojection_error(2.0) == b.total_reprojection_error(2.0)
+        out = str(tmp_path / ("out." + ext))
+        a.write(out)
+        assert open(out, "rb").read() == open(path, "rb").read()        # read -> write is the identity on the file
+        a.close()
+        b.close()
+    # several 8-MiB chunks (27 MB of records): the count walk crosses chunk boundaries
+    from city2ba_amd import synthetic as S
+    g = S.synthetic_grid(10, 10, 32, 20.0, 1.0, 1.0, 1.0, 10.0, False)
+    big = str(tmp_path / "g.bbal")
+    g.write(big)
+    h = c2b.BAProblem.from_file(big)
+    assert np.array_equal(h.row_ptr, g.row_ptr) and np.array_equal(h.pt_idx, g.pt_idx)
+    assert np.array_equal(h.observations(), g.observations()) and np.array_equal(h.points(), g.points())
+    assert np.array_equal(h.cameras_bal(), g.cameras_bal())
+    g.close()
+    h.close()
+    # malformed input: truncated, a count running past the end, a point index out of range, trailing bytes (allowed)
+    data = open(str(tmp_path / "in.bbal"), "rb").read()
+    ba = c2b.BAProblem(0)
+    def status(blob, name):
+        q = str(tmp_path / name)
+        open(q, "wb").write(blob)
+        return L.lib().c2b_problem_read(ba._h, q.encode(), -1)
+    assert status(data[:len(data) - 16], "trunc.bbal") == L.ERR_INVALID_ARGUMENT
+    assert status(data[:20], "tiny.bbal") == L.ERR_INVALID_ARGUMENT
+    huge = bytearray(data); huge[24:32] = (10 ** 12).to_bytes(8, "big")
+    assert status(bytes(huge), "count.bbal") == L.ERR_INVALID_ARGUMENT
+    first = next(c for c in range(len(P["row_ptr"]) - 1) if P["row_ptr"][c + 1] > P["row_ptr"][c])
+    off = 24 + 8 * (first + 1) + 24 * int(P["row_ptr"][first])
+    bad = bytearray(data); bad[off:off + 8] = (700).to_bytes(8, "big")      # point 700 of 700
+    assert status(bytes(bad), "index.bbal") == L.ERR_INDEX_OUT_OF_RANGE
+    assert status(data + b"\\0" * 24, "trailing.bbal") == L.OK             # nom leaves trailing input unread
+    assert L.lib().c2b_problem_read(ba._h, str(tmp_path / "missing.bbal").encode(), -1) == L.ERR_INVALID_ARGUMENT
+    ba.close()
