@@ -211,7 +211,7 @@ void generate_cull_write(c2b_problem *p, const Layout &lay, double max_dist, con
     ck(c2b_problem_sizes(p, &nc, &np, &no));
     std::printf("Bundle Adjustment Problem with %lld cameras, %lld points, and %lld observations\n", (long long)nc, (long long)np, (long long)no);
     ck(c2b_problem_write(p, out.c_str(), -1));
-    timer.mark("write (file image built on the device for .bbal)");
+    timer.mark("write (c2b_problem_write: a .bbal image is built on the device)");
 }
 
 int run_synthetic(int argc, char **argv) {
@@ -449,7 +449,7 @@ int run_noise(int argc, char **argv) {
         std::printf("Final error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
         timer.mark("errors + drift + noise (device)");
         ck(c2b_problem_write(p, a.positional[1].c_str(), -1));
-        timer.mark("write (file image built on the device for .bbal)");
+        timer.mark("write (c2b_problem_write: a .bbal image is built on the device)");
         c2b_problem_destroy(p);
         return 0;
     }
