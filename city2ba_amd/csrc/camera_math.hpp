@@ -445,20 +445,34 @@ C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32
     z1 = rad * s;
 }
 
+// Philox2x32-10 (Salmon et al., SC'11; Random123's philox2x32_R(10, ...)): one 32 x 32 -> 64 multiply per round where
+// Philox4x32 has two -- the multiplies run at a quarter of the vector rate, and with its xors Philox4x32-10 was 42 % of
+// the observation-noise kernel's issue cycles (19 v_mad_u64_u32 + 40 v_xor of 214 vector instructions, r03 ISA).
+C2B_DEV void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t out[2]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p = (uint64_t)0xD256D193u * c0;
+        const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+
 // add_noise's observation draw (src/noise.rs:152-170: a uniformly distributed unit 2-vector times Normal(0, std)) from
-// ONE Philox block, counter = (observation, slot 0): words 0-1 -> the radius uniform u1 of the magnitude, word 3 -> its
-// angle, word 2 -> the direction (the normalised Gaussian pair of unit_random has a uniform direction and its radius
-// cancels, so only the direction is drawn).  The CPU restatement under tests/ reads the same bits of the block.
-// Rounds 1-2 spent two blocks here: 20 more quarter-rate 32x32->64 multiplies per observation.
-// c, s = the direction; returns the standard normal z.
+// ONE Philox2x32-10 block (r04; rounds 1-2 spent two Philox4x32 blocks here, r03 one): counter = the observation's global
+// index, its high word xor-ed with the seed's high word; key = the seed's low word.  Word 0 -> the radius uniform
+// u1 = (w0 + 1) 2^-32 in (0, 1] (the magnitude's tail ends at sqrt(-2 ln 2^-32) = 6.7 sigma); word 1, high half -> the
+// Box-Muller angle, low half -> the direction (16-bit fractions of a turn each).  The normalised Gaussian pair of
+// unit_random has a uniform direction and its radius cancels, so only the direction is drawn.  The CPU restatement
+// under oracle/ reads the same bits.  c, s = the direction; returns the standard normal z.
 C2B_DEV double obs_noise_draw(uint64_t seed, uint64_t observation, double &c, double &s) {
-    uint32_t o[4];
-    philox4x32_10((uint32_t)observation, (uint32_t)(observation >> 32), 0u, kStreamNoiseObs, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), o);
-    const uint64_t a = ((uint64_t)o[1] << 32) | o[0];
-    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;   // (0,1]
-    sincos_turns32(o[2], s, c);
-    return sqrt(-2.0 * log_unit(u1)) * cos_turns32(o[3]);
+    uint32_t o[2];
+    philox2x32_10((uint32_t)observation, (uint32_t)(observation >> 32) ^ (uint32_t)(seed >> 32), (uint32_t)seed, o);
+    const double u1 = fma((double)o[0], 0x1.0p-32, 0x1.0p-32);          // exact: (w0 + 1) 2^-32
+    sincos_turns32(o[1] << 16, s, c);
+    return sqrt(-2.0 * log_unit(u1)) * cos_turns32(o[1] & 0xffff0000u);
 }
 
 }  // namespace c2b

@@ -74,6 +74,7 @@ def lib():
     sig("orc_residual_jacobian_bal", None, _dp, _i64, _dp, _u64p, _u64p, _dp, _dp, _dp, _dp)
     sig("orc_residual_jacobian", None, _dp, _i64, _dp, _u64p, _u64p, _dp, _dp, _dp, _dp)
     sig("orc_philox4x32_10", None, _u32p, _u32p, _u32p)
+    sig("orc_philox2x32_10", None, _u32p, C.c_uint32, _u32p)
     sig("orc_normal_pair", None, _u64, C.c_uint32, _u64, C.c_uint32, _dp)
     sig("orc_drift_origin", None, _dp, _i64, _dp, _i64, _dp, C.POINTER(_i64))
     sig("orc_add_drift", None, _dp, _i64, _dp, _i64, _d, _d, _d, _dp, _u64)
@@ -352,6 +353,12 @@ def philox4x32_10(ctr, key):
     out = np.empty(4, dtype=np.uint32)
     lib().orc_philox4x32_10(np.ascontiguousarray(ctr, dtype=np.uint32),
                             np.ascontiguousarray(key, dtype=np.uint32), out)
+    return out
+
+
+def philox2x32_10(ctr, key):
+    out = np.empty(2, dtype=np.uint32)
+    lib().orc_philox2x32_10(np.ascontiguousarray(ctr, dtype=np.uint32), int(key), out)
     return out
 
 

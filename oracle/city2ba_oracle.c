@@ -641,6 +641,19 @@ void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/* Philox2x32-10 (Random123's philox2x32_R(10, ...)): the observation stream's generator */
+void orc_philox2x32_10(const uint32_t ctr_in[2], uint32_t key, uint32_t out[2]) {
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], k = key;
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p = (uint64_t)0xD256D193u * c0;
+        uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+
 /* two independent N(0,1) for (seed, stream, entity, slot) */
 void orc_normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32_t slot, double z[2]) {
     uint32_t ctr[4] = { (uint32_t)entity, (uint32_t)(entity >> 32), slot, stream };
@@ -751,20 +764,20 @@ void orc_add_noise(double *cams15, int64_t n_cam, double *pts, int64_t n_pts, do
         for (int k = 0; k < 3; ++k) pts[3 * j + k] = pts[3 * j + k] + ax[k] * m;
     }
     for (int64_t o = 0; o < n_obs; ++o) {
-        /* ONE Philox block per observation (counter = observation, slot 0): words 0-1 -> the radius uniform of the
-         * magnitude draw, word 3 -> its angle, word 2 -> the direction.  unit_random::<Vector2>() normalises a pair
-         * of standard normals (src/noise.rs:35-45): its direction is uniform on the circle and its radius cancels,
-         * so the pair is drawn with radius 1, i.e. as (cos, sin) of a uniform angle, and normalised like the reference
-         * does; the magnitude is Normal(0, std) by Box-Muller (src/noise.rs:160-163). */
+        /* ONE Philox2x32-10 block per observation: counter = (low word of the global observation index, its high word
+         * xor the seed's high word), key = the seed's low word.  Word 0 -> the radius uniform of the magnitude draw,
+         * (w0 + 1) 2^-32 in (0, 1]; word 1: high half -> its angle, low half -> the direction (16-bit fractions of a
+         * turn).  unit_random::<Vector2>() normalises a pair of standard normals (src/noise.rs:35-45): its direction is
+         * uniform on the circle and its radius cancels, so the pair is drawn with radius 1, i.e. as (cos, sin) of a
+         * uniform angle, and normalised like the reference does; the magnitude is Normal(0, std) by Box-Muller
+         * (src/noise.rs:160-163). */
         uint64_t ent = obs_offset + (uint64_t)o;
-        uint32_t ctr[4] = { (uint32_t)ent, (uint32_t)(ent >> 32), 0u, ORC_STREAM_NOISE_OBS };
-        uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-        uint32_t w[4];
-        orc_philox4x32_10(ctr, key, w);
-        uint64_t a = ((uint64_t)w[1] << 32) | w[0];
-        double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;                     /* (0,1] */
-        double dir = 6.283185307179586476925286766559 * ((double)w[2] * 0x1.0p-32);
-        double ang = 6.283185307179586476925286766559 * ((double)w[3] * 0x1.0p-32);
+        uint32_t ctr[2] = { (uint32_t)ent, (uint32_t)(ent >> 32) ^ (uint32_t)(seed >> 32) };
+        uint32_t w[2];
+        orc_philox2x32_10(ctr, (uint32_t)seed, w);
+        double u1 = ((double)w[0] + 1.0) * 0x1.0p-32;                         /* (0,1] */
+        double dir = 6.283185307179586476925286766559 * ((double)(w[1] & 0xffffu) * 0x1.0p-16);
+        double ang = 6.283185307179586476925286766559 * ((double)(w[1] >> 16) * 0x1.0p-16);
         double z = sqrt(-2.0 * log(u1)) * cos(ang);
         double nx = cos(dir), ny = sin(dir);
         double m = sqrt(nx * nx + ny * ny);       /* powf(2.0) == x*x exactly */

@@ -44,6 +44,10 @@ def test_philox_known_answers():           # Random123 kat_vectors (Philox4x32-1
     assert [int(x) for x in O.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
                                             [0xa4093822, 0x299f31d0])] == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # ... and Philox2x32-10 (the observation-noise stream since r04), same file
+    assert [int(x) for x in O.philox2x32_10([0, 0], 0)] == [0xff1dae59, 0x6cd10df2]
+    assert [int(x) for x in O.philox2x32_10([0xffffffff, 0xffffffff], 0xffffffff)] == [0x2c3f628b, 0xab4fd7ad]
+    assert [int(x) for x in O.philox2x32_10([0x243f6a88, 0x85a308d3], 0x13198a2e)] == [0xdd7ce038, 0xf62a4c12]
 
 
 # --- (2) mpmath golden vectors --------------------------------------------------------
