@@ -319,6 +319,7 @@ def light_kernels(sh, dev, ws):
     uv_out = torch.empty_like(sh["uv"])
     keep = torch.empty(n, dtype=torch.uint8, device=dev)
     err = torch.zeros(1, dtype=torch.float64, device=dev)
+    err2 = torch.zeros(2, dtype=torch.float64, device=dev)
     st = torch.empty(20, dtype=torch.float64, device=dev)
     uv2 = sh["uv"].clone()
     sweep = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
@@ -326,6 +327,10 @@ def light_kernels(sh, dev, ws):
     cases = {
         "project_rows": (lambda: D.project_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], uv_out), n * 20 + ent),
         "error_sum_rows_L2": (lambda: D.reprojection_error_sum_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], 2.0, ws, err), n * 20 + ent),
+        # r04: the pair run_noise evaluates back to back (src/bin/city2ba.rs:283-287, 350-354) as ONE pass, and add_noise's
+        # observation pass (src/noise.rs:152-170) fused with it
+        "error_sums2_rows_L1_and_L2": (lambda: D.reprojection_error_sums2_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], ws, err2), n * 20 + ent),
+        "add_noise_observations+error_sums2_rows": (lambda: D.add_noise_observations_error_sums2_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], uv2, 0, 1e-9, 7, ws, err2), n * 36 + ent),
         "visibility_rows": (lambda: D.visibility_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], 10.0, uv_out, keep), n * 21 + ent),
         "add_noise_observations": (lambda: D.add_noise_observations(uv2, 0, 1e-9, 7), n * 32),
         "stats": (lambda: D.stats(sh["camblk"], sh["pts4"], ws, st), n_cam * 24 + n_pts * 24),
