@@ -6,7 +6,11 @@
 // reference.  Camera payloads are opaque rows of `stride` doubles (cam15 or bal9).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <charconv>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -178,6 +182,12 @@ inline Graph cull(const Graph &g, bool faithful, int mode = 0) {
 }
 
 // ---- .bal / .bbal -----------------------------------------------------------------------------------
+// threads of the text formatter / parser: the usable cores (at most 16), or C2B_IO_THREADS
+inline int io_threads() {
+    if (const char *e = std::getenv("C2B_IO_THREADS")) { const int v = std::atoi(e); if (v >= 1) return std::min(v, 64); }
+    return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
 // Rust's `{}` for f64: shortest digits that round-trip, never an exponent, "1" for 1.0, "-0", "NaN", "inf".
 inline void fmt_f64(double v, std::string &out) {
     if (v != v) { out += "NaN"; return; }
@@ -186,38 +196,104 @@ inline void fmt_f64(double v, std::string &out) {
     out.append(buf, r.ptr);
 }
 
-// write_text, src/baproblem.rs:709-733 (cameras: 9 values on ONE line, space-joined)
-inline bool write_text(const char *path, const Graph &g, std::string *err) {
+// write_text, src/baproblem.rs:709-733 (cameras: 9 values on ONE line, space-joined).  Shortest round-trip decimals are
+// the cost (170 MB/s on one thread: 7 s for the 1.2 GB of `synthetic --blocks 128`), so the lines are formatted by a
+// pool of threads in tasks of kTextTask lines -- observation lines, then camera lines, then point lines -- while this
+// thread writes the finished tasks in order (and frees them): the file is byte for byte the sequential writer's.
+constexpr int64_t kTextTask = 1 << 17;
+inline bool write_text(const char *path, const Graph &g, std::string *err, int n_threads = 0) {
     if (g.stride != 9) { *err = "write_text needs bal9 camera rows"; return false; }
     FILE *f = std::fopen(path, "wb");
     if (!f) { *err = std::string("cannot create ") + path; return false; }
-    std::string s;
-    s.reserve(1 << 20);
-    s += std::to_string(g.n_cam) + " " + std::to_string(g.n_pts) + " " + std::to_string(g.n_obs()) + "\n";
-    auto flush = [&](bool force) {
-        if (force || s.size() > (1u << 20)) { std::fwrite(s.data(), 1, s.size(), f); s.clear(); }
-    };
-    for (int64_t c = 0; c < g.n_cam; ++c)
-        for (uint64_t e = g.row_ptr[(size_t)c]; e < g.row_ptr[(size_t)c + 1]; ++e) {
-            s += std::to_string(c); s += ' ';
-            s += std::to_string(g.pt_idx[(size_t)e]); s += ' ';
-            fmt_f64(g.uv[2 * (size_t)e], s); s += ' ';
-            fmt_f64(g.uv[2 * (size_t)e + 1], s); s += '\n';
-            flush(false);
+    const int64_t n_obs = g.n_obs();
+    const int64_t t_obs = (n_obs + kTextTask - 1) / kTextTask, t_cam = (g.n_cam + kTextTask - 1) / kTextTask,
+                  t_pts = (g.n_pts + kTextTask - 1) / kTextTask, n_tasks = t_obs + t_cam + t_pts;
+    auto format_task = [&](int64_t k, std::string &s) {
+        s.clear();
+        if (k < t_obs) {
+            const int64_t a = k * kTextTask, b = std::min(n_obs, a + kTextTask);
+            s.reserve((size_t)(b - a) * 52);
+            // the camera whose list holds observation a, then walk
+            int64_t c = (int64_t)(std::upper_bound(g.row_ptr.begin(), g.row_ptr.end(), (uint64_t)a) - g.row_ptr.begin()) - 1;
+            for (int64_t e = a; e < b; ++e) {
+                while ((uint64_t)e >= g.row_ptr[(size_t)c + 1]) ++c;
+                s += std::to_string(c); s += ' ';
+                s += std::to_string(g.pt_idx[(size_t)e]); s += ' ';
+                fmt_f64(g.uv[2 * (size_t)e], s); s += ' ';
+                fmt_f64(g.uv[2 * (size_t)e + 1], s); s += '\n';
+            }
+        } else if (k < t_obs + t_cam) {
+            const int64_t a = (k - t_obs) * kTextTask, b = std::min(g.n_cam, a + kTextTask);
+            for (int64_t c = a; c < b; ++c) {
+                for (int q = 0; q < 9; ++q) { if (q) s += ' '; fmt_f64(g.cams[(size_t)c * 9 + q], s); }
+                s += '\n';
+            }
+        } else {
+            const int64_t a = (k - t_obs - t_cam) * kTextTask, b = std::min(g.n_pts, a + kTextTask);
+            for (int64_t p = a; p < b; ++p) {
+                fmt_f64(g.pts[(size_t)p * 3], s); s += ' ';
+                fmt_f64(g.pts[(size_t)p * 3 + 1], s); s += ' ';
+                fmt_f64(g.pts[(size_t)p * 3 + 2], s); s += '\n';
+            }
         }
-    for (int64_t c = 0; c < g.n_cam; ++c) {
-        for (int k = 0; k < 9; ++k) { if (k) s += ' '; fmt_f64(g.cams[(size_t)c * 9 + k], s); }
-        s += '\n';
-        flush(false);
+    };
+    bool ok = true;
+    {
+        const std::string head = std::to_string(g.n_cam) + " " + std::to_string(g.n_pts) + " " + std::to_string(n_obs) + "\n";
+        ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
     }
-    for (int64_t p = 0; p < g.n_pts; ++p) {
-        fmt_f64(g.pts[(size_t)p * 3], s); s += ' ';
-        fmt_f64(g.pts[(size_t)p * 3 + 1], s); s += ' ';
-        fmt_f64(g.pts[(size_t)p * 3 + 2], s); s += '\n';
-        flush(false);
+    if (n_threads <= 0) n_threads = io_threads();
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n_tasks));
+    if (n_threads <= 1) {
+        std::string s;
+        for (int64_t k = 0; k < n_tasks && ok; ++k) { format_task(k, s); ok = std::fwrite(s.data(), 1, s.size(), f) == s.size(); }
+    } else {
+        // at most 4 * n_threads formatted tasks wait for the writer at any time (a few hundred MB at worst)
+        std::vector<std::string> out((size_t)n_tasks);
+        std::vector<char> done((size_t)n_tasks, 0);
+        std::mutex mu;
+        std::condition_variable cv;
+        int64_t next = 0, written = 0;
+        bool stop = false;
+        auto worker = [&]() {
+            while (true) {
+                int64_t k;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || next >= n_tasks || next < written + 4 * n_threads; });
+                    if (stop || next >= n_tasks) return;
+                    k = next++;
+                }
+                std::string s;
+                format_task(k, s);
+                std::lock_guard<std::mutex> lk(mu);
+                out[(size_t)k] = std::move(s);
+                done[(size_t)k] = 1;
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+        for (int64_t k = 0; k < n_tasks; ++k) {
+            std::string s;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return done[(size_t)k] != 0; });
+                s = std::move(out[(size_t)k]);
+            }
+            if (ok) ok = std::fwrite(s.data(), 1, s.size(), f) == s.size();
+            std::lock_guard<std::mutex> lk(mu);
+            written = k + 1;
+            cv.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : pool) t.join();
     }
-    flush(true);
-    const bool ok = std::fclose(f) == 0;
+    ok = (std::fclose(f) == 0) && ok;
     if (!ok) *err = std::string("write failed: ") + path;
     return ok;
 }
@@ -304,6 +380,15 @@ inline bool write_binary(const char *path, const Graph &g, std::string *err) {
 inline bool read_all(const char *path, std::string &buf, std::string *err) {
     FILE *f = std::fopen(path, "rb");
     if (!f) { *err = std::string("cannot open ") + path; return false; }
+    if (std::fseek(f, 0, SEEK_END) == 0) {                   // sized in one go when the file says how long it is
+        const long n = std::ftell(f);
+        std::rewind(f);
+        if (n > 0) {
+            buf.resize((size_t)n);
+            const size_t got = std::fread(&buf[0], 1, (size_t)n, f);
+            buf.resize(got);
+        }
+    }
     char tmp[1 << 16];
     size_t n;
     while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
@@ -313,9 +398,7 @@ inline bool read_all(const char *path, std::string &buf, std::string *err) {
 
 // from_file_text, src/baproblem.rs:580-628: unsigned/float tokens separated by any whitespace; observations
 // are (camera, point, u, v) tuples in file order and are pushed per camera like BAProblem::new (:342-355).
-inline bool read_text(const char *path, Graph &g, std::string *err) {
-    std::string buf;
-    if (!read_all(path, buf, err)) return false;
+inline bool read_text_sequential(const std::string &buf, Graph &g, std::string *err) {
     const char *p = buf.c_str(), *end = p + buf.size();
     auto skip = [&]() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; };
     auto get_u = [&](uint64_t &v) -> bool {
@@ -369,6 +452,137 @@ inline bool read_text(const char *path, Graph &g, std::string *err) {
     }
     g.row_ptr.assign((size_t)nc + 1, 0);
     for (uint64_t c = 0; c < nc; ++c) g.row_ptr[(size_t)c + 1] = g.row_ptr[(size_t)c] + count[(size_t)c + 1];
+    std::vector<uint64_t> fill(g.row_ptr.begin(), g.row_ptr.end() - 1);
+    g.pt_idx.resize((size_t)no);
+    g.uv.resize((size_t)no * 2);
+    for (uint64_t i = 0; i < no; ++i) {
+        const uint64_t d = fill[(size_t)oc[(size_t)i]]++;
+        g.pt_idx[(size_t)d] = op[(size_t)i];
+        g.uv[2 * (size_t)d] = ou[2 * (size_t)i];
+        g.uv[2 * (size_t)d + 1] = ou[2 * (size_t)i + 1];
+    }
+    return true;
+}
+
+// The same parse on several threads, for files whose numbers are separated by whitespace (every file this writer or the
+// reference's writer produces; nom's grammar also accepts numbers glued to each other, e.g. "1.5-3").  The token stream
+// is positional -- 3 header tokens, 4 per observation, 9 per camera, 3 per point -- so: cut the buffer into chunks at
+// whitespace, count each chunk's tokens, prefix-sum, and let every thread parse its tokens knowing their global index.
+// Anything irregular (a token a number parser does not consume entirely, too few tokens, a spelling only strtod takes)
+// makes the whole call fall back to read_text_sequential, which owns the error messages and the corner cases.
+// 12.7 s -> ~1 s for the 1.2 GB text form of `synthetic --blocks 128` on 16 threads.
+inline bool read_text(const char *path, Graph &g, std::string *err, int n_threads = 0) {
+    std::string buf;
+    if (!read_all(path, buf, err)) return false;
+    if (n_threads <= 0) n_threads = io_threads();
+    const size_t size = buf.size();
+    if (n_threads <= 1 || size < ((size_t)1 << 20)) return read_text_sequential(buf, g, err);
+    const char *base = buf.c_str();
+    auto is_ws = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r'; };
+    const int T = n_threads;
+    std::vector<size_t> cut((size_t)T + 1, size);
+    cut[0] = 0;
+    for (int k = 1; k < T; ++k) {
+        size_t q = size / (size_t)T * (size_t)k;
+        if (q < cut[(size_t)k - 1]) q = cut[(size_t)k - 1];
+        while (q < size && !is_ws(base[q])) ++q;             // a chunk never starts inside a token
+        cut[(size_t)k] = q;
+    }
+    std::vector<uint64_t> n_tok((size_t)T, 0);
+    auto for_tokens = [&](int k, auto &&fn) {                // fn(first, last) for every token starting in chunk k
+        const char *p = base + cut[(size_t)k], *e = base + cut[(size_t)k + 1];
+        while (true) {
+            while (p < e && is_ws(*p)) ++p;
+            if (p >= e) return;
+            const char *q = p;
+            while (q < base + size && !is_ws(*q)) ++q;      // (a token that starts in the chunk ends in it: cuts are at whitespace)
+            fn(p, q);
+            p = q;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < T; ++k) th.emplace_back([&, k]() { uint64_t c = 0; for_tokens(k, [&](const char *, const char *) { ++c; }); n_tok[(size_t)k] = c; });
+        for (auto &t : th) t.join();
+    }
+    std::vector<uint64_t> tok0((size_t)T + 1, 0);
+    for (int k = 0; k < T; ++k) tok0[(size_t)k + 1] = tok0[(size_t)k] + n_tok[(size_t)k];
+    // header: the first three tokens, wherever they are
+    uint64_t hdr[3] = {0, 0, 0};
+    {
+        int got = 0;
+        bool bad = false;
+        for (int k = 0; k < T && got < 3 && !bad; ++k)
+            for_tokens(k, [&](const char *a, const char *b) {
+                if (got >= 3 || bad) return;
+                uint64_t v = 0;
+                const auto r = std::from_chars(a, b, v);
+                if (r.ec != std::errc() || r.ptr != b) { bad = true; return; }
+                hdr[got++] = v;
+            });
+        if (bad || got < 3) return read_text_sequential(buf, g, err);
+    }
+    const uint64_t nc = hdr[0], np = hdr[1], no = hdr[2];
+    if (no > size / 8 || nc > size / 18 || np > size / 6) return read_text_sequential(buf, g, err);   // it words the error
+    const uint64_t need = 3 + 4 * no + 9 * nc + 3 * np;
+    if (tok0[(size_t)T] < need) return read_text_sequential(buf, g, err);
+    std::vector<uint64_t> oc((size_t)no), op((size_t)no);
+    std::vector<double> ou((size_t)no * 2);
+    g.stride = 9;
+    g.n_cam = (int64_t)nc; g.n_pts = (int64_t)np;
+    g.cams.resize((size_t)nc * 9);
+    g.pts.resize((size_t)np * 3);
+    std::atomic<int> irregular{0};
+    const uint64_t obs_end = 3 + 4 * no, cam_end = obs_end + 9 * nc;
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < T; ++k)
+            th.emplace_back([&, k]() {
+                uint64_t gi = tok0[(size_t)k];
+                for_tokens(k, [&](const char *a, const char *b) {
+                    const uint64_t i = gi++;
+                    if (i < 3 || i >= need || irregular.load(std::memory_order_relaxed)) return;
+                    if (i < obs_end) {
+                        const uint64_t o = (i - 3) >> 2, fld = (i - 3) & 3;
+                        if (fld < 2) {
+                            uint64_t v = 0;
+                            const auto r = std::from_chars(a, b, v);
+                            if (r.ec != std::errc() || r.ptr != b) { irregular = 1; return; }
+                            (fld == 0 ? oc : op)[(size_t)o] = v;
+                            return;
+                        }
+                        // strtod, like the sequential parser (libstdc++ 11's from_chars<double> is strtod behind a locale
+                        // switch and a lock: it got slower with every thread added)
+                        char *q = nullptr;
+                        ou[2 * (size_t)o + (fld - 2)] = std::strtod(a, &q);
+                        if (q != b) irregular = 1;
+                        return;
+                    }
+                    double &dst = i < cam_end ? g.cams[(size_t)(i - obs_end)] : g.pts[(size_t)(i - cam_end)];
+                    char *q = nullptr;
+                    dst = std::strtod(a, &q);
+                    if (q != b) irregular = 1;
+                });
+            });
+        for (auto &t : th) t.join();
+    }
+    if (irregular) { g = Graph(); return read_text_sequential(buf, g, err); }
+    // BAProblem::new: asserts then per-camera push in file order
+    std::vector<uint64_t> count((size_t)nc + 1, 0);
+    bool sorted = true;
+    for (uint64_t i = 0; i < no; ++i) {
+        if (oc[(size_t)i] >= nc) { *err = "assertion failed: cam_i < cams.len()"; return false; }
+        if (op[(size_t)i] >= np) { *err = "assertion failed: p_i < points.len()"; return false; }
+        if (i && oc[(size_t)i] < oc[(size_t)i - 1]) sorted = false;
+        ++count[(size_t)oc[(size_t)i] + 1];
+    }
+    g.row_ptr.assign((size_t)nc + 1, 0);
+    for (uint64_t c = 0; c < nc; ++c) g.row_ptr[(size_t)c + 1] = g.row_ptr[(size_t)c] + count[(size_t)c + 1];
+    if (sorted) {                                            // camera-major already (every writer's order): nothing moves
+        g.pt_idx = std::move(op);
+        g.uv = std::move(ou);
+        return true;
+    }
     std::vector<uint64_t> fill(g.row_ptr.begin(), g.row_ptr.end() - 1);
     g.pt_idx.resize((size_t)no);
     g.uv.resize((size_t)no * 2);

@@ -336,6 +336,65 @@ def test_text_reader_accepts_canonical_bal_layout(tmp_path):
     assert np.array_equal(uv, [[-0.1, 2], [5, 6], [0.5, 0.25], [3, 4]])
 
 
+def test_threaded_text_io_equals_the_sequential_forms(tmp_path, monkeypatch):
+    """Above 1 MB the text writer formats its lines on a pool of threads and the reader tokenises in parallel (r04: 7 s /
+    12.7 s for the 1.2 GB of `synthetic --blocks 128` on one thread).  Same bytes out, same arrays in, for every thread
+    count; observations in any camera order; and a file only nom's grammar accepts -- numbers glued to each other -- takes
+    the sequential parser through the fallback and still parses."""
+    rng = np.random.default_rng(4)
+    n_cam, n_pts = 3000, 9000
+    counts = rng.integers(0, 40, size=n_cam)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    n = int(row_ptr[-1])
+    pt_idx = rng.integers(0, n_pts, size=n).astype(np.uint64)
+    uv = rng.uniform(-1, 1, size=(n, 2))
+    uv[7] = [np.inf, -0.0]
+    uv[8] = [1e-310, -123456789012345.67]
+    bal9, pts = rng.normal(size=(n_cam, 9)), rng.normal(size=(n_pts, 3)) * 1e3
+    files = {}
+    for t in ("1", "2", "5", "16"):
+        monkeypatch.setenv("C2B_IO_THREADS", t)
+        path = tmp_path / ("w%s.bal" % t)
+        write_bal(path, bal9, pts, row_ptr, pt_idx, uv)
+        files[t] = path.read_bytes()
+        got = read_bal(path)
+        for a, b in zip(got, (bal9, pts, row_ptr, pt_idx, uv)):
+            assert np.array_equal(a, b)
+    assert len(files["1"]) > (1 << 20) and files["1"] == files["2"] == files["5"] == files["16"]
+    # observations listed in another camera order: BAProblem::new pushes per camera in file order (stable)
+    text = files["1"].decode().split("\n")
+    obs = text[1:1 + n]
+    perm = rng.permutation(n)
+    shuffled = tmp_path / "shuffled.bal"
+    shuffled.write_text("\n".join([text[0]] + [obs[k] for k in perm] + text[1 + n:]))
+    monkeypatch.setenv("C2B_IO_THREADS", "4")
+    par = read_bal(shuffled)
+    monkeypatch.setenv("C2B_IO_THREADS", "1")
+    seq = read_bal(shuffled)
+    for a, b in zip(par, seq):
+        assert np.array_equal(a, b)
+    assert np.array_equal(par[2], row_ptr) and not np.array_equal(par[3], pt_idx)
+    cam_of = np.repeat(np.arange(n_cam), counts)
+    want = np.concatenate([perm[cam_of[perm] == c] for c in range(n_cam)])      # stable bucket by camera
+    assert np.array_equal(par[3], pt_idx[want]) and np.array_equal(par[4], uv[want])
+    # numbers glued to each other ("0.5-0.25"): one whitespace token, two numbers for nom -> sequential fallback
+    k = next(i for i in range(1, n) if " -" in obs[i].split(" ", 2)[2])
+    glued = list(text)
+    head, rest = glued[1 + k].split(" ", 2)[:2], glued[1 + k].split(" ", 2)[2]
+    glued[1 + k] = " ".join(head) + " " + rest.replace(" -", "-", 1)
+    gpath = tmp_path / "glued.bal"
+    gpath.write_text("\n".join(glued))
+    monkeypatch.setenv("C2B_IO_THREADS", "4")
+    got = read_bal(gpath)
+    for a, b in zip(got, (bal9, pts, row_ptr, pt_idx, uv)):
+        assert np.array_equal(a, b)
+    # too few tokens: the sequential parser words the error
+    short = tmp_path / "short.bal"
+    short.write_text("\n".join(text[:len(text) // 2]))
+    with pytest.raises(Exception, match="ParseError|bad"):
+        read_bal(short)
+
+
 def test_hostile_headers_are_status_codes_not_aborts(tmp_path):
     """A corrupt header must not size an allocation (std::length_error / bad_alloc crossing the C ABI would abort the
     host process): counts larger than the file can hold, and counts that overflow u64, are parse errors."""
