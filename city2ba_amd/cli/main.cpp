@@ -657,19 +657,17 @@ int run_generate(int argc, char **argv) {
     ck(c2b_problem_adopt_visibility(p));
     if (!a.has("no-lcc")) ck(c2b_problem_cull(p, a.has("exact-lcc") ? 0 : 1));
     timer.mark("from_visibility + cull (device)");
-    download_problem(p, hp);
-    if (hp.n_cam == 0 || hp.n_pts == 0) die("EmptyProblem(\"No cameras remain\")");
-    const size_t n_obs = hp.pt_idx.size();
-    timer.mark("download");
-    std::printf("Computed LCC with %lld cameras, %lld points, %zu edges\n", (long long)hp.n_cam, (long long)hp.n_pts, n_obs);
+    int64_t nc = 0, np = 0, no = 0;
+    ck(c2b_problem_sizes(p, &nc, &np, &no));
+    if (nc == 0 || np == 0) die("EmptyProblem(\"No cameras remain\")");
+    std::printf("Computed LCC with %lld cameras, %lld points, %lld edges\n", (long long)nc, (long long)np, (long long)no);
 
     double l1 = 0;
     ck(c2b_problem_total_reprojection_error(p, 1.0, &l1));
     std::printf("Total reprojection error: %s\n", display_f64(l1).c_str());
-    std::vector<double> bal9((size_t)hp.n_cam * 9);
-    ck(c2b_problem_download_bal(p, bal9.data()));
-    timer.mark("upload + error + to_vec");
-    ck(c2b_bal_write(a.positional[1].c_str(), hp.n_cam, bal9.data(), hp.n_pts, hp.pts.data(), hp.row_ptr.data(), hp.pt_idx.data(), hp.uv.data()));
+    timer.mark("error");
+    // BAProblem::write of the resident problem: to_vec and a .bbal's file image on the device, nothing downloaded
+    ck(c2b_problem_write(p, a.positional[1].c_str(), -1));
     timer.mark("write");
     c2b_problem_destroy(p);
     return 0;
