@@ -1033,12 +1033,12 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
     const int64_t n_cells = (int64_t)g.ncx * g.ncz;
 
     DevArena arena;
-    DevBuf cell_of, counts, cursor, sorted, tiles, total, cam_count, pos, sum64, row64;
+    DevBuf cell_of, counts, cursor, sorted, tiles, total, cam_count, pos, sum64, max32, row64;
     struct Want { DevBuf *b; size_t bytes; };
     const int64_t big = std::max(n_cells + 1, n_cam + 1);
     const Want wants[] = {{&cell_of, 4 * (size_t)n_pts}, {&counts, 4 * (size_t)(n_cells + 1)}, {&cursor, 4 * (size_t)(n_cells + 1)},
                           {&sorted, 4 * (size_t)n_pts}, {&tiles, 4 * (size_t)(big / kScanTile + 2)}, {&total, 4},
-                          {&cam_count, 4 * (size_t)(n_cam + 1)}, {&pos, 4 * (size_t)(n_cam + 1)}, {&sum64, 8}};
+                          {&cam_count, 4 * (size_t)(n_cam + 1)}, {&pos, 4 * (size_t)(n_cam + 1)}, {&sum64, 8}, {&max32, 4}};
     size_t arena_bytes = 0;
     for (const Want &w : wants) arena_bytes += DevArena::rounded(w.bytes ? w.bytes : 16);
     hipError_t e = arena.reserve(arena_bytes);
@@ -1051,6 +1051,7 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
     HIP_TRY(hipMemsetAsync(cursor.ptr, 0, 4 * (size_t)(n_cells + 1), st));
     HIP_TRY(hipMemsetAsync(cam_count.ptr, 0, 4 * (size_t)(n_cam + 1), st));
     HIP_TRY(hipMemsetAsync(sum64.ptr, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(max32.ptr, 0, 4, st));
     if (n_pts) hipLaunchKernelGGL(k_cells_assign, dim3(blocks_of(n_pts, 256)), dim3(256), 0, st, reinterpret_cast<const double4 *>(p->pts4), n_pts,
                                   g, cell_of.as<uint32_t>(), counts.as<uint32_t>());
     uint32_t n_sorted = 0, n_kept32 = 0;
@@ -1070,10 +1071,13 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
                            (uint32_t *)nullptr, (double2 *)nullptr);
         hipLaunchKernelGGL(k_sum_u32_u64, dim3(256), dim3(256), 0, st, (const uint32_t *)cam_count.as<uint32_t>(), n_cam,
                            sum64.as<unsigned long long>());
+        hipLaunchKernelGGL(k_max_u32, dim3(256), dim3(256), 0, st, (const uint32_t *)cam_count.as<uint32_t>(), n_cam, max32.as<uint32_t>());
     }
     if (e == hipSuccess) e = scan_flags(st, cam_count.as<uint32_t>(), n_cam + 1, pos.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &n_kept32);
     unsigned long long n_kept = 0;
+    uint32_t longest = 0;
     if (e == hipSuccess) e = hipMemcpy(&n_kept, sum64.ptr, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&longest, max32.ptr, 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && n_kept != (unsigned long long)n_kept32)
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_within_distance: more than 2^32 observations");
     if (e == hipSuccess) {
@@ -1093,10 +1097,50 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
                            reinterpret_cast<const double4 *>(p->pts4), g, (const uint32_t *)start, (const uint32_t *)sorted.as<uint32_t>(),
                            max_dist, occlusion ? 1 : 0, block_length, block_inset, (uint32_t *)nullptr, (const uint64_t *)row64.as<uint64_t>(),
                            tmp_pt.as<uint32_t>(), tmp_uv.as<double2>());
-        hipLaunchKernelGGL(k_rows_rank_sort, dim3(cam_blocks), dim3(kCellWPB * 64), 0, st, (const uint64_t *)row64.as<uint64_t>(), n_cam,
-                           (const uint32_t *)tmp_pt.as<uint32_t>(), (const double2 *)tmp_uv.as<double2>(), out_pt.as<uint32_t>(),
-                           out_uv.as<double2>());
-        e = launch_error();
+        // The device row sort is quadratic in the row length: right for the generators' rows (a few dozen entries), wrong
+        // for a radius that makes one camera see tens of thousands of points.  Beyond `long_row` entries the rows are sorted on the
+        // host instead (threads over cameras) -- a path for odd inputs, not a fast one; such problems belong to the dense
+        // sweep (c2b_problem_visibility_dense).
+        uint32_t long_row = 8192;
+        if (const char *ev = std::getenv("C2B_RANK_SORT_MAX_ROW")) long_row = (uint32_t)std::max(1, std::atoi(ev));
+        if (longest <= long_row) {
+            hipLaunchKernelGGL(k_rows_rank_sort, dim3(cam_blocks), dim3(kCellWPB * 64), 0, st, (const uint64_t *)row64.as<uint64_t>(), n_cam,
+                               (const uint32_t *)tmp_pt.as<uint32_t>(), (const double2 *)tmp_uv.as<double2>(), out_pt.as<uint32_t>(),
+                               out_uv.as<double2>());
+            e = launch_error();
+        } else {
+            e = launch_error();
+            std::vector<uint64_t> rp((size_t)n_cam + 1);
+            std::vector<uint32_t> hp(w), hq(w);
+            std::vector<double> hu(2 * w), hv(2 * w);
+            if (e == hipSuccess) e = hipMemcpyAsync(rp.data(), row64.ptr, 8 * ((size_t)n_cam + 1), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), tmp_pt.ptr, 4 * w, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(hu.data(), tmp_uv.ptr, 16 * w, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) {
+                const int T = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<int64_t>(1, n_cam));
+                std::vector<std::thread> th;
+                for (int t = 0; t < T; ++t)
+                    th.emplace_back([&, t]() {
+                        std::vector<uint32_t> order;
+                        for (int64_t c = n_cam * t / T; c < n_cam * (t + 1) / T; ++c) {
+                            const size_t b = (size_t)rp[(size_t)c], k = (size_t)(rp[(size_t)c + 1] - rp[(size_t)c]);
+                            order.resize(k);
+                            for (size_t i = 0; i < k; ++i) order[i] = (uint32_t)i;
+                            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return hp[b + x] < hp[b + y]; });
+                            for (size_t i = 0; i < k; ++i) {
+                                hq[b + i] = hp[b + order[i]];
+                                hv[2 * (b + i)] = hu[2 * (b + order[i])];
+                                hv[2 * (b + i) + 1] = hu[2 * (b + order[i]) + 1];
+                            }
+                        }
+                    });
+                for (auto &x : th) x.join();
+                e = hipMemcpyAsync(out_pt.ptr, hq.data(), 4 * w, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(out_uv.ptr, hv.data(), 16 * w, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+            }
+        }
     }
     if (e == hipSuccess && row_ptr)
         e = hipMemcpyAsync(row_ptr, row64.ptr, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, st);

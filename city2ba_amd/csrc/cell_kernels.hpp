@@ -178,6 +178,15 @@ __global__ __launch_bounds__(kCellWPB * 64) void k_rows_rank_sort(const uint64_t
     }
 }
 
+// largest of n u32 counts (the longest row: k_rows_rank_sort is quadratic in it)
+__global__ __launch_bounds__(256) void k_max_u32(const uint32_t *__restrict__ v, int64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = v[i] > m ? v[i] : m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // sum of n u32 counts in 64 bits (the scans run in 32 bits: this catches a total that does not fit them)
 __global__ __launch_bounds__(256) void k_sum_u32_u64(const uint32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ out) {
     unsigned long long s = 0;

@@ -57,7 +57,7 @@ def test_reference_test_grid_equals_the_host_route_and_the_oracle(c2b, occlusion
     ba.close()
 
 
-def test_arbitrary_point_clouds_cameras_outside_the_points_and_degenerate_radii(c2b):
+def test_arbitrary_point_clouds_cameras_outside_the_points_and_degenerate_radii(c2b, monkeypatch):
     """nothing in the cell list assumes the grid: clustered points, cameras far outside their bounding box, a radius
     larger than the whole scene (one cell), a tiny one (the cell-count cap widens the cells), zero"""
     rng = np.random.default_rng(8)
@@ -76,6 +76,14 @@ def test_arbitrary_point_clouds_cameras_outside_the_points_and_degenerate_radii(
         assert np.array_equal(kept, pi[k].astype(np.uint64)) and np.array_equal(uv, uv0[k]), max_dist
         if max_dist >= 25.0:
             assert len(kept) > 500
+    # rows longer than the device row sort is meant for take the host sort instead: same result (threshold lowered here)
+    want = ba.visibility_within_distance(25.0)
+    monkeypatch.setenv("C2B_RANK_SORT_MAX_ROW", "8")
+    got = ba.visibility_within_distance(25.0)
+    monkeypatch.delenv("C2B_RANK_SORT_MAX_ROW")
+    assert int(np.diff(want[0].astype(np.int64)).max()) > 8
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
     ba.close()
     # no points / no cameras: an empty graph, not an error
     e = _empty_problem(c2b, cams[:4], np.zeros((0, 3)))
