@@ -15,6 +15,10 @@ T() {
 }
 for B in 32 128 128; do rm -f $D/g$B.bbal; T synthetic $D/g$B.bbal --blocks $B; done
 T synthetic $D/g32.bal --blocks 32
+# the text form of the headline grid (1.2 GB of shortest round-trip decimals: formatted / parsed on a pool of host threads)
+T synthetic $D/g128.bal --blocks 128
+T noise $D/g128.bal $D/n128.bal --drift-strength 1e-5 --rotation-std 0.01 --observation-std 0.001 --seed 1
+rm -f $D/g128.bal $D/n128.bal
 for i in 1 2; do rm -f $D/n128.bbal; T noise $D/g128.bbal $D/n128.bbal --drift-strength 1e-5 --rotation-std 0.01 --observation-std 0.001 --seed 1; done
 echo "# rounds 1-3's route: layout, candidate search, hits_building and file (de)serialisation on the host"
 export C2B_HOST_CANDIDATES=1 C2B_HOST_IO=1; PREFIX="C2B_HOST_CANDIDATES=1 C2B_HOST_IO=1"
