@@ -30,7 +30,7 @@ struct CellGrid {
 
 C2B_DEV int cell_coord(double v, double v0, double inv_cs, int n) {
     const double f = floor((v - v0) * inv_cs);
-    return f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f);       // clamped (NaN -> last cell): conservative, the distance test decides
+    return f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f);       // clamped (NaN converts to cell 0): conservative, the distance test decides
 }
 
 // cell of every point + points per cell (integer atomics: the counts do not depend on their order)
