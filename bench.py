@@ -41,14 +41,17 @@ class Watchdog:
     def __init__(self, rank, seconds):
         import threading
         self.rank, self.seconds, self.what, self.t = rank, float(seconds), "start", time.monotonic()
+        self.limit = self.seconds
         self._stop = threading.Event()
         self._thread = None
         if self.seconds > 0:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
 
-    def beat(self, what):
-        self.what, self.t = what, time.monotonic()
+    def beat(self, what, limit=None):
+        """`limit`: this phase's own allowance in seconds (communicator start-up on a cold node can take longer than any
+        collective should)"""
+        self.what, self.t, self.limit = what, time.monotonic(), (float(limit) if limit else self.seconds)
 
     def stop(self):
         self._stop.set()
@@ -56,7 +59,7 @@ class Watchdog:
     def _run(self):
         while not self._stop.wait(1.0):
             idle = time.monotonic() - self.t
-            if idle > self.seconds:
+            if idle > self.limit:
                 sys.stderr.write("bench.py watchdog: rank %d made no progress for %.0f s in: %s -- exiting with status 3\n"
                                  % (self.rank, idle, self.what))
                 sys.stderr.flush()
@@ -570,7 +573,7 @@ def main():
             # fails on its own is caught by the gathered flag below (and a rank stuck inside it by the watchdog).
             from city2ba_amd import comm as Comm
             ok, why = 1, ""
-            dog.beat("c2b_comm_init_rank (RCCL communicator over %d ranks)" % world)
+            dog.beat("c2b_comm_init_rank (RCCL communicator over %d ranks)" % world, limit=max(300.0, args.watchdog_seconds))
             t_init = time.perf_counter()
             try:
                 comm = Comm.Comm.from_process_group(dev_index)
