@@ -470,6 +470,15 @@ def read_bal(path, fmt=None):
     return bal9, pts, row_ptr, pt_idx, uv
 
 
+def format_f64(values):
+    """the texts write_text gives these doubles (Rust's `{}`: shortest round-trip digits, no exponent) -- c2b_format_f64"""
+    v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+    buf = C.create_string_buffer(max(1, 331 * len(v)))
+    n = C.c_int64()
+    L.check(L.lib().c2b_format_f64(len(v), _ptr(v), buf, len(buf), C.byref(n)))
+    return buf.raw[:n.value].decode("ascii").split("\n")[:-1]
+
+
 def write_bal(path, bal9, pts, row_ptr, pt_idx, uv, fmt=None):
     """write (by extension), write_text or write_binary (src/baproblem.rs:709, :736, :768)"""
     bal9 = _f64(bal9, (-1, 9))

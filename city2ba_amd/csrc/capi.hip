@@ -35,6 +35,7 @@
 #endif
 #include "cull_kernels.hpp"
 #include "cell_kernels.hpp"
+#include "text_kernels.hpp"
 #include "comm_rccl.hpp"
 
 using namespace c2b;

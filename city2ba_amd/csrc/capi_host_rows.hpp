@@ -448,6 +448,23 @@ int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n
     C2B_API_END("bal_write")
 }
 
+int c2b_format_f64(int64_t n, const double *values, char *buf, int64_t cap, int64_t *len) {
+    C2B_API_BEGIN
+    if (n < 0 || (n && !values) || !buf || !len) return fail(C2B_ERR_INVALID_ARGUMENT, "format_f64: NULL argument");
+    const c2b_dec::Tables &T = c2b_dec::host_tables();
+    int64_t at = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const c2b_dec::Text t = c2b_dec::describe(values[i], &T);
+        if (at + (int64_t)t.len + 1 > cap) return fail(C2B_ERR_INVALID_ARGUMENT, "format_f64: buffer too small");
+        c2b_dec::emit(t, buf + at);
+        at += t.len;
+        buf[at++] = '\n';
+    }
+    *len = at;
+    return C2B_OK;
+    C2B_API_END("format_f64")
+}
+
 int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,
                   const uint64_t *row_ptr, const uint64_t *pt_idx) {
     C2B_API_BEGIN

@@ -1157,11 +1157,107 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
     C2B_API_END("problem_visibility_within_distance")
 }
 
+static bool env_flag(const char *name) {
+    const char *v = std::getenv(name);
+    return v && *v && std::strcmp(v, "0") != 0;
+}
+
+// decimal.hpp's tables on the device: computed once on the host, copied once per device
+static int device_dec_tables(int device, const c2b_dec::Tables **out) {
+    static std::mutex mu;
+    static const c2b_dec::Tables *on_device[64] = {};
+    if (device < 0 || device >= 64) return fail(C2B_ERR_INVALID_ARGUMENT, "device %d out of range", device);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!on_device[device]) {
+        HIP_TRY(hipSetDevice(device));
+        void *addr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&addr, HIP_SYMBOL(g_dec_tables)));
+        HIP_TRY(hipMemcpy(addr, &c2b_dec::host_tables(), sizeof(c2b_dec::Tables), hipMemcpyHostToDevice));
+        on_device[device] = static_cast<const c2b_dec::Tables *>(addr);
+    }
+    *out = on_device[device];
+    return C2B_OK;
+}
+
+// A device-resident file image -> `path`.  The image leaves through a ring of pinned slots: this thread copies chunk k
+// into slot k % kSlots (26 GB/s over the link), ONE writer thread pwrite()s the slots in order (8-9 GB/s into the page
+// cache: the longer pole), so the two overlap.  More writers do not help -- buffered writes to one file serialise on its
+// inode lock -- and more threads calling into the runtime cost more than they hide: measured at --blocks 128 (564 MB):
+// 8 threads each with its own pinned buffer and stream 151 ms (67 ms each just setting up), 1 thread 107 ms, this
+// arrangement ~75 ms.
+static int image_to_file(const char *path, const void *dev, size_t bytes) {
+    const int fd = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "cannot create %s", path);
+    if (::ftruncate(fd, (off_t)bytes) != 0) { ::close(fd); return fail(C2B_ERR_INVALID_ARGUMENT, "write failed: %s", path); }
+    constexpr size_t kChunk = (size_t)8 << 20;
+    constexpr int kSlots = 4;
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    char *pin = nullptr;
+    if (hipHostMalloc((void **)&pin, kChunk * kSlots, hipHostMallocDefault) != hipSuccess) {
+        ::close(fd);
+        return fail(C2B_ERR_OOM, "problem_write: no pinned staging memory");
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t copied = 0, written = 0;                           // chunks copied into / written out of the ring
+    int failed = 0;
+    auto write_loop = [&]() {
+        for (size_t k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return copied > k || failed; });
+                if (failed) return;
+            }
+            const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+            const char *src = pin + (k % kSlots) * kChunk;
+            size_t done = 0;
+            while (done < len) {
+                const ssize_t r = ::pwrite(fd, src + done, len - done, (off_t)(off + done));
+                if (r <= 0) break;
+                done += (size_t)r;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (done < len) failed = 2;
+            written = k + 1;
+            cv.notify_all();
+            if (failed) return;
+        }
+    };
+    std::thread writer;
+    try {
+        writer = std::thread(write_loop);
+    } catch (...) {
+        (void)hipHostFree(pin);
+        ::close(fd);
+        return fail(C2B_ERR_OOM, "problem_write: cannot start the writer thread");
+    }
+    for (size_t k = 0; k < n_chunks; ++k) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return k < written + kSlots || failed; });      // the slot's previous chunk is on its way out
+            if (failed) break;
+        }
+        const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+        const hipError_t ce = hipMemcpy(pin + (k % kSlots) * kChunk, static_cast<const char *>(dev) + off, len, hipMemcpyDeviceToHost);
+        std::lock_guard<std::mutex> lk(mu);
+        if (ce != hipSuccess) failed = 1;
+        copied = k + 1;
+        cv.notify_all();
+        if (failed) break;
+    }
+    writer.join();
+    (void)hipHostFree(pin);
+    const bool closed = ::close(fd) == 0;
+    if (failed == 1) return fail(C2B_ERR_HIP, "problem_write: device-to-host copy failed");
+    if (failed || !closed) return fail(C2B_ERR_INVALID_ARGUMENT, "write failed: %s", path);
+    return C2B_OK;
+}
+
 // BAProblem::write (src/baproblem.rs:768-785) of the RESIDENT problem.  `.bbal` (format 1): the file image is assembled
 // on the device (cell_kernels.hpp: k_bbal_*: to_vec of every camera, the per-camera counts, the byte order) and leaves
-// through a few host threads, each copying its chunks into a pinned buffer and pwrite()-ing them -- the host touches no
-// observation.  `.bal` (format 0): the text writer of csrc/host_baproblem.hpp over a download (shortest round-trip
-// decimals are host work).  format -1: by extension, like the reference.
+// through a ring of pinned slots (image_to_file) -- the host touches no observation.  `.bal` (format 0): the same, the
+// image being text (text_kernels.hpp: shortest round-trip decimals on the device; C2B_HOST_TEXT=1 = the host formatter of
+// csrc/host_baproblem.hpp over a download, the same bytes).  format -1: by extension, like the reference.
 int c2b_problem_write(c2b_problem *p, const char *path, int format) {
     C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_write");
@@ -1174,7 +1270,7 @@ int c2b_problem_write(c2b_problem *p, const char *path, int format) {
         rc = c2b_cameras_to_bal(p->cam15, n_cam, p->bal9, p->stream);
         if (rc) return rc;
     }
-    if (!binary) {
+    if (!binary && env_flag("C2B_HOST_TEXT")) {             // the host formatter over a download (rounds 1-3's route)
         std::vector<double> bal9((size_t)n_cam * 9 + 1), pts((size_t)n_pts * 3 + 1), uv((size_t)n_obs * 2 + 1);
         std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs + 1);
         if (n_cam) HIP_TRY(hipMemcpyAsync(bal9.data(), p->bal9, sizeof(double) * 9 * (size_t)n_cam, hipMemcpyDeviceToHost, p->stream));
@@ -1182,6 +1278,53 @@ int c2b_problem_write(c2b_problem *p, const char *path, int format) {
         if (!rc) rc = c2b_problem_download_graph(p, row_ptr.data(), pt_idx.data());
         if (rc) return rc;
         return c2b_bal_write_as(path, 0, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data());
+    }
+    if (!binary) {
+        // text_kernels.hpp: tile byte counts, 64-bit tile bases, then the characters.  Units: one observation line, or one
+        // value of a camera / point line with the separator behind it.
+        const c2b_dec::Tables *T = nullptr;
+        rc = device_dec_tables(p->device, &T);
+        if (rc) return rc;
+        hipStream_t st = p->stream;
+        const int64_t t_obs = (n_obs + kTextTile - 1) / kTextTile, t_cam = (9 * n_cam + kTextTile - 1) / kTextTile,
+                      t_pts = (3 * n_pts + kTextTile - 1) / kTextTile, n_tiles = t_obs + t_cam + t_pts;
+        char head[80];
+        const int head_len = std::snprintf(head, sizeof head, "%lld %lld %lld\n", (long long)n_cam, (long long)n_pts, (long long)n_obs);
+        DevBuf tile_len, tile_base, total;
+        hipError_t e = tile_len.alloc(4 * (size_t)(n_tiles + 1));
+        if (e == hipSuccess) e = tile_base.alloc(8 * (size_t)(n_tiles + 1));
+        if (e == hipSuccess) e = total.alloc(8);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_write: %s", hipGetErrorString(e));
+        uint32_t *tl = tile_len.as<uint32_t>();
+        uint64_t *tb = tile_base.as<uint64_t>();
+        const uint32_t *ci = (const uint32_t *)p->cam_idx, *pi = (const uint32_t *)p->pt_idx;
+        const double2 *uvd = reinterpret_cast<const double2 *>(p->uv);
+        if (t_obs) hipLaunchKernelGGL((k_text_obs<false>), dim3((unsigned)t_obs), dim3(kTextTile), 0, st, ci, pi, uvd, n_obs, T, tl,
+                                      (const uint64_t *)nullptr, (char *)nullptr);
+        if (t_cam) hipLaunchKernelGGL((k_text_vals<false>), dim3((unsigned)t_cam), dim3(kTextTile), 0, st, (const double *)p->bal9, n_cam, 9, 9, T,
+                                      tl + t_obs, (const uint64_t *)nullptr, (char *)nullptr);
+        if (t_pts) hipLaunchKernelGGL((k_text_vals<false>), dim3((unsigned)t_pts), dim3(kTextTile), 0, st, (const double *)p->pts4, n_pts, 3, 4, T,
+                                      tl + t_obs + t_cam, (const uint64_t *)nullptr, (char *)nullptr);
+        hipLaunchKernelGGL(k_text_tile_bases, dim3(1), dim3(1024), 0, st, (const uint32_t *)tl, n_tiles, (uint64_t)head_len, tb, total.as<uint64_t>());
+        e = launch_error();
+        uint64_t bytes = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bytes, total.ptr, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        DevBuf img;
+        if (e == hipSuccess) e = img.alloc((size_t)bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(img.ptr, head, (size_t)head_len, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_write: %s", hipGetErrorString(e));
+        char *im = img.as<char>();
+        if (t_obs) hipLaunchKernelGGL((k_text_obs<true>), dim3((unsigned)t_obs), dim3(kTextTile), 0, st, ci, pi, uvd, n_obs, T, (uint32_t *)nullptr,
+                                      (const uint64_t *)tb, im);
+        if (t_cam) hipLaunchKernelGGL((k_text_vals<true>), dim3((unsigned)t_cam), dim3(kTextTile), 0, st, (const double *)p->bal9, n_cam, 9, 9, T,
+                                      (uint32_t *)nullptr, (const uint64_t *)(tb + t_obs), im);
+        if (t_pts) hipLaunchKernelGGL((k_text_vals<true>), dim3((unsigned)t_pts), dim3(kTextTile), 0, st, (const double *)p->pts4, n_pts, 3, 4, T,
+                                      (uint32_t *)nullptr, (const uint64_t *)(tb + t_obs + t_cam), im);
+        e = launch_error();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_write: %s", hipGetErrorString(e));
+        return image_to_file(path, img.ptr, (size_t)bytes);
     }
     rc = ensure_rows(p);
     if (rc) return rc;
@@ -1203,68 +1346,7 @@ int c2b_problem_write(c2b_problem *p, const char *path, int format) {
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_write: %s", hipGetErrorString(e));
 
-    const int fd = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
-    if (fd < 0) return fail(C2B_ERR_INVALID_ARGUMENT, "cannot create %s", path);
-    if (::ftruncate(fd, (off_t)bytes) != 0) { ::close(fd); return fail(C2B_ERR_INVALID_ARGUMENT, "write failed: %s", path); }
-    // The image leaves through a ring of pinned slots: this thread copies chunk k into slot k % kSlots (26 GB/s over the
-    // link), ONE writer thread pwrite()s the slots in order (8-9 GB/s into the page cache: the longer pole), so the two
-    // overlap.  More writers do not help -- buffered writes to one file serialise on its inode lock -- and more threads
-    // calling into the runtime cost more than they hide: measured at --blocks 128 (564 MB): 8 threads each with its own
-    // pinned buffer and stream 151 ms (67 ms each just setting up), 1 thread 107 ms, this arrangement ~75 ms.
-    constexpr size_t kChunk = (size_t)8 << 20;
-    constexpr int kSlots = 4;
-    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
-    char *pin = nullptr;
-    if (hipHostMalloc((void **)&pin, kChunk * kSlots, hipHostMallocDefault) != hipSuccess) {
-        ::close(fd);
-        return fail(C2B_ERR_OOM, "problem_write: no pinned staging memory");
-    }
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t copied = 0, written = 0;                           // chunks copied into / written out of the ring
-    int failed = 0;
-    std::thread writer([&]() {
-        for (size_t k = 0; k < n_chunks; ++k) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return copied > k || failed; });
-                if (failed) return;
-            }
-            const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
-            const char *src = pin + (k % kSlots) * kChunk;
-            size_t done = 0;
-            while (done < len) {
-                const ssize_t r = ::pwrite(fd, src + done, len - done, (off_t)(off + done));
-                if (r <= 0) break;
-                done += (size_t)r;
-            }
-            std::lock_guard<std::mutex> lk(mu);
-            if (done < len) failed = 2;
-            written = k + 1;
-            cv.notify_all();
-            if (failed) return;
-        }
-    });
-    for (size_t k = 0; k < n_chunks; ++k) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return k < written + kSlots || failed; });      // the slot's previous chunk is on its way out
-            if (failed) break;
-        }
-        const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
-        const hipError_t ce = hipMemcpy(pin + (k % kSlots) * kChunk, reinterpret_cast<const char *>(img.ptr) + off, len, hipMemcpyDeviceToHost);
-        std::lock_guard<std::mutex> lk(mu);
-        if (ce != hipSuccess) failed = 1;
-        copied = k + 1;
-        cv.notify_all();
-        if (failed) break;
-    }
-    writer.join();
-    (void)hipHostFree(pin);
-    const bool closed = ::close(fd) == 0;
-    if (failed == 1) return fail(C2B_ERR_HIP, "problem_write: device-to-host copy failed");
-    if (failed || !closed) return fail(C2B_ERR_INVALID_ARGUMENT, "write failed: %s", path);
-    return C2B_OK;
+    return image_to_file(path, img.ptr, bytes);
     C2B_API_END("problem_write")
 }
 
@@ -1363,7 +1445,18 @@ int c2b_problem_read(c2b_problem *p, const char *path, int format) {
         }
     };
     std::vector<std::thread> readers;
-    for (int t = 0; t < (int)std::min<size_t>(kReaders, n_chunks); ++t) readers.emplace_back(read_loop);
+    readers.reserve(kReaders);
+    try {
+        for (int t = 0; t < (int)std::min<size_t>(kReaders, n_chunks); ++t) readers.emplace_back(read_loop);
+    } catch (...) {                                          // no more threads to be had: the ones started must be joined
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            failed = 2;
+        }
+        cv.notify_all();
+        for (auto &t : readers) t.join();
+        return fail(C2B_ERR_OOM, "problem_read: cannot start a reader thread");
+    }
     for (size_t k = 0; k < n_chunks; ++k) {
         {
             std::unique_lock<std::mutex> lk(mu);

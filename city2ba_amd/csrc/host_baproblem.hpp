@@ -20,6 +20,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "decimal.hpp"
+
 namespace c2b_host {
 
 struct Graph {
@@ -189,11 +191,12 @@ inline int io_threads() {
 }
 
 // Rust's `{}` for f64: shortest digits that round-trip, never an exponent, "1" for 1.0, "-0", "NaN", "inf".
+// (decimal.hpp -- the code the device writer runs; std::to_chars(fixed) prints the exact integer above 2^53 instead.)
 inline void fmt_f64(double v, std::string &out) {
-    if (v != v) { out += "NaN"; return; }
-    char buf[400];
-    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
-    out.append(buf, r.ptr);
+    const c2b_dec::Text t = c2b_dec::describe(v, &c2b_dec::host_tables());
+    const size_t at = out.size();
+    out.resize(at + t.len);
+    c2b_dec::emit(t, &out[at]);
 }
 
 // write_text, src/baproblem.rs:709-733 (cameras: 9 values on ONE line, space-joined).  Shortest round-trip decimals are

@@ -502,6 +502,11 @@ int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n
 int c2b_bal_read_as(const char *path, int format, c2b_balfile **out);
 int c2b_bal_write_as(const char *path, int format, int64_t n_cam, const double *bal9, int64_t n_pts,
                      const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv);
+/* one f64 as write_text prints it -- Rust's `{}` (src/baproblem.rs:713-731): the shortest digits that read back to the
+ * same double, no exponent, "-0", "NaN", "inf".  n values -> their texts back to back in buf, each followed by '\n';
+ * *len = bytes written.  C2B_ERR_INVALID_ARGUMENT if cap is too small (330 bytes per value always suffice).  Host code
+ * (csrc/decimal.hpp); the device writer of c2b_problem_write runs the same functions. */
+int c2b_format_f64(int64_t n, const double *values, char *buf, int64_t cap, int64_t *len);
 /* write_cameras of the `ply` subcommand (src/bin/city2ba.rs:359-439): ASCII PLY with one red vertex per camera
  * centre, one green vertex per point (f32) and one edge per observation (camera, n_cam + point) */
 int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,
@@ -539,7 +544,8 @@ int c2b_problem_download_bal(c2b_problem *p, double *bal9);
 /* BAProblem::write / write_text / write_binary (src/baproblem.rs:709-785) of the RESIDENT problem: format -1 = by
  * extension (.bal text, .bbal binary, anything else an error, like the reference), 0 = text, 1 = binary.  The binary
  * image -- to_vec of every camera, per-camera counts, big-endian words -- is assembled on the device and leaves through
- * pinned chunks written by a few host threads; the bytes equal c2b_bal_write's on the downloaded arrays. */
+ * a ring of pinned chunks; so is the text image (csrc/text_kernels.hpp: every decimal is formatted on the device).  The
+ * bytes equal c2b_bal_write's on the downloaded arrays. */
 int c2b_problem_write(c2b_problem *p, const char *path, int format);
 /* BAProblem::from_file / from_file_text / from_file_binary (src/baproblem.rs:580-706) INTO the resident problem (what
  * it held is dropped): format as above.  A `.bbal` is streamed to the device through pinned chunks while the host walks

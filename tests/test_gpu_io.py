@@ -116,3 +116,49 @@ def test_resident_read_equals_the_host_reader_plus_upload(c2b, tmp_path):
     assert status(data + b"\\0" * 24, "trailing.bbal") == L.OK             # nom leaves trailing input unread
     assert L.lib().c2b_problem_read(ba._h, str(tmp_path / "missing.bbal").encode(), -1) == L.ERR_INVALID_ARGUMENT
     ba.close()
+
+
+def test_text_image_from_the_device_equals_the_host_formatter(c2b, tmp_path, monkeypatch):
+    """.bal from the resident problem (r04: csrc/text_kernels.hpp -- every decimal of write_text, src/baproblem.rs:709-733,
+    formatted on the device by the functions of csrc/decimal.hpp): the same bytes as the host formatter over the
+    downloaded arrays, for values of every magnitude -- subnormals, 1e300 (309 characters), exact ties, -0, NaN, inf --
+    for a problem without observations, and for a file of several pinned chunks (58 MB)."""
+    rng = np.random.default_rng(21)
+    P = random_problem(300, 4000, 7, seed=22, noise=1e-3, empty_every=6)
+    n_obs = len(P["pt_idx"])
+    wild = np.concatenate([rng.integers(0, 2**64, 6000, dtype=np.uint64).view(np.float64),            # any bit pattern
+                           np.ldexp(rng.integers(0, 4096, 3000).astype(np.float64), -rng.integers(0, 60, 3000)),
+                           rng.integers(0, 2_000_000, 3000) / 1000.0, 10.0 ** rng.integers(-300, 300, 3000),
+                           [0.0, -0.0, np.inf, -np.inf, 1e22, 1e23, 5e-324, 1.7976931348623157e308, 0.30000000000000004]])
+    uv = P["uv"].copy()
+    uv.ravel()[:min(uv.size, len(wild))] = wild[:min(uv.size, len(wild))]
+    pts = P["pts"].copy()
+    pts.ravel()[:3000] = wild[-3000:]
+    bal9 = P["bal9"].copy()
+    bal9[:, 3:6].ravel()[:600] = wild[5000:5600]              # translations only: the file holds to_vec of the device state
+    bal9[:, 6:9].ravel()[:600] = wild[9000:9600]
+    ba = c2b.BAProblem.from_bal(bal9, pts, P["row_ptr"], P["pt_idx"], uv)
+    a, b, h = tmp_path / "dev.bal", tmp_path / "host.bal", tmp_path / "route.bal"
+    ba.write(str(a))
+    dev = open(a, "rb").read()
+    assert dev == _host_file(c2b, ba, str(b), None)
+    assert dev.count(b"\n") == 1 + n_obs + len(bal9) + len(pts)
+    monkeypatch.setenv("C2B_HOST_TEXT", "1")                  # rounds 1-3's route: download + host formatter
+    ba.write(str(h))
+    monkeypatch.delenv("C2B_HOST_TEXT")
+    assert open(h, "rb").read() == dev
+    ba.close()
+    e = c2b.BAProblem.from_bal(P["bal9"][:5], P["pts"][:40], np.zeros(6, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros((0, 2)))
+    e.write(str(a))
+    assert open(a, "rb").read() == _host_file(c2b, e, str(b), None)
+    e.close()
+    from city2ba_amd import synthetic as S
+    g = S.synthetic_grid(10, 10, 32, 20.0, 1.0, 1.0, 1.0, 10.0, False)
+    g.write(str(a))
+    text = open(a, "rb").read()
+    assert len(text) > 50_000_000 and text == _host_file(c2b, g, str(b), None)
+    back = c2b.BAProblem.from_file(str(a))
+    assert np.array_equal(back.observations(), g.observations()) and np.array_equal(back.points(), g.points())
+    assert np.array_equal(back.cameras_bal(), g.cameras_bal()) and np.array_equal(back.pt_idx, g.pt_idx)
+    g.close()
+    back.close()
