@@ -1350,17 +1350,215 @@ int c2b_problem_write(c2b_problem *p, const char *path, int format) {
     C2B_API_END("problem_write")
 }
 
+// decimal.hpp's reading tables on the device, like device_dec_tables
+static int device_parse_tables(int device, const c2b_dec::ParseTables **out) {
+    static std::mutex mu;
+    static const c2b_dec::ParseTables *on_device[64] = {};
+    if (device < 0 || device >= 64) return fail(C2B_ERR_INVALID_ARGUMENT, "device %d out of range", device);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!on_device[device]) {
+        HIP_TRY(hipSetDevice(device));
+        void *addr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&addr, HIP_SYMBOL(g_parse_tables)));
+        HIP_TRY(hipMemcpy(addr, &c2b_dec::host_parse_tables(), sizeof(c2b_dec::ParseTables), hipMemcpyHostToDevice));
+        on_device[device] = static_cast<const c2b_dec::ParseTables *>(addr);
+    }
+    *out = on_device[device];
+    return C2B_OK;
+}
+
+// `bytes` of an open file -> device memory through a ring of pinned slots: a few reader threads pread() chunk k into
+// slot k % kSlots (reads of one file from the page cache run in parallel, unlike buffered writes), this thread sends the
+// slots to the device in order.  0 = ok, 1 = copy failed, 2 = read failed, 3 = no resources.
+static int file_to_device(int fd, size_t bytes, char *dev) {
+    constexpr size_t kChunk = (size_t)8 << 20;
+    constexpr int kSlots = 6, kReaders = 3;
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    char *pin = nullptr;
+    if (hipHostMalloc((void **)&pin, kChunk * kSlots, hipHostMallocDefault) != hipSuccess) return 3;
+    struct PinFree { char *q; ~PinFree() { (void)hipHostFree(q); } } pin_free{pin};
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t claimed = 0, drained = 0;
+    std::vector<char> ready(n_chunks, 0);
+    int failed = 0;
+    auto read_loop = [&]() {
+        while (true) {
+            size_t k;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                k = claimed;
+                if (k >= n_chunks || failed) return;
+                ++claimed;
+                cv.wait(lk, [&] { return k < drained + kSlots || failed; });      // its slot's previous chunk has left
+                if (failed) return;
+            }
+            const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+            char *dst = pin + (k % kSlots) * kChunk;
+            size_t done = 0;
+            while (done < len) {
+                const ssize_t r = ::pread(fd, dst + done, len - done, (off_t)(off + done));
+                if (r <= 0) break;
+                done += (size_t)r;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (done < len) failed = 2;
+            ready[k] = 1;
+            cv.notify_all();
+            if (failed) return;
+        }
+    };
+    std::vector<std::thread> readers;
+    readers.reserve(kReaders);
+    try {
+        for (int t = 0; t < (int)std::min<size_t>(kReaders, n_chunks); ++t) readers.emplace_back(read_loop);
+    } catch (...) {
+        { std::lock_guard<std::mutex> lk(mu); failed = 3; }
+        cv.notify_all();
+        for (auto &t : readers) t.join();
+        return 3;
+    }
+    for (size_t k = 0; k < n_chunks; ++k) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready[k] || failed; });
+            if (failed) break;
+        }
+        const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+        const hipError_t ce = hipMemcpy(dev + off, pin + (k % kSlots) * kChunk, len, hipMemcpyHostToDevice);
+        std::lock_guard<std::mutex> lk(mu);
+        if (ce != hipSuccess) failed = 1;
+        drained = k + 1;
+        cv.notify_all();
+        if (failed) break;
+    }
+    int outcome;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        outcome = failed;
+        if (!failed) failed = 4;                             // done: readers still waiting for a slot leave
+    }
+    cv.notify_all();
+    for (auto &t : readers) t.join();
+    return outcome;
+}
+
+// from_file_text (src/baproblem.rs:580-629) on the device (text_kernels.hpp).  *handled = false: the device declined --
+// a small file, a spelling or a digit count decimal.hpp leaves to strtod, observations not in camera order, counts that
+// do not fit the file, an index out of range -- and the caller runs the host parser, which owns every corner of the
+// grammar and the wording of every error.  The problem is replaced only after the whole file has parsed.
+static int read_text_device(c2b_problem *p, const char *path, bool *handled) {
+    *handled = false;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return C2B_OK;                                // the host path words the error
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    const off_t end = ::lseek(fd, 0, SEEK_END);
+    size_t min_bytes = (size_t)64 << 10;
+    if (const char *ev = std::getenv("C2B_TEXT_DEVICE_MIN_BYTES")) min_bytes = (size_t)std::strtoull(ev, nullptr, 10);
+    if (end < 6 || (size_t)end < min_bytes || (uint64_t)end >= ((uint64_t)1 << 32)) return C2B_OK;
+    const size_t bytes = (size_t)end;
+    // the three counts, from the first bytes
+    char head[256];
+    const ssize_t got = ::pread(fd, head, sizeof head, 0);
+    if (got <= 0) return C2B_OK;
+    uint64_t hdr[3];
+    {
+        auto ws = [](char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; };
+        ssize_t i = 0;
+        for (int k = 0; k < 3; ++k) {
+            while (i < got && ws(head[i])) ++i;
+            const ssize_t b = i;
+            uint64_t v = 0;
+            while (i < got && head[i] >= '0' && head[i] <= '9' && i - b < 19) v = v * 10 + (uint64_t)(head[i++] - '0');
+            if (i == b || i >= got || !ws(head[i])) return C2B_OK;
+            hdr[k] = v;
+        }
+    }
+    const uint64_t nc = hdr[0], np = hdr[1], no = hdr[2];
+    if (no > bytes / 8 || nc > bytes / 18 || np > bytes / 6 || nc >= ((uint64_t)1 << 32) || np >= ((uint64_t)1 << 32) || no >= ((uint64_t)1 << 31))
+        return C2B_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    const c2b_dec::ParseTables *T = nullptr;
+    int rc = device_parse_tables(p->device, &T);
+    if (rc) return rc;
+    hipStream_t st = p->stream;
+    const size_t padded = ((bytes + 15) & ~(size_t)15) + 16;
+    const int64_t n_tiles = (int64_t)((bytes + kParseTile - 1) / kParseTile);
+    DevBuf raw, cnt, base, total, flags, t_cam, t_pt, t_uv, t_bal, t_pts;
+    hipError_t e = raw.alloc(padded);
+    if (e == hipSuccess) e = cnt.alloc(4 * (size_t)n_tiles);
+    if (e == hipSuccess) e = base.alloc(8 * (size_t)n_tiles);
+    if (e == hipSuccess) e = total.alloc(8);
+    if (e == hipSuccess) e = flags.alloc(16);
+    if (e == hipSuccess) e = t_cam.alloc(4 * (size_t)no);
+    if (e == hipSuccess) e = t_pt.alloc(4 * (size_t)no);
+    if (e == hipSuccess) e = t_uv.alloc(16 * (size_t)no);
+    if (e == hipSuccess) e = t_bal.alloc(72 * (size_t)nc);
+    if (e == hipSuccess) e = t_pts.alloc(32 * (size_t)np);
+    if (e == hipSuccess) e = hipMemsetAsync(raw.as<char>() + (padded - 32), 0, 32, st);
+    if (e == hipSuccess) e = hipMemsetAsync(flags.ptr, 0, 16, st);
+    if (e == hipSuccess) e = hipMemsetAsync(t_pts.ptr, 0, np ? 32 * (size_t)np : 16, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+    const int io = file_to_device(fd, bytes, raw.as<char>());
+    if (io == 1) return fail(C2B_ERR_HIP, "problem_read: host-to-device copy failed");
+    if (io) return C2B_OK;                                   // unreadable: the host path says so
+    hipLaunchKernelGGL(k_text_count_tokens, dim3((unsigned)n_tiles), dim3(kTextTile), 0, st, (const char *)raw.as<char>(), (int64_t)bytes, cnt.as<uint32_t>());
+    hipLaunchKernelGGL(k_text_tile_bases, dim3(1), dim3(1024), 0, st, (const uint32_t *)cnt.as<uint32_t>(), n_tiles, (uint64_t)0, base.as<uint64_t>(),
+                       total.as<uint64_t>());
+    e = launch_error();
+    uint64_t n_tokens = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_tokens, total.ptr, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+    if (n_tokens < 3 + 4 * no + 9 * nc + 3 * np) return C2B_OK;           // too short: the host parser says where
+    hipLaunchKernelGGL(k_text_parse, dim3((unsigned)n_tiles), dim3(kTextTile), 0, st, (const char *)raw.as<char>(), (int64_t)bytes,
+                       (const uint64_t *)base.as<uint64_t>(), T, nc, np, no, t_cam.as<uint32_t>(), t_pt.as<uint32_t>(), t_uv.as<double>(),
+                       t_bal.as<double>(), t_pts.as<double>(), flags.as<uint32_t>());
+    if (no > 1) hipLaunchKernelGGL(k_text_check_sorted, dim3(blocks_of((int64_t)no, 256)), dim3(256), 0, st, (const uint32_t *)t_cam.as<uint32_t>(), (int64_t)no,
+                                   flags.as<uint32_t>());
+    e = launch_error();
+    uint32_t fl[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(fl, flags.ptr, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+    if (fl[0] || fl[1] || fl[2] || fl[3]) return C2B_OK;
+    rc = alloc_problem(p, (int64_t)nc, (int64_t)np, (int64_t)no);
+    if (rc) return rc;
+    if (no) e = hipMemcpyAsync(p->cam_idx, t_cam.ptr, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && no) e = hipMemcpyAsync(p->pt_idx, t_pt.ptr, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && no) e = hipMemcpyAsync(p->uv, t_uv.ptr, 16 * (size_t)no, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(p->bal9, t_bal.ptr, 72 * (size_t)nc, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && np) e = hipMemcpyAsync(p->pts4, t_pts.ptr, 32 * (size_t)np, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { free_buffers(p); return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e)); }
+    rc = c2b_cameras_from_bal(p->bal9, (int64_t)nc, p->cam15, st);         // SnavelyCamera::from_vec, src/baproblem.rs:180-186
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(C2B_ERR_HIP, "problem_read: synchronize failed");
+    if (rc) { free_buffers(p); return rc; }
+    p->bal_valid = true;
+    p->blk_valid = false;
+    *handled = true;
+    return C2B_OK;
+}
+
 // BAProblem::from_file (src/baproblem.rs:697-706) into the resident problem.  `.bbal`: a reader thread streams the file
 // through a ring of pinned slots, this thread sends every slot to the device as it arrives and walks the per-camera
 // counts (the only part of the format that must be read in order); the per-observation decoding -- byte order, index
-// range checks, the split into index and uv arrays -- and from_vec of every camera run on the device.  `.bal`: the host
-// parser (decimal text is host work), then an ordinary upload.  format: -1 by extension, 0 text, 1 binary.
+// range checks, the split into index and uv arrays -- and from_vec of every camera run on the device.  `.bal`: tokenised
+// and parsed on the device (read_text_device above); whatever that declines goes through the host parser and an ordinary
+// upload (C2B_HOST_TEXT=1: always).  format: -1 by extension, 0 text, 1 binary.
 int c2b_problem_read(c2b_problem *p, const char *path, int format) {
     C2B_API_BEGIN
     if (!p || !path) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_read: NULL argument");
     bool binary = false;
     int rc = bal_format(path, format, &binary);
     if (rc) return rc;
+    if (!binary && !env_flag("C2B_HOST_TEXT")) {
+        bool handled = false;
+        rc = read_text_device(p, path, &handled);
+        if (rc || handled) return rc;
+        if (env_flag("C2B_TEXT_DEVICE_STRICT"))              // tests: make sure the device path is the one that ran
+            return fail(C2B_ERR_INVALID_ARGUMENT, "problem_read: the device parser declined %s", path);
+    }
     if (!binary) {
         c2b_balfile *f = nullptr;
         rc = c2b_bal_read_as(path, 0, &f);

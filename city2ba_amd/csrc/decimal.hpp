@@ -298,3 +298,173 @@ C2B_HD void uint_emit(uint64_t v, uint32_t n, char *dst) {
 }
 
 }  // namespace c2b_dec
+
+// ================================================================================================================
+// Reading: decimal text -> the nearest double (from_file_text, src/baproblem.rs:580-629, reads its numbers with nom's
+// `double`, i.e. str::parse::<f64>: correctly rounded).  The significand's digits go into a 64-bit integer w (at most
+// 19 significant digits; the writer above never makes more than 17), the value is w * 10^q, and it is rounded by
+//   * Clinger's exact case: w <= 2^53 and |q| <= 22 -- both operands are exact doubles, one IEEE multiply or divide;
+//   * otherwise Eisel-Lemire (Lemire, "Number parsing at a gigabyte per second", SPE 2021): w times a 128-bit
+//     truncation of 5^q gives the leading bits of the product and a bound on what was cut; when that bound cannot
+//     decide the rounding the parse reports `unsure` (and the caller hands the file to the host's strtod) instead of
+//     guessing.  The table -- 5^q for q in [-342, 308], normalised to 128 bits, reciprocals rounded up -- is computed at
+//     start-up by the exact arithmetic above, like the writer's.
+// Anything but [+-]digits[.digits][(e|E)[+-]digits] is `irregular` -- the host parser owns every other spelling.
+namespace c2b_dec {
+
+constexpr int kPow10Min = -342, kPow10Max = 308;
+struct ParseTables {
+    uint64_t pow5_128[kPow10Max - kPow10Min + 1][2];      // {high, low}
+    double exact10[23];                                     // 10^0 .. 10^22
+};
+
+namespace big {
+// floor(a / b), any sizes (restoring division, bit by bit -- start-up code)
+inline N div_floor(const N &a, const N &b) {
+    const int ba = bits(a), bb = bits(b);
+    N q((size_t)(ba / 32 + 1), 0u), rem = a;
+    for (int bit = ba - bb; bit >= 0; --bit) {
+        const N d = shl(b, bit);
+        if (cmp(rem, d) >= 0) { sub(rem, d); q[(size_t)(bit / 32)] |= 1u << (bit % 32); }
+    }
+    trim(q);
+    return q;
+}
+inline void add_one(N &a) {
+    for (auto &l : a) { if (++l != 0) return; }
+    a.push_back(1u);
+}
+}  // namespace big
+
+inline void build_parse_tables(ParseTables &t) {
+    auto store = [&](int q, big::N c) {                   // c has exactly 128 bits
+        uint64_t lohi[2];
+        big::low128(c, lohi);
+        t.pow5_128[q - kPow10Min][0] = lohi[1];
+        t.pow5_128[q - kPow10Min][1] = lohi[0];
+    };
+    big::N p(1, 1u);                                      // 5^k
+    std::vector<big::N> pow5;
+    for (int k = 0; k <= 342; ++k) { pow5.push_back(p); big::mul_small(p, 5u); }
+    for (int q = 0; q <= kPow10Max; ++q) {                // 5^q with its top bit at bit 127, truncated
+        const big::N &v = pow5[(size_t)q];
+        const int b = big::bits(v);
+        store(q, b <= 128 ? big::shl(v, 128 - b) : big::shr(v, b - 128));
+    }
+    for (int q = -1; q >= kPow10Min; --q) {               // 2^b / 5^-q, rounded up, 128 bits
+        const big::N &v = pow5[(size_t)(-q)];
+        int z = 0;                                        // smallest z with 2^z >= 5^-q
+        { const int b = big::bits(v); z = b; big::N one = big::shl(big::N(1, 1u), b - 1); if (big::cmp(one, v) >= 0) z = b - 1; }
+        const int b = q >= -27 ? z + 127 : 2 * z + 128;
+        big::N c = big::div_floor(big::shl(big::N(1, 1u), b), v);
+        big::add_one(c);
+        const int cb = big::bits(c);
+        if (cb > 128) c = big::shr(c, cb - 128);
+        store(q, c);
+    }
+    double e = 1.0;
+    for (int k = 0; k < 23; ++k) { t.exact10[k] = e; e *= 10.0; }
+}
+inline const ParseTables &host_parse_tables() {
+    static const ParseTables *t = [] { ParseTables *x = new ParseTables; build_parse_tables(*x); return x; }();
+    return *t;
+}
+
+enum { PARSE_OK = 0, PARSE_IRREGULAR = 1, PARSE_UNSURE = 2 };
+
+// w * 10^q, w != 0, rounded to nearest even; *status = PARSE_UNSURE when the truncated product cannot decide
+C2B_HD double scale10(uint64_t w, int32_t q, const ParseTables *T, int *status) {
+    const double inf = __builtin_huge_val();
+    if (q < kPow10Min) return 0.0;                        // w < 2^64 < 10^20: below half the smallest subnormal
+    if (q > kPow10Max) return inf;
+    if (w <= (1ull << 53) && q >= -22 && q <= 22) {       // both exact: one correctly rounded operation
+        const double d = (double)w;
+        return q < 0 ? d / T->exact10[-q] : d * T->exact10[q];
+    }
+    const int lz0 = __builtin_clzll(w);
+    w <<= lz0;
+    const uint64_t *five = T->pow5_128[q - kPow10Min];
+    unsigned __int128 first = (unsigned __int128)w * five[0];
+    uint64_t upper = (uint64_t)(first >> 64), lower = (uint64_t)first;
+    if ((upper & 0x1ffu) == 0x1ffu) {                     // the nine bits below the rounding bit are all ones: look further
+        const unsigned __int128 second = (unsigned __int128)w * five[1];
+        const uint64_t sh = (uint64_t)(second >> 64);
+        lower += sh;
+        if (sh > lower) ++upper;
+        if (lower == 0xffffffffffffffffull) { *status = PARSE_UNSURE; return 0.0; }     // what was cut could still carry
+    }
+    const int upperbit = (int)(upper >> 63);
+    uint64_t mantissa = upper >> (upperbit + 9);          // 54 bits: the 53 of the result and the rounding bit
+    // floor(log2 10^q) + 63 is the binary exponent of bit 63 of 5^q's table entry times 2^q; the bias of 1023 goes in here
+    int32_t power2 = (int32_t)((((int64_t)(152170 + 65536) * q) >> 16) + 63) + upperbit - lz0 + 1023;
+    if (power2 <= 0) {                                    // subnormal (or zero)
+        if (-power2 + 1 >= 64) return 0.0;
+        mantissa >>= -power2 + 1;
+        mantissa += mantissa & 1;
+        mantissa >>= 1;
+        const uint64_t bits = mantissa;                   // exponent field 0, or 1 if the rounding carried into it
+        double d;
+        memcpy(&d, &bits, 8);
+        return d;
+    }
+    // exactly half way between two doubles: only possible when 5^q fits 64 bits; then the product is exact
+    if (lower <= 1 && q >= -4 && q <= 23 && (mantissa & 3) == 1 && (mantissa << (upperbit + 9)) == upper) mantissa &= ~1ull;
+    mantissa += mantissa & 1;
+    mantissa >>= 1;
+    if (mantissa >= (2ull << 52)) { mantissa = 1ull << 52; ++power2; }
+    mantissa &= ~(1ull << 52);
+    if (power2 >= 0x7ff) return inf;
+    const uint64_t bits = ((uint64_t)power2 << 52) | mantissa;
+    double d;
+    memcpy(&d, &bits, 8);
+    return d;
+}
+
+// one whitespace-delimited token [s, s + n) -> double
+C2B_HD double parse_f64(const char *s, int32_t n, const ParseTables *T, int *status) {
+    int32_t i = 0;
+    bool neg = false;
+    if (i < n && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; ++i; }
+    uint64_t w = 0;
+    int32_t sig = 0, q = 0, digits = 0;
+    bool lost = false;                                    // a non-zero digit beyond the 19 kept
+    for (; i < n && s[i] >= '0' && s[i] <= '9'; ++i, ++digits) {
+        const uint32_t d = (uint32_t)(s[i] - '0');
+        if (sig < 19) { w = w * 10 + d; sig += (w != 0) ? 1 : 0; }
+        else { ++q; lost |= d != 0; }
+    }
+    if (i < n && s[i] == '.') {
+        ++i;
+        for (; i < n && s[i] >= '0' && s[i] <= '9'; ++i, ++digits) {
+            const uint32_t d = (uint32_t)(s[i] - '0');
+            if (sig < 19) { w = w * 10 + d; sig += (w != 0) ? 1 : 0; --q; }
+            else lost |= d != 0;
+        }
+    }
+    if (digits == 0) { *status = PARSE_IRREGULAR; return 0.0; }
+    if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+        ++i;
+        bool eneg = false;
+        if (i < n && (s[i] == '-' || s[i] == '+')) { eneg = s[i] == '-'; ++i; }
+        int32_t e = 0, ed = 0;
+        for (; i < n && s[i] >= '0' && s[i] <= '9'; ++i, ++ed) if (e < 100000) e = e * 10 + (s[i] - '0');
+        if (ed == 0) { *status = PARSE_IRREGULAR; return 0.0; }
+        q += eneg ? -e : e;
+    }
+    if (i != n || lost) { *status = i != n ? PARSE_IRREGULAR : PARSE_UNSURE; return 0.0; }
+    const double v = w == 0 ? 0.0 : scale10(w, q, T, status);
+    return neg ? -v : v;
+}
+
+// an index or a count: digits only
+C2B_HD uint64_t parse_u64(const char *s, int32_t n, int *status) {
+    uint64_t v = 0;
+    if (n <= 0 || n > 19) { *status = PARSE_IRREGULAR; return 0; }
+    for (int32_t i = 0; i < n; ++i) {
+        if (s[i] < '0' || s[i] > '9') { *status = PARSE_IRREGULAR; return 0; }
+        v = v * 10 + (uint64_t)(s[i] - '0');
+    }
+    return v;
+}
+
+}  // namespace c2b_dec

@@ -162,3 +162,96 @@ def test_text_image_from_the_device_equals_the_host_formatter(c2b, tmp_path, mon
     assert np.array_equal(back.cameras_bal(), g.cameras_bal()) and np.array_equal(back.pt_idx, g.pt_idx)
     g.close()
     back.close()
+
+
+def _same_state(a, b):
+    assert np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.pt_idx, b.pt_idx)
+    for x, y in ((a.cameras(), b.cameras()), (a.cameras_bal(), b.cameras_bal()), (a.points(), b.points()), (a.observations(), b.observations())):
+        assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+
+
+def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, monkeypatch):
+    """from_file_text (src/baproblem.rs:580-629) on the device (r04: csrc/text_kernels.hpp -- tokens ranked by a scan,
+    every number rounded by csrc/decimal.hpp: Clinger's exact case or Eisel-Lemire): the resident state equals the host
+    parser's (strtod) bit for bit.  C2B_TEXT_DEVICE_STRICT makes a file the device declines an error, so these are the
+    device's own results; files it must decline (observations out of camera order, NaN, more than 19 digits, glued numbers,
+    an index out of range) reach the host parser and come back as its result or its error."""
+    from city2ba_amd.baproblem import read_bal, write_bal
+    rng = np.random.default_rng(31)
+    monkeypatch.setenv("C2B_TEXT_DEVICE_MIN_BYTES", "0")
+    P = random_problem(61, 700, 9, seed=12, noise=1e-3, empty_every=5)
+    uv = P["uv"].copy()
+    wild = np.concatenate([rng.integers(0, 2**64, 4000, dtype=np.uint64).view(np.float64),
+                           np.ldexp(rng.integers(0, 4096, 1000).astype(np.float64), -rng.integers(0, 60, 1000)),
+                           10.0 ** rng.integers(-300, 300, 500), [0.0, -0.0, 1e22, 1e23, 5e-324, 1.7976931348623157e308, 0.30000000000000004]])
+    wild = wild[np.isfinite(wild)]
+    uv.ravel()[:min(uv.size, len(wild))] = wild[:min(uv.size, len(wild))]
+    path = str(tmp_path / "w.bal")
+    write_bal(path, P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], uv)
+    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    a = c2b.BAProblem.from_file(path)                          # the device parsed it (strict)
+    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+    b = c2b.BAProblem.from_bal(*read_bal(path))
+    _same_state(a, b)
+    assert np.array_equal(a.observations().view(np.uint64), uv.view(np.uint64))          # and the file round-trips exactly
+    # other spellings of the same numbers: exponents, explicit signs, leading zeros, tabs and blank lines, 17 digits
+    lines = open(path).read().split("\n")
+    alt = [lines[0].replace(" ", "\t")]
+    for i, ln in enumerate(lines[1:]):
+        t = ln.split(" ")
+        if len(t) == 4:
+            t[2], t[3] = "%.17g" % float(t[2]), "%+.16E" % float(t[3])
+            alt.append(("  " if i % 3 else "\r\n") + "\t".join(t))
+        elif ln:
+            alt.append(" ".join(("%.17e" % float(x)) if k % 2 else ("000" + x if x[0].isdigit() else x) for k, x in enumerate(t)))
+    path2 = str(tmp_path / "alt.bal")
+    open(path2, "w").write("\n".join(alt) + "\n\n  trailing tokens are left unread 1 2 3\n")
+    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    a2 = c2b.BAProblem.from_file(path2)
+    _same_state(a2, b)
+    # what the device must decline
+    declined = {}
+    # (two observation lines of different cameras swapped)
+    declined["unsorted"] = "\n".join(lines[:1] + [lines[len(uv)]] + lines[2:len(uv)] + [lines[1]] + lines[len(uv) + 1:])
+    declined["nan"] = "\n".join(lines[:2] + [lines[2].rsplit(" ", 1)[0] + " NaN"] + lines[3:])
+    declined["digits"] = "\n".join(lines[:2] + [lines[2].rsplit(" ", 1)[0] + " 0.12345678901234567890123"] + lines[3:])
+    declined["glued"] = "\n".join(lines[:2] + [lines[2].rsplit(" ", 1)[0] + "-1.5"] + lines[3:])
+    for name, text in declined.items():
+        q = str(tmp_path / (name + ".bal"))
+        open(q, "w").write(text)
+        with pytest.raises(c2b.City2baError, match="declined"):
+            c2b.BAProblem.from_file(q)
+    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+    for name in ("unsorted", "digits", "glued"):               # ... and the host parser takes them
+        q = str(tmp_path / (name + ".bal"))
+        x, y = c2b.BAProblem.from_file(q), c2b.BAProblem.from_bal(*read_bal(q))
+        _same_state(x, y)
+        x.close(); y.close()
+    bad = lines[:]
+    bad[1] = "%d %s" % (len(P["bal9"]), bad[1].split(" ", 1)[1])          # camera index out of range
+    q = str(tmp_path / "range.bal")
+    open(q, "w").write("\n".join(bad))
+    with pytest.raises(c2b.City2baError, match="cam_i < cams.len"):
+        c2b.BAProblem.from_file(q)
+    q = str(tmp_path / "short.bal")
+    open(q, "w").write("\n".join(lines[:len(lines) // 2]))
+    with pytest.raises(c2b.City2baError):
+        c2b.BAProblem.from_file(q)
+    assert a.num_observations() == len(uv)                     # a failed read leaves other problems alone
+    for x in (a, a2, b):
+        x.close()
+    # 58 MB of text across several pinned chunks: written by the device, parsed by the device, equal to the host's parse
+    from city2ba_amd import synthetic as S
+    g = S.synthetic_grid(10, 10, 32, 20.0, 1.0, 1.0, 1.0, 10.0, False)
+    path = str(tmp_path / "g.bal")
+    g.write(path)
+    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    monkeypatch.delenv("C2B_TEXT_DEVICE_MIN_BYTES")
+    d = c2b.BAProblem.from_file(path)
+    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+    monkeypatch.setenv("C2B_HOST_TEXT", "1")
+    h = c2b.BAProblem.from_file(path)
+    _same_state(d, h)
+    assert np.array_equal(d.observations(), g.observations()) and np.array_equal(d.cameras_bal(), g.cameras_bal())
+    for x in (g, d, h):
+        x.close()
