@@ -24,8 +24,20 @@ cmp $D/n128.bal $D/nh128.bal && echo "noise (.bal): both routes wrote the same f
 ls -la $D | awk 'NR>1 {print "  " $5, $9}'
 rm -f $D/n128.bal $D/nh128.bal $D/h128.bal
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $D/prof -o t -- "$CLI" synthetic $D/p128.bal --blocks 128 > /dev/null 2>&1
-f=$(find $D/prof -name '*kernel_stats.csv' | head -1)
-echo "# rocprofv3 --kernel-trace --stats: city2ba synthetic out.bal --blocks 128"
-[ -n "$f" ] && head -12 "$f"
+for what in "synthetic $D/p128.bal --blocks 128" "noise $D/g128.bal $D/pn128.bal --drift-strength 1e-5 --rotation-std 0.01 --observation-std 0.001 --seed 1"; do
+  rm -rf $D/prof
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof -- "$CLI" $what > $D/prof.log 2>&1
+  f=$(find $D/prof -name '*kernel_stats.csv' | head -1)
+  echo "# rocprofv3 --kernel-trace --stats -- city2ba ${what//$D\//}"
+  if [ -n "$f" ]; then python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("  all kernels: %.2f ms" % (tot / 1e6))
+for r in rows[:12]:
+    name = r["Name"].replace("void ", "").replace("c2b::", "").split("(")[0]
+    print("  %-34s calls %3d  avg %9.1f us  total %8.2f ms" % (name, int(float(r["Calls"])), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+  else tail -5 $D/prof.log; fi
+done
 rm -rf "$D"
