@@ -265,8 +265,9 @@ C2B_HD Text describe(double v, const Tables *T) {
     return t;
 }
 
-// writes exactly t.len bytes at dst
-C2B_HD void emit(const Text &t, char *dst) {
+// writes exactly t.len bytes at dst (P: a pointer to char in any address space -- the device kernels write into LDS)
+template <typename P>
+C2B_HD void emit(const Text &t, P dst) {
     if (t.neg) *dst++ = '-';
     if (t.kind == 1) { *dst = '0'; return; }
     if (t.kind == 2) { dst[0] = 'N'; dst[1] = 'a'; dst[2] = 'N'; return; }
@@ -282,7 +283,7 @@ C2B_HD void emit(const Text &t, char *dst) {
     } else {
         dst[0] = '0'; dst[1] = '.';
         for (int32_t i = 0; i < -point; ++i) dst[2 + i] = '0';
-        char *q = dst + 2 - point;
+        P q = dst + 2 - point;
         for (int32_t i = n - 1; i >= 0; --i) { q[i] = (char)('0' + m % 10); m /= 10; }
     }
 }
@@ -293,7 +294,8 @@ C2B_HD uint32_t uint_len(uint64_t v) {
     while (v >= 10) { v /= 10; ++n; }
     return n;
 }
-C2B_HD void uint_emit(uint64_t v, uint32_t n, char *dst) {
+template <typename P>
+C2B_HD void uint_emit(uint64_t v, uint32_t n, P dst) {
     for (int32_t i = (int32_t)n - 1; i >= 0; --i) { dst[i] = (char)('0' + v % 10); v /= 10; }
 }
 
@@ -420,8 +422,9 @@ C2B_HD double scale10(uint64_t w, int32_t q, const ParseTables *T, int *status) 
     return d;
 }
 
-// one whitespace-delimited token [s, s + n) -> double
-C2B_HD double parse_f64(const char *s, int32_t n, const ParseTables *T, int *status) {
+// one whitespace-delimited token [s, s + n) -> double (P: a pointer to const char in any address space)
+template <typename P>
+C2B_HD double parse_f64(P s, int32_t n, const ParseTables *T, int *status) {
     int32_t i = 0;
     bool neg = false;
     if (i < n && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; ++i; }
@@ -457,7 +460,8 @@ C2B_HD double parse_f64(const char *s, int32_t n, const ParseTables *T, int *sta
 }
 
 // an index or a count: digits only
-C2B_HD uint64_t parse_u64(const char *s, int32_t n, int *status) {
+template <typename P>
+C2B_HD uint64_t parse_u64(P s, int32_t n, int *status) {
     uint64_t v = 0;
     if (n <= 0 || n > 19) { *status = PARSE_IRREGULAR; return 0; }
     for (int32_t i = 0; i < n; ++i) {

@@ -6,6 +6,9 @@
 // newline behind it): pass 1 leaves each tile's byte count, one small kernel turns the counts into 64-bit tile bases,
 // pass 2 recomputes its tile's lengths, scans them inside the workgroup and writes the characters.  Nothing per line
 // is stored between the passes; the digits are simply found twice (a few hundred integer operations per value).
+// The characters of a tile are one contiguous piece of the file: they are written into LDS first -- at the offset
+// that gives every byte its global address modulo 16 -- and leave as whole 16-byte stores (a tile whose text does not
+// fit the LDS window, i.e. one full of 300-character values, writes its bytes to global memory directly).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -13,6 +16,12 @@
 #include "decimal.hpp"
 
 constexpr int kTextTile = 256;
+constexpr int kEmitCap = 24 * 1024;                   // LDS window of one tile's characters
+
+typedef __attribute__((address_space(3))) char *lds_char;
+typedef const __attribute__((address_space(3))) char *lds_cchar;
+typedef unsigned int text_u4 __attribute__((ext_vector_type(4)));      // a plain vector (uint4 is a class: no address spaces)
+typedef __attribute__((address_space(3))) text_u4 *lds_u4;
 
 __device__ c2b_dec::Tables g_dec_tables;              // filled once per device (capi_problem.hpp: device_dec_tables)
 
@@ -38,6 +47,28 @@ __device__ __forceinline__ uint32_t text_tile_scan(uint32_t v, uint32_t *sh, uin
     return base + inc - v;
 }
 
+// out[shift + k] -> dst[k] for k < total, where shift = (address of dst) mod 16: whole aligned 16-byte stores, the ragged
+// ends byte by byte
+__device__ __forceinline__ void text_copy_out(char *out_generic, uint32_t shift, uint32_t total, char *__restrict__ dst) {
+    const lds_cchar out = (lds_cchar)out_generic;
+    const uint32_t head = total < ((16u - shift) & 15u) ? total : ((16u - shift) & 15u);
+    if (threadIdx.x < head) dst[threadIdx.x] = out[shift + threadIdx.x];
+    const uint32_t nb = (total - head) >> 4;
+    for (uint32_t c = threadIdx.x; c < nb; c += kTextTile)
+        *reinterpret_cast<text_u4 *>(dst + head + 16 * c) = *(lds_u4)(out_generic + shift + head + 16 * c);
+    const uint32_t t0 = head + 16 * nb;
+    if (threadIdx.x < total - t0) dst[t0 + threadIdx.x] = out[shift + t0 + threadIdx.x];
+}
+
+// one observation line / one value with its separator, written at q (global memory or LDS)
+template <typename P>
+__device__ __forceinline__ void text_put_obs(P q, uint32_t c, uint32_t lc, uint32_t p, uint32_t lp, const c2b_dec::Text &tu, const c2b_dec::Text &tv) {
+    c2b_dec::uint_emit(c, lc, q); q += lc; *q++ = ' ';
+    c2b_dec::uint_emit(p, lp, q); q += lp; *q++ = ' ';
+    c2b_dec::emit(tu, q); q += tu.len; *q++ = ' ';
+    c2b_dec::emit(tv, q); q += tv.len; *q = '\n';
+}
+
 // observation lines: "camera point u v\n"
 template <bool EMIT>
 __global__ __launch_bounds__(kTextTile) void k_text_obs(const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -45,6 +76,7 @@ __global__ __launch_bounds__(kTextTile) void k_text_obs(const uint32_t *__restri
                                                         const c2b_dec::Tables *__restrict__ T, uint32_t *__restrict__ tile_len,
                                                         const uint64_t *__restrict__ tile_base, char *__restrict__ img) {
     __shared__ uint32_t sh[kTextTile / 64];
+    __shared__ __attribute__((aligned(16))) char out[EMIT ? kEmitCap + 16 : 16];
     const int64_t i = (int64_t)blockIdx.x * kTextTile + threadIdx.x;
     uint32_t len = 0, lc = 0, lp = 0, c = 0, p = 0;
     c2b_dec::Text tu, tv;
@@ -63,12 +95,15 @@ __global__ __launch_bounds__(kTextTile) void k_text_obs(const uint32_t *__restri
         if (threadIdx.x == 0) tile_len[blockIdx.x] = total;
         return;
     }
-    if (i >= n) return;
-    char *q = img + tile_base[blockIdx.x] + at;
-    c2b_dec::uint_emit(c, lc, q); q += lc; *q++ = ' ';
-    c2b_dec::uint_emit(p, lp, q); q += lp; *q++ = ' ';
-    c2b_dec::emit(tu, q); q += tu.len; *q++ = ' ';
-    c2b_dec::emit(tv, q); q += tv.len; *q = '\n';
+    char *dst = img + tile_base[blockIdx.x];
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+    if (total + shift <= (uint32_t)kEmitCap) {                // workgroup-uniform
+        if (i < n) text_put_obs((lds_char)out + shift + at, c, lc, p, lp, tu, tv);
+        __syncthreads();
+        text_copy_out(out, shift, total, dst);
+    } else if (i < n) {
+        text_put_obs(dst + at, c, lc, p, lp, tu, tv);
+    }
 }
 
 // rows of `width` values (`stride` doubles apart) joined by spaces, one row per line: a unit = one value + what follows it
@@ -77,6 +112,7 @@ __global__ __launch_bounds__(kTextTile) void k_text_vals(const double *__restric
                                                          const c2b_dec::Tables *__restrict__ T, uint32_t *__restrict__ tile_len,
                                                          const uint64_t *__restrict__ tile_base, char *__restrict__ img) {
     __shared__ uint32_t sh[kTextTile / 64];
+    __shared__ __attribute__((aligned(16))) char out[EMIT ? kEmitCap + 16 : 16];
     const int64_t j = (int64_t)blockIdx.x * kTextTile + threadIdx.x, n = n_rows * width;
     c2b_dec::Text t;
     t.len = 0;
@@ -94,10 +130,22 @@ __global__ __launch_bounds__(kTextTile) void k_text_vals(const double *__restric
         if (threadIdx.x == 0) tile_len[blockIdx.x] = total;
         return;
     }
-    if (j >= n) return;
-    char *q = img + tile_base[blockIdx.x] + at;
-    c2b_dec::emit(t, q);
-    q[t.len] = col == width - 1 ? '\n' : ' ';
+    char *dst = img + tile_base[blockIdx.x];
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+    const char sep = col == width - 1 ? '\n' : ' ';
+    if (total + shift <= (uint32_t)kEmitCap) {                // workgroup-uniform
+        if (j < n) {
+            const lds_char q = (lds_char)out + shift + at;
+            c2b_dec::emit(t, q);
+            q[t.len] = sep;
+        }
+        __syncthreads();
+        text_copy_out(out, shift, total, dst);
+    } else if (j < n) {
+        char *q = dst + at;
+        c2b_dec::emit(t, q);
+        q[t.len] = sep;
+    }
 }
 
 // tile byte counts -> 64-bit tile bases (exclusive, starting at `first`); total[0] = first + every tile.  One workgroup:
@@ -130,15 +178,14 @@ __global__ __launch_bounds__(1024) void k_text_tile_bases(const uint32_t *__rest
 // to the host parser; flags[1] / flags[2]: a camera / point index out of range (BAProblem::new's asserts, :344-345).
 constexpr int kParseBytes = 16;                              // per thread
 constexpr int kParseTile = kTextTile * kParseBytes;         // bytes per workgroup
+constexpr int kParseLong = 400;                              // a longer token is declined
+constexpr int kParseOver = 448;                              // bytes of the next tile staged with this one (>= kParseLong + 1, x16)
 
 __device__ __forceinline__ bool text_ws(uint32_t c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
 
-// bit b of the result: byte b of this thread's 16 starts a token
-__device__ __forceinline__ uint32_t text_starts(const char *__restrict__ raw, int64_t at, int64_t n) {
-    if (at >= n) return 0u;
-    const uint4 v = *reinterpret_cast<const uint4 *>(raw + at);          // the buffer is padded to a multiple of 16
+// bit b of the result: byte b of these 16 (the file's bytes [at, at + 16)) starts a token
+__device__ __forceinline__ uint32_t text_starts(const text_u4 v, bool prev_ws, int64_t at, int64_t n) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    bool prev_ws = at == 0 ? true : text_ws((uint32_t)(uint8_t)raw[at - 1]);
     uint32_t m = 0;
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
@@ -150,49 +197,85 @@ __device__ __forceinline__ uint32_t text_starts(const char *__restrict__ raw, in
     return m;
 }
 
+// (the buffer is padded with zeros to a multiple of 16 and one chunk more)
 __global__ __launch_bounds__(kTextTile) void k_text_count_tokens(const char *__restrict__ raw, int64_t n, uint32_t *__restrict__ tile_cnt) {
     __shared__ uint32_t sh[kTextTile / 64];
     const int64_t at = ((int64_t)blockIdx.x * kTextTile + threadIdx.x) * kParseBytes;
+    uint32_t starts = 0;
+    if (at < n) starts = text_starts(*reinterpret_cast<const text_u4 *>(raw + at), at == 0 ? true : text_ws((uint32_t)(uint8_t)raw[at - 1]), at, n);
     uint32_t total;
-    (void)text_tile_scan((uint32_t)__builtin_popcount(text_starts(raw, at, n)), sh, &total);
+    (void)text_tile_scan((uint32_t)__builtin_popcount(starts), sh, &total);
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
 }
 
+// The tile's bytes and the first kParseOver of the next tile go to LDS with 16-byte loads; tokens are measured and
+// parsed from there (a token's bytes are read one by one, twice: dependent loads, 64 cycles each from LDS instead of a
+// trip through the vector memory path).
 __global__ __launch_bounds__(kTextTile) void k_text_parse(const char *__restrict__ raw, int64_t n, const uint64_t *__restrict__ tile_base,
                                                           const c2b_dec::ParseTables *__restrict__ T, uint64_t n_cam, uint64_t n_pts, uint64_t n_obs,
                                                           uint32_t *__restrict__ cam_idx, uint32_t *__restrict__ pt_idx,
                                                           double *__restrict__ uv, double *__restrict__ bal9, double *__restrict__ pts4,
                                                           uint32_t *__restrict__ flags) {
     __shared__ uint32_t sh[kTextTile / 64];
-    const int64_t at = ((int64_t)blockIdx.x * kTextTile + threadIdx.x) * kParseBytes;
-    uint32_t starts = text_starts(raw, at, n);
+    __shared__ __attribute__((aligned(16))) char tile[kParseTile + kParseOver];
+    __shared__ uint16_t tok[kParseTile / 2];                  // a token and the whitespace behind it take two bytes at least
+    const int64_t tile0 = (int64_t)blockIdx.x * kParseTile, at = tile0 + (int64_t)threadIdx.x * kParseBytes;
+    const int64_t n16 = (n + 15) & ~(int64_t)15;
+    text_u4 mine = {0u, 0u, 0u, 0u};
+    if (at < n16) mine = *reinterpret_cast<const text_u4 *>(raw + at);
+    *(lds_u4)(tile + threadIdx.x * kParseBytes) = mine;
+    if (threadIdx.x < kParseOver / 16) {
+        const int64_t o = tile0 + kParseTile + (int64_t)threadIdx.x * 16;
+        text_u4 v = {0u, 0u, 0u, 0u};
+        if (o < n16) v = *reinterpret_cast<const text_u4 *>(raw + o);
+        *(lds_u4)(tile + kParseTile + threadIdx.x * 16) = v;
+    }
+    __syncthreads();
+    const lds_cchar text = (lds_cchar)tile;
+    const int32_t here = (int32_t)threadIdx.x * kParseBytes;
+    const bool prev_ws = threadIdx.x > 0 ? text_ws((uint32_t)(uint8_t)text[here - 1]) : (at == 0 ? true : text_ws((uint32_t)(uint8_t)raw[at - 1]));
+    uint32_t starts = at < n ? text_starts(mine, prev_ws, at, n) : 0u;
     uint32_t total;
-    uint64_t k = tile_base[blockIdx.x] + text_tile_scan((uint32_t)__builtin_popcount(starts), sh, &total);
+    uint32_t rank = text_tile_scan((uint32_t)__builtin_popcount(starts), sh, &total);
+    // Where the tile's tokens start, in token order: the parsing below takes ONE token per lane and trip, whatever the
+    // spacing of the file (16 bytes per lane hold 0-8 tokens: parsing them where they were found left most lanes idle
+    // behind the fullest one), and deals the tokens of a group of 256 so that each wave sees ONE kind: consecutive
+    // tokens of the observation block are camera, point, u, v, so wave w takes the tokens whose index is w mod 4 past
+    // the block's first -- an integer parse or a decimal parse per wave, not both (8.2 -> see DESIGN 3.2).
+    for (; starts != 0; starts &= starts - 1) tok[rank++] = (uint16_t)(here + __builtin_ctz(starts));
+    __syncthreads();
+    const uint64_t k0 = tile_base[blockIdx.x];
     const uint64_t k_obs = 3, k_cam = k_obs + 4 * n_obs, k_pts = k_cam + 9 * n_cam, k_end = k_pts + 3 * n_pts;
-    for (; starts != 0; starts &= starts - 1, ++k) {
+    const int64_t left = n - tile0;                           // bytes of the file from this tile's first on
+    const int32_t limit = left < (int64_t)(kParseTile + kParseOver) ? (int32_t)left : kParseTile + kParseOver;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t slot = 4u * lane + ((wave - (uint32_t)(k0 - k_obs)) & 3u);          // a bijection of 0..255
+    for (uint32_t r = slot; r < total; r += kTextTile) {
+        const uint64_t k = k0 + r;
         if (k < k_obs || k >= k_end) continue;                // the header is the host's; nom leaves what follows the last point unread
-        const int64_t s = at + __builtin_ctz(starts);
+        const int32_t s = (int32_t)tok[r];
         int32_t len = 1;
-        while (s + len < n && len <= 400 && !text_ws((uint32_t)(uint8_t)raw[s + len])) ++len;
-        int status = len > 400 ? (int)c2b_dec::PARSE_IRREGULAR : (int)c2b_dec::PARSE_OK;
+        while (s + len < limit && len <= kParseLong && !text_ws((uint32_t)(uint8_t)text[s + len])) ++len;
+        int status = len > kParseLong ? (int)c2b_dec::PARSE_IRREGULAR : (int)c2b_dec::PARSE_OK;
+        const lds_cchar t = text + s;
         if (k < k_cam) {
             const uint64_t j = k - k_obs, i = j >> 2;
             const int f = (int)(j & 3);
             if (f < 2) {
-                const uint64_t v = status ? 0 : c2b_dec::parse_u64(raw + s, len, &status);
+                const uint64_t v = status ? 0 : c2b_dec::parse_u64(t, len, &status);
                 if (!status) {
                     if (v >= (f == 0 ? n_cam : n_pts)) atomicOr(flags + 1 + f, 1u);
                     else (f == 0 ? cam_idx : pt_idx)[i] = (uint32_t)v;
                 }
             } else {
-                const double v = status ? 0.0 : c2b_dec::parse_f64(raw + s, len, T, &status);
+                const double v = status ? 0.0 : c2b_dec::parse_f64(t, len, T, &status);
                 if (!status) uv[2 * i + (f - 2)] = v;
             }
         } else {
-            const double v = status ? 0.0 : c2b_dec::parse_f64(raw + s, len, T, &status);
+            const double v = status ? 0.0 : c2b_dec::parse_f64(t, len, T, &status);
             if (!status) {
                 if (k < k_pts) bal9[k - k_cam] = v;
-                else { const uint64_t j = k - k_pts, r = j / 3; pts4[4 * r + (j - 3 * r)] = v; }
+                else { const uint64_t j = k - k_pts, q = j / 3; pts4[4 * q + (j - 3 * q)] = v; }
             }
         }
         if (status) atomicAdd(flags, 1u);
