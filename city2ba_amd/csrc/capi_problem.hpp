@@ -1372,7 +1372,8 @@ static int device_parse_tables(int device, const c2b_dec::ParseTables **out) {
 // slots to the device in order.  0 = ok, 1 = copy failed, 2 = read failed, 3 = no resources.
 static int file_to_device(int fd, size_t bytes, char *dev) {
     constexpr size_t kChunk = (size_t)8 << 20;
-    constexpr int kSlots = 6, kReaders = 3;
+    int kSlots = 6, kReaders = 3;
+    if (const char *ev = std::getenv("C2B_READ_THREADS")) { kReaders = std::max(1, std::atoi(ev)); kSlots = 2 * kReaders; }
     const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
     char *pin = nullptr;
     if (hipHostMalloc((void **)&pin, kChunk * kSlots, hipHostMallocDefault) != hipSuccess) return 3;
@@ -1390,11 +1391,11 @@ static int file_to_device(int fd, size_t bytes, char *dev) {
                 k = claimed;
                 if (k >= n_chunks || failed) return;
                 ++claimed;
-                cv.wait(lk, [&] { return k < drained + kSlots || failed; });      // its slot's previous chunk has left
+                cv.wait(lk, [&] { return k < drained + (size_t)kSlots || failed; });      // its slot's previous chunk has left
                 if (failed) return;
             }
             const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
-            char *dst = pin + (k % kSlots) * kChunk;
+            char *dst = pin + (k % (size_t)kSlots) * kChunk;
             size_t done = 0;
             while (done < len) {
                 const ssize_t r = ::pread(fd, dst + done, len - done, (off_t)(off + done));
