@@ -255,3 +255,31 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
     assert np.array_equal(d.observations(), g.observations()) and np.array_equal(d.cameras_bal(), g.cameras_bal())
     for x in (g, d, h):
         x.close()
+
+
+def test_both_file_forms_round_trip_at_the_headline_size(c2b, tmp_path):
+    """`synthetic --blocks 128` (BASELINE configs[3]: 660 480 cameras before cull, 19.3 M observations) written and read
+    back on the device in both forms -- 564 MB of big-endian words, 972 MB of decimal text (89 M shortest round-trip
+    decimals out, 89 M correctly rounded parses in) -- returns every array bit for bit; the noised state (cameras
+    through to_vec / from_vec, 17-digit observations) too."""
+    import os
+    from city2ba_amd import synthetic as S
+    g = S.synthetic_grid(10, 10, 128, 20.0, 1.0, 1.0, 1.0, 10.0, False)
+    assert g.num_observations() > 19_000_000
+    c2b.noise.add_noise(g, 0.0, 0.0, 0.0, 1e-3, seed=5)       # observations with all their digits
+    os.environ["C2B_TEXT_DEVICE_STRICT"] = "1"
+    try:
+        for ext, size in (("bbal", 500_000_000), ("bal", 900_000_000)):
+            path = str(tmp_path / ("g128." + ext))
+            g.write(path)
+            assert os.path.getsize(path) > size
+            back = c2b.BAProblem.from_file(path)
+            assert np.array_equal(back.row_ptr, g.row_ptr) and np.array_equal(back.pt_idx, g.pt_idx)
+            assert np.array_equal(back.observations().view(np.uint64), g.observations().view(np.uint64))
+            assert np.array_equal(back.points().view(np.uint64), g.points().view(np.uint64))
+            assert np.array_equal(back.cameras_bal().view(np.uint64), g.cameras_bal().view(np.uint64))
+            back.close()
+            os.remove(path)
+    finally:
+        del os.environ["C2B_TEXT_DEVICE_STRICT"]
+    g.close()
