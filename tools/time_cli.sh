@@ -15,7 +15,7 @@ T() {
 }
 for B in 32 128 128; do rm -f $D/g$B.bbal; T synthetic $D/g$B.bbal --blocks $B; done
 T synthetic $D/g32.bal --blocks 32
-# the text form of the headline grid (1.2 GB of shortest round-trip decimals: formatted / parsed on a pool of host threads)
+# the text form of the headline grid (972 MB of shortest round-trip decimals: formatted / parsed on the device since r04; tools/time_text.sh compares with the host route)
 T synthetic $D/g128.bal --blocks 128
 T noise $D/g128.bal $D/n128.bal --drift-strength 1e-5 --rotation-std 0.01 --observation-std 0.001 --seed 1
 rm -f $D/g128.bal $D/n128.bal
