@@ -43,12 +43,27 @@ inline bool load_obj(const char *path, std::vector<ObjModel> &models, std::strin
     ObjModel cur;
     cur.name = "unnamed_object";
     std::map<std::tuple<int64_t, int64_t, int64_t>, uint32_t> remap;
+    // position-only corners (no texture / normal index: every mesh of the tests and of tools/make_city_obj.py) are
+    // looked up in a table by vertex instead of in the map: `seen_in[iv]` = the model that last used vertex iv
+    // (a 0.8 M-triangle city spent most of its 218 ms load in the map)
+    std::vector<uint32_t> plain_id, seen_in;
+    uint32_t model_no = 1;
     auto flush = [&]() {
-        if (!cur.indices.empty()) models.push_back(cur);
+        if (!cur.indices.empty()) models.push_back(std::move(cur));
         cur = ObjModel();
         remap.clear();
+        ++model_no;
     };
     auto vertex = [&](int64_t iv, int64_t it, int64_t in) -> uint32_t {
+        if (it < 0 && in < 0) {
+            if ((size_t)iv >= seen_in.size()) { seen_in.resize(v.size() / 3, 0u); plain_id.resize(v.size() / 3, 0u); }
+            if (seen_in[(size_t)iv] == model_no) return plain_id[(size_t)iv];
+            const uint32_t id = (uint32_t)(cur.positions.size() / 3);
+            cur.positions.insert(cur.positions.end(), {v[3 * iv], v[3 * iv + 1], v[3 * iv + 2]});
+            seen_in[(size_t)iv] = model_no;
+            plain_id[(size_t)iv] = id;
+            return id;
+        }
         auto key = std::make_tuple(iv, it, in);
         auto hit = remap.find(key);
         if (hit != remap.end()) return hit->second;
