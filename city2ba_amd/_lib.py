@@ -143,6 +143,7 @@ SIGNATURES = {
     "c2b_bal_read_as": (_int, [C.c_char_p, _int, C.POINTER(_vp)]),
     "c2b_bal_write_as": (_int, [C.c_char_p, _int, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "c2b_format_f64": (_int, [_i64, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "c2b_parse_f64": (_int, [C.c_char_p, _i64, _i64, _vp, _vp]),
     "c2b_ply_write": (_int, [C.c_char_p, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_problem_create": (_int, [_int, C.POINTER(_vp)]),
     "c2b_problem_destroy": (None, [_vp]),

@@ -479,6 +479,15 @@ def format_f64(values):
     return buf.raw[:n.value].decode("ascii").split("\n")[:-1]
 
 
+def parse_f64(tokens):
+    """(values, status) of decimal tokens as from_file_text reads them -- c2b_parse_f64: status 0 parsed (correctly
+    rounded), 1 a spelling left to strtod, 2 too many digits / an undecided rounding"""
+    text = " ".join(tokens).encode("ascii")
+    vals, st = np.empty(len(tokens)), np.empty(len(tokens), dtype=np.int32)
+    L.check(L.lib().c2b_parse_f64(text, len(text), len(tokens), _ptr(vals), _ptr(st)))
+    return vals, st
+
+
 def write_bal(path, bal9, pts, row_ptr, pt_idx, uv, fmt=None):
     """write (by extension), write_text or write_binary (src/baproblem.rs:709, :736, :768)"""
     bal9 = _f64(bal9, (-1, 9))

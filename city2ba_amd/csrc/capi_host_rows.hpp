@@ -465,6 +465,25 @@ int c2b_format_f64(int64_t n, const double *values, char *buf, int64_t cap, int6
     C2B_API_END("format_f64")
 }
 
+int c2b_parse_f64(const char *text, int64_t len, int64_t n, double *values, int32_t *status) {
+    C2B_API_BEGIN
+    if (len < 0 || n < 0 || (len && !text) || (n && (!values || !status))) return fail(C2B_ERR_INVALID_ARGUMENT, "parse_f64: bad argument");
+    const c2b_dec::ParseTables &T = c2b_dec::host_parse_tables();
+    auto ws = [](char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; };
+    int64_t i = 0, k = 0;
+    for (; k < n; ++k) {
+        while (i < len && ws(text[i])) ++i;
+        if (i >= len) return fail(C2B_ERR_INVALID_ARGUMENT, "parse_f64: %lld tokens expected, %lld found", (long long)n, (long long)k);
+        const int64_t b = i;
+        while (i < len && !ws(text[i])) ++i;
+        int st = c2b_dec::PARSE_OK;
+        values[k] = i - b > 400 ? 0.0 : c2b_dec::parse_f64(text + b, (int32_t)(i - b), &T, &st);
+        status[k] = i - b > 400 ? (int32_t)c2b_dec::PARSE_IRREGULAR : (int32_t)st;
+    }
+    return C2B_OK;
+    C2B_API_END("parse_f64")
+}
+
 int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,
                   const uint64_t *row_ptr, const uint64_t *pt_idx) {
     C2B_API_BEGIN

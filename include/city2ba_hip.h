@@ -507,6 +507,12 @@ int c2b_bal_write_as(const char *path, int format, int64_t n_cam, const double *
  * *len = bytes written.  C2B_ERR_INVALID_ARGUMENT if cap is too small (330 bytes per value always suffice).  Host code
  * (csrc/decimal.hpp); the device writer of c2b_problem_write runs the same functions. */
 int c2b_format_f64(int64_t n, const double *values, char *buf, int64_t cap, int64_t *len);
+/* the other direction, as from_file_text reads a number (nom's `double`, i.e. str::parse::<f64>: correctly rounded;
+ * src/baproblem.rs:580-629): `text` holds n whitespace-separated tokens; values[i] = token i, status[i] = 0 parsed,
+ * 1 a spelling this parser leaves to strtod (anything but [+-]digits[.digits][(e|E)[+-]digits], e.g. "NaN"), 2 more
+ * than 19 significant digits or a rounding its 128-bit arithmetic cannot decide (the device reader hands such files to
+ * the host parser).  Host code (csrc/decimal.hpp); the device reader of c2b_problem_read runs the same functions. */
+int c2b_parse_f64(const char *text, int64_t len, int64_t n, double *values, int32_t *status);
 /* write_cameras of the `ply` subcommand (src/bin/city2ba.rs:359-439): ASCII PLY with one red vertex per camera
  * centre, one green vertex per point (f32) and one edge per observation (camera, n_cam + point) */
 int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,

@@ -67,3 +67,47 @@ def test_texts_read_back_to_the_same_bits():
         if "." in s and len(s.rstrip("0")) > 3:
             assert float(s[:-1]) != x, (x, s)
     assert struct.pack("<d", float(format_f64([-0.0])[0])) == struct.pack("<d", -0.0)
+
+
+# ---- the other direction: from_file_text's numbers (src/baproblem.rs:580-629: nom `double` = str::parse::<f64>) -----
+def test_parser_against_python_float_on_every_spelling():
+    """c2b_parse_f64 (csrc/decimal.hpp: Clinger's exact case, then Eisel-Lemire) against CPython's float() -- David Gay's
+    correctly rounded strtod, an independent implementation: shortest and 17-digit forms of random bit patterns,
+    exponent spellings, integers up to 19 digits, and decimal strings lying EXACTLY half way between two doubles."""
+    from city2ba_amd.baproblem import parse_f64
+    rng = np.random.default_rng(13)
+    toks = []
+    bits = rng.integers(0, 2**64, 60_000, dtype=np.uint64).view(np.float64)
+    bits = bits[np.isfinite(bits)]
+    toks += [repr(float(x)) for x in bits[:20_000]]                                   # shortest, exponent form for large / small
+    toks += ["%.17g" % x for x in bits[20_000:40_000]] + ["%+.16E" % x for x in bits[40_000:]]
+    toks += format_f64(rng.uniform(-1000, 1000, 20_000)) + format_f64(10.0 ** rng.integers(-320, 308, 3_000) * rng.uniform(1, 10, 3_000))
+    toks += [str(int(x) >> int(s)) for x, s in zip(rng.integers(0, 2**63, 20_000), rng.integers(0, 63, 20_000))]
+    toks += ["%de%d" % (int(x) >> int(s), int(e)) for x, s, e in zip(rng.integers(0, 2**63, 20_000), rng.integers(0, 63, 20_000), rng.integers(-360, 340, 20_000))]
+    toks += ["%d.%de%+d" % (a, b, e) for a, b, e in zip(rng.integers(0, 10**5, 10_000), rng.integers(0, 10**11, 10_000), rng.integers(-30, 30, 10_000))]
+    for m, e in zip(rng.integers(2**52, 2**53, 10_000), rng.integers(-3, 9, 10_000)):   # (2m + 1) * 2^e written out exactly: a tie
+        m, e = int(m), int(e)
+        toks.append(str((2 * m + 1) << e) if e >= 0 else format(Decimal(2 * m + 1) / Decimal(2 ** -e), "f"))
+    toks += ["0", "-0", "0.0", "-0.000e5", "1e400", "-1e400", "1e-400", "4.9e-324", "2.4703282292062327e-324", "2.4703282292062328e-324",
+             "1.7976931348623157e308", "1.7976931348623158e308", "1.7976931348623159e308", "9007199254740993", "9007199254740992.5",
+             "0.000000000000000000000000000001", "100000000000000000000000", "+1.5", ".5", "5.", "1E5"]
+    vals, st = parse_f64(toks)
+    assert (st == 1).sum() == 0
+    ok = st == 0
+    assert ok.sum() > 0.9 * len(toks)                          # `unsure` only for the > 19-digit ties
+    want = np.array([float(t) for t in toks])
+    bad = [(t, v, w) for t, v, w, o in zip(toks, vals.tolist(), want.tolist(), ok.tolist()) if o and np.float64(v).view(np.uint64) != np.float64(w).view(np.uint64)]
+    assert not bad, bad[:5]
+    assert all(len(t.replace(".", "").replace("-", "").lstrip("0")) > 19 for t, s in zip(toks, st.tolist()) if s == 2)
+    # spellings the parser leaves to the host's strtod
+    vals, st = parse_f64(["NaN", "inf", "0x1p3", "1e", "1.5.2", "1-2", "--1", "e5", ".", "1_000"])
+    assert (st == 1).all()
+
+
+def test_format_then_parse_is_the_identity():
+    from city2ba_amd.baproblem import parse_f64
+    rng = np.random.default_rng(14)
+    v = rng.integers(0, 2**64, 200_000, dtype=np.uint64).view(np.float64)
+    v = v[np.isfinite(v)]
+    back, st = parse_f64(format_f64(v))
+    assert (st == 0).all() and np.array_equal(back.view(np.uint64), v.view(np.uint64))
