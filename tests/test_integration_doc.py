@@ -7,7 +7,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-C_BASE = {"double": "f64", "float": "f32", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8",
+C_BASE = {"double": "f64", "float": "f32", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "uint8_t": "u8",
           "int": "c_int", "char": "c_char", "void": "c_void"}
 
 
