@@ -614,6 +614,19 @@ int run_generate(int argc, char **argv) {
     std::vector<float> tri((size_t)n_tri * 9 + 1);
     ck(c2b_obj_triangles(obj, path_model, tri.data(), &n_tri));
 
+    // The occlusion rays' hierarchy needs only the triangles: it is built on a second thread (c2b_bvh_build, itself
+    // multi-threaded) while the cameras are placed, the points sampled and the dense sweep runs.
+    c2b_bvh *bvh = nullptr;
+    int bvh_rc = C2B_OK;
+    std::string bvh_err;
+    std::thread bvh_builder;
+    const bool own_bvh = n_tri >= 4096;
+    if (own_bvh) bvh_builder = std::thread([&]() {
+        bvh_rc = c2b_bvh_build(tri.data(), n_tri, &bvh);
+        if (bvh_rc != C2B_OK) bvh_err = c2b_last_error();
+    });
+    struct JoinBvh { std::thread &t; c2b_bvh *&b; ~JoinBvh() { if (t.joinable()) t.join(); if (b) c2b_bvh_free(b); } } join_bvh{bvh_builder, bvh};
+
     int64_t n_cam = 0;
     std::vector<double> pos, dir;
     if (path_model >= 0) {
@@ -659,8 +672,14 @@ int run_generate(int argc, char **argv) {
     hp.row_ptr.assign((size_t)n_cam + 1, 0);
     ck(c2b_problem_visibility_dense(p, max_dist, hp.row_ptr.data()));
     timer.mark("upload + dense sweep");
-    ck(c2b_problem_visibility_dense_occlude(p, tri.data(), n_tri, hp.row_ptr.data()));
-    timer.mark("hierarchy build + occlusion rays + compaction");
+    if (own_bvh) {
+        bvh_builder.join();
+        if (bvh_rc != C2B_OK) die(bvh_err);
+        ck(c2b_problem_visibility_dense_occlude_bvh(p, bvh, hp.row_ptr.data()));
+    } else {
+        ck(c2b_problem_visibility_dense_occlude(p, tri.data(), n_tri, hp.row_ptr.data()));
+    }
+    timer.mark("occlusion rays + compaction (the hierarchy was built beside the phases above)");
     const size_t n_edges = (size_t)hp.row_ptr[(size_t)n_cam];
     std::printf("Computed visibility graph with %zu edges\n", n_edges);
 

@@ -1204,12 +1204,14 @@ int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_
     C2B_API_END("problem_visibility_dense")
 }
 
-int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int64_t n_tri, uint64_t *row_ptr) {
+// `ready`: a hierarchy the caller built over the same triangles (c2b_bvh_build), or NULL: built here when the mesh is
+// large enough for one
+static int occlude_impl(c2b_problem *p, const float *tri9, int64_t n_tri, const c2b_bvh *ready, uint64_t *row_ptr) {
     C2B_API_BEGIN
     NEED_UPLOADED(p, "problem_visibility_dense_occlude");
     if (!p->dense_pt || !p->dense_uv || !p->dense_row)
         return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: no sweep result");
-    if (!row_ptr || n_tri < 0 || (n_tri && !tri9)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: bad arguments");
+    if (!row_ptr || n_tri < 0 || (n_tri && !tri9 && !ready)) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude: bad arguments");
     const int64_t n = p->dense_n, n_cam = p->n_cam;
     if (!n || !n_tri) {
         HIP_TRY(hipMemcpyAsync(row_ptr, p->dense_row, sizeof(uint64_t) * (size_t)(n_cam + 1), hipMemcpyDeviceToHost, p->stream));
@@ -1224,15 +1226,16 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
     double *d_uv_new = nullptr;
     int rc = C2B_OK;
     // small meshes: every ray against every triangle; larger ones through a hierarchy built here on the host
-    const bool use_bvh = n_tri >= kBvhMinTriangles;
-    c2b_bvh *bvh = nullptr;
+    const bool use_bvh = ready || n_tri >= kBvhMinTriangles;
+    c2b_bvh *built = nullptr;
     void *d_nodes = nullptr;
     int64_t n_nodes = 0;
-    if (use_bvh) {
-        rc = c2b_bvh_build(tri9, n_tri, &bvh);
+    if (use_bvh && !ready) {
+        rc = c2b_bvh_build(tri9, n_tri, &built);
         if (rc) return rc;
-        n_nodes = (int64_t)bvh->b.nodes.size();
     }
+    const c2b_bvh *bvh = ready ? ready : built;
+    if (use_bvh) n_nodes = (int64_t)bvh->b.nodes.size();
     const size_t tri_bytes = use_bvh ? (size_t)C2B_BVH_TRI_BYTES * (size_t)n_tri : sizeof(float) * 9 * (size_t)n_tri;
     const void *tri_src = use_bvh ? (const void *)bvh->b.tris.data() : (const void *)tri9;
     hipError_t e = hipMalloc((void **)&d_tri, tri_bytes);
@@ -1279,11 +1282,19 @@ int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int6
     if (d_row_new) (void)hipFree(d_row_new);
     if (d_pt_new) (void)hipFree(d_pt_new);
     if (d_uv_new) (void)hipFree(d_uv_new);
-    c2b_bvh_free(bvh);
+    c2b_bvh_free(built);
     if (rc) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_visibility_dense_occlude: %s", hipGetErrorString(e));
     return C2B_OK;
     C2B_API_END("problem_visibility_dense_occlude")
+}
+
+int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int64_t n_tri, uint64_t *row_ptr) {
+    return occlude_impl(p, tri9, n_tri, nullptr, row_ptr);
+}
+int c2b_problem_visibility_dense_occlude_bvh(c2b_problem *p, const c2b_bvh *bvh, uint64_t *row_ptr) {
+    if (!bvh) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_visibility_dense_occlude_bvh: bvh is NULL");
+    return occlude_impl(p, nullptr, (int64_t)(bvh->b.tris.size() / (C2B_BVH_TRI_BYTES / sizeof(bvh->b.tris[0]))), bvh, row_ptr);
 }
 
 int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double *uv) {

@@ -631,6 +631,9 @@ int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double 
 /* filter the survivors of the last dense sweep through c2b_occlusion_filter against host triangles
  * tri9 [n_tri][9] (f32); rewrites row_ptr[n_cam + 1]; a following _fetch returns the filtered lists */
 int c2b_problem_visibility_dense_occlude(c2b_problem *p, const float *tri9, int64_t n_tri, uint64_t *row_ptr);
+/* the same with a hierarchy the caller built (c2b_bvh_build runs on the host and needs only the triangles, so a caller
+ * can build it on another thread while cameras are placed, points sampled and the sweep runs -- cli/main.cpp does) */
+int c2b_problem_visibility_dense_occlude_bvh(c2b_problem *p, const c2b_bvh *bvh, uint64_t *row_ptr);
 int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength, double std,
                           const double dir[3], uint64_t seed);
 int c2b_problem_add_drift_normalized(c2b_problem *p, double strength, double angle_strength,
