@@ -128,6 +128,7 @@ SIGNATURES = {
     "c2b_obj_free": (None, [_vp]),
     "c2b_generate_cameras_path": (_int, [_vp, _i64, _i64, _d, _u64, _vp, _vp]),
     "c2b_generate_cameras_poisson": (_int, [_vp, _i64, _i64, _d, _d, _u64, _i64, _vp, _vp, C.POINTER(_i64)]),
+    "c2b_generate_cameras_poisson_bvh": (_int, [_vp, _i64, _vp, _i64, _d, _d, _u64, _i64, _vp, _vp, C.POINTER(_i64)]),
     "c2b_modify_intrinsics": (_int, [_vp, _i64, _vp, _vp, _u64]),
     "c2b_generate_world_points": (_int, [_vp, _i64, _vp, _i64, _i64, _d, _u64, _vp, C.POINTER(_i64)]),
     "c2b_cull": (_int, [C.POINTER(_i64), _vp, _int, C.POINTER(_i64), _vp, _vp, _vp, _vp, _int]),

@@ -621,15 +621,18 @@ int run_generate(int argc, char **argv) {
     std::string bvh_err;
     std::thread bvh_builder;
     const bool own_bvh = n_tri >= 4096;
-    if (own_bvh) bvh_builder = std::thread([&]() {
-        bvh_rc = c2b_bvh_build(tri.data(), n_tri, &bvh);
-        if (bvh_rc != C2B_OK) bvh_err = c2b_last_error();
-    });
+    auto start_bvh = [&]() {
+        if (own_bvh) bvh_builder = std::thread([&]() {
+            bvh_rc = c2b_bvh_build(tri.data(), n_tri, &bvh);
+            if (bvh_rc != C2B_OK) bvh_err = c2b_last_error();
+        });
+    };
     struct JoinBvh { std::thread &t; c2b_bvh *&b; ~JoinBvh() { if (t.joinable()) t.join(); if (b) c2b_bvh_free(b); } } join_bvh{bvh_builder, bvh};
 
     int64_t n_cam = 0;
     std::vector<double> pos, dir;
     if (path_model >= 0) {
+        start_bvh();
         n_cam = num_cameras;
         pos.resize((size_t)n_cam * 3 + 1); dir.resize((size_t)n_cam * 9 + 1);
         ck(c2b_generate_cameras_path(obj, path_model, num_cameras, step_size, seed, pos.data(), dir.data()));
@@ -637,12 +640,15 @@ int run_generate(int argc, char **argv) {
         // 2 * num_cameras disks at the densest packing bound the sample count (plus a rim for the open boundary)
         int64_t cap = 2 * num_cameras + 8 * (int64_t)std::sqrt((double)(2 * num_cameras)) + 64;
         pos.resize((size_t)cap * 3 + 1); dir.resize((size_t)cap * 9 + 1);
+        // (the placement builds its own hierarchy for the downward rays while it throws its darts -- the longer of the
+        // two; the one for the occlusion rays is started afterwards and hides behind the sampling and the sweep)
         ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, cap, pos.data(), dir.data(), &n_cam));
         if (n_cam > cap) {                                  // same seed => same cameras
             cap = n_cam;
             pos.resize((size_t)cap * 3 + 1); dir.resize((size_t)cap * 9 + 1);
             ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, cap, pos.data(), dir.data(), &n_cam));
         }
+        start_bvh();
     }
     c2b_obj_free(obj);
     timer.mark("triangles + camera placement");
@@ -673,7 +679,7 @@ int run_generate(int argc, char **argv) {
     ck(c2b_problem_visibility_dense(p, max_dist, hp.row_ptr.data()));
     timer.mark("upload + dense sweep");
     if (own_bvh) {
-        bvh_builder.join();
+        if (bvh_builder.joinable()) bvh_builder.join();
         if (bvh_rc != C2B_OK) die(bvh_err);
         ck(c2b_problem_visibility_dense_occlude_bvh(p, bvh, hp.row_ptr.data()));
     } else {

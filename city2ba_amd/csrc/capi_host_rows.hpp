@@ -172,14 +172,14 @@ int c2b_generate_cameras_path(const c2b_obj *o, int64_t path_model, int64_t num_
     C2B_API_END("generate_cameras_path")
 }
 
-int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_points, double height, double ground,
-                                 uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out) {
+static int cameras_poisson_impl(const float *tri9, int64_t n_tri, const c2b_host::Bvh *ready, int64_t num_points, double height, double ground,
+                                uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out) {
     C2B_API_BEGIN
     if (!tri9 || n_tri <= 0 || num_points < 0 || capacity < 0 || !n_out || (capacity && (!cam_pos3 || !cam_dir9)))
         return fail(C2B_ERR_INVALID_ARGUMENT, "generate_cameras_poisson: bad arguments");
     const std::vector<float> tri(tri9, tri9 + 9 * n_tri);
     c2b_host::CameraSamples cs;
-    c2b_host::cameras_poisson(tri, num_points, height, ground, seed, cs);
+    c2b_host::cameras_poisson(tri, num_points, height, ground, seed, cs, ready);
     const int64_t n = std::min<int64_t>((int64_t)cs.size(), capacity);
     if (n) {
         std::copy(cs.pos.begin(), cs.pos.begin() + 3 * n, cam_pos3);
@@ -188,6 +188,16 @@ int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_p
     *n_out = (int64_t)cs.size();
     return C2B_OK;
     C2B_API_END("generate_cameras_poisson")
+}
+int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_points, double height, double ground,
+                                 uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out) {
+    return cameras_poisson_impl(tri9, n_tri, nullptr, num_points, height, ground, seed, capacity, cam_pos3, cam_dir9, n_out);
+}
+int c2b_generate_cameras_poisson_bvh(const float *tri9, int64_t n_tri, const c2b_bvh *bvh, int64_t num_points, double height,
+                                     double ground, uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9,
+                                     int64_t *n_out) {
+    if (!bvh) return fail(C2B_ERR_INVALID_ARGUMENT, "generate_cameras_poisson_bvh: bvh is NULL");
+    return cameras_poisson_impl(tri9, n_tri, &bvh->b, num_points, height, ground, seed, capacity, cam_pos3, cam_dir9, n_out);
 }
 
 int c2b_modify_intrinsics(double *cams15, int64_t n_cam, const double start[3], const double end[3], uint64_t seed) {

@@ -445,6 +445,11 @@ int c2b_generate_cameras_path(const c2b_obj *o, int64_t path_model, int64_t num_
  * min(*n_out, capacity) are written (same seed => same cameras, so call with capacity 0 to size the buffers). */
 int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_points, double height, double ground,
                                  uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out);
+/* the same with a hierarchy the caller already built over tri9 (c2b_bvh_build) for the downward rays; without one the
+ * function builds its own while it throws the darts.  The rays are cast on all host threads, gathered in sample order. */
+int c2b_generate_cameras_poisson_bvh(const float *tri9, int64_t n_tri, const c2b_bvh *bvh, int64_t num_points, double height,
+                                     double ground, uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9,
+                                     int64_t *n_out);
 /* modify_intrinsics (:530-544) */
 int c2b_modify_intrinsics(double *cams15, int64_t n_cam, const double start[3], const double end[3], uint64_t seed);
 /* generate_world_points_uniform (:356-420): area-weighted samples on the triangles that lie within max_dist of
