@@ -218,7 +218,7 @@ class BAProblem:
         s = self._stats()
         return s[15:18].copy(), int(s[18])
 
-    def visibility_graph(self, max_dist, triangles=None, fetch=True):
+    def visibility_graph(self, max_dist, triangles=None, fetch=True, prebuilt_hierarchy=False):
         """The camera x point sweep of generate::visibility_graph (src/generate.rs:424-481): every camera of
         the problem against every point; with `triangles` ([n,9] f32 mesh) the survivors also pass the occlusion
         rays of :455-476 (brute force over the triangles on the device in place of Embree).  Returns the CSR graph
@@ -228,7 +228,17 @@ class BAProblem:
         L.check(L.lib().c2b_problem_visibility_dense(self._h, float(max_dist), _ptr(row_ptr)))
         if triangles is not None:
             tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
-            L.check(L.lib().c2b_problem_visibility_dense_occlude(self._h, _ptr(tri), len(tri), _ptr(row_ptr)))
+            if prebuilt_hierarchy and len(tri):
+                # the caller-built form (c2b_bvh_build needs only the triangles: cli/main.cpp builds it on a second
+                # thread while cameras are placed and points sampled)
+                h = C.c_void_p()
+                L.check(L.lib().c2b_bvh_build(_ptr(tri), len(tri), C.byref(h)))
+                try:
+                    L.check(L.lib().c2b_problem_visibility_dense_occlude_bvh(self._h, h, _ptr(row_ptr)))
+                finally:
+                    L.lib().c2b_bvh_free(h)
+            else:
+                L.check(L.lib().c2b_problem_visibility_dense_occlude(self._h, _ptr(tri), len(tri), _ptr(row_ptr)))
         if not fetch:                     # lists stay on the device for adopt_visibility()
             return row_ptr
         n = int(row_ptr[-1])

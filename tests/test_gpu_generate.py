@@ -108,6 +108,10 @@ def test_visibility_graph_with_occlusion(c2b, seed, n_tri):
     assert np.array_equal(row, want_row)
     assert np.array_equal(pi, pi_k[~occ].astype(np.uint64))
     assert np.allclose(uv, uv_k[~occ], rtol=0, atol=1e-12)
+    # the hierarchy built by the caller (c2b_problem_visibility_dense_occlude_bvh; also for meshes below the size at which
+    # the library would build one itself): the same lists
+    row_b, pi_b, uv_b = ba.visibility_graph(max_dist, triangles=tri, prebuilt_hierarchy=True)
+    assert np.array_equal(row_b, row) and np.array_equal(pi_b, pi) and np.array_equal(uv_b, uv)
     # a second fetch after the filter returns the same lists; an empty mesh filters nothing
     row2, pi2, _ = ba.visibility_graph(max_dist, triangles=np.zeros((0, 9), f32))
     assert np.array_equal(row2, row0) and np.array_equal(pi2, pi0)

@@ -449,3 +449,40 @@ def test_file_errors(tmp_path):
         assert "does not have an extension" in str(ei.value)
     assert (tmp_path / "explicit_binary").read_bytes()[:8] == struct.pack(">Q", len(bal9))
     assert (tmp_path / "explicit_text").read_text().split("\n")[0] == "%d %d %d" % (len(bal9), len(pts), len(pt_idx))
+
+
+def test_poisson_placement_with_a_callers_hierarchy_equals_its_own():
+    """c2b_generate_cameras_poisson_bvh (the downward rays of src/generate.rs:240-262 through a hierarchy the caller built)
+    places the same cameras as the entry that builds its own; more samples than one thread's share of rays, so the
+    gathering in sample order is exercised."""
+    import ctypes as C
+    from city2ba_amd import _lib as L
+    from city2ba_amd.generate import generate_cameras_poisson
+    rng = np.random.default_rng(5)
+    n = 40
+    xs, zs = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32))
+    h = rng.uniform(0, 0.3, (n + 1, n + 1)).astype(np.float32)
+    tri = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = (i, h[i, j], j), (i + 1, h[i + 1, j], j), (i, h[i, j + 1], j + 1), (i + 1, h[i + 1, j + 1], j + 1)
+            tri += [a + b + c, b + d + c]
+    tri = np.array(tri, dtype=np.float32)
+    pos, dirs = generate_cameras_poisson(tri, 6000, 1.7, 100.0, seed=9)
+    assert len(pos) > 4096
+    bvh = C.c_void_p()
+    L.check(L.lib().c2b_bvh_build(tri.ctypes.data_as(C.c_void_p), len(tri), C.byref(bvh)))
+    try:
+        cap = 4 * 6000
+        p2, d2, m = np.empty((cap, 3)), np.empty((cap, 9)), C.c_int64()
+        L.check(L.lib().c2b_generate_cameras_poisson_bvh(tri.ctypes.data_as(C.c_void_p), len(tri), bvh, 6000, 1.7, 100.0, 9, cap,
+                                                         p2.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), C.byref(m)))
+    finally:
+        L.lib().c2b_bvh_free(bvh)
+    assert m.value == len(pos) and np.array_equal(p2[:m.value], pos) and np.array_equal(d2[:m.value], dirs)
+    # minimum distance of the blue-noise set (the nearest-cells-first rejection must reject exactly what the scan did)
+    r = np.sqrt(1.1547005383792515 / 12000) * (n - 0)
+    xy = pos[:, [0, 2]]
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(xy).query(xy, k=2)
+    assert d[:, 1].min() >= r * (1 - 1e-6)
