@@ -22,10 +22,28 @@ _u64 = C.c_uint64
 _d = C.c_double
 
 
+def _digest():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("city2ba_oracle.c", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "city2ba_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    """rebuilt when the SOURCE TEXT changed (a digest next to the library), not by time stamps: a snapshot of the tree on
+    another machine does not keep their order"""
+    stamp = _SO + ".stamp"
+    try:
+        with open(stamp) as fh:
+            fresh = os.path.exists(_SO) and fh.read().strip() == _digest()
+    except OSError:
+        fresh = False
+    if force or not fresh:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+        with open(stamp, "w") as fh:
+            fh.write(_digest() + "\n")
     return _SO
 
 
