@@ -38,9 +38,13 @@
 
 namespace {
 
+// Leaves at once: std::exit would run static destructors (the HIP runtime's among them) while a helper thread -- the
+// mesh loader, the hierarchy builder of run_generate -- may still be running.
 [[noreturn]] void die(const std::string &msg) {
+    std::fflush(stdout);
     std::fprintf(stderr, "Error: %s\n", msg.c_str());
-    std::exit(1);
+    std::fflush(stderr);
+    std::_Exit(1);
 }
 
 void ck(int rc) {

@@ -290,8 +290,8 @@ static int file_to_device(int fd, size_t bytes, char *dev) {
 }
 
 // from_file_text (src/baproblem.rs:580-629) on the device (text_kernels.hpp).  *handled = false: the device declined --
-// a small file, a spelling or a digit count decimal.hpp leaves to strtod, observations not in camera order, counts that
-// do not fit the file, an index out of range -- and the caller runs the host parser, which owns every corner of the
+// a small file, a spelling or a digit count decimal.hpp leaves to strtod, counts that do not fit the file, an index out
+// of range -- and the caller runs the host parser, which owns every corner of the
 // grammar and the wording of every error.  The problem is replaced only after the whole file has parsed.
 static int read_text_device(c2b_problem *p, const char *path, bool *handled) {
     *handled = false;
@@ -368,12 +368,56 @@ static int read_text_device(c2b_problem *p, const char *path, bool *handled) {
     if (e == hipSuccess) e = hipMemcpyAsync(fl, flags.ptr, 16, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
-    if (fl[0] || fl[1] || fl[2] || fl[3]) return C2B_OK;
+    if (fl[0] || fl[1] || fl[2]) return C2B_OK;
+    DevBuf s_cam, s_pt, s_uv;                               // the camera-major lists when the file's are not
+    if (fl[3]) {
+        // BAProblem::new's per-camera push in file order = a stable sort by camera (text_kernels.hpp: k_sort_*): 8 bits
+        // a pass over (camera, position in the file), then one gather of the point indices and the observations
+        const int64_t n = (int64_t)no, n_st = (n + kSortTile - 1) / kSortTile, n_hist = 256 * n_st;
+        DevBuf k2, v1, v2, hist, offs, tiles, total32;
+        e = k2.alloc(4 * (size_t)n);
+        if (e == hipSuccess) e = v1.alloc(4 * (size_t)n);
+        if (e == hipSuccess) e = v2.alloc(4 * (size_t)n);
+        if (e == hipSuccess) e = hist.alloc(4 * (size_t)n_hist);
+        if (e == hipSuccess) e = offs.alloc(4 * (size_t)n_hist);
+        if (e == hipSuccess) e = tiles.alloc(4 * (size_t)(n_hist / kScanTile + 2));
+        if (e == hipSuccess) e = total32.alloc(4);
+        if (e == hipSuccess) e = s_cam.alloc(4 * (size_t)n);
+        if (e == hipSuccess) e = s_pt.alloc(4 * (size_t)n);
+        if (e == hipSuccess) e = s_uv.alloc(16 * (size_t)n);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+        int bits = 1;
+        while (bits < 32 && (nc - 1) >> bits) ++bits;
+        // keys ping-pong between t_cam / k2 so that the last pass lands in s_cam; values between v1 / v2
+        const int passes = (bits + 7) / 8;
+        const uint32_t *k_in = t_cam.as<uint32_t>(), *v_in = nullptr;
+        for (int ps = 0; ps < passes; ++ps) {
+            uint32_t *k_out = ps == passes - 1 ? s_cam.as<uint32_t>() : (ps % 2 == 0 ? k2.as<uint32_t>() : t_cam.as<uint32_t>());
+            uint32_t *v_out = ps % 2 == 0 ? v1.as<uint32_t>() : v2.as<uint32_t>();
+            hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)n_st), dim3(64), 0, st, k_in, n, 8 * ps, n_st, hist.as<uint32_t>());
+            uint32_t sum = 0;
+            e = scan_flags(st, hist.as<uint32_t>(), n_hist, offs.as<uint32_t>(), tiles.as<uint32_t>(), total32.as<uint32_t>(), &sum);
+            if (e == hipSuccess && (int64_t)sum != n) return fail(C2B_ERR_HIP, "problem_read: the sort's histogram does not add up");
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)n_st), dim3(64), 0, st, k_in, v_in, n, 8 * ps, n_st, (const uint32_t *)offs.as<uint32_t>(),
+                                   k_out, v_out);
+                e = launch_error();
+            }
+            if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+            k_in = k_out; v_in = v_out;
+        }
+        hipLaunchKernelGGL(k_text_gather_obs, dim3(blocks_of(n, 256)), dim3(256), 0, st, v_in, n, (const uint32_t *)t_pt.as<uint32_t>(),
+                           (const double2 *)t_uv.as<double2>(), s_pt.as<uint32_t>(), s_uv.as<double2>());
+        e = launch_error();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
+    }
+    const void *f_cam = fl[3] ? s_cam.ptr : t_cam.ptr, *f_pt = fl[3] ? s_pt.ptr : t_pt.ptr, *f_uv = fl[3] ? s_uv.ptr : t_uv.ptr;
     rc = alloc_problem(p, (int64_t)nc, (int64_t)np, (int64_t)no);
     if (rc) return rc;
-    if (no) e = hipMemcpyAsync(p->cam_idx, t_cam.ptr, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess && no) e = hipMemcpyAsync(p->pt_idx, t_pt.ptr, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess && no) e = hipMemcpyAsync(p->uv, t_uv.ptr, 16 * (size_t)no, hipMemcpyDeviceToDevice, st);
+    if (no) e = hipMemcpyAsync(p->cam_idx, f_cam, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && no) e = hipMemcpyAsync(p->pt_idx, f_pt, 4 * (size_t)no, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && no) e = hipMemcpyAsync(p->uv, f_uv, 16 * (size_t)no, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && nc) e = hipMemcpyAsync(p->bal9, t_bal.ptr, 72 * (size_t)nc, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && np) e = hipMemcpyAsync(p->pts4, t_pts.ptr, 32 * (size_t)np, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { free_buffers(p); return fail(C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e)); }

@@ -290,3 +290,79 @@ __global__ __launch_bounds__(256) void k_text_check_sorted(const uint32_t *__res
 }
 
 __device__ c2b_dec::ParseTables g_parse_tables;
+
+// ---- observations that are not in camera order ----------------------------------------------------------------------
+// BAProblem::new (src/baproblem.rs:342-355) pushes every observation onto its camera's list in FILE order: a stable sort
+// of the observations by camera.  The files of the generators are camera-major already; the Bundle Adjustment in the
+// Large datasets list their observations point by point.  A least-significant-digit radix sort, 8 bits a pass, of
+// (camera, index of the observation in the file): per pass a histogram per tile, one scan over [digit][tile] (which is
+// exactly the order "smaller digit first, then earlier tile"), and a scatter in which one wave walks its tile 64 keys
+// at a time -- the lanes holding the same digit find each other with eight ballots, their order among themselves is
+// their lane order, and the tile's running count per digit lives in LDS -- so every pass is stable by construction.
+constexpr int kSortTile = 2048;                              // keys per wave
+
+__global__ __launch_bounds__(64) void k_sort_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int64_t n_tiles,
+                                                  uint32_t *__restrict__ hist) {
+    __shared__ uint32_t cnt[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) cnt[d] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    for (int c = 0; c < kSortTile; c += 64) {
+        const int64_t i = base + c + lane;
+        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < 256; d += 64) hist[(int64_t)d * n_tiles + blockIdx.x] = cnt[d];
+}
+
+// vals_in == nullptr: the value of key i is i (the first pass)
+__global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n,
+                                                     int shift, int64_t n_tiles, const uint32_t *__restrict__ offs,
+                                                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    __shared__ uint32_t at[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) at[d] = offs[(int64_t)d * n_tiles + blockIdx.x];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int c = 0; c < kSortTile; c += 64) {
+        const int64_t i = base + c + lane;
+        if (base + c >= n) break;                             // wave-uniform
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t val = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        uint64_t same = __builtin_amdgcn_ballot_w64(valid);  // the lanes of this chunk with my digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t has = __builtin_amdgcn_ballot_w64(((d >> b) & 1u) != 0);
+            same &= ((d >> b) & 1u) ? has : ~has;
+        }
+        const uint32_t start = at[d];                         // every lane of `same` reads the same count ...
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint32_t dst = start + (uint32_t)__builtin_popcountll(same & below);
+            keys_out[dst] = key;
+            vals_out[dst] = val;
+            if ((same & below) == 0) at[d] = start + (uint32_t)__builtin_popcountll(same);      // ... its first lane moves it on
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the observations in their sorted order: perm[j] = position in the file of the j-th observation of the camera-major list
+__global__ __launch_bounds__(256) void k_text_gather_obs(const uint32_t *__restrict__ perm, int64_t n, const uint32_t *__restrict__ pt_in,
+                                                         const double2 *__restrict__ uv_in, uint32_t *__restrict__ pt_out,
+                                                         double2 *__restrict__ uv_out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = perm[j];
+    pt_out[j] = pt_in[i];
+    uv_out[j] = uv_in[i];
+}

@@ -174,7 +174,7 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
     """from_file_text (src/baproblem.rs:580-629) on the device (r04: csrc/text_kernels.hpp -- tokens ranked by a scan,
     every number rounded by csrc/decimal.hpp: Clinger's exact case or Eisel-Lemire): the resident state equals the host
     parser's (strtod) bit for bit.  C2B_TEXT_DEVICE_STRICT makes a file the device declines an error, so these are the
-    device's own results; files it must decline (observations out of camera order, NaN, more than 19 digits, glued numbers,
+    device's own results; files it must decline (NaN, more than 19 digits, glued numbers,
     an index out of range) reach the host parser and come back as its result or its error."""
     from city2ba_amd.baproblem import read_bal, write_bal
     rng = np.random.default_rng(31)
@@ -211,8 +211,6 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
     _same_state(a2, b)
     # what the device must decline
     declined = {}
-    # (two observation lines of different cameras swapped)
-    declined["unsorted"] = "\n".join(lines[:1] + [lines[len(uv)]] + lines[2:len(uv)] + [lines[1]] + lines[len(uv) + 1:])
     declined["nan"] = "\n".join(lines[:2] + [lines[2].rsplit(" ", 1)[0] + " NaN"] + lines[3:])
     declined["digits"] = "\n".join(lines[:2] + [lines[2].rsplit(" ", 1)[0] + " 0.12345678901234567890123"] + lines[3:])
     declined["glued"] = "\n".join(lines[:2] + [lines[2].rsplit(" ", 1)[0] + "-1.5"] + lines[3:])
@@ -222,7 +220,7 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
         with pytest.raises(c2b.City2baError, match="declined"):
             c2b.BAProblem.from_file(q)
     monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
-    for name in ("unsorted", "digits", "glued"):               # ... and the host parser takes them
+    for name in ("digits", "glued"):                           # ... and the host parser takes them
         q = str(tmp_path / (name + ".bal"))
         x, y = c2b.BAProblem.from_file(q), c2b.BAProblem.from_bal(*read_bal(q))
         _same_state(x, y)
@@ -283,3 +281,35 @@ def test_both_file_forms_round_trip_at_the_headline_size(c2b, tmp_path):
     finally:
         del os.environ["C2B_TEXT_DEVICE_STRICT"]
     g.close()
+
+
+@pytest.mark.parametrize("n_cam,n_pts,per_cam,order", [(300, 2000, 9, "point"), (70_001, 3000, 4, "random"), (1, 50, 30, "random")])
+def test_text_file_in_any_observation_order_is_sorted_on_the_device(c2b, tmp_path, monkeypatch, n_cam, n_pts, per_cam, order):
+    """BAProblem::new pushes observations onto their camera's list in FILE order (src/baproblem.rs:347-353).  The Bundle
+    Adjustment in the Large datasets list observations point by point, not camera by camera: the device reader then
+    sorts them by camera, stably (csrc/text_kernels.hpp: k_sort_*, one to three 8-bit passes for these camera counts)
+    -- the same lists, in the same order, as the host parser's sequential push."""
+    from city2ba_amd.baproblem import read_bal, write_bal
+    rng = np.random.default_rng(41)
+    P = random_problem(n_cam, n_pts, per_cam, seed=42, noise=1e-3, empty_every=7 if n_cam > 1 else 0)
+    path = str(tmp_path / "sorted.bal")
+    write_bal(path, P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    lines = open(path).read().split("\n")
+    n_obs = len(P["pt_idx"])
+    obs = lines[1:1 + n_obs]
+    if order == "point":                                       # stable by point index: the BAL datasets' order
+        obs = [obs[i] for i in np.argsort(P["pt_idx"], kind="stable")]
+    else:
+        obs = [obs[i] for i in rng.permutation(n_obs)]
+    mixed = str(tmp_path / "mixed.bal")
+    open(mixed, "w").write("\n".join(lines[:1] + obs + lines[1 + n_obs:]))
+    monkeypatch.setenv("C2B_TEXT_DEVICE_MIN_BYTES", "0")
+    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    d = c2b.BAProblem.from_file(mixed)
+    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+    h = c2b.BAProblem.from_bal(*read_bal(mixed))              # the host parser: sequential per-camera push
+    _same_state(d, h)
+    assert np.array_equal(d.row_ptr, P["row_ptr"])
+    if n_cam > 1:
+        assert not np.array_equal(d.pt_idx, P["pt_idx"])      # file order within a camera, not the sorted file's
+    d.close(); h.close()
