@@ -218,14 +218,19 @@ class BAProblem:
         s = self._stats()
         return s[15:18].copy(), int(s[18])
 
-    def visibility_graph(self, max_dist, triangles=None, fetch=True, prebuilt_hierarchy=False):
-        """The camera x point sweep of generate::visibility_graph (src/generate.rs:424-481): every camera of
-        the problem against every point; with `triangles` ([n,9] f32 mesh) the survivors also pass the occlusion
-        rays of :455-476 (brute force over the triangles on the device in place of Embree).  Returns the CSR graph
-        (row_ptr u64, pt_idx u64, uv) with points in ascending order per camera, like the reference's push order."""
+    def visibility_graph(self, max_dist, triangles=None, fetch=True, prebuilt_hierarchy=False, dense=False):
+        """generate::visibility_graph (src/generate.rs:424-481): for every camera the points within max_dist of its centre
+        (`locate_within_distance`) that pass the predicate -- through the cell list of c2b_problem_visibility_within_distance,
+        or, with dense=True, by the brute-force sweep of every camera against every point (the same lists: the sweep is
+        what BASELINE's 1e10-pair configuration times); with `triangles` ([n,9] f32 mesh) the survivors also pass the
+        occlusion rays of :455-476 (a hierarchy on the device in place of Embree).  Returns the CSR graph (row_ptr u64,
+        pt_idx u64, uv) with points in ascending order per camera, like the reference's push order."""
         n_cam = self.num_cameras()
         row_ptr = np.zeros(n_cam + 1, dtype=np.uint64)
-        L.check(L.lib().c2b_problem_visibility_dense(self._h, float(max_dist), _ptr(row_ptr)))
+        if dense:
+            L.check(L.lib().c2b_problem_visibility_dense(self._h, float(max_dist), _ptr(row_ptr)))
+        else:
+            L.check(L.lib().c2b_problem_visibility_within_distance(self._h, float(max_dist), 0, 0.0, 0.0, _ptr(row_ptr)))
         if triangles is not None:
             tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
             if prebuilt_hierarchy and len(tri):

@@ -677,11 +677,15 @@ int run_generate(int argc, char **argv) {
     timer.mark("centres + world points");
     std::printf("Generated %lld world points\n", (long long)hp.n_pts);
 
-    // visibility_graph, src/generate.rs:424-481: dense (camera, point) sweep, then the occlusion rays
+    // visibility_graph, src/generate.rs:424-481: the points within max_dist of every camera that pass the predicate (the
+    // cell list of the synthetic generators stands in for rstar here too since r04: the same lists as the brute-force
+    // sweep of every camera against every point, 4x sooner at these sizes; C2B_DENSE_SWEEP=1 selects the sweep), then
+    // the occlusion rays
     ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), rows.data(), nullptr, nullptr));
     hp.row_ptr.assign((size_t)n_cam + 1, 0);
-    ck(c2b_problem_visibility_dense(p, max_dist, hp.row_ptr.data()));
-    timer.mark("upload + dense sweep");
+    if (std::getenv("C2B_DENSE_SWEEP")) ck(c2b_problem_visibility_dense(p, max_dist, hp.row_ptr.data()));
+    else ck(c2b_problem_visibility_within_distance(p, max_dist, 0, 0.0, 0.0, hp.row_ptr.data()));
+    timer.mark("upload + candidates within max_dist + predicate");
     if (own_bvh) {
         if (bvh_builder.joinable()) bvh_builder.join();
         if (bvh_rc != C2B_OK) die(bvh_err);

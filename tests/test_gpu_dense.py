@@ -33,7 +33,7 @@ def test_dense_matches_oracle_on_grids(c2b, blocks, cpb, ppb, L, max_dist):
     cams, pts = grid_cameras_points(blocks, cpb=cpb, ppb=ppb, L=L)
     want = _oracle_dense(cams, pts, max_dist)
     ba = c2b.BAProblem.from_visibility(cams, pts, np.zeros(len(cams) + 1, dtype=np.uint64), [], np.zeros((0, 2)))
-    row_ptr, pt_idx, uv = ba.visibility_graph(max_dist)
+    row_ptr, pt_idx, uv = ba.visibility_graph(max_dist, dense=True)
     assert np.array_equal(row_ptr, want[0]) and np.array_equal(pt_idx, want[1])       # indices: exact, in order
     assert np.array_equal(uv, want[2])                                                 # k2 == 0: bit-exact
     assert len(pt_idx) > 100
@@ -47,12 +47,12 @@ def test_dense_random_cameras_ragged_sizes(c2b):
     with O.pow4_mode(1):                                       # k2 != 0: correctly rounded |p|^4, like the device
         want = _oracle_dense(cams, pts, 6.0)
     ba = c2b.BAProblem.from_visibility(cams, pts, np.zeros(len(cams) + 1, dtype=np.uint64), [], np.zeros((0, 2)))
-    row_ptr, pt_idx, uv = ba.visibility_graph(6.0)
+    row_ptr, pt_idx, uv = ba.visibility_graph(6.0, dense=True)
     assert np.array_equal(row_ptr, want[0]) and np.array_equal(pt_idx, want[1])
     assert np.array_equal(uv, want[2])                          # bit-exact with distortion on
     assert (np.diff(row_ptr.astype(np.int64)) == 0).any() and len(pt_idx) > 50
     # degenerate: no points within range
-    row_ptr, pt_idx, uv = ba.visibility_graph(0.0)
+    row_ptr, pt_idx, uv = ba.visibility_graph(0.0, dense=True)
     assert int(row_ptr[-1]) == 0 and len(pt_idx) == 0
 
 
@@ -61,7 +61,7 @@ def test_dense_boundary_distance_is_decided_exactly(c2b):
     cam = O.camera_from_bal([0, 0, 0, 0, 0, 0, 1.0, 0, 0])
     pts = np.array([[0, 0, -5.0], [0, 0, -np.nextafter(5.0, 0.0)], [3.0, 0, -4.0], [0.3, 0.4, -np.sqrt(24.75)]])
     ba = c2b.BAProblem.from_visibility(cam, pts, np.zeros(2, dtype=np.uint64), [], np.zeros((0, 2)))
-    row_ptr, pt_idx, uv = ba.visibility_graph(5.0)
+    row_ptr, pt_idx, uv = ba.visibility_graph(5.0, dense=True)
     want = _oracle_dense(cam, pts, 5.0)
     assert np.array_equal(pt_idx, want[1]) and np.array_equal(uv, want[2])
     assert 0 not in pt_idx and 1 in pt_idx
@@ -116,7 +116,7 @@ def test_predicate_at_the_u_equals_one_boundary_with_k2(c2b, k1, k2):
     uv_d, keep_d = ba.visibility_pairs(ci, pi, 10.0)
     assert np.array_equal(keep_d, keep_cr), "pair-list predicate must keep exactly the oracle's set"
     assert np.array_equal(uv_d.view(np.uint64), uv_cr.view(np.uint64)), "uv bits"
-    row_ptr, pt_idx, uv_s = ba.visibility_graph(10.0)
+    row_ptr, pt_idx, uv_s = ba.visibility_graph(10.0, dense=True)
     kept = np.nonzero(keep_cr == 1)[0]
     assert np.array_equal(pt_idx, kept.astype(np.uint64)) and int(row_ptr[-1]) == len(kept)
     assert np.array_equal(uv_s.view(np.uint64), uv_cr[kept].view(np.uint64))

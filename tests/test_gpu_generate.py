@@ -93,7 +93,11 @@ def test_visibility_graph_with_occlusion(c2b, seed, n_tri):
     empty = np.zeros(n_cam + 1, dtype=np.uint64)
     ba = c2b.BAProblem.from_visibility(cams, pts, empty, [], np.zeros((0, 2)))
     row0, pi0, uv0 = ba.visibility_graph(max_dist)
+    row_d, pi_d, uv_d = ba.visibility_graph(max_dist, dense=True)         # the brute-force sweep: the same lists, bit for bit
+    assert np.array_equal(row_d, row0) and np.array_equal(pi_d, pi0) and np.array_equal(uv_d.view(np.uint64), uv0.view(np.uint64))
+    row_t, pi_t, uv_t = ba.visibility_graph(max_dist, triangles=tri, dense=True)
     row, pi, uv = ba.visibility_graph(max_dist, triangles=tri)
+    assert np.array_equal(row_t, row) and np.array_equal(pi_t, pi) and np.array_equal(uv_t.view(np.uint64), uv.view(np.uint64))
     # checker: the oracle's predicate over all pairs, then the numpy rays over the survivors
     ci_all = np.repeat(np.arange(n_cam, dtype=np.uint32), n_pts)
     pi_all = np.tile(np.arange(n_pts, dtype=np.uint32), n_cam)
