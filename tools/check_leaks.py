@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device-memory leak check of the Level-1 object: many create / upload / sweep / occlude / adopt / cull / noise /
 destroy cycles must leave the free-memory reading where it started.
-python tools/check_leaks.py [--cycles 60] [--what all|grid|noise|index|jac|generate|dense]"""
+python tools/check_leaks.py [--cycles 60] [--what all|grid|noise|index|jac|generate|dense|files|each]"""
 import argparse
 import gc
 import os
@@ -37,6 +37,23 @@ def cycle(k, what):
             ba.total_reprojection_error(2.0)
             ba.residual_jacobian()
         ba.close()
+    if what in ("all", "files"):
+        # both file forms written and read back on the device (r04): .bbal words, .bal decimal text, and a text file whose
+        # observations are not camera-major (the device's stable sort)
+        import tempfile
+        import numpy as np
+        os.environ["C2B_TEXT_DEVICE_MIN_BYTES"] = "0"
+        ba = S.synthetic_grid(10, 20, 3, 5.0, 1.0, 1.0, 1.0, 10.0, False)
+        with tempfile.TemporaryDirectory() as d:
+            for ext in ("bbal", "bal"):
+                ba.write(os.path.join(d, "p." + ext))
+                c2b.BAProblem.from_file(os.path.join(d, "p." + ext)).close()
+            lines = open(os.path.join(d, "p.bal")).read().split("\n")
+            n = ba.num_observations()
+            obs = [lines[1 + i] for i in np.random.default_rng(k).permutation(n)]
+            open(os.path.join(d, "m.bal"), "w").write("\n".join(lines[:1] + obs + lines[1 + n:]))
+            c2b.BAProblem.from_file(os.path.join(d, "m.bal")).close()
+        ba.close()
     if what in ("all", "generate", "dense"):
         g = G.generate(scene, num_cameras=60, num_world_points=400, path_name="path", seed=k)
         if what in ("all", "dense"):
@@ -51,7 +68,7 @@ def free_mib():
 
 
 worst = 0.0
-for what in (["grid", "noise", "index", "jac", "generate", "dense"] if a.what == "each" else [a.what]):
+for what in (["grid", "noise", "index", "jac", "generate", "dense", "files"] if a.what == "each" else [a.what]):
     cycle(0, what)
     f0 = free_mib()
     for k in range(a.cycles):
