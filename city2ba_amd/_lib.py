@@ -183,6 +183,7 @@ SIGNATURES = {
     "c2b_problem_visibility_dense_fetch": (_int, [_vp, _vp, _vp]),
     "c2b_problem_visibility_dense_occlude": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_problem_visibility_dense_occlude_bvh": (_int, [_vp, _vp, _vp]),
+    "c2b_problem_generate_world_points": (_int, [_vp, _vp, _i64, _i64, _d, _u64, C.POINTER(_i64)]),
     "c2b_problem_add_drift": (_int, [_vp, _d, _d, _d, _vp, _u64]),
     "c2b_problem_add_drift_normalized": (_int, [_vp, _d, _d, _d, _u64]),
     "c2b_problem_add_noise": (_int, [_vp, _d, _d, _d, _d, _u64]),

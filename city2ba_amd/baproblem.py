@@ -218,6 +218,16 @@ class BAProblem:
         s = self._stats()
         return s[15:18].copy(), int(s[18])
 
+    def generate_world_points(self, triangles, num_points, max_dist, seed=0):
+        """generate_world_points_uniform (src/generate.rs:356-420) for this problem's cameras, on the device: its points
+        are replaced by `num_points` points sampled on the mesh by area, each within max_dist of some camera (the same
+        points as generate.generate_world_points_uniform with the same seed).  The problem must hold no observations."""
+        tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
+        n = C.c_int64()
+        L.check(L.lib().c2b_problem_generate_world_points(self._h, _ptr(tri), len(tri), int(num_points), float(max_dist),
+                                                          int(seed), C.byref(n)))
+        return n.value
+
     def visibility_graph(self, max_dist, triangles=None, fetch=True, prebuilt_hierarchy=False, dense=False):
         """generate::visibility_graph (src/generate.rs:424-481): for every camera the points within max_dist of its centre
         (`locate_within_distance`) that pass the predicate -- through the cell list of c2b_problem_visibility_within_distance,

@@ -666,26 +666,30 @@ int run_generate(int argc, char **argv) {
     timer.mark("from_position_direction + intrinsics");
     std::printf("Modified intrinsics\n");
 
-    std::vector<double> centers((size_t)n_cam * 3 + 1);
     std::vector<uint64_t> rows((size_t)n_cam + 1, 0);
-    if (n_cam) {
-        ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), 0, nullptr, rows.data(), nullptr, nullptr));
-        ck(c2b_problem_centers(p, centers.data()));
+    ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), 0, nullptr, rows.data(), nullptr, nullptr));
+    // generate_world_points_uniform on the resident cameras (r04: candidates evaluated on the device, the host sampler's
+    // points bit for bit; C2B_HOST_SAMPLER=1 = the host sampler and a second upload)
+    if (std::getenv("C2B_HOST_SAMPLER")) {
+        std::vector<double> centers((size_t)n_cam * 3 + 1);
+        if (n_cam) ck(c2b_problem_centers(p, centers.data()));
+        hp.pts.resize((size_t)num_points * 3 + 1);
+        ck(c2b_generate_world_points(tri.data(), n_tri, centers.data(), n_cam, num_points, max_dist, seed + 2, hp.pts.data(), &hp.n_pts));
+        ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), rows.data(), nullptr, nullptr));
+    } else {
+        ck(c2b_problem_generate_world_points(p, tri.data(), n_tri, num_points, max_dist, seed + 2, &hp.n_pts));
     }
-    hp.pts.resize((size_t)num_points * 3 + 1);
-    ck(c2b_generate_world_points(tri.data(), n_tri, centers.data(), n_cam, num_points, max_dist, seed + 2, hp.pts.data(), &hp.n_pts));
-    timer.mark("centres + world points");
+    timer.mark("world points");
     std::printf("Generated %lld world points\n", (long long)hp.n_pts);
 
     // visibility_graph, src/generate.rs:424-481: the points within max_dist of every camera that pass the predicate (the
     // cell list of the synthetic generators stands in for rstar here too since r04: the same lists as the brute-force
     // sweep of every camera against every point, 4x sooner at these sizes; C2B_DENSE_SWEEP=1 selects the sweep), then
     // the occlusion rays
-    ck(c2b_problem_upload(p, n_cam, hp.cams15.data(), hp.n_pts, hp.pts.data(), rows.data(), nullptr, nullptr));
     hp.row_ptr.assign((size_t)n_cam + 1, 0);
     if (std::getenv("C2B_DENSE_SWEEP")) ck(c2b_problem_visibility_dense(p, max_dist, hp.row_ptr.data()));
     else ck(c2b_problem_visibility_within_distance(p, max_dist, 0, 0.0, 0.0, hp.row_ptr.data()));
-    timer.mark("upload + candidates within max_dist + predicate");
+    timer.mark("candidates within max_dist + predicate");
     if (own_bvh) {
         if (bvh_builder.joinable()) bvh_builder.join();
         if (bvh_rc != C2B_OK) die(bvh_err);

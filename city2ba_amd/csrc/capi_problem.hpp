@@ -1157,6 +1157,136 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
     C2B_API_END("problem_visibility_within_distance")
 }
 
+// generate_world_points_uniform (src/generate.rs:356-420) for the cameras of the resident problem, on the device
+// (cell_kernels.hpp: k_world_*): the problem's points are REPLACED by the sampled ones (its observations must be empty).
+// Candidate k draws from the k-th splitmix64 stream of `seed` exactly like c2b_generate_world_points, and candidates are
+// accepted in order, so the points are that function's, bit for bit.  tri9: HOST triangles [n_tri][9] f32.
+int c2b_problem_generate_world_points(c2b_problem *p, const float *tri9, int64_t n_tri, int64_t num_points, double max_dist,
+                                      uint64_t seed, int64_t *n_out) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_generate_world_points");
+    if (!tri9 || n_tri < 0 || num_points < 0 || !n_out || num_points >= ((int64_t)1 << 31))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_generate_world_points: bad arguments");
+    if (p->n_obs != 0) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_generate_world_points: the problem already has observations");
+    if (p->n_cam == 0)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "Cannot generate world points with 0 cameras. Try increasing the number of cameras generated (via --cameras).");
+    if (n_tri == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "the model has no triangles");
+    int rc = ensure_camblk(p);
+    if (rc) return rc;
+    hipStream_t st = p->stream;
+    const int64_t n_cam = p->n_cam;
+    // triangle areas and their running sum, on the host in the host sampler's own arithmetic (a sequential sum: 1 ms)
+    std::vector<double> cum((size_t)n_tri);
+    {
+        double acc = 0.0;
+        for (int64_t t = 0; t < n_tri; ++t) {
+            const float *q = tri9 + 9 * t;
+            const double a[3] = {(double)q[3] - (double)q[0], (double)q[4] - (double)q[1], (double)q[5] - (double)q[2]};
+            const double b[3] = {(double)q[6] - (double)q[0], (double)q[7] - (double)q[1], (double)q[8] - (double)q[2]};
+            const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            acc += std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) / 2.0;
+            cum[(size_t)t] = acc;
+        }
+    }
+    // the cell list over the camera centres
+    DevBuf centres, d_tri, d_cum;
+    hipError_t e = centres.alloc(32 * (size_t)n_cam);
+    if (e == hipSuccess) e = d_tri.alloc(36 * (size_t)n_tri);
+    if (e == hipSuccess) e = d_cum.alloc(8 * (size_t)n_tri);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tri.ptr, tri9, 36 * (size_t)n_tri, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cum.ptr, cum.data(), 8 * (size_t)n_tri, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_generate_world_points: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_centres4, dim3(blocks_of(n_cam, 256)), dim3(256), 0, st, (const double *)p->camblk, n_cam, centres.as<double4>());
+    // the centres' extent (a reduction the statistics kernel already is: cameras only)
+    double stats[C2B_STATS_DOUBLES];
+    rc = c2b_stats(p->camblk, n_cam, p->pts4, 0, p->ws, p->stats, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stats, p->stats, sizeof stats, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    CellGrid g;
+    g.x0 = stats[6]; g.z0 = stats[8];
+    const double ex = stats[9] - stats[6], ez = stats[11] - stats[8];
+    double cs = (max_dist > 0.0 ? max_dist : 1.0) * (1.0 + 0x1.0p-20);
+    if (!(ex >= 0.0) || !(ez >= 0.0) || !std::isfinite(ex) || !std::isfinite(ez) || !std::isfinite(cs))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_generate_world_points: non-finite coordinates");
+    auto cells = [&](double c) { return (std::floor(ex / c) + 1.0) * (std::floor(ez / c) + 1.0); };
+    while (cells(cs) > (double)(1 << 24)) cs *= 2.0;
+    g.inv_cs = 1.0 / cs;
+    g.ncx = (int)std::floor(ex / cs) + 1; g.ncz = (int)std::floor(ez / cs) + 1;
+    const int64_t n_cells = (int64_t)g.ncx * g.ncz;
+    const int64_t chunk = std::max<int64_t>(4096, std::min<int64_t>(num_points, (int64_t)1 << 20));      // the host sampler's chunks
+    DevBuf cell_of, counts, startb, sorted, tiles, total, cand, ok, pos, cutoff, out;
+    const int64_t big = std::max(n_cells + 1, chunk);
+    e = cell_of.alloc(4 * (size_t)n_cam);
+    if (e == hipSuccess) e = counts.alloc(4 * (size_t)(n_cells + 1));
+    if (e == hipSuccess) e = startb.alloc(4 * (size_t)(n_cells + 1));
+    if (e == hipSuccess) e = sorted.alloc(4 * (size_t)n_cam);
+    if (e == hipSuccess) e = tiles.alloc(4 * (size_t)(big / kScanTile + 2));
+    if (e == hipSuccess) e = total.alloc(4);
+    if (e == hipSuccess) e = cand.alloc(32 * (size_t)chunk);
+    if (e == hipSuccess) e = ok.alloc(4 * (size_t)chunk);
+    if (e == hipSuccess) e = pos.alloc(4 * (size_t)chunk);
+    if (e == hipSuccess) e = cutoff.alloc(8);
+    if (e == hipSuccess) e = out.alloc(32 * (size_t)std::max<int64_t>(num_points, 1));
+    if (e == hipSuccess) e = hipMemsetAsync(counts.ptr, 0, 4 * (size_t)(n_cells + 1), st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_generate_world_points: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_cells_assign, dim3(blocks_of(n_cam, 256)), dim3(256), 0, st, (const double4 *)centres.as<double4>(), n_cam, g,
+                       cell_of.as<uint32_t>(), counts.as<uint32_t>());
+    uint32_t n_sorted = 0;
+    e = scan_flags(st, counts.as<uint32_t>(), n_cells + 1, startb.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &n_sorted);
+    if (e == hipSuccess && (int64_t)n_sorted != n_cam) return fail(C2B_ERR_HIP, "problem_generate_world_points: cell counts do not add up");
+    if (e == hipSuccess) e = hipMemsetAsync(counts.ptr, 0, 4 * (size_t)(n_cells + 1), st);
+    if (e == hipSuccess)
+        hipLaunchKernelGGL(k_cells_fill, dim3(blocks_of(n_cam, 256)), dim3(256), 0, st, (const uint32_t *)cell_of.as<uint32_t>(), n_cam,
+                           (const uint32_t *)startb.as<uint32_t>(), counts.as<uint32_t>(), sorted.as<uint32_t>());
+    if (e == hipSuccess) e = launch_error();
+    // the reference's loop, a chunk of candidates at a time
+    int64_t accepted = 0, failed = 0;
+    const int64_t fail_threshold = 10 * num_points;
+    for (int64_t k0 = 0; e == hipSuccess && accepted < num_points && failed < fail_threshold; k0 += chunk) {
+        const unsigned long long all = (unsigned long long)chunk;
+        e = hipMemcpyAsync(cutoff.ptr, &all, 8, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_world_candidates, dim3(blocks_of(chunk, 256)), dim3(256), 0, st, (const float *)d_tri.as<float>(), n_tri,
+                           (const double *)d_cum.as<double>(), seed, k0, chunk, (const double4 *)centres.as<double4>(), g,
+                           (const uint32_t *)startb.as<uint32_t>(), (const uint32_t *)sorted.as<uint32_t>(), max_dist, cand.as<double4>(),
+                           ok.as<uint32_t>());
+        uint32_t n_ok = 0;
+        e = scan_flags(st, ok.as<uint32_t>(), chunk, pos.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &n_ok);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_world_cutoff, dim3(blocks_of(chunk, 256)), dim3(256), 0, st, (const uint32_t *)pos.as<uint32_t>(), chunk,
+                           (uint64_t)(num_points - accepted), (uint64_t)(fail_threshold - failed), cutoff.as<unsigned long long>());
+        hipLaunchKernelGGL(k_world_accept, dim3(blocks_of(chunk, 256)), dim3(256), 0, st, (const double4 *)cand.as<double4>(),
+                           (const uint32_t *)ok.as<uint32_t>(), (const uint32_t *)pos.as<uint32_t>(), chunk,
+                           (const unsigned long long *)cutoff.as<unsigned long long>(), out.as<double4>() + accepted);
+        e = launch_error();
+        unsigned long long cut = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&cut, cutoff.ptr, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) break;
+        uint32_t took = n_ok;                                 // accepted among the candidates before the cutoff
+        if ((int64_t)cut < chunk) {
+            e = hipMemcpy(&took, pos.as<uint32_t>() + cut, 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) break;
+        }
+        accepted += (int64_t)took;
+        failed += (int64_t)cut - (int64_t)took;
+    }
+    if (e != hipSuccess) return fail(C2B_ERR_HIP, "problem_generate_world_points: %s", hipGetErrorString(e));
+    if (failed >= fail_threshold && num_points > 0)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "Failed to generate enough points. %lld successes, %lld failures, %lld requested points.",
+                    (long long)accepted, (long long)failed, (long long)num_points);
+    // the sampled points become the problem's
+    free_dense(p);
+    drop_rows(p);
+    if (p->pts4) (void)hipFree(p->pts4);
+    p->pts4 = (double *)out.release();
+    p->n_pts = accepted;
+    *n_out = accepted;
+    return C2B_OK;
+    C2B_API_END("problem_generate_world_points")
+}
+
 #include "capi_files.hpp"        // c2b_problem_write / c2b_problem_read: both file forms assembled / taken apart on the device
 
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr) {

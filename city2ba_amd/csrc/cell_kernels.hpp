@@ -349,4 +349,85 @@ __global__ __launch_bounds__(256) void k_bbal_read_rows_f64(const uint64_t *__re
     out[i] = k < width ? __longlong_as_double((long long)bswap64(in[r * width + k])) : 0.0;
 }
 
+// ---- generate_world_points_uniform (src/generate.rs:356-420) on the device ---------------------------------------------
+// The reference's loop: draw a triangle by area, a point in it, keep it if some camera lies within max_dist (an rstar
+// query), stop at num_points successes or 10 * num_points failures.  csrc/host_generate.hpp gives candidate k its own
+// splitmix64 stream and accepts candidates in order; these kernels evaluate the same candidates -- the same stream, the
+// same operations in the same order, the same `<=` on the squared distance -- so the accepted points are the host's,
+// bit for bit.  "Some camera within max_dist" is decided through the cell list over the camera centres (cells at least
+// max_dist wide: such a camera sits in the 3 x 3 cells around the point's, and the clamp of cell_coord never hides one).
+__global__ __launch_bounds__(256) void k_centres4(const double *__restrict__ camblk, int64_t n, double4 *__restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const double *q = camblk + c * kCamBlk + kCenter;
+    out[c] = make_double4(q[0], q[1], q[2], 0.0);
+}
+
+struct SplitMix {                                            // host_generate.hpp: CounterRng
+    uint64_t s;
+    C2B_DEV SplitMix(uint64_t seed, uint64_t k) : s(seed * 0xD6E8FEB86659FD93ull + k * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull) {}
+    C2B_DEV uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    C2B_DEV double uniform01() { return (double)(next() >> 11) * 0x1.0p-53; }
+};
+
+// candidates k0 .. k0 + chunk: cand[i] = the point, ok[i] = 1 if a camera is near
+__global__ __launch_bounds__(256) void k_world_candidates(const float *__restrict__ tri9, int64_t n_tri, const double *__restrict__ cum,
+                                                         uint64_t seed, int64_t k0, int64_t chunk, const double4 *__restrict__ centres,
+                                                         CellGrid g, const uint32_t *__restrict__ start, const uint32_t *__restrict__ sorted,
+                                                         double max_dist, double4 *__restrict__ cand, uint32_t *__restrict__ ok) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunk) return;
+    SplitMix rng(seed, (uint64_t)(k0 + i));
+    // WeightedIndex::at: the first cumulative area above u (std::upper_bound), clamped to the last triangle
+    const double u = rng.uniform01() * cum[n_tri - 1];
+    int64_t lo = 0, hi = n_tri;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (!(u < cum[mid])) lo = mid + 1; else hi = mid;
+    }
+    const int64_t t = lo < n_tri - 1 ? lo : n_tri - 1;
+    const float *q = tri9 + 9 * t;
+    double rx = rng.uniform01(), ry = rng.uniform01();
+    if (rx + ry > 1.0) { rx = 1.0 - rx; ry = 1.0 - ry; }
+    double p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = (double)q[c] + rx * ((double)q[3 + c] - (double)q[c]) + ry * ((double)q[6 + c] - (double)q[c]);
+    cand[i] = make_double4(p[0], p[1], p[2], 0.0);
+    const int cx = cell_coord(p[0], g.x0, g.inv_cs, g.ncx), cz = cell_coord(p[2], g.z0, g.inv_cs, g.ncz);
+    const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz + 1 < g.ncz ? cz + 1 : g.ncz - 1;
+    const double r2 = max_dist * max_dist;
+    bool near = false;
+    for (int x = (cx > 0 ? cx - 1 : 0); x <= (cx + 1 < g.ncx ? cx + 1 : g.ncx - 1) && !near; ++x) {
+        const uint32_t a = start[x * g.ncz + z0], b = start[x * g.ncz + z1 + 1];      // three cells of a column: one range
+        for (uint32_t j = a; j < b; ++j) {
+            const double4 c = centres[sorted[j]];
+            const double e0 = c.x - p[0], e1 = c.y - p[1], e2 = c.z - p[2];
+            if ((e0 * e0 + e1 * e1) + e2 * e2 <= r2) { near = true; break; }
+        }
+    }
+    ok[i] = near ? 1u : 0u;
+}
+
+// The sequential loop takes candidate i while fewer than `need` were accepted and fewer than `fails_left` failed before
+// it: cutoff = the first candidate it does not take (chunk if it takes them all).  pos = exclusive scan of ok.
+__global__ __launch_bounds__(256) void k_world_cutoff(const uint32_t *__restrict__ pos, int64_t chunk, uint64_t need, uint64_t fails_left,
+                                                     unsigned long long *__restrict__ cutoff) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunk) return;
+    const uint64_t acc = pos[i], failed = (uint64_t)i - acc;
+    if (acc >= need || failed >= fails_left) atomicMin(cutoff, (unsigned long long)i);
+}
+__global__ __launch_bounds__(256) void k_world_accept(const double4 *__restrict__ cand, const uint32_t *__restrict__ ok,
+                                                     const uint32_t *__restrict__ pos, int64_t chunk,
+                                                     const unsigned long long *__restrict__ cutoff, double4 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunk || (unsigned long long)i >= *cutoff || !ok[i]) return;
+    out[pos[i]] = cand[i];
+}
+
 }  // namespace c2b

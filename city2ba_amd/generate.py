@@ -141,9 +141,8 @@ def generate(path, num_cameras=100, num_world_points=1000, max_dist=100.0, intri
     cams = modify_intrinsics(cams, intrinsics_start, intrinsics_end, seed + 1)
     n_cam = len(cams)
     empty = np.zeros(n_cam + 1, dtype=np.uint64)
-    centers = BAProblem.from_visibility(cams, np.zeros((0, 3)), empty, [], np.zeros((0, 2)), device)._camera_centers()
-    pts = generate_world_points_uniform(tri, centers, num_world_points, max_dist, seed + 2)
-    ba = BAProblem.from_visibility(cams, pts, empty, [], np.zeros((0, 2)), device)
+    ba = BAProblem.from_visibility(cams, np.zeros((0, 3)), empty, [], np.zeros((0, 2)), device)
+    ba.generate_world_points(tri, num_world_points, max_dist, seed + 2)   # on the device: the points of the host sampler
     ba.visibility_graph(max_dist, triangles=tri, fetch=False)             # sweep + occlusion rays, lists stay on the device
     ba.adopt_visibility()
     if not no_lcc:

@@ -631,6 +631,13 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
 /* dense sweep (src/generate.rs:446-469, no occlusion) over the problem's cameras and points: writes
  * row_ptr[n_cam + 1] and keeps the survivors on the device; _fetch copies pt_idx[row_ptr[n_cam]] and
  * uv[row_ptr[n_cam]][2] out (either may be NULL). */
+/* generate_world_points_uniform (src/generate.rs:356-420) for the cameras of the resident problem, on the device: the
+ * problem's points are REPLACED by num_points points sampled on the triangles (HOST array tri9 [n_tri][9] f32) by area,
+ * each within max_dist of some camera; the problem must hold no observations.  The same points, bit for bit, as
+ * c2b_generate_world_points with the same seed (candidate k draws from its own counter-based stream in both).  The
+ * reference's errors -- no cameras; 10 * num_points failures -- come back as C2B_ERR_INVALID_ARGUMENT with its text. */
+int c2b_problem_generate_world_points(c2b_problem *p, const float *tri9, int64_t n_tri, int64_t num_points, double max_dist,
+                                      uint64_t seed, int64_t *n_out);
 int c2b_problem_visibility_dense(c2b_problem *p, double max_dist, uint64_t *row_ptr);
 int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double *uv);
 /* filter the survivors of the last dense sweep through c2b_occlusion_filter against host triangles

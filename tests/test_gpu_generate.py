@@ -351,3 +351,48 @@ def test_bvh_stack_overflow_is_flagged_not_silent(c2b):
     keep = torch.full((2,), 7, dtype=torch.uint8, device=dev)
     good.filter(camblk, pts4, ci, pi, keep)
     assert keep.tolist() == [1, 1]
+
+
+def test_world_points_sampled_on_the_device_are_the_host_samplers(c2b):
+    """generate_world_points_uniform (src/generate.rs:356-420) on the device (c2b_problem_generate_world_points: candidate
+    k from its own splitmix64 stream, the triangle by area, the point, `some camera within max_dist` through a cell
+    list, acceptance in candidate order): the same points, bit for bit, as the host sampler -- with most candidates
+    rejected, with a request that ends inside a chunk, with max_dist larger than the scene -- and its errors."""
+    from city2ba_amd import generate as G
+    rng = np.random.default_rng(7)
+    n = 24
+    h = rng.uniform(0, 0.5, (n + 1, n + 1)).astype(np.float32)
+    tri = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = (i, h[i, j], j), (i + 1, h[i + 1, j], j), (i, h[i, j + 1], j + 1), (i + 1, h[i + 1, j + 1], j + 1)
+            tri += [a + b + c, b + d + c]
+    tri = np.array(tri, dtype=np.float32)
+    pos = np.column_stack([rng.uniform(2, 9, 40), rng.uniform(1, 2, 40), rng.uniform(3, 20, 40)])
+    dirs = np.tile(np.eye(3).ravel(), (40, 1))
+    stage = c2b.BAProblem(0)
+    cams = stage._cameras_from_position_direction(pos, dirs)
+    empty = np.zeros(len(cams) + 1, dtype=np.uint64)
+    for num, max_dist, seed in ((5000, 2.5, 3), (70_000, 1.6, 4), (300, 100.0, 5), (0, 3.0, 6)):
+        ba = c2b.BAProblem.from_visibility(cams, np.zeros((0, 3)), empty, [], np.zeros((0, 2)))
+        centers = ba._camera_centers()
+        want = G.generate_world_points_uniform(tri, centers, num, max_dist, seed)
+        got_n = ba.generate_world_points(tri, num, max_dist, seed)
+        assert got_n == len(want) == num
+        assert np.array_equal(ba.points().view(np.uint64), want.view(np.uint64))
+        if num:
+            d = np.sqrt(((want[:, None, :] - centers[None, :, :]) ** 2).sum(-1)).min(1) if num <= 5000 else None
+            assert d is None or d.max() <= max_dist * (1 + 1e-12)
+        ba.close()
+    # the reference's errors: nothing near any camera (10 * num failures); no cameras; then a problem that has observations
+    ba = c2b.BAProblem.from_visibility(cams, np.zeros((0, 3)), empty, [], np.zeros((0, 2)))
+    far = tri + np.float32(1000.0)
+    with pytest.raises(c2b.City2baError, match="Failed to generate enough points. 0 successes, 500 failures, 50 requested"):
+        ba.generate_world_points(far, 50, 2.0, 1)
+    with pytest.raises(c2b.City2baError, match="Failed to generate enough points"):
+        G.generate_world_points_uniform(far, ba._camera_centers(), 50, 2.0, 1)
+    ba.close()
+    e = c2b.BAProblem.from_visibility(np.zeros((0, 15)), np.zeros((0, 3)), np.zeros(1, dtype=np.uint64), [], np.zeros((0, 2)))
+    with pytest.raises(c2b.City2baError, match="0 cameras"):
+        e.generate_world_points(tri, 10, 2.0, 1)
+    e.close()
