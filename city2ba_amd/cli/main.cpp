@@ -31,6 +31,8 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -585,58 +587,68 @@ int run_generate(int argc, char **argv) {
     else { std::random_device rd; seed = ((uint64_t)rd() << 32) ^ rd(); }   // the reference: unseeded thread_rng()
 
     PhaseTimer timer;
-    // The mesh is loaded on a second thread while this one starts the HIP runtime (c2b_problem_create: ~90-200 ms that
-    // need nothing from the file); the loader's status and message come back with the join.
-    c2b_obj *obj = nullptr;
-    int obj_rc = C2B_OK;
-    std::string obj_err;
-    std::thread loader([&]() {
-        obj_rc = c2b_obj_load(a.positional[0].c_str(), &obj);
-        if (obj_rc != C2B_OK) obj_err = c2b_last_error();     // the message is per thread
+    // Everything that needs only the file runs on a second thread while this one starts the HIP runtime (c2b_problem_create:
+    // 60-260 ms that need nothing from the file) and then works on the cameras: load the mesh, find the path, move to
+    // the origin, extract the triangles -- "mesh ready" -- and, when the cameras follow a path, go straight on to the
+    // hierarchy of the occlusion rays (c2b_bvh_build, itself multi-threaded), which is not needed before the points are
+    // sampled and the candidates found.  (Poisson placement builds the hierarchy of its downward rays itself, beside its
+    // darts; the one for the occlusion rays is then started after the placement, on the same thread object.)  The
+    // worker's status and message come back through `mesh`.
+    struct Mesh {
+        std::mutex mu;
+        std::condition_variable cv;
+        int stage = 0;                                        // 1: obj / path_model / tri are ready; 2: bvh too (or failed)
+        int rc = C2B_OK;
+        std::string err;
+        c2b_obj *obj = nullptr;
+        int64_t path_model = -1, n_tri = 0;
+        std::vector<float> tri;
+        c2b_bvh *bvh = nullptr;
+        bool want_bvh = false;
+        void fail_with(const std::string &m) { std::lock_guard<std::mutex> lk(mu); rc = -1; err = m; stage = 2; cv.notify_all(); }
+        void reach(int s) { std::lock_guard<std::mutex> lk(mu); stage = s; cv.notify_all(); }
+        void wait_for(int s) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stage >= s; }); }
+    } mesh;
+    auto build_bvh = [&]() {
+        if (c2b_bvh_build(mesh.tri.data(), mesh.n_tri, &mesh.bvh) != C2B_OK) mesh.fail_with(c2b_last_error());
+        else mesh.reach(2);
+    };
+    std::thread worker([&]() {
+        if (c2b_obj_load(a.positional[0].c_str(), &mesh.obj) != C2B_OK) return mesh.fail_with(c2b_last_error());   // the message is per thread
+        if (a.has("path")) {
+            const std::string want = a.opt.at("path");
+            std::string names;
+            for (int64_t m = 0; m < c2b_obj_model_count(mesh.obj); ++m) {
+                const std::string name = c2b_obj_model_name(mesh.obj, m);
+                if (name == want && mesh.path_model < 0) mesh.path_model = m;
+                names += (m ? ", " : "") + name;
+            }
+            if (mesh.path_model < 0) return mesh.fail_with("Could not find a path named " + want + ". Available model names are " + names);
+        }
+        if (a.has("move-to-origin") && c2b_obj_move_to_origin(mesh.obj, mesh.path_model) != C2B_OK) return mesh.fail_with(c2b_last_error());
+        if (c2b_obj_triangles(mesh.obj, mesh.path_model, nullptr, &mesh.n_tri) != C2B_OK) return mesh.fail_with(c2b_last_error());
+        mesh.tri.resize((size_t)mesh.n_tri * 9 + 1);
+        if (c2b_obj_triangles(mesh.obj, mesh.path_model, mesh.tri.data(), &mesh.n_tri) != C2B_OK) return mesh.fail_with(c2b_last_error());
+        mesh.want_bvh = mesh.n_tri >= 4096;                   // smaller meshes: the all-triangles kernel
+        mesh.reach(1);
+        if (mesh.want_bvh && mesh.path_model >= 0) build_bvh();
     });
+    struct JoinWorker { std::thread &t; Mesh &m; ~JoinWorker() { if (t.joinable()) t.join(); if (m.bvh) c2b_bvh_free(m.bvh); } } join_worker{worker, mesh};
     c2b_problem *p = nullptr;
     const int create_rc = c2b_problem_create((int)a.i("device", 0), &p);
     const std::string create_err = create_rc != C2B_OK ? c2b_last_error() : "";
-    loader.join();
-    if (obj_rc != C2B_OK) die(obj_err);
+    mesh.wait_for(1);
+    if (mesh.rc != C2B_OK) die(mesh.err);
     if (create_rc != C2B_OK) die(create_err);
-    timer.mark("load .obj || HIP runtime start");
-    int64_t path_model = -1;
-    if (a.has("path")) {
-        const std::string want = a.opt.at("path");
-        std::string names;
-        for (int64_t m = 0; m < c2b_obj_model_count(obj); ++m) {
-            const std::string name = c2b_obj_model_name(obj, m);
-            if (name == want && path_model < 0) path_model = m;
-            names += (m ? ", " : "") + name;
-        }
-        if (path_model < 0) die("Could not find a path named " + want + ". Available model names are " + names);
-    }
-    if (a.has("move-to-origin")) ck(c2b_obj_move_to_origin(obj, path_model));
-    int64_t n_tri = 0;
-    ck(c2b_obj_triangles(obj, path_model, nullptr, &n_tri));
-    std::vector<float> tri((size_t)n_tri * 9 + 1);
-    ck(c2b_obj_triangles(obj, path_model, tri.data(), &n_tri));
-
-    // The occlusion rays' hierarchy needs only the triangles: it is built on a second thread (c2b_bvh_build, itself
-    // multi-threaded) while the cameras are placed, the points sampled and the dense sweep runs.
-    c2b_bvh *bvh = nullptr;
-    int bvh_rc = C2B_OK;
-    std::string bvh_err;
-    std::thread bvh_builder;
-    const bool own_bvh = n_tri >= 4096;
-    auto start_bvh = [&]() {
-        if (own_bvh) bvh_builder = std::thread([&]() {
-            bvh_rc = c2b_bvh_build(tri.data(), n_tri, &bvh);
-            if (bvh_rc != C2B_OK) bvh_err = c2b_last_error();
-        });
-    };
-    struct JoinBvh { std::thread &t; c2b_bvh *&b; ~JoinBvh() { if (t.joinable()) t.join(); if (b) c2b_bvh_free(b); } } join_bvh{bvh_builder, bvh};
+    timer.mark("load .obj + triangles || HIP runtime start");
+    c2b_obj *obj = mesh.obj;
+    const int64_t path_model = mesh.path_model, n_tri = mesh.n_tri;
+    const std::vector<float> &tri = mesh.tri;
+    const bool own_bvh = mesh.want_bvh;
 
     int64_t n_cam = 0;
     std::vector<double> pos, dir;
     if (path_model >= 0) {
-        start_bvh();
         n_cam = num_cameras;
         pos.resize((size_t)n_cam * 3 + 1); dir.resize((size_t)n_cam * 9 + 1);
         ck(c2b_generate_cameras_path(obj, path_model, num_cameras, step_size, seed, pos.data(), dir.data()));
@@ -652,7 +664,10 @@ int run_generate(int argc, char **argv) {
             pos.resize((size_t)cap * 3 + 1); dir.resize((size_t)cap * 9 + 1);
             ck(c2b_generate_cameras_poisson(tri.data(), n_tri, num_cameras, height, ground, seed, cap, pos.data(), dir.data(), &n_cam));
         }
-        start_bvh();
+        if (own_bvh) {                                      // the worker has finished (stage 1 was its last): reuse the thread object
+            worker.join();
+            worker = std::thread(build_bvh);
+        }
     }
     c2b_obj_free(obj);
     timer.mark("triangles + camera placement");
@@ -691,9 +706,9 @@ int run_generate(int argc, char **argv) {
     else ck(c2b_problem_visibility_within_distance(p, max_dist, 0, 0.0, 0.0, hp.row_ptr.data()));
     timer.mark("candidates within max_dist + predicate");
     if (own_bvh) {
-        if (bvh_builder.joinable()) bvh_builder.join();
-        if (bvh_rc != C2B_OK) die(bvh_err);
-        ck(c2b_problem_visibility_dense_occlude_bvh(p, bvh, hp.row_ptr.data()));
+        mesh.wait_for(2);
+        if (mesh.rc != C2B_OK) die(mesh.err);
+        ck(c2b_problem_visibility_dense_occlude_bvh(p, mesh.bvh, hp.row_ptr.data()));
     } else {
         ck(c2b_problem_visibility_dense_occlude(p, tri.data(), n_tri, hp.row_ptr.data()));
     }
