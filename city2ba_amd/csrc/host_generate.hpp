@@ -374,22 +374,52 @@ inline void poisson_unit_square(int64_t n_target, std::mt19937_64 &rng, std::vec
                 for (int oy = -2; oy <= 2; ++oy)
                     if (ox * ox + oy * oy == d2) { nb[k][0] = ox; nb[k][1] = oy; ++k; }
     }
-    for (int64_t a = 0; a < attempts; ++a) {
-        const double x = uniform01(rng), y = uniform01(rng);
-        const int64_t gx = std::min(g - 1, (int64_t)(x / cell)), gy = std::min(g - 1, (int64_t)(y / cell));
-        bool ok = true;
+    // A dart that an EXISTING sample rejects stays rejected whatever happens later (samples are only ever added), and
+    // drawing a dart does not depend on the fate of the one before it.  So the darts go in batches: the generator draws
+    // a batch's coordinates (sequentially: one stream), all host threads test the batch against the samples present at
+    // its start, and only the survivors -- 1 in 20 once the square fills up -- go through the sequential test-and-insert,
+    // in dart order.  The same samples as one dart at a time.
+    auto rejected_by = [&](double x, double y, int64_t gx, int64_t gy) {
         for (int k = 0; k < 25; ++k) {
             const int64_t ix = gx + nb[k][0], iy = gy + nb[k][1];
             if (ix < 0 || iy < 0 || ix >= g || iy >= g) continue;
             const int64_t j = grid[(size_t)(ix * g + iy)];
             if (j >= 0) {
                 const double dx = xy[2 * j] - x, dy = xy[2 * j + 1] - y;
-                if (dx * dx + dy * dy < r * r) { ok = false; break; }
+                if (dx * dx + dy * dy < r * r) return true;
             }
         }
-        if (!ok) continue;
-        grid[(size_t)(gx * g + gy)] = (int64_t)(xy.size() / 2);
-        xy.push_back(x); xy.push_back(y);
+        return false;
+    };
+    const int64_t batch = 1 << 16;
+    const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<double> bx((size_t)batch), by((size_t)batch);
+    std::vector<char> dead((size_t)batch);
+    for (int64_t a0 = 0; a0 < attempts; a0 += batch) {
+        const int64_t nb_ = std::min(batch, attempts - a0);
+        for (int64_t i = 0; i < nb_; ++i) { bx[(size_t)i] = uniform01(rng); by[(size_t)i] = uniform01(rng); }
+        // the parallel pre-test pays once most darts die (before that nearly every dart survives it)
+        const bool pre = T > 1 && (int64_t)(xy.size() / 2) * 4 > n_target;
+        if (pre) {
+            auto test = [&](int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) {
+                    const double x = bx[(size_t)i], y = by[(size_t)i];
+                    dead[(size_t)i] = rejected_by(x, y, std::min(g - 1, (int64_t)(x / cell)), std::min(g - 1, (int64_t)(y / cell))) ? 1 : 0;
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(test, nb_ * t / T, nb_ * (t + 1) / T);
+            test(0, nb_ / T);
+            for (auto &q : th) q.join();
+        }
+        for (int64_t i = 0; i < nb_; ++i) {
+            if (pre && dead[(size_t)i]) continue;
+            const double x = bx[(size_t)i], y = by[(size_t)i];
+            const int64_t gx = std::min(g - 1, (int64_t)(x / cell)), gy = std::min(g - 1, (int64_t)(y / cell));
+            if (rejected_by(x, y, gx, gy)) continue;
+            grid[(size_t)(gx * g + gy)] = (int64_t)(xy.size() / 2);
+            xy.push_back(x); xy.push_back(y);
+        }
     }
 }
 
