@@ -83,6 +83,24 @@ inline void sub(N &a, const N &b) {                   // a -= b, a >= b
     }
     trim(a);
 }
+inline void div_small(N &a, uint32_t d) {              // a = floor(a / d)
+    uint64_t rem = 0;
+    for (size_t i = a.size(); i-- > 0;) {
+        const uint64_t cur = (rem << 32) | a[i];
+        a[i] = (uint32_t)(cur / d);
+        rem = cur % d;
+    }
+    trim(a);
+}
+// floor(2^b / 5^k): floor divisions by positive integers compose, so k divisions by 5 -- thirteen at a time, 5^13 < 2^32
+inline N pow2_over_pow5(int b, int k) {
+    N a = shl(N(1, 1u), b);
+    for (; k >= 13; k -= 13) div_small(a, 1220703125u);
+    uint32_t d = 1;
+    for (int i = 0; i < k; ++i) d *= 5u;
+    if (d > 1) div_small(a, d);
+    return a;
+}
 inline void low128(const N &a, uint64_t out[2]) {
     auto limb = [&](size_t i) { return (uint64_t)(i < a.size() ? a[i] : 0); };
     out[0] = limb(0) | (limb(1) << 32);
@@ -95,12 +113,8 @@ inline void build_tables(Tables &t) {
     for (int i = 0; i < kPow5InvCount; ++i) {
         const int b = big::bits(p);                   // = Ryu's pow5bits(i): 1 for i = 0
         if (i < kPow5Count) big::low128(b >= kPow5Bits ? big::shr(p, b - kPow5Bits) : big::shl(p, kPow5Bits - b), t.pow5[i]);
-        // floor(2^(b - 1 + 125) / 5^i): the quotient has at most 126 bits -- restoring division, one bit at a time
-        big::N rem = big::shl(big::N(1, 1u), b - 1 + kPow5Bits), q(5, 0u);
-        for (int bit = 126; bit >= 0; --bit) {
-            const big::N d = big::shl(p, bit);
-            if (big::cmp(rem, d) >= 0) { big::sub(rem, d); q[(size_t)(bit / 32)] |= 1u << (bit % 32); }
-        }
+        big::N q = big::pow2_over_pow5(b - 1 + kPow5Bits, i);     // floor(2^(b - 1 + 125) / 5^i): at most 126 bits
+        q.resize(5, 0u);
         uint64_t carry = 1;                           // + 1
         for (auto &l : q) { const uint64_t s = (uint64_t)l + carry; l = (uint32_t)s; carry = s >> 32; }
         big::low128(q, t.pow5_inv[i]);
@@ -321,17 +335,6 @@ struct ParseTables {
 };
 
 namespace big {
-// floor(a / b), any sizes (restoring division, bit by bit -- start-up code)
-inline N div_floor(const N &a, const N &b) {
-    const int ba = bits(a), bb = bits(b);
-    N q((size_t)(ba / 32 + 1), 0u), rem = a;
-    for (int bit = ba - bb; bit >= 0; --bit) {
-        const N d = shl(b, bit);
-        if (cmp(rem, d) >= 0) { sub(rem, d); q[(size_t)(bit / 32)] |= 1u << (bit % 32); }
-    }
-    trim(q);
-    return q;
-}
 inline void add_one(N &a) {
     for (auto &l : a) { if (++l != 0) return; }
     a.push_back(1u);
@@ -358,7 +361,7 @@ inline void build_parse_tables(ParseTables &t) {
         int z = 0;                                        // smallest z with 2^z >= 5^-q
         { const int b = big::bits(v); z = b; big::N one = big::shl(big::N(1, 1u), b - 1); if (big::cmp(one, v) >= 0) z = b - 1; }
         const int b = q >= -27 ? z + 127 : 2 * z + 128;
-        big::N c = big::div_floor(big::shl(big::N(1, 1u), b), v);
+        big::N c = big::pow2_over_pow5(b, -q);
         big::add_one(c);
         const int cb = big::bits(c);
         if (cb > 128) c = big::shr(c, cb - 128);
