@@ -257,6 +257,53 @@ def cpu_baseline(sh, seconds):
     return out
 
 
+def generator_and_files(dev_index):
+    """The rows of SURVEY section 8 next to the hot path, end to end at the headline size and inside this process (so the HIP
+    runtime's start, 60-260 ms of every command-line run, is not in them): `synthetic_grid(--blocks 128)` -- layout,
+    candidates, hits_building, predicate, cull, all on the device -- and BAProblem::write / from_file of the result in
+    both forms (.bbal words and .bal decimal text assembled / taken apart on the device; the host only moves bytes).
+    Wall-clock milliseconds, second of two runs; informational, never `value`."""
+    import shutil
+    import tempfile
+    import time
+    import city2ba_amd as c2b
+    from city2ba_amd import synthetic as S
+    res = {}
+    d = tempfile.mkdtemp(prefix="c2b_bench_")
+    try:
+        g = None
+        for _ in range(2):
+            if g is not None:
+                g.close()
+            t = time.perf_counter()
+            g = S.synthetic_grid(10, 10, 128, 20.0, 1.0, 1.0, 1.0, 10.0, False, device=dev_index)
+            res["synthetic_grid_ms"] = round((time.perf_counter() - t) * 1e3, 1)
+        res["cameras_points_observations_after_cull"] = [g.num_cameras(), g.num_points(), g.num_observations()]
+        for ext in ("bbal", "bal"):
+            path = os.path.join(d, "g128." + ext)
+            for _ in range(2):
+                if os.path.exists(path):
+                    os.remove(path)                                  # (truncating 1 GB of cached pages is not the writer's time)
+                t = time.perf_counter()
+                g.write(path)
+                res[ext + "_write_ms"] = round((time.perf_counter() - t) * 1e3, 1)
+            res[ext + "_bytes"] = os.path.getsize(path)
+            for _ in range(2):
+                t = time.perf_counter()
+                back = c2b.BAProblem.from_file(path)
+                res[ext + "_read_ms"] = round((time.perf_counter() - t) * 1e3, 1)
+                same = back.num_observations() == g.num_observations()
+                back.close()
+            res[ext + "_read_back_same_size"] = bool(same)
+            os.remove(path)
+        g.close()
+    except Exception as exc:                                      # informational: never fails the bench line
+        res["failed"] = "%s: %s" % (type(exc).__name__, exc)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def other_configs(dev):
     """BASELINE.json's smaller single-GPU configurations, reported next to the headline (not `value`):
     configs[1] `--blocks 4` project-only (a latency test: 0.6 MB of data) and configs[2] `--blocks 32`
@@ -937,6 +984,7 @@ def main():
             out["other_configs"] = other_configs(dev)
             out["other_configs"]["blocks128_uniform_random_point_gather"] = adversarial_gather(sh, r, Jc, Jp, ws)
             out["other_configs"]["blocks128_other_passes"] = light_kernels(sh, dev, ws)
+            out["other_configs"]["blocks128_generator_and_files"] = generator_and_files(dev.index)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
