@@ -313,3 +313,43 @@ def test_text_file_in_any_observation_order_is_sorted_on_the_device(c2b, tmp_pat
     if n_cam > 1:
         assert not np.array_equal(d.pt_idx, P["pt_idx"])      # file order within a camera, not the sorted file's
     d.close(); h.close()
+
+
+def test_text_reader_edge_files_device_and_host_agree(c2b, tmp_path, monkeypatch):
+    """small and odd files: no observations, nothing at all, no trailing newline, signed zeros, values that overflow /
+    underflow -- the device's result is the host parser's; a short file, a bad header, an index out of range, a float
+    where an index belongs -- the device declines and the host parser words the error"""
+    monkeypatch.setenv("C2B_TEXT_DEVICE_MIN_BYTES", "0")
+    nine = " ".join(["-1.5e+0"] * 9)
+    good = {"empty": "0 0 0\n", "noobs": "1 2 0\n" + " ".join(["0.5"] * 9) + "\n1 2 3\n4 5 6\n",
+            "one": "1 1 1\n0 0 0.25 -0.5\n" + "\n".join(["1e-3"] * 9) + "\n1 2 3",
+            "notrail": "1 1 1 0 0 0.25 -0.5 1 2 3 4 5 6 7 8 9 1 2 3",
+            "neg": "1 1 1\n0 0 -0 +0.5\n" + nine + "\n-1 -2 -3\n",
+            "range": "1 1 1\n0 0 1e400 -1e400\n" + " ".join(["1e-400"] * 9) + "\n1 2 3\n"}
+    bad = {"short": ("1 1 1 0 0 0.25 -0.5 1 2 3 4 5 6 7 8 9 1 2", "bad point block"), "badhdr": ("x 1 1\n", "bad header"),
+           "idx": ("1 1 1\n0 1 0.5 0.5\n" + nine + "\n1 2 3\n", "p_i < points.len"),
+           "float_idx": ("1 1 1\n0.0 0 0.5 0.5\n" + nine + "\n1 2 3\n", "bad observation 0")}
+
+    def state(b):
+        return (b.num_cameras(), b.num_points(), b.num_observations(), b.cameras_bal().tobytes(), b.points().tobytes(),
+                b.observations().tobytes(), b.pt_idx.tobytes(), b.row_ptr.tobytes())
+    for name, text in good.items():
+        path = str(tmp_path / (name + ".bal"))
+        open(path, "w").write(text)
+        monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+        d = c2b.BAProblem.from_file(path)
+        monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+        monkeypatch.setenv("C2B_HOST_TEXT", "1")
+        h = c2b.BAProblem.from_file(path)
+        monkeypatch.delenv("C2B_HOST_TEXT")
+        assert state(d) == state(h), name
+        d.close(); h.close()
+    for name, (text, words) in bad.items():
+        path = str(tmp_path / (name + ".bal"))
+        open(path, "w").write(text)
+        monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+        with pytest.raises(c2b.City2baError, match="declined"):
+            c2b.BAProblem.from_file(path)
+        monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+        with pytest.raises(c2b.City2baError, match=words):
+            c2b.BAProblem.from_file(path)
