@@ -217,7 +217,7 @@ void generate_cull_write(c2b_problem *p, const Layout &lay, double max_dist, con
     ck(c2b_problem_sizes(p, &nc, &np, &no));
     std::printf("Bundle Adjustment Problem with %lld cameras, %lld points, and %lld observations\n", (long long)nc, (long long)np, (long long)no);
     ck(c2b_problem_write(p, out.c_str(), -1));
-    timer.mark("write (c2b_problem_write: a .bbal image is built on the device)");
+    timer.mark("write (c2b_problem_write: the file image is built on the device)");
 }
 
 int run_synthetic(int argc, char **argv) {
@@ -431,7 +431,7 @@ int run_noise(int argc, char **argv) {
         ck(c2b_problem_create((int)a.i("device", 0), &p));
         timer.mark("problem_create (HIP runtime start)");
         ck(c2b_problem_read(p, a.positional[0].c_str(), -1));
-        timer.mark("read (decoded on the device for .bbal)");
+        timer.mark("read (c2b_problem_read: decoded on the device)");
         double l1, l2;
         ck(c2b_problem_total_reprojection_errors_l1_l2(p, &l1, &l2));
         std::printf("Initial error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
@@ -455,7 +455,7 @@ int run_noise(int argc, char **argv) {
         std::printf("Final error: %s (L1) %s (L2)\n", sci2(l1).c_str(), sci2(l2).c_str());
         timer.mark("errors + drift + noise (device)");
         ck(c2b_problem_write(p, a.positional[1].c_str(), -1));
-        timer.mark("write (c2b_problem_write: a .bbal image is built on the device)");
+        timer.mark("write (c2b_problem_write: the file image is built on the device)");
         c2b_problem_destroy(p);
         return 0;
     }

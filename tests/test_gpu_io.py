@@ -1,7 +1,8 @@
-"""BAProblem::write of the RESIDENT problem (c2b_problem_write; src/baproblem.rs:709-785): the .bbal image assembled on
-the device -- to_vec of every camera, per-camera counts, big-endian words -- must be byte for byte the file the host
-writer (c2b_bal_write, checked against the reference's format in tests/test_host_rows.py) produces from the downloaded
-arrays; the text form goes through that host writer."""
+"""BAProblem::write / from_file of the RESIDENT problem (c2b_problem_write, c2b_problem_read; src/baproblem.rs:580-785): both
+file forms are assembled / taken apart on the device -- the .bbal image (to_vec of every camera, per-camera counts,
+big-endian words) and the .bal decimal text (shortest round-trip digits out, correctly rounded in, observations in any
+order) -- and must be byte for byte / bit for bit what the host writer and parser (c2b_bal_write / c2b_bal_read, checked
+against the reference's formats in tests/test_host_rows.py) make of the same arrays."""
 import numpy as np
 import pytest
 
