@@ -396,3 +396,20 @@ def test_world_points_sampled_on_the_device_are_the_host_samplers(c2b):
     with pytest.raises(c2b.City2baError, match="0 cameras"):
         e.generate_world_points(tri, 10, 2.0, 1)
     e.close()
+
+
+def test_cli_generate_device_and_host_routes_write_the_same_file(c2b, cli, tmp_path):
+    """`city2ba generate` samples its world points on the device and takes its candidates from the cell list (r04); the
+    host sampler (C2B_HOST_SAMPLER=1) and the all-pairs sweep (C2B_DENSE_SWEEP=1) are the rounds 1-3 routes: every
+    combination writes the same file, along the scene's path and with Poisson cameras (tools/probes/generate_routes_probe.sh
+    does the same on a 32 x 32 block city, where the occlusion hierarchy is built on the worker thread)."""
+    scene_obj = os.path.join(os.path.dirname(BOX), "test_scene.obj")
+    for extra in (["--path", "path"], []):
+        files = []
+        for k, env in enumerate(({}, {"C2B_HOST_SAMPLER": "1"}, {"C2B_DENSE_SWEEP": "1"}, {"C2B_HOST_SAMPLER": "1", "C2B_DENSE_SWEEP": "1"})):
+            out = tmp_path / ("r%d%d.bbal" % (len(extra), k))
+            r = subprocess.run([cli, "generate", scene_obj, str(out), "--cameras", "120", "--points", "900", "--seed", "4"] + extra,
+                               capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr
+            files.append(out.read_bytes())
+        assert len(files[0]) > 1000 and all(f == files[0] for f in files[1:])
