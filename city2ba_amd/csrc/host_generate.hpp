@@ -375,10 +375,10 @@ inline void poisson_unit_square(int64_t n_target, std::mt19937_64 &rng, std::vec
                     if (ox * ox + oy * oy == d2) { nb[k][0] = ox; nb[k][1] = oy; ++k; }
     }
     // A dart that an EXISTING sample rejects stays rejected whatever happens later (samples are only ever added), and
-    // drawing a dart does not depend on the fate of the one before it.  So the darts go in batches: the generator draws
-    // a batch's coordinates (sequentially: one stream), all host threads test the batch against the samples present at
-    // its start, and only the survivors -- 1 in 20 once the square fills up -- go through the sequential test-and-insert,
-    // in dart order.  The same samples as one dart at a time.
+    // drawing a dart does not depend on the fate of the one before it.  So the darts go in batches: all host threads
+    // draw a batch's coordinates and test them against the samples present at its start, and only the survivors -- 1 in
+    // 20 once the square fills up -- go through the sequential test-and-insert, in dart order.  The same samples as one
+    // dart at a time, whatever the thread count.
     auto rejected_by = [&](double x, double y, int64_t gx, int64_t gy) {
         for (int k = 0; k < 25; ++k) {
             const int64_t ix = gx + nb[k][0], iy = gy + nb[k][1];
@@ -391,26 +391,33 @@ inline void poisson_unit_square(int64_t n_target, std::mt19937_64 &rng, std::vec
         }
         return false;
     };
-    const int64_t batch = 1 << 16;
+    // Dart k draws its coordinates from its own counter-based stream (CounterRng: the generator that the world-point
+    // sampler uses), keyed by one draw of the caller's generator: 12 M sequential Mersenne-twister draws were most of
+    // what was left of this function (r04), and a dart's coordinates never depended on the darts before it.
+    const uint64_t dart_seed = rng();
+    const int64_t batch = 1 << 18;                            // (a thread per share and batch: larger batches, fewer thread starts)
     const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<double> bx((size_t)batch), by((size_t)batch);
     std::vector<char> dead((size_t)batch);
     for (int64_t a0 = 0; a0 < attempts; a0 += batch) {
         const int64_t nb_ = std::min(batch, attempts - a0);
-        for (int64_t i = 0; i < nb_; ++i) { bx[(size_t)i] = uniform01(rng); by[(size_t)i] = uniform01(rng); }
-        // the parallel pre-test pays once most darts die (before that nearly every dart survives it)
-        const bool pre = T > 1 && (int64_t)(xy.size() / 2) * 4 > n_target;
-        if (pre) {
-            auto test = [&](int64_t lo, int64_t hi) {
-                for (int64_t i = lo; i < hi; ++i) {
-                    const double x = bx[(size_t)i], y = by[(size_t)i];
-                    dead[(size_t)i] = rejected_by(x, y, std::min(g - 1, (int64_t)(x / cell)), std::min(g - 1, (int64_t)(y / cell))) ? 1 : 0;
-                }
-            };
+        // the pre-test pays once most darts die (before that nearly every dart survives it)
+        const bool pre = (int64_t)(xy.size() / 2) * 4 > n_target;
+        auto draw_and_test = [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                CounterRng r(dart_seed, (uint64_t)(a0 + i));
+                const double x = r.uniform01(), y = r.uniform01();
+                bx[(size_t)i] = x; by[(size_t)i] = y;
+                dead[(size_t)i] = (pre && rejected_by(x, y, std::min(g - 1, (int64_t)(x / cell)), std::min(g - 1, (int64_t)(y / cell)))) ? 1 : 0;
+            }
+        };
+        if (T > 1) {
             std::vector<std::thread> th;
-            for (int t = 1; t < T; ++t) th.emplace_back(test, nb_ * t / T, nb_ * (t + 1) / T);
-            test(0, nb_ / T);
+            for (int t = 1; t < T; ++t) th.emplace_back(draw_and_test, nb_ * t / T, nb_ * (t + 1) / T);
+            draw_and_test(0, nb_ / T);
             for (auto &q : th) q.join();
+        } else {
+            draw_and_test(0, nb_);
         }
         for (int64_t i = 0; i < nb_; ++i) {
             if (pre && dead[(size_t)i]) continue;
