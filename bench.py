@@ -368,6 +368,7 @@ def light_kernels(sh, dev, ws):
     n, n_cam, n_pts = sh["n_obs"], sh["n_cam_local"], sh["n_pts"]
     uv_out = torch.empty_like(sh["uv"])
     keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    keep_bits = torch.empty((n + 63) // 64, dtype=torch.int64, device=dev)
     err = torch.zeros(1, dtype=torch.float64, device=dev)
     err2 = torch.zeros(2, dtype=torch.float64, device=dev)
     st = torch.empty(20, dtype=torch.float64, device=dev)
@@ -382,6 +383,7 @@ def light_kernels(sh, dev, ws):
         "error_sums2_rows_L1_and_L2": (lambda: D.reprojection_error_sums2_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], ws, err2), n * 20 + ent),
         "add_noise_observations+error_sums2_rows": (lambda: D.add_noise_observations_error_sums2_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], uv2, 0, 1e-9, 7, ws, err2), n * 36 + ent),
         "visibility_rows": (lambda: D.visibility_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], 10.0, uv_out, keep), n * 21 + ent),
+        "visibility_rows_bits": (lambda: D.visibility_rows_bits(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], 10.0, uv_out, keep_bits), n * 20 + n // 8 + ent),
         "add_noise_observations": (lambda: D.add_noise_observations(uv2, 0, 1e-9, 7), n * 32),
         "stats": (lambda: D.stats(sh["camblk"], sh["pts4"], ws, st), n_cam * 24 + n_pts * 24),
     }

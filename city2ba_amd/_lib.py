@@ -52,6 +52,7 @@ SIGNATURES = {
     "c2b_project_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "c2b_reprojection_error_sum_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_visibility_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
+    "c2b_visibility_rows_bits": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_reprojection_error_sums2_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "c2b_add_noise_observations_error_sums2_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _u64, _vp, _vp, _vp]),
     "c2b_jacobian_stream_policy": (_int, [_i64, _i64, _i64]),

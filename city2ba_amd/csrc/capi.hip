@@ -224,7 +224,7 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
     // camera footprint is small (project, error: tables + indices of the --blocks 128 problem fit the 256 MB cache and
     // the next call finds them there) and is non-temporal where it is not (visibility, Jacobian: 256 B per camera).
     // (the fused observation noise reads and rewrites uv exactly once: both directions bypass the caches)
-    constexpr int kNTL = (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) ? 2 : (MODE == MODE_VISIBILITY ? 1 : 0);
+    constexpr int kNTL = (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) ? 2 : ((MODE == MODE_VISIBILITY || MODE == MODE_VISIBILITY_BITS) ? 1 : 0);
     if (row_ptr) {          // the *_rows entry points: cam_idx = the tile records of c2b_rows_pack
 #define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base, seed
 #ifdef C2B_TUNE

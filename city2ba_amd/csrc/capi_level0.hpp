@@ -294,6 +294,23 @@ int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t
     C2B_API_END("visibility_rows")
 }
 
+int c2b_visibility_rows_bits(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam, const void *tiles,
+                             const uint32_t *pt_idx, int64_t n_pairs, double max_dist, double *uv_out, uint64_t *keep_bits, void *stream) {
+    C2B_API_BEGIN
+    int rc = check_obs_args("visibility_rows_bits", camblk, pts4, tiles, pt_idx, n_pairs);
+    if (!rc) rc = check_rows_args("visibility_rows_bits", row_ptr, n_cam, tiles, n_pairs);
+    if (rc) return rc;
+    if (!n_pairs) return C2B_OK;
+    if (!uv_out || !keep_bits || !aligned16(uv_out) || (reinterpret_cast<uintptr_t>(keep_bits) & 7u))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "visibility_rows_bits: NULL or misaligned output");
+    rc = launch_obs<MODE_VISIBILITY_BITS>(camblk, pts4, reinterpret_cast<const uint32_t *>(tiles), pt_idx, nullptr, n_pairs, 0.0, max_dist,
+                                          uv_out, reinterpret_cast<uint8_t *>(keep_bits), nullptr, nullptr, S(stream), row_ptr, n_cam);
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return C2B_OK;
+    C2B_API_END("visibility_rows_bits")
+}
+
 int c2b_residual_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                           const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs, double *r, double *Jc,
                           double *Jp, double norm, void *workspace, void *stream) {

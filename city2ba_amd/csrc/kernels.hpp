@@ -447,7 +447,9 @@ C2B_DEV void store16(char *dst, const double2 v) {
 // MODE_ERROR12: the L1 and the L2 error sum in one pass (run_noise evaluates them back to back on the same data,
 // src/bin/city2ba.rs:283-287, 350-354); MODE_NOISE_ERROR12: add_noise's observation pass (src/noise.rs:152-170) -- draw,
 // perturb and store uv -- fused with the two error sums of the perturbed observations that follow it in run_noise.
-enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2, MODE_ERROR12 = 3, MODE_NOISE_ERROR12 = 4 };
+// MODE_VISIBILITY_BITS: the predicate with the keep mask as ONE 64-bit ballot word per tile of 64 pairs (bit l = pair 64 t + l)
+// instead of a byte per pair -- 1 of the pass's 26 bytes per pair less, and what a compaction wants anyway
+enum { MODE_PROJECT = 0, MODE_ERROR = 1, MODE_VISIBILITY = 2, MODE_ERROR12 = 3, MODE_NOISE_ERROR12 = 4, MODE_VISIBILITY_BITS = 5 };
 constexpr int kObsWPB = 8;                     // waves per workgroup
 constexpr int kCamLight = 16;
 
@@ -522,7 +524,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     // MODE_NOISE_ERROR12: `norm` carries observations_std, uv_out is the observation array (read, perturbed, written
     // back), obs_base the global index of this launch's first observation (the draws' counter), uv_obs is unused
     // per staged camera: R, t, intrinsics (16 doubles) and, for the visibility predicate, the centre (camblk 24..27)
-    constexpr int HOT = MODE == MODE_VISIBILITY ? 20 : kCamLight;
+    constexpr bool VIS = MODE == MODE_VISIBILITY || MODE == MODE_VISIBILITY_BITS;
+    constexpr int HOT = VIS ? 20 : kCamLight;
     constexpr int CH = HOT / 2;                                           // 16-byte chunks per camera
     constexpr int kPerWave = 2 * kCamW * HOT + 8;                        // staged cameras | slow-path slots | picked ids
     __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kPerWave];
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             lds_cptr cam = (lds_cptr)sCam + (in ? local : 0u) * HOT;
             Proj p = project_obs(cam, X[t].x, X[t].y, X[t].z);
             double gx = 0.0, gy = 0.0, gz = 0.0;
-            if (MODE == MODE_VISIBILITY) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
+            if (VIS) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
             uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
             while (todo != 0) {                                          // wave-uniform; never taken on sorted input
                 int my;
@@ -610,19 +613,22 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 const Proj q = project_obs(cam, X[t].x, X[t].y, X[t].z);
                 if (in) {
                     p = q;
-                    if (MODE == MODE_VISIBILITY) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
+                    if (VIS) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
                 }
                 todo &= ~__builtin_amdgcn_ballot_w64(in);
             }
-            if (MODE == MODE_VISIBILITY) {
+            if (VIS) {
                 // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1   (src/synthetic.rs:285-291, src/generate.rs:448-454)
                 const double dx = gx - X[t].x, dy = gy - X[t].y, dz = gz - X[t].z;
                 const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
                 const bool front = dist < max_dist && p.qz <= 0.0;
                 const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
                 const double nan = __longlong_as_double(0x7ff8000000000000LL);
-                if (valid) {
-                    store16<NTS>(reinterpret_cast<char *>(uv_out + o), front ? make_double2(p.u, p.v) : make_double2(nan, nan));
+                if (valid) store16<NTS>(reinterpret_cast<char *>(uv_out + o), front ? make_double2(p.u, p.v) : make_double2(nan, nan));
+                if (MODE == MODE_VISIBILITY_BITS) {
+                    const uint64_t word = __builtin_amdgcn_ballot_w64(valid && k);       // tile0 is a multiple of 64
+                    if (lane == 0) __builtin_nontemporal_store(word, reinterpret_cast<uint64_t *>(keep) + (tile0 >> 6));
+                } else if (valid) {
                     if (NTS) __builtin_nontemporal_store((uint8_t)(k ? 1 : 0), keep + o);
                     else keep[o] = k ? 1 : 0;
                 }

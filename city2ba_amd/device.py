@@ -164,6 +164,12 @@ def visibility_rows(camblk, pts4, rows, pt_idx, max_dist, uv_out, keep):
                                         rows.n_obs, float(max_dist), _p(uv_out), _p(keep), _stream()))
 
 
+def visibility_rows_bits(camblk, pts4, rows, pt_idx, max_dist, uv_out, keep_bits):
+    """visibility_rows with the mask as one 64-bit word per 64 pairs (keep_bits: int64 tensor of ceil(n / 64) words)"""
+    L.check(L.lib().c2b_visibility_rows_bits(_p(camblk), _p(pts4), _p(rows.row_ptr), rows.n_cam, _p(rows.tiles), _p(pt_idx),
+                                             rows.n_obs, float(max_dist), _p(uv_out), _p(keep_bits), _stream()))
+
+
 def residual_jacobian_rows(camblk, pts4, rows, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None, out_sum=None, obs_base=0,
                            n_obs=None):
     """residual + Jacobian (+ sum |r|^norm when ws is given: into out_sum, or into ws for error_sum_finish) of the

@@ -135,6 +135,12 @@ int c2b_reprojection_error_sum_rows(const double *camblk, const double *pts4, co
 int c2b_visibility_rows(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
                         const void *tiles, const uint32_t *pt_idx, int64_t n_pairs, double max_dist,
                         double *uv_out, uint8_t *keep, void *stream);
+/* the same pass with the keep mask as one 64-bit word per 64 pairs -- bit l of keep_bits[t] = pair 64 t + l; the bits
+ * past n_pairs in the last word are 0 -- written as ONE ballot per wave and tile instead of a byte per lane:
+ * keep_bits (device, 8-byte aligned) holds ceil(n_pairs / 64) words.  Same predicate, same uv_out. */
+int c2b_visibility_rows_bits(const double *camblk, const double *pts4, const uint64_t *row_ptr, int64_t n_cam,
+                             const void *tiles, const uint32_t *pt_idx, int64_t n_pairs, double max_dist,
+                             double *uv_out, uint64_t *keep_bits, void *stream);
 /* total_reprojection_error's numerators for norm 1 AND norm 2 from ONE pass -- run_noise evaluates exactly this pair,
  * back to back on the same data, before and after the noise (src/bin/city2ba.rs:283-287, 350-354):
  * out_sums[0] = sum |du| + |dv|, out_sums[1] = sum du^2 + dv^2 (device pointer, 2 doubles).  Each is bit-identical to

@@ -124,6 +124,14 @@ def test_rows_forms_give_the_bits_of_the_index_forms(env, kind):
     assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
     if n > 100:
         assert 0 < int(ka.sum().item())
+    # the mask as one ballot word per 64 pairs (c2b_visibility_rows_bits): bit l of word t = pair 64 t + l, nothing past n
+    words = torch.full(((n + 63) // 64,), -1, dtype=torch.int64, device=dev)
+    c = torch.full_like(a, 3.0)
+    D.visibility_rows_bits(camblk, pts4, rows, pi, 60.0, c, words)
+    torch.cuda.synchronize()
+    bits = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+    assert np.array_equal(bits[:n], kb.cpu().numpy()) and not bits[n:].any()
+    assert np.array_equal(c.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
 
 
 def test_rows_property_random_list_shapes(env):
