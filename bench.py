@@ -107,79 +107,61 @@ def parse():
     return ap.parse_args()
 
 
-def build_shard(args, rank, world, dev, bounds=None):
-    """This rank's shard of `synthetic --blocks B` (defaults of src/bin/city2ba.rs:113-152), on device.
-    bounds = camera range boundaries per rank; None = equal camera counts (the first pass of
-    balanced_bounds, which then re-splits on the observation prefix sum)."""
+def build_shard(args, rank, world, dev, balanced=True):
+    """This rank's shard of `synthetic --blocks B` (defaults of src/bin/city2ba.rs:113-152), on device -- built ON the
+    device (r05): synthetic_grid's layout loops, the candidate search, hits_building and the
+    predicate run on the resident problem (c2b_problem_synthetic_grid_layout + c2b_problem_visibility_within_distance:
+    src/synthetic.rs:178-299), every rank over the WHOLE grid (tens of milliseconds), so that every rank holds the same
+    global row pointer and cuts the same camera ranges from it with no collective (contiguous camera
+    ranges split on the observation prefix sum, c2b_partition_cameras); its own range then moves device to device into
+    the tensors the Level-0 launchers take (c2b_problem_export_device).  Rounds 1-4 searched the candidates on host
+    threads, twice per rank when the split was re-balanced: most of the driver's 20.8 s around a 17-ms timed region."""
     import numpy as np
     import torch
     from city2ba_amd import device as D
     from city2ba_amd import dist as Dist
     from city2ba_amd import synthetic as S
 
+    t_setup = time.perf_counter()
     B, max_dist, L, inset = args.blocks, 10.0, 20.0, 1.0
-    pos, dirs, pts = S.grid_layout(B)
-    n_cam, n_pts = len(pos), len(pts)
-    if bounds is None:
-        bounds = Dist.camera_count_bounds(n_cam, world)
+    ba = S.synthetic_grid(10, 10, B, L, inset, 1.0, 1.0, max_dist, cull=False, device=dev.index, mirror=False)
+    n_cam, n_pts, n_obs_total = ba._sizes()
+    row_ptr_all = ba._row_ptr                                            # the whole list's row pointer (host, 8 B per camera)
+    assert int(row_ptr_all[-1]) == n_obs_total
+    bounds = Dist.partition_by_observations(row_ptr_all, world) if (balanced and world > 1) else Dist.camera_count_bounds(n_cam, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-
-    pts4 = D.points_pad(torch.from_numpy(pts).to(dev))
-    cam15 = D.cameras_from_position_direction(torch.from_numpy(pos[lo:hi]).to(dev),
-                                              torch.from_numpy(dirs[lo:hi]).to(dev))
-    camblk = D.cameras_prepare_state(cam15)
-    centers = camblk[:, 24:27].contiguous().cpu().numpy()
-
-    threads = max(1, usable_cores()[0] // max(1, min(world, 8)))     # the cgroup quota, not the 256 logical CPUs the box shows
-    ci, pi = S.candidate_pairs(centers, pts, max_dist, occlusion=True, block_length=L, block_inset=inset,
-                               n_threads=threads)
-    n_cand = len(ci)
-    ci_d = torch.from_numpy(ci.view(np.int32)).to(dev)
-    pi_d = torch.from_numpy(pi.view(np.int32)).to(dev)
-    uv_c = torch.empty((n_cand, 2), dtype=torch.float64, device=dev)
-    keep = torch.empty(n_cand, dtype=torch.uint8, device=dev)
-    D.visibility_pairs(camblk, pts4, ci_d, pi_d, max_dist, uv_c, keep)
-    m = keep.bool()
-    cam_idx = ci_d[m].contiguous()
-    pt_idx = pi_d[m].contiguous()
-    uv = uv_c[m].contiguous()
-    del ci_d, pi_d, uv_c, keep, m
-    n_obs = int(cam_idx.shape[0])
-    # observation noise so that the reduced error is a non-trivial number (seeded, shard-independent)
-    obs_base, n_obs_total = Dist.exclusive_offset(n_obs)
+    ex = ba.export_device(lo, hi)
+    ba.close()
+    cam15, pts4, pt_idx, uv, row_ptr = ex["cam15"], ex["pts4"], ex["pt_idx"], ex["uv"], ex["row_ptr"]
+    n_obs, obs_base = ex["n_obs"], ex["obs_lo"]
+    cen4 = D.centers_table(hi - lo, dev)
+    camblk = D.cameras_prepare_state(cam15, centers=cen4)
+    # observation noise so that the reduced error is a non-trivial number (seeded, shard-independent: draws keyed by the
+    # observation's index in the whole list)
     D.add_noise_observations(uv, obs_base, 1e-3, seed=20243)
     # the list's row structure (what the reference holds: one list per camera) for the *_rows launchers
-    row_ptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
-    row_ptr[1:] = torch.cumsum(torch.bincount(cam_idx.long(), minlength=hi - lo), 0)
     rows = D.Rows(row_ptr, n_obs)
+    cam_idx = D.expand_rows(row_ptr, n_obs)                               # COO form: the cam_idx launchers, tools/
     torch.cuda.synchronize()
-    return dict(camblk=camblk, cam15=cam15, pts4=pts4, cam_idx=cam_idx, pt_idx=pt_idx, uv=uv, n_obs=n_obs, rows=rows,
-                n_obs_total=n_obs_total, n_cam=n_cam, n_pts=n_pts, n_cam_local=hi - lo, n_candidates=n_cand,
-                pts_host=pts, cam_lo=lo, cam_hi=hi, obs_base=obs_base)
-
-
-def balanced_bounds(sh, rank, world):
-    """contiguous camera ranges split on the observation prefix sum.  Every rank counts the
-    observations of its equal-camera-count slice, the per-camera counts are all-gathered, and
-    c2b_partition_cameras (Dist.partition_by_observations) cuts the global row_ptr into `world` ranges of ~equal
-    observation counts."""
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from city2ba_amd import dist as Dist
-    counts = torch.bincount(sh["cam_idx"].long(), minlength=sh["n_cam_local"]).cpu().numpy().astype(np.int64)
-    parts = [None] * world
-    dist.all_gather_object(parts, (sh["cam_lo"], counts))
-    allc = np.zeros(sh["n_cam"], dtype=np.int64)
-    for lo, c in parts:
-        allc[lo:lo + len(c)] = c
-    row_ptr = np.concatenate([[0], np.cumsum(allc)]).astype(np.uint64)
-    return Dist.partition_by_observations(row_ptr, world)
+    return dict(camblk=camblk, cen4=cen4, cam15=cam15, pts4=pts4, cam_idx=cam_idx, pt_idx=pt_idx, uv=uv, n_obs=n_obs, rows=rows,
+                n_obs_total=n_obs_total, n_cam=n_cam, n_pts=n_pts, n_cam_local=hi - lo, cam_lo=lo, cam_hi=hi, obs_base=obs_base,
+                bounds=[int(b) for b in bounds], setup_s=time.perf_counter() - t_setup)
 
 
 def algorithmic_bytes(n_obs, n_cam, n_pts):
     """SURVEY section 8(d), residual+Jacobian: each camera and point read once, 4-B device indices."""
     return n_obs * (4 + 16 + 16 + 192) + (n_cam + 1) * 8 + n_cam * 72 + n_pts * 24
+
+
+def store_class(rates_GBs):
+    """"slow" = every output set this process tried streams below 6.0 TB/s, "fast" = every one at 6.8 or above, "mixed" =
+    both kinds (or in between); None when no set was measured (small problems).  A search that met a fast set first
+    stopped there: "fast" then describes the sets it saw."""
+    if not rates_GBs:
+        return None
+    if max(rates_GBs) < 6000.0:
+        return "slow"
+    return "fast" if min(rates_GBs) >= 6800.0 else "mixed"
 
 
 def usable_cores():
@@ -216,13 +198,12 @@ def cpu_baseline(sh, seconds):
     single-thread figure.  Baseline, not target."""
     import numpy as np
     import oracle as O
-    cam_idx = sh["cam_idx"].cpu().numpy().astype(np.int64)
-    n_all, n_cam = len(cam_idx), sh["n_cam_local"]
-    row_ptr = np.concatenate([[0], np.cumsum(np.bincount(cam_idx, minlength=n_cam))]).astype(np.uint64)
+    n_all, n_cam = sh["n_obs"], sh["n_cam_local"]
+    row_ptr = sh["rows"].row_ptr.cpu().numpy().astype(np.uint64)
     pt_idx = sh["pt_idx"].cpu().numpy().astype(np.uint64)
     uv = sh["uv"].cpu().numpy()
     cams15 = sh["cam15"].cpu().numpy()
-    pts = np.ascontiguousarray(sh["pts_host"])
+    pts = np.ascontiguousarray(sh["pts4"][:, :3].cpu().numpy())
     r, Jc, Jp = np.empty((n_all, 2)), np.empty((n_all, 18)), np.empty((n_all, 6))
     cores, cores_note = usable_cores()
     # prefix of whole cameras holding ~2 M observations for the single-thread legs
@@ -385,7 +366,7 @@ def light_kernels(sh, dev, ws):
         "visibility_rows": (lambda: D.visibility_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], 10.0, uv_out, keep), n * 21 + ent),
         "visibility_rows_bits": (lambda: D.visibility_rows_bits(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], 10.0, uv_out, keep_bits), n * 20 + n // 8 + ent),
         "add_noise_observations": (lambda: D.add_noise_observations(uv2, 0, 1e-9, 7), n * 32),
-        "stats": (lambda: D.stats(sh["camblk"], sh["pts4"], ws, st), n_cam * 24 + n_pts * 24),
+        "stats": (lambda: D.stats(sh["camblk"], sh["pts4"], ws, st, centers=sh["cen4"]), n_cam * 24 + n_pts * 24),
     }
     out = {}
     for name, (fn, alg) in cases.items():
@@ -555,18 +536,16 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # every rank builds the grid's visibility on its own device and cuts its camera range from the same global row
+    # pointer (split on the observation prefix sum): no collective, no second build
     sh = build_shard(args, rank, world, dev)
-    bounds = None
+    bounds = sh["bounds"]
+    setup_s = sh["setup_s"]
     if dist_on:
-        # re-split on the observation prefix sum and rebuild the shard for the balanced range
-        bounds = balanced_bounds(sh, rank, world)
-        # build_shard contains a collective (the observation offsets), so the decision to rebuild must be the SAME on
-        # every rank: rebuild everywhere if ANY range moved (the bounds array is identical on all ranks)
-        equal = Dist.camera_count_bounds(sh["n_cam"], world)
-        if any(int(a) != int(b) for a, b in zip(bounds, equal)):
-            del sh
-            torch.cuda.empty_cache()
-            sh = build_shard(args, rank, world, dev, bounds=bounds)
+        t = torch.tensor([setup_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        setup_s = float(t.item())
+    torch.cuda.empty_cache()
     n = sh["n_obs"]
     ws = D.workspace(n, dev)
     err = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -902,12 +881,15 @@ def main():
                             "residual + 2x(9+3) Jacobian + fused L2 error reduce in ONE launch, f64; 1-scalar all-reduce "
                             "when N>1" % args.blocks,
                 "blocks": args.blocks, "n_cameras": sh["n_cam"], "n_points": sh["n_pts"],
-                "n_observations": n_total, "n_candidates_rank0": sh["n_candidates"],
+                "n_observations": n_total,
+                # set-up (untimed): the whole grid's layout + visibility loop on the device and this rank's range exported
+                # to the Level-0 tensors, max over ranks
+                "setup_s": round(setup_s, 3),
                 "occlusion": True, "cull": False,
                 "sharding": "contiguous camera ranges balanced on the observation prefix sum (c2b_partition_cameras), "
                             "points replicated, outputs sharded",
                 "observations_per_rank": [int(x) for x in per_rank_obs],
-                "camera_bounds": [int(x) for x in bounds] if bounds is not None else [0, sh["n_cam"]],
+                "camera_bounds": [int(x) for x in bounds],
                 "total_L2_error": total_err,
                 "collective": collective, "collective_note": collective_note,
                 "hip_graph": ("one graph launch per step (%s captured)" % ("kernel + all-reduce" if collective_in_graph else "kernel")
@@ -935,6 +917,11 @@ def main():
                 "algorithmic_bytes_per_launch": alg, "observations_per_launch": n,
                 "bytes_per_observation": round(alg / max(n, 1), 2),
                 "kernel_avg_us": round(kern_avg_s * 1e6, 2), "kernel_min_us": round(kern_ms[0] * 1e3, 2),
+                # MI355X devices differ in how fast they take streaming stores (5.6-5.9 TB/s on some,
+                # 7.0-7.1 on others, both inside one process on a third kind) and this launch is 85 % stores: the class of
+                # the device this line was measured on, from the store rates of the output sets the placement search tried
+                "device_store_class": store_class(placement_log),
+                "kept_set_store_GBs": (placement_log[placement_chosen] if placement_log and 0 <= placement_chosen < len(placement_log) else None),
                 # the same launch writing into the FIRST allocation the library hands out (no search): what a caller
                 # that passes max_attempts = 1 gets on this device
                 "kernel_us_first_allocation": round(first_us, 2) if first_us else None,
@@ -975,7 +962,10 @@ def main():
         if world == 1 and not args.no_extras:
             cal = same_run_calibration(n, r, Jc, Jp, dev, alg)
             out["roofline"].update(cal)
-            out["roofline"]["kernel_over_same_run_store_floor"] = round(kern_avg_s * 1e6 / cal["same_run_algorithmic_floor_us"], 4)
+            # THE device-independent figure of merit: this kernel against the launch's algorithmic bytes at the store rate
+            # this very device sustains in this very output set (1.0 = every byte at this box's own streaming rate)
+            out["roofline"]["kernel_over_same_run_algorithmic_floor"] = round(kern_avg_s * 1e6 / cal["same_run_algorithmic_floor_us"], 4)
+            out["roofline"]["kernel_over_same_run_store_floor"] = round(kern_avg_s * 1e6 / cal["same_run_store_floor_us"], 4)
             # the same-run copy moves exactly the launch's algorithmic byte count (read + write)
             out["roofline"]["kernel_over_same_run_copy"] = round(kern_avg_s * 1e6 / cal["same_run_copy_us"], 4)
         if world == 1 and not args.no_cpu_baseline:

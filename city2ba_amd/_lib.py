@@ -36,8 +36,8 @@ SIGNATURES = {
     "c2b_workspace_selfcheck": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "c2b_cameras_from_bal": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_to_bal": (_int, [_vp, _i64, _vp, _vp]),
-    "c2b_cameras_prepare_state": (_int, [_vp, _i64, _vp, _vp]),
-    "c2b_cameras_prepare_bal": (_int, [_vp, _i64, _vp, _vp]),
+    "c2b_cameras_prepare_state": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "c2b_cameras_prepare_bal": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "c2b_cameras_from_position_direction": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "c2b_project_world": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "c2b_to_world": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
@@ -80,9 +80,9 @@ SIGNATURES = {
     "c2b_bvh_copy": (_int, [_vp, _vp, _vp, _vp]),
     "c2b_bvh_free": (None, [_vp]),
     "c2b_occlusion_filter_bvh": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
-    "c2b_stats": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
-    "c2b_stats_partial_pass1": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "c2b_stats_partial_pass2": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "c2b_stats": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "c2b_stats_partial_pass1": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "c2b_stats_partial_pass2": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "c2b_stats_combine_shares": (_int, [_vp, _int, _vp]),
     "c2b_stats_finish_shares": (_int, [_vp, _int, _i64, _vp]),
     "c2b_comm_backend": (C.c_char_p, []),
@@ -95,7 +95,7 @@ SIGNATURES = {
     "c2b_comm_all_reduce_sum_f64": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_comm_all_gather_f64": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "c2b_comm_destroy": (None, [_vp]),
-    "c2b_stats_sharded": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "c2b_stats_sharded": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_add_drift_sharded": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _d, _d, _d, _d, _d, _d, _u64, _vp]),
     "c2b_add_noise_entities_sharded": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _d, _d, _d, _u64, _vp]),
     "c2b_add_drift": (_int, [_vp, _i64, _vp, _i64, _vp, _d, _d, _d, _d, _d, _d, _u64, _vp]),
@@ -178,6 +178,7 @@ SIGNATURES = {
     "c2b_remove_singletons": (_int, [C.POINTER(_i64), _vp, _int, C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "c2b_problem_adopt_visibility": (_int, [_vp]),
     "c2b_problem_download_graph": (_int, [_vp, _vp, _vp]),
+    "c2b_problem_export_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "c2b_problem_visibility_pairs_compact": (_int, [_vp, _i64, _vp, _vp, _d, _vp]),
     "c2b_problem_visibility_within_distance": (_int, [_vp, _d, _int, _d, _d, _vp]),
     "c2b_problem_visibility_dense": (_int, [_vp, _d, _vp]),

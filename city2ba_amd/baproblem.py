@@ -326,11 +326,36 @@ class BAProblem:
         self._row_ptr, self._pt_idx = row_ptr, pt_idx
         return self
 
-    def adopt_visibility(self):
+    def adopt_visibility(self, mirror=True):
         """BAProblem::from_visibility (src/baproblem.rs:360-376) on the device: the pending result of
-        visibility_pairs_compact(fetch=False) / visibility_graph(fetch=False) becomes this problem's vis_graph"""
+        visibility_pairs_compact(fetch=False) / visibility_graph(fetch=False) becomes this problem's vis_graph.
+        mirror = False leaves the host copies of the graph (row_ptr(), pt_idx()) stale: for callers that stay on the
+        device (export_device) and do not want 12 bytes per observation to cross PCIe"""
         L.check(L.lib().c2b_problem_adopt_visibility(self._h))
-        return self._refresh_graph()
+        return self._refresh_graph() if mirror else self
+
+    def export_device(self, cam_lo=0, cam_hi=None):
+        """c2b_problem_export_device: the resident problem -- or the shard of the camera range [cam_lo, cam_hi) -- as
+        torch tensors on the problem's device, copied device to device (Level 1 -> Level 0 without PCIe):
+        dict(cam15 [nc,15], pts4 [n_pts,4], row_ptr int64 [nc+1] rebased to 0, pt_idx int32 [n], uv [n,2], obs_lo, n_obs)."""
+        import torch
+        n_cam, n_pts, _ = self._sizes()
+        cam_hi = n_cam if cam_hi is None else int(cam_hi)
+        lo, n = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().c2b_problem_export_device(self._h, int(cam_lo), cam_hi, None, None, None, None, None, C.byref(lo), C.byref(n)))
+        dev = torch.device("cuda", self._device)
+        nc = cam_hi - int(cam_lo)
+        out = dict(cam15=torch.empty((nc, 15), dtype=torch.float64, device=dev),
+                   pts4=torch.empty((n_pts, 4), dtype=torch.float64, device=dev),
+                   row_ptr=torch.empty(nc + 1, dtype=torch.int64, device=dev),
+                   pt_idx=torch.empty(n.value, dtype=torch.int32, device=dev),
+                   uv=torch.empty((n.value, 2), dtype=torch.float64, device=dev))
+        torch.cuda.synchronize(dev)                          # the buffers exist before the problem's own stream writes them
+        p = lambda t: C.c_void_p(t.data_ptr()) if t.numel() else None
+        L.check(L.lib().c2b_problem_export_device(self._h, int(cam_lo), cam_hi, p(out["cam15"]), p(out["pts4"]), C.c_void_p(out["row_ptr"].data_ptr()),
+                                                  p(out["pt_idx"]), p(out["uv"]), C.byref(lo), C.byref(n)))
+        out["obs_lo"], out["n_obs"] = int(lo.value), int(n.value)
+        return out
 
     def cull_host(self, faithful=True):
         """the same through the host implementation (c2b_cull on downloaded arrays); returns a NEW device problem"""

@@ -102,11 +102,14 @@ class Comm:
                                                 self._stream()))
         return out
 
-    def stats_sharded(self, camblk, cam_base, n_cam_global, pts4, ws, out=None):
+    def stats_sharded(self, camblk, cam_base, n_cam_global, pts4, ws, out=None, centers=None):
         """c2b_stats_sharded: the statistics record over sharded cameras, identical bits on every rank"""
         import torch
         out = out if out is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=camblk.device)
-        L.check(L.lib().c2b_stats_sharded(self._h, C.c_void_p(camblk.data_ptr()), camblk.shape[0], int(cam_base),
+        if centers is not None and (tuple(centers.shape) != (camblk.shape[0], 4) or centers.dtype != torch.float64):
+            raise ValueError("centers must be the [n_cam][4] f64 table cameras_prepare_* filled")
+        L.check(L.lib().c2b_stats_sharded(self._h, C.c_void_p(camblk.data_ptr()),
+                                          C.c_void_p(centers.data_ptr()) if centers is not None else None, camblk.shape[0], int(cam_base),
                                           int(n_cam_global), C.c_void_p(pts4.data_ptr()), pts4.shape[0],
                                           C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()))
         return out

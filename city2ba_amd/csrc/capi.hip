@@ -127,6 +127,7 @@ inline unsigned *ws_ticket(void *workspace) {
 // whose outputs are wrong by construction.  None of this exists in the product library.
 int g_jac_variant = 0;        // 0 = the shipped kernel
 int g_obs_variant = 308;
+int g_stats_variant = 0;      // 0 = the shipped shape (kStatBlock x kStatBatch)
 
 template <typename K>
 int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
@@ -289,14 +290,14 @@ void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_
 
 // CSR: cam_idx = the tile records of c2b_rows_pack for this launch's first observation (= observation obs_base of
 // the list row_ptr describes)
-template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false, int NTL = 0>
+template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false, int NTL = 0, bool NTS = true>
 void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
                   const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0) {
     const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, true, OPL, MINW, XK, OBUP, CSR, NTL>), dim3((unsigned)btiles),        \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, NTS, OPL, MINW, XK, OBUP, CSR, NTL>), dim3((unsigned)btiles),        \
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
                        reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum, row_ptr, (int)n_cam, obs_base)
@@ -352,6 +353,21 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
                     default: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
                 }
                 return C2B_OK;
+            // r05: the A/B of VERDICT r04 item 1 (tools/ab_slow_store.py): the shipped instance at --blocks 128 is <8, 2, ntl 3>
+            case 700: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // = shipped there
+            case 701: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // one tile per wave
+            case 702: launch_jac_l<WITH_ERR, 8, 3, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // three
+            case 703: launch_jac_l<WITH_ERR, 4, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 256-thread workgroups
+            case 704: launch_jac_l<WITH_ERR, 4, 4, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // ... four tiles per wave
+            case 705: launch_jac_l<WITH_ERR, 8, 2, 1, 0, false, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // observed uv requested per tile
+            case 706: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3, false>(C2B_ROWS_ARGS); return C2B_OK;   // plain (cached) stores
+            case 707: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;          // every load cached
+            case 708: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 1>(C2B_ROWS_ARGS); return C2B_OK;          // point index non-temporal only
+            case 709: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;          // observed uv non-temporal only
+            case 712: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3, false>(C2B_ROWS_ARGS); return C2B_OK;   // one tile, plain stores
+            case 713: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 256 threads, one tile
+            case 714: launch_jac_l<WITH_ERR, 8, 2, 1, 4, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // XCD map in chunks of 4 workgroups
+            case 715: launch_jac_l<WITH_ERR, 8, 2, 1, 64, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // ... of 64
             case 64:                                                                                      // two tiles per wave whatever the size
                 switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
                     case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
@@ -424,8 +440,8 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
     return C2B_OK;
 }
 
-inline int stats_grid(int64_t n) {
-    int grid = (int)((n + kBlock - 1) / kBlock);
+inline int stats_grid(int64_t n, int block = kBlock) {
+    int grid = (int)((n + block - 1) / block);
     if (grid > kRedBlocks) grid = kRedBlocks;
     return grid < 1 ? 1 : grid;
 }
@@ -435,7 +451,24 @@ template <typename Src>
 int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStream_t st) {
     double *rec = reinterpret_cast<double *>(workspace);
     const ShardMap whole{src.n_cam, 0, src.n_cam, 0};
-    hipLaunchKernelGGL((k_stats_pass1<Src, true>), dim3(stats_grid(n)), dim3(kBlock), 0, st, src, n, (double)n, rec,
+#ifdef C2B_TUNE
+#define C2B_STATS_GO(BLOCK, BATCH)                                                                                       \
+    hipLaunchKernelGGL((k_stats_pass1<Src, true, BLOCK, BATCH>), dim3(stats_grid(n, BLOCK)), dim3(BLOCK), 0, st, src, n, \
+                       (double)n, rec, ws_ticket(workspace), whole, stats);                                              \
+    LAUNCH_CHECK();                                                                                                      \
+    return C2B_OK
+    switch (g_stats_variant) {                  // workgroup size x entities per thread and trip
+        case 1: C2B_STATS_GO(256, 4);           // the r03 / r04 shape
+        case 2: C2B_STATS_GO(512, 5);
+        case 3: C2B_STATS_GO(512, 8);
+        case 4: C2B_STATS_GO(512, 2);
+        case 5: C2B_STATS_GO(256, 8);
+        case 6: C2B_STATS_GO(512, 3);
+        default: break;
+    }
+#undef C2B_STATS_GO
+#endif
+    hipLaunchKernelGGL((k_stats_pass1<Src, true>), dim3(stats_grid(n, kStatBlock)), dim3(kStatBlock), 0, st, src, n, (double)n, rec,
                        ws_ticket(workspace), whole, stats);
     LAUNCH_CHECK();
     return C2B_OK;
@@ -546,6 +579,7 @@ int64_t c2b_workspace_bytes(int64_t n_obs) {
 // tuning hooks of libcity2ba_hip_tune.so (tools/tune_jac.py, tools/tune_obs.py); absent from the product library
 int c2b_tune_set_jacobian_variant(int v) { g_jac_variant = v; return C2B_OK; }
 int c2b_tune_set_observation_variant(int v) { g_obs_variant = v; return C2B_OK; }
+int c2b_tune_set_stats_variant(int v) { g_stats_variant = v; return C2B_OK; }
 #endif
 
 #include "capi_level0.hpp"

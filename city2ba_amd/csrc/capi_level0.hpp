@@ -24,23 +24,23 @@ int c2b_cameras_to_bal(const double *cam15, int64_t n, double *bal9, void *strea
     C2B_API_END("cameras_to_bal")
 }
 
-int c2b_cameras_prepare_state(const double *cam15, int64_t n, double *camblk, void *stream) {
+int c2b_cameras_prepare_state(const double *cam15, int64_t n, double *camblk, double *cen4, void *stream) {
     C2B_API_BEGIN
     if (n < 0 || (n && (!cam15 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_state: bad arguments");
     if (!n) return C2B_OK;
-    if (!aligned16(camblk)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk must be 16-byte aligned");
-    hipLaunchKernelGGL(k_cameras_prepare<false>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n, camblk);
+    if (!aligned16(camblk) || !aligned16(cen4)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk / cen4 must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cameras_prepare<false>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n, camblk, cen4);
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("cameras_prepare_state")
 }
 
-int c2b_cameras_prepare_bal(const double *bal9, int64_t n, double *camblk, void *stream) {
+int c2b_cameras_prepare_bal(const double *bal9, int64_t n, double *camblk, double *cen4, void *stream) {
     C2B_API_BEGIN
     if (n < 0 || (n && (!bal9 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_bal: bad arguments");
     if (!n) return C2B_OK;
-    if (!aligned16(camblk)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk must be 16-byte aligned");
-    hipLaunchKernelGGL(k_cameras_prepare<true>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), bal9, n, camblk);
+    if (!aligned16(camblk) || !aligned16(cen4)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk / cen4 must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cameras_prepare<true>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), bal9, n, camblk, cen4);
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("cameras_prepare_bal")
@@ -651,44 +651,44 @@ int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uin
     C2B_API_END("occlusion_filter_bvh")
 }
 
-int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, void *workspace,
+int c2b_stats(const double *camblk, const double *cen4, int64_t n_cam, const double *pts4, int64_t n_pts, void *workspace,
               double *stats, void *stream) {
     C2B_API_BEGIN
     if (n_cam < 0 || n_pts < 0 || !stats || !workspace) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: bad arguments");
     if (n_cam + n_pts == 0) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: empty problem (the reference's fold1().unwrap() panics)");
-    if ((n_cam && !camblk) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: NULL input");
-    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: camblk/pts4 must be 16-byte aligned");
-    const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
+    if ((n_cam && !camblk && !cen4) || (n_pts && !pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: NULL input");
+    if (!aligned16(camblk) || !aligned16(cen4) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats: camblk/cen4/pts4 must be 16-byte aligned");
+    const SrcBlk src = SrcBlk::make(camblk, cen4, pts4, n_cam);
     return stats_impl(src, n_cam + n_pts, workspace, stats, S(stream));
     C2B_API_END("stats")
 }
 
-int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+int c2b_stats_partial_pass1(const double *camblk, const double *cen4, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
                             const double *pts4, int64_t n_pts, int64_t pt_base, int64_t n_entities_global,
                             void *workspace, double *part, void *stream) {
     C2B_API_BEGIN
     if (n_cam < 0 || n_pts < 0 || cam_base < 0 || pt_base < 0 || n_cam_global < cam_base + n_cam || n_entities_global < 1 ||
-        !part || !workspace || (n_cam && !camblk) || (n_pts && !pts4))
+        !part || !workspace || (n_cam && !camblk && !cen4) || (n_pts && !pts4))
         return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass1: bad arguments");
-    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass1: camblk/pts4 must be 16-byte aligned");
-    const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
+    if (!aligned16(camblk) || !aligned16(cen4) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass1: camblk/cen4/pts4 must be 16-byte aligned");
+    const SrcBlk src = SrcBlk::make(camblk, cen4, pts4, n_cam);
     const int64_t n = n_cam + n_pts;
     double *rec = reinterpret_cast<double *>(workspace);
     const ShardMap map{n_cam, cam_base, n_cam_global, pt_base};
-    hipLaunchKernelGGL((k_stats_pass1<SrcBlk, false>), dim3(stats_grid(n)), dim3(kBlock), 0, S(stream), src, n, (double)n_entities_global, rec,
+    hipLaunchKernelGGL((k_stats_pass1<SrcBlk, false>), dim3(stats_grid(n, kStatBlock)), dim3(kStatBlock), 0, S(stream), src, n, (double)n_entities_global, rec,
                        ws_ticket(workspace), map, part);
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("stats_partial_pass1")
 }
 
-int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts, const double *mean3,
+int c2b_stats_partial_pass2(const double *camblk, const double *cen4, int64_t n_cam, const double *pts4, int64_t n_pts, const double *mean3,
                             void *workspace, double *sumsq3, void *stream) {
     C2B_API_BEGIN
-    if (n_cam < 0 || n_pts < 0 || !mean3 || !sumsq3 || !workspace || (n_cam && !camblk) || (n_pts && !pts4))
+    if (n_cam < 0 || n_pts < 0 || !mean3 || !sumsq3 || !workspace || (n_cam && !camblk && !cen4) || (n_pts && !pts4))
         return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass2: bad arguments");
-    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass2: camblk/pts4 must be 16-byte aligned");
-    const SrcBlk src{camblk, reinterpret_cast<const double4 *>(pts4), n_cam};
+    if (!aligned16(camblk) || !aligned16(cen4) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_partial_pass2: camblk/cen4/pts4 must be 16-byte aligned");
+    const SrcBlk src = SrcBlk::make(camblk, cen4, pts4, n_cam);
     const int64_t n = n_cam + n_pts;
     double *rec = reinterpret_cast<double *>(workspace);
     hipLaunchKernelGGL((k_stats_pass2<SrcBlk, true>), dim3(stats_grid(n)), dim3(kBlock), 0, S(stream), src, n, mean3, rec,
@@ -882,12 +882,12 @@ int c2b_stats_finish_shares(const double *sumsq, int world, int64_t n_entities, 
 // [cam_base, cam_base + n_cam) of n_cam_global, pts4 is the whole replicated table and rank r of W reduces its r-th
 // slice.  Two all-gathers (20 and 3 doubles per rank) through the communicator; sums in rank order on the host, so
 // every rank ends with the same bits.  Synchronous; `stats` (device, 20 doubles) is complete on return.
-int c2b_stats_sharded(c2b_comm *c, const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+int c2b_stats_sharded(c2b_comm *c, const double *camblk, const double *cen4, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
                       const double *pts4, int64_t n_pts, void *workspace, double *stats, void *stream) {
     C2B_API_BEGIN
     if (!c || !c->comm || !workspace || !stats || n_cam < 0 || n_pts < 0 || cam_base < 0 || n_cam_global < cam_base + n_cam)
         return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: bad arguments");
-    if (!aligned16(camblk) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: camblk/pts4 must be 16-byte aligned");
+    if (!aligned16(camblk) || !aligned16(cen4) || !aligned16(pts4)) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: camblk/cen4/pts4 must be 16-byte aligned");
     const int W = c->world, R = c->rank;
     const int64_t lo = n_pts * R / W, hi = n_pts * (R + 1) / W, n_ent = n_cam_global + n_pts;
     if (n_ent < 1) return fail(C2B_ERR_INVALID_ARGUMENT, "stats_sharded: empty problem");
@@ -914,13 +914,13 @@ int c2b_stats_sharded(c2b_comm *c, const double *camblk, int64_t n_cam, int64_t 
         if (e != hipSuccess) note(fail(C2B_ERR_HIP, "stats_sharded: %s: %s", what, hipGetErrorString(e)));
         return e == hipSuccess;
     };
-    note(c2b_stats_partial_pass1(camblk, n_cam, cam_base, n_cam_global, pts4 + 4 * lo, hi - lo, lo, n_ent, workspace, d_mine, stream));
+    note(c2b_stats_partial_pass1(camblk, cen4, n_cam, cam_base, n_cam_global, pts4 + 4 * lo, hi - lo, lo, n_ent, workspace, d_mine, stream));
     note(c2b_comm_all_gather_f64(c, d_mine, 20, d_all, stream));
     if (hip(hipMemcpyAsync(shares.data(), d_all, shares.size() * sizeof(double), hipMemcpyDeviceToHost, st), "copy of the shares") &&
         hip(hipStreamSynchronize(st), "synchronize") && !first)
         note(c2b_stats_combine_shares(shares.data(), W, host_stats));
     hip(hipMemcpyAsync(d_mean, host_stats, 3 * sizeof(double), hipMemcpyHostToDevice, st), "upload of the mean");
-    if (!first) note(c2b_stats_partial_pass2(camblk, n_cam, pts4 + 4 * lo, hi - lo, d_mean, workspace, d_sq, stream));
+    if (!first) note(c2b_stats_partial_pass2(camblk, cen4, n_cam, pts4 + 4 * lo, hi - lo, d_mean, workspace, d_sq, stream));
     note(c2b_comm_all_gather_f64(c, d_sq, 3, d_sqall, stream));
     if (hip(hipMemcpyAsync(sq.data(), d_sqall, sq.size() * sizeof(double), hipMemcpyDeviceToHost, st), "copy of the squared sums") &&
         hip(hipStreamSynchronize(st), "synchronize") && !first)

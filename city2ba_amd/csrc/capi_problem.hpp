@@ -8,7 +8,9 @@ struct c2b_problem {
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t n_cam = 0, n_pts = 0, n_obs = 0;
-    double *cam15 = nullptr, *bal9 = nullptr, *camblk = nullptr, *pts4 = nullptr, *uv = nullptr;
+    double *cam15 = nullptr, *bal9 = nullptr, *camblk = nullptr, *cen4 = nullptr, *pts4 = nullptr, *uv = nullptr;
+    // cen4[n_cam][4]: the cameras' centres as 32-byte rows (derived with camblk, valid when blk_valid): what the statistics
+    // and the centre-keyed cell lists read -- a 128-byte line of camblk per camera otherwise
     uint32_t *cam_idx = nullptr, *pt_idx = nullptr;
     void *ws = nullptr;
     double *stats = nullptr, *scalar = nullptr;
@@ -48,12 +50,12 @@ static void drop_rows(c2b_problem *p) {
 }
 
 static void free_buffers(c2b_problem *p) {
-    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar, p->jac_ring};
+    void *ptrs[] = {p->cam15, p->bal9, p->camblk, p->cen4, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws, p->stats, p->scalar, p->jac_ring};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     p->jac_ring = nullptr;
     free_dense(p);
     drop_rows(p);
-    p->cam15 = p->bal9 = p->camblk = p->pts4 = p->uv = nullptr;
+    p->cam15 = p->bal9 = p->camblk = p->cen4 = p->pts4 = p->uv = nullptr;
     p->cam_idx = p->pt_idx = nullptr;
     p->ws = nullptr; p->stats = p->scalar = nullptr;
     p->n_cam = p->n_pts = p->n_obs = 0;
@@ -94,8 +96,8 @@ void c2b_problem_destroy(c2b_problem *p) {
 
 static int ensure_camblk(c2b_problem *p) {
     if (p->blk_valid) return C2B_OK;
-    int rc = p->bal_valid ? c2b_cameras_prepare_bal(p->bal9, p->n_cam, p->camblk, p->stream)
-                          : c2b_cameras_prepare_state(p->cam15, p->n_cam, p->camblk, p->stream);
+    int rc = p->bal_valid ? c2b_cameras_prepare_bal(p->bal9, p->n_cam, p->camblk, p->cen4, p->stream)
+                          : c2b_cameras_prepare_state(p->cam15, p->n_cam, p->camblk, p->cen4, p->stream);
     if (rc) return rc;
     p->blk_valid = true;
     return C2B_OK;
@@ -109,6 +111,7 @@ static int alloc_problem(c2b_problem *p, int64_t n_cam, int64_t n_pts, int64_t n
     HIP_TRY(dalloc((void **)&p->cam15, sizeof(double) * 15 * n_cam));
     HIP_TRY(dalloc((void **)&p->bal9, sizeof(double) * 9 * n_cam));
     HIP_TRY(dalloc((void **)&p->camblk, sizeof(double) * kCamBlk * n_cam));
+    HIP_TRY(dalloc((void **)&p->cen4, sizeof(double) * 4 * n_cam));
     HIP_TRY(dalloc((void **)&p->pts4, sizeof(double) * 4 * n_pts));
     HIP_TRY(dalloc((void **)&p->uv, sizeof(double) * 2 * n_obs));
     HIP_TRY(dalloc((void **)&p->cam_idx, sizeof(uint32_t) * n_obs));
@@ -344,8 +347,8 @@ int c2b_problem_centers(c2b_problem *p, double *centers3) {
     if (!centers3) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_centers: centers3 is NULL");
     int rc = ensure_camblk(p);
     if (rc) return rc;
-    // camblk rows are C2B_CAMBLK_DOUBLES doubles; the center sits at [24..26]
-    HIP_TRY(hipMemcpy2DAsync(centers3, 3 * sizeof(double), p->camblk + kCenter, kCamBlk * sizeof(double),
+    // the compact centre table: 32-byte rows, the centre in the first three doubles
+    HIP_TRY(hipMemcpy2DAsync(centers3, 3 * sizeof(double), p->cen4, 4 * sizeof(double),
                              3 * sizeof(double), (size_t)p->n_cam, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return C2B_OK;
@@ -583,7 +586,7 @@ void c2b_host_free(void *ptr) {
 static int compute_stats(c2b_problem *p) {
     int rc = ensure_camblk(p);
     if (rc) return rc;
-    return c2b_stats(p->camblk, p->n_cam, p->pts4, p->n_pts, p->ws, p->stats, p->stream);
+    return c2b_stats(p->camblk, p->cen4, p->n_cam, p->pts4, p->n_pts, p->ws, p->stats, p->stream);
 }
 
 int c2b_problem_stats(c2b_problem *p, double *stats) {
@@ -799,10 +802,10 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
     }
 
     // gather the payloads once and swap them in
-    DevBuf n_cam15, n_bal9, n_camblk, n_pts4, n_uv, n_ws;
+    DevBuf n_cam15, n_bal9, n_camblk, n_cen4, n_pts4, n_uv, n_ws;
     if (e == hipSuccess) {
         A(n_cam15, sizeof(double) * 15 * (size_t)nc); A(n_bal9, sizeof(double) * 9 * (size_t)nc);
-        A(n_camblk, sizeof(double) * kCamBlk * (size_t)nc); A(n_pts4, sizeof(double) * 4 * (size_t)np);
+        A(n_camblk, sizeof(double) * kCamBlk * (size_t)nc); A(n_cen4, sizeof(double) * 4 * (size_t)nc); A(n_pts4, sizeof(double) * 4 * (size_t)np);
         A(n_uv, sizeof(double) * 2 * (size_t)no); A(n_ws, (size_t)c2b_workspace_bytes(no));
     }
     if (e == hipSuccess && c2b_workspace_init(n_ws.ptr, st) != C2B_OK) e = hipErrorUnknown;
@@ -822,9 +825,10 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
         (void)hipStreamSynchronize(st);
         return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_cull: %s", hipGetErrorString(e));
     }
-    void *old[] = {p->cam15, p->bal9, p->camblk, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws};
+    void *old[] = {p->cam15, p->bal9, p->camblk, p->cen4, p->pts4, p->uv, p->cam_idx, p->pt_idx, p->ws};
     for (void *q : old) if (q) (void)hipFree(q);
     p->cam15 = (double *)n_cam15.release(); p->bal9 = (double *)n_bal9.release(); p->camblk = (double *)n_camblk.release();
+    p->cen4 = (double *)n_cen4.release();
     p->pts4 = (double *)n_pts4.release(); p->uv = (double *)n_uv.release(); p->ws = n_ws.release();
     p->cam_idx = (uint32_t *)cam[cur].release(); p->pt_idx = (uint32_t *)pt[cur].release();
     drop_rows(p);
@@ -887,6 +891,51 @@ int c2b_problem_download_graph(c2b_problem *p, uint64_t *row_ptr, uint64_t *pt_i
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_download_graph: %s", hipGetErrorString(e));
     return C2B_OK;
     C2B_API_END("problem_download_graph")
+}
+
+// The bridge from a problem that was BORN on the device (layout, visibility loop, cull, file read) to the Level-0
+// launchers: the resident arrays -- or the slice that belongs to the camera range [cam_lo, cam_hi) -- copied device to
+// device into buffers the caller owns.  No byte crosses PCIe but the two row-pointer words that size the slice.
+__global__ __launch_bounds__(256) void k_rows_rebase(const uint64_t *__restrict__ in, int64_t n, uint64_t base, uint64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] - base;
+}
+
+int c2b_problem_export_device(c2b_problem *p, int64_t cam_lo, int64_t cam_hi, double *cam15, double *pts4, uint64_t *row_ptr,
+                              uint32_t *pt_idx, double *uv, int64_t *obs_lo, int64_t *n_obs_slice) {
+    C2B_API_BEGIN
+    NEED_UPLOADED(p, "problem_export_device");
+    if (cam_lo < 0 || cam_hi < cam_lo || cam_hi > p->n_cam)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_export_device: camera range [%lld, %lld) outside [0, %lld]", (long long)cam_lo,
+                    (long long)cam_hi, (long long)p->n_cam);
+    int rc = ensure_rows(p);
+    if (rc) return rc;
+    hipStream_t st = p->stream;
+    uint64_t ends[2] = {0, 0};
+    if (p->n_obs) {
+        HIP_TRY(hipMemcpyAsync(&ends[0], p->rows_ptr + cam_lo, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&ends[1], p->rows_ptr + cam_hi, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    const int64_t o0 = (int64_t)ends[0], n = (int64_t)(ends[1] - ends[0]), nc = cam_hi - cam_lo;
+    if (obs_lo) *obs_lo = o0;
+    if (n_obs_slice) *n_obs_slice = n;
+    if (cam15 && nc) HIP_TRY(hipMemcpyAsync(cam15, p->cam15 + 15 * cam_lo, sizeof(double) * 15 * (size_t)nc, hipMemcpyDeviceToDevice, st));
+    if (pts4 && p->n_pts) HIP_TRY(hipMemcpyAsync(pts4, p->pts4, sizeof(double) * 4 * (size_t)p->n_pts, hipMemcpyDeviceToDevice, st));
+    if (row_ptr) {
+        if (p->n_obs) {
+            hipLaunchKernelGGL(k_rows_rebase, dim3(blocks_of(nc + 1, 256)), dim3(256), 0, st, (const uint64_t *)(p->rows_ptr + cam_lo), nc + 1,
+                               ends[0], row_ptr);
+            LAUNCH_CHECK();
+        } else {
+            HIP_TRY(hipMemsetAsync(row_ptr, 0, sizeof(uint64_t) * (size_t)(nc + 1), st));
+        }
+    }
+    if (pt_idx && n) HIP_TRY(hipMemcpyAsync(pt_idx, p->pt_idx + o0, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (uv && n) HIP_TRY(hipMemcpyAsync(uv, p->uv + 2 * o0, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return C2B_OK;
+    C2B_API_END("problem_export_device")
 }
 
 // Stable compaction of CSR lists (point index, uv) by a keep mask, on the device: kept count per row -> row scan ->
@@ -1189,17 +1238,16 @@ int c2b_problem_generate_world_points(c2b_problem *p, const float *tri9, int64_t
         }
     }
     // the cell list over the camera centres
-    DevBuf centres, d_tri, d_cum;
-    hipError_t e = centres.alloc(32 * (size_t)n_cam);
-    if (e == hipSuccess) e = d_tri.alloc(36 * (size_t)n_tri);
+    DevBuf d_tri, d_cum;
+    const double4 *centres = reinterpret_cast<const double4 *>(p->cen4);     // written with camblk (ensure_camblk above)
+    hipError_t e = d_tri.alloc(36 * (size_t)n_tri);
     if (e == hipSuccess) e = d_cum.alloc(8 * (size_t)n_tri);
     if (e == hipSuccess) e = hipMemcpyAsync(d_tri.ptr, tri9, 36 * (size_t)n_tri, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cum.ptr, cum.data(), 8 * (size_t)n_tri, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_generate_world_points: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_centres4, dim3(blocks_of(n_cam, 256)), dim3(256), 0, st, (const double *)p->camblk, n_cam, centres.as<double4>());
     // the centres' extent (a reduction the statistics kernel already is: cameras only)
     double stats[C2B_STATS_DOUBLES];
-    rc = c2b_stats(p->camblk, n_cam, p->pts4, 0, p->ws, p->stats, st);
+    rc = c2b_stats(p->camblk, p->cen4, n_cam, p->pts4, 0, p->ws, p->stats, st);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(stats, p->stats, sizeof stats, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1230,7 +1278,7 @@ int c2b_problem_generate_world_points(c2b_problem *p, const float *tri9, int64_t
     if (e == hipSuccess) e = out.alloc(32 * (size_t)std::max<int64_t>(num_points, 1));
     if (e == hipSuccess) e = hipMemsetAsync(counts.ptr, 0, 4 * (size_t)(n_cells + 1), st);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_generate_world_points: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_cells_assign, dim3(blocks_of(n_cam, 256)), dim3(256), 0, st, (const double4 *)centres.as<double4>(), n_cam, g,
+    hipLaunchKernelGGL(k_cells_assign, dim3(blocks_of(n_cam, 256)), dim3(256), 0, st, centres, n_cam, g,
                        cell_of.as<uint32_t>(), counts.as<uint32_t>());
     uint32_t n_sorted = 0;
     e = scan_flags(st, counts.as<uint32_t>(), n_cells + 1, startb.as<uint32_t>(), tiles.as<uint32_t>(), total.as<uint32_t>(), &n_sorted);
@@ -1248,7 +1296,7 @@ int c2b_problem_generate_world_points(c2b_problem *p, const float *tri9, int64_t
         e = hipMemcpyAsync(cutoff.ptr, &all, 8, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_world_candidates, dim3(blocks_of(chunk, 256)), dim3(256), 0, st, (const float *)d_tri.as<float>(), n_tri,
-                           (const double *)d_cum.as<double>(), seed, k0, chunk, (const double4 *)centres.as<double4>(), g,
+                           (const double *)d_cum.as<double>(), seed, k0, chunk, centres, g,
                            (const uint32_t *)startb.as<uint32_t>(), (const uint32_t *)sorted.as<uint32_t>(), max_dist, cand.as<double4>(),
                            ok.as<uint32_t>());
         uint32_t n_ok = 0;
@@ -1579,7 +1627,7 @@ int c2b_problem_set_shard(c2b_problem *p, int64_t cam_base, int64_t n_cam_global
 static int sharded_stats(c2b_problem *p, c2b_comm *comm) {
     int rc = ensure_camblk(p);
     if (rc) return rc;
-    return c2b_stats_sharded(comm, p->camblk, p->n_cam, p->shard_cam_base, p->shard_n_cam_global, p->pts4, p->n_pts, p->ws,
+    return c2b_stats_sharded(comm, p->camblk, p->cen4, p->n_cam, p->shard_cam_base, p->shard_n_cam_global, p->pts4, p->n_pts, p->ws,
                              p->stats, p->stream);
 }
 

@@ -356,13 +356,6 @@ __global__ __launch_bounds__(256) void k_bbal_read_rows_f64(const uint64_t *__re
 // same operations in the same order, the same `<=` on the squared distance -- so the accepted points are the host's,
 // bit for bit.  "Some camera within max_dist" is decided through the cell list over the camera centres (cells at least
 // max_dist wide: such a camera sits in the 3 x 3 cells around the point's, and the clamp of cell_coord never hides one).
-__global__ __launch_bounds__(256) void k_centres4(const double *__restrict__ camblk, int64_t n, double4 *__restrict__ out) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
-    const double *q = camblk + c * kCamBlk + kCenter;
-    out[c] = make_double4(q[0], q[1], q[2], 0.0);
-}
-
 struct SplitMix {                                            // host_generate.hpp: CounterRng
     uint64_t s;
     C2B_DEV SplitMix(uint64_t seed, uint64_t k) : s(seed * 0xD6E8FEB86659FD93ull + k * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull) {}

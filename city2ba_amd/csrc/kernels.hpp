@@ -25,6 +25,7 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kRedBlocks = 512;      // largest grid of the entity reductions (one record per workgroup in the workspace): 2 per CU.  A/B at 2.6 M entities (r03): 256 / 512 / 768 / 1024 / 2048 / 4096 workgroups -> 35 / 37 / 38 / 40 / 49 / 68 us
 constexpr int kStatRec = 20;         // doubles per stats partial record (18 used)
 constexpr int kStatBatch = 4;        // entities a thread of the statistics passes loads before it uses any
+constexpr int kStatBlock = 512;      // threads per workgroup of the one-launch statistics pass (k_stats_pass1)
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(kBlock) void k_cameras_to_bal(const double *__restr
 // lines: written straight from registers every one of the 32 store instructions touched 64 different lines (lane stride
 // 256 B) -- 2 048 line visits per wave for 128 lines of output (59 us for 660 480 cameras, r02).
 template <bool FROM_BAL>
-__global__ __launch_bounds__(kBlock) void k_cameras_prepare(const double *__restrict__ in, int64_t n, double *__restrict__ camblk) {
+__global__ __launch_bounds__(kBlock) void k_cameras_prepare(const double *__restrict__ in, int64_t n, double *__restrict__ camblk,
+                                                           double *__restrict__ cen4) {
     constexpr int kStride = kCamBlk + 1;                                 // doubles per staged record
     __shared__ __attribute__((aligned(16))) double sOut[kWaves][32 * kStride + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -275,6 +277,13 @@ __global__ __launch_bounds__(kBlock) void k_cameras_prepare(const double *__rest
         }
     }
     fill_camblk(c, w[0], w[1], w[2], blk);
+    // the compact centre table (one 32-byte row per camera, the same bits as the record's centre field): what the
+    // statistics passes and the generators' cell list read instead of a 128-byte line of the record per camera
+    if (cen4 != nullptr && valid) {
+        double2 *o = reinterpret_cast<double2 *>(cen4 + 4 * i);
+        o[0] = make_double2(blk[kCenter], blk[kCenter + 1]);
+        o[1] = make_double2(blk[kCenter + 2], 0.0);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if ((lane >> 5) == h) {
@@ -1011,13 +1020,20 @@ template <typename T> struct V4;
 template <> struct V4<double> { typedef double4 type; };
 template <> struct V4<float> { typedef float4 type; };
 
-struct SrcBlk {                                  // f64: camblk centres + pts4
-    const double *camblk; const double4 *pts; int64_t n_cam;
+struct SrcBlk {                                  // f64: camera centres + pts4
+    // Where camera i's centre lives: cen + i * cen_stride.  The compact centre table the camera-record kernels write
+    // next to camblk (cen4[n_cam][4], 32-byte rows like pts4: stride 4) -- or, for a caller that kept none, the centre
+    // field inside the 256-byte camblk records (stride kCamBlk: a whole 128-byte line fetched per camera for 24 useful
+    // bytes -- 148.7 MB per pass over the --blocks 128 entities where the compact table moves 84.5, r04f / r05).
+    const double *cen; int64_t cen_stride; const double4 *pts; int64_t n_cam;
+    static SrcBlk make(const double *camblk, const double *cen4, const double *pts4, int64_t n_cam) {
+        return SrcBlk{cen4 ? cen4 : camblk + kCenter, cen4 ? 4 : kCamBlk, reinterpret_cast<const double4 *>(pts4), n_cam};
+    }
     // branch-free: both kinds of entity are three consecutive doubles at a 16-byte aligned address, so the address is
     // selected and the loads are unconditional -- a thread's batch of loads then issues back to back (with a branch per
     // entity every arm ended in s_waitcnt vmcnt(0) and the batch was serial again)
     C2B_DEV void get(int64_t i, double &x, double &y, double &z) const {
-        const double *c = i < n_cam ? camblk + i * kCamBlk + kCenter : reinterpret_cast<const double *>(pts + (i - n_cam));
+        const double *c = i < n_cam ? cen + i * cen_stride : reinterpret_cast<const double *>(pts + (i - n_cam));
         const double2 xy = *reinterpret_cast<const double2 *>(c);
         x = xy.x; y = xy.y; z = c[2];
     }
@@ -1151,8 +1167,8 @@ C2B_DEV StatRec stat_from(const double *o) {
     return r;
 }
 
-// the workgroup's waves (one record each, on lane 0) -> one record on thread 0, waves in order
-template <bool STD>
+// the workgroup's WAVES waves (one record each, on lane 0) -> one record on thread 0, waves in order
+template <bool STD, int WAVES = kWaves>
 C2B_DEV StatRec stat_block_reduce(StatRec r, double (*sh)[kStatRec]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     stat_wave_reduce<STD>(r);
@@ -1161,7 +1177,8 @@ C2B_DEV StatRec stat_block_reduce(StatRec r, double (*sh)[kStatRec]) {
     __syncthreads();
     if (threadIdx.x == 0) {
         r = stat_from(sh[0]);
-        for (int w = 1; w < kWaves; ++w) stat_merge<STD>(r, stat_from(sh[w]));
+#pragma unroll 1                                                  // one record live at a time (unrolled, eight records' loads are hoisted and spill)
+        for (int w = 1; w < WAVES; ++w) stat_merge<STD>(r, stat_from(sh[w]));
     }
     return r;
 }
@@ -1170,38 +1187,58 @@ C2B_DEV StatRec stat_block_reduce(StatRec r, double (*sh)[kStatRec]) {
 // index (map).  STD (the unsharded call): [3..5]=std, [19]=|std| from the Chan triples, all in this one launch.  !STD (a
 // shard's share, c2b_stats_partial_pass1): [19]=the origin's distance (compared across ranks), no moments.
 // rec: gridDim.x records of kStatRec doubles in the workspace.
-template <typename Src, bool STD>
-__global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, double num, double *__restrict__ rec,
+//
+// Shape (r05).  BLOCK = 512 threads and at most kRedBlocks = 512 workgroups: two workgroups = 16 waves per CU, four per
+// SIMD (128 VGPRs: __launch_bounds__(BLOCK, 4)), where r03's 256-thread workgroups left two waves per SIMD to hide a
+// dependent batch of loads each -- and the fold's cost does not grow, because it is per RECORD (one per workgroup).
+// The origin search no longer takes a square root per entity: fold1 (src/noise.rs:80-86) compares the ROUNDED distances
+// sqrt(x.x), so the exact rule "the latest entity among those whose rounded distance is smallest" is kept by comparing
+// the squared distance with a threshold just above the square of the thread's current best distance -- 8 ulps above,
+// where 1 would do: sqrt is monotone, so a squared distance beyond it cannot round to a distance <= the best -- and only
+// an entity under the threshold (a handful per thread: the running minimum of a sequence improves O(log n) times) takes
+// the square root and the exact comparison.  NaN coordinates never become the origin (the reference's fold would let
+// the LAST NaN win; not reproduced, like every NaN rule of the reductions).
+template <typename Src, bool STD, int BLOCK = kStatBlock, int BATCH = kStatBatch>
+__global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(Src src, int64_t n, double num, double *__restrict__ rec,
                                                        unsigned *__restrict__ ticket, ShardMap map,
                                                        double *__restrict__ stats) {
-    __shared__ double sh[kWaves + 1][kStatRec];
+    constexpr int WAVES = BLOCK / 64;
+    __shared__ double sh[WAVES + 1][kStatRec];
     unsigned magic = 0u;
     if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
     StatRec a = stat_empty();
-    // kStatBatch entities per thread and trip, all loads issued before the first use (indices past the end re-read the
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double best_thr = inf;                                  // squared distances above it cannot round to <= a.best.d
+    // BATCH entities per thread and trip, all loads issued before the first use (indices past the end re-read the
     // last entity and are not accumulated).
     // mean(), src/baproblem.rs:282-289, folds `a + b / num` over the entities; here every element is scaled by the
     // one reciprocal instead of divided (three IEEE divides per entity were a third of this pass's instructions).  The
     // sums are tree-ordered already, so the last bits differ from the sequential fold either way (tested at 1e-12).
     const double inv_num = 1.0 / num;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride * kStatBatch) {
-        double x[kStatBatch], y[kStatBatch], z[kStatBatch];
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride * BATCH) {
+        double x[BATCH], y[BATCH], z[BATCH];
 #pragma unroll
-        for (int u = 0; u < kStatBatch; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             const int64_t j = i + u * stride;
             src.get(j < n ? j : n - 1, x[u], y[u], z[u]);
         }
         double c = 0.0, bs[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < kStatBatch; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             const int64_t j = i + u * stride;
             if (j < n) {
                 a.s[0] += x[u] * inv_num; a.s[1] += y[u] * inv_num; a.s[2] += z[u] * inv_num;
                 a.mn[0] = fmin(a.mn[0], x[u]); a.mn[1] = fmin(a.mn[1], y[u]); a.mn[2] = fmin(a.mn[2], z[u]);
                 a.mx[0] = fmax(a.mx[0], x[u]); a.mx[1] = fmax(a.mx[1], y[u]); a.mx[2] = fmax(a.mx[2], z[u]);
-                const Best cand = {sqrt(dot3(x[u], y[u], z[u], x[u], y[u], z[u])), (double)j};
-                a.best = best_merge(a.best, cand);
+                const double d2 = dot3(x[u], y[u], z[u], x[u], y[u], z[u]);
+                if (d2 <= best_thr) {                            // rare after the first few entities of a thread
+                    const double d = sqrt(d2);
+                    if (a.best.i < 0.0 || d <= a.best.d) {       // j grows within a thread: an equal distance is the later entity
+                        a.best.d = d; a.best.i = (double)j;
+                        best_thr = (d * d) * (1.0 + 0x1.0p-49);
+                    }
+                }
                 if (STD) { c += 1.0; bs[0] += x[u]; bs[1] += y[u]; bs[2] += z[u]; }
             }
         }
@@ -1211,7 +1248,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
             bt.cnt = c;
             bt.mu[0] = bs[0] * ic; bt.mu[1] = bs[1] * ic; bt.mu[2] = bs[2] * ic;
 #pragma unroll
-            for (int u = 0; u < kStatBatch; ++u) {
+            for (int u = 0; u < BATCH; ++u) {
                 if (i + u * stride < n) {
                     const double dx = x[u] - bt.mu[0], dy = y[u] - bt.mu[1], dz = z[u] - bt.mu[2];
                     bt.m2[0] += dx * dx; bt.m2[1] += dy * dy; bt.m2[2] += dz * dz;
@@ -1227,7 +1264,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
             a.cnt = tot;
         }
     }
-    a = stat_block_reduce<STD>(a, sh);
+    a = stat_block_reduce<STD, WAVES>(a, sh);
     if (threadIdx.x == 0) {
         double t[kStatRec];
         stat_to_lds(a, t);
@@ -1240,12 +1277,12 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
             for (int k = 0; k < 20; ++k) stats[k] = nan;
         }
-        sh[kWaves][0] = last ? 1.0 : 0.0;
+        sh[WAVES][0] = last ? 1.0 : 0.0;
     }
     __syncthreads();
-    if (sh[kWaves][0] == 0.0) return;                  // workgroup-uniform
+    if (sh[WAVES][0] == 0.0) return;                   // workgroup-uniform
     StatRec f = stat_empty();
-    for (unsigned r = threadIdx.x; r < gridDim.x; r += kBlock) {
+    for (unsigned r = threadIdx.x; r < gridDim.x; r += BLOCK) {
         const double *q = rec + (int64_t)r * kStatRec;
         StatRec g = stat_empty();
 #pragma unroll
@@ -1258,9 +1295,8 @@ __global__ __launch_bounds__(kBlock) void k_stats_pass1(Src src, int64_t n, doub
         }
         stat_merge<STD>(f, g);
     }
-    f = stat_block_reduce<STD>(f, sh);
+    f = stat_block_reduce<STD, WAVES>(f, sh);
     if (threadIdx.x != 0) return;
-    const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double x = 0, y = 0, z = 0;
     if (f.best.i >= 0.0) src.get((int64_t)f.best.i, x, y, z);
 #pragma unroll

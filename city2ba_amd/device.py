@@ -14,6 +14,14 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _pn(t, n_rows):
+    """pointer of an optional [n_rows][4] f64 table (None -> NULL)"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64 and tuple(t.shape) == (n_rows, 4), "centers"
+    return C.c_void_p(t.data_ptr())
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -68,19 +76,26 @@ def cameras_to_bal(cam15):
     return bal9
 
 
-def cameras_prepare_state(cam15, out=None):
+def centers_table(n_cam, device):
+    """cen4[n_cam][4]: the compact table of camera centres cameras_prepare_* fill next to camblk and the statistics
+    read (32 bytes per camera instead of a 128-byte line of the 256-byte record)"""
+    return torch.empty((n_cam, 4), dtype=torch.float64, device=device)
+
+
+def cameras_prepare_state(cam15, out=None, centers=None):
+    """camblk from the in-memory cameras; `centers` (centers_table) also receives every camera's centre"""
     _chk(cam15, torch.float64, "cam15")
     n = cam15.shape[0]
     blk = out if out is not None else torch.empty((n, L.CAMBLK_DOUBLES), dtype=torch.float64, device=cam15.device)
-    L.check(L.lib().c2b_cameras_prepare_state(_p(cam15), n, _p(blk), _stream()))
+    L.check(L.lib().c2b_cameras_prepare_state(_p(cam15), n, _p(blk), _pn(centers, n), _stream()))
     return blk
 
 
-def cameras_prepare_bal(bal9, out=None):
+def cameras_prepare_bal(bal9, out=None, centers=None):
     _chk(bal9, torch.float64, "bal9")
     n = bal9.shape[0]
     blk = out if out is not None else torch.empty((n, L.CAMBLK_DOUBLES), dtype=torch.float64, device=bal9.device)
-    L.check(L.lib().c2b_cameras_prepare_bal(_p(bal9), n, _p(blk), _stream()))
+    L.check(L.lib().c2b_cameras_prepare_bal(_p(bal9), n, _p(blk), _pn(centers, n), _stream()))
     return blk
 
 
@@ -345,25 +360,28 @@ class OcclusionBVH:
             raise L.City2baError(L.ERR_INVALID_ARGUMENT, "occlusion_filter_bvh: hierarchy deeper than the traversal stack")
 
 
-def stats(camblk, pts4, ws, out=None):
+def stats(camblk, pts4, ws, out=None, centers=None):
+    """centers = the table cameras_prepare_* filled for these cameras (None: the centres are read out of camblk, one
+    128-byte line per camera)"""
     out = out if out is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=camblk.device)
-    L.check(L.lib().c2b_stats(_p(camblk), camblk.shape[0], _p(pts4), pts4.shape[0], _p(ws), _p(out), _stream()))
+    L.check(L.lib().c2b_stats(_p(camblk), _pn(centers, camblk.shape[0]), camblk.shape[0], _p(pts4), pts4.shape[0], _p(ws),
+                              _p(out), _stream()))
     return out
 
 
-def stats_partial_pass1(camblk, cam_base, n_cam_global, pts4_slice, pt_base, n_entities_global, ws, part=None):
+def stats_partial_pass1(camblk, cam_base, n_cam_global, pts4_slice, pt_base, n_entities_global, ws, part=None, centers=None):
     """this shard's share of the statistics (c2b_stats_partial_pass1); pts4_slice = the rows of the point table this
     rank reduces"""
     part = part if part is not None else torch.empty(L.STATS_DOUBLES, dtype=torch.float64, device=camblk.device)
-    L.check(L.lib().c2b_stats_partial_pass1(_p(camblk), camblk.shape[0], int(cam_base), int(n_cam_global), _p(pts4_slice),
+    L.check(L.lib().c2b_stats_partial_pass1(_p(camblk), _pn(centers, camblk.shape[0]), camblk.shape[0], int(cam_base), int(n_cam_global), _p(pts4_slice),
                                             pts4_slice.shape[0], int(pt_base), int(n_entities_global), _p(ws), _p(part),
                                             _stream()))
     return part
 
 
-def stats_partial_pass2(camblk, pts4_slice, mean3, ws, out=None):
+def stats_partial_pass2(camblk, pts4_slice, mean3, ws, out=None, centers=None):
     out = out if out is not None else torch.empty(3, dtype=torch.float64, device=camblk.device)
-    L.check(L.lib().c2b_stats_partial_pass2(_p(camblk), camblk.shape[0], _p(pts4_slice), pts4_slice.shape[0], _p(mean3),
+    L.check(L.lib().c2b_stats_partial_pass2(_p(camblk), _pn(centers, camblk.shape[0]), camblk.shape[0], _p(pts4_slice), pts4_slice.shape[0], _p(mean3),
                                             _p(ws), _p(out), _stream()))
     return out
 

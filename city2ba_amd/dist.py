@@ -111,7 +111,7 @@ def _all_gather_rows(row, group=None):
     return np.stack([t.cpu().numpy() for t in every])
 
 
-def stats_sharded(camblk, cam_base, n_cam_global, pts4, ws, group=None):
+def stats_sharded(camblk, cam_base, n_cam_global, pts4, ws, group=None, centers=None):
     """BAProblem::mean/std/extent/dimensions + add_drift's origin (src/baproblem.rs:282-337, src/noise.rs:75-87) when
     cameras are sharded: this rank's camblk holds cameras [cam_base, cam_base + len) of n_cam_global, pts4 is the whole
     replicated table and rank r of W reduces its r-th slice.  Two small all-gathers (20 and 3 doubles per rank), no
@@ -124,11 +124,11 @@ def stats_sharded(camblk, cam_base, n_cam_global, pts4, ws, group=None):
     n_pts = pts4.shape[0]
     lo, hi = n_pts * rank // world, n_pts * (rank + 1) // world
     n_ent = int(n_cam_global) + int(n_pts)
-    part = D.stats_partial_pass1(camblk, cam_base, n_cam_global, pts4[lo:hi], lo, n_ent, ws)
+    part = D.stats_partial_pass1(camblk, cam_base, n_cam_global, pts4[lo:hi], lo, n_ent, ws, centers=centers)
     parts = _all_gather_rows(part.cpu().numpy(), group)
     mean, mn, mx, origin, oidx = combine_stats_partials(parts, n_ent)
     mean_d = torch.from_numpy(mean).to(camblk.device)
-    sq = D.stats_partial_pass2(camblk, pts4[lo:hi], mean_d, ws)
+    sq = D.stats_partial_pass2(camblk, pts4[lo:hi], mean_d, ws, centers=centers)
     rows = _all_gather_rows(sq.cpu().numpy(), group)            # summed in rank order: identical on every rank
     return torch.from_numpy(finish_stats(mean, mn, mx, origin, oidx, rows, n_ent)).to(camblk.device)
 

@@ -63,7 +63,7 @@ def candidate_pairs(centers, pts, max_dist, cam_lo=0, cam_hi=None, occlusion=Fal
     return ci, pi
 
 
-def _visibility_problem(layout, max_dist, occlusion, block_length, block_inset, cull, device, host_candidates=False):
+def _visibility_problem(layout, max_dist, occlusion, block_length, block_inset, cull, device, host_candidates=False, mirror=True):
     """Shared tail of synthetic_grid / synthetic_line (src/synthetic.rs:260-299, 346-380).  `layout` = ("grid", cpb, ppb,
     blocks, L, inset, cam_h, pt_h) or ("line", n_cam, n_pts, length, point_offset, cam_h, pt_h).  By default everything
     -- the layout loops, the candidate search, hits_building, the predicate, cull -- runs on the resident problem;
@@ -71,6 +71,7 @@ def _visibility_problem(layout, max_dist, occlusion, block_length, block_inset, 
     compaction on the device): the same problem, element for element -- kept for the tests that compare the two."""
     from .baproblem import BAProblem
     ba = BAProblem(device)
+    rows = None
     if host_candidates:
         pos, dirs, pts = grid_layout(*layout[3:4], *layout[1:3], *layout[4:]) if layout[0] == "grid" else line_layout(*layout[1:])
         cam15 = ba._cameras_from_position_direction(pos, dirs)
@@ -86,17 +87,21 @@ def _visibility_problem(layout, max_dist, occlusion, block_length, block_inset, 
             L.check(L.lib().c2b_problem_synthetic_line_layout(ba._h, int(layout[1]), int(layout[2]), *[float(v) for v in layout[3:]]))
         ba._row_ptr = np.zeros(ba._sizes()[0] + 1, dtype=np.uint64)
         ba._pt_idx = np.zeros(0, dtype=np.uint64)
-        ba.visibility_within_distance(max_dist, occlusion, block_length, block_inset, fetch=False)
-    ba.adopt_visibility()                                                  # ... where they become the vis_graph
+        rows = ba.visibility_within_distance(max_dist, occlusion, block_length, block_inset, fetch=False)
+    ba.adopt_visibility(mirror=mirror or cull or rows is None)             # ... where they become the vis_graph
+    if not (mirror or cull) and rows is not None:
+        ba._row_ptr = rows                                                 # the row pointer came back with the loop; pt_idx() stays stale
     return ba.cull() if cull else ba
 
 
 def synthetic_grid(num_cameras_per_block, num_points_per_block, num_blocks, block_length, block_inset,
-                   camera_height, point_height, max_dist, verbose=False, cull=True, device=0, host_candidates=False):
+                   camera_height, point_height, max_dist, verbose=False, cull=True, device=0, host_candidates=False,
+                   mirror=True):
     """synthetic_grid (src/synthetic.rs:163-300), same argument order.  In-camera observation order is
-    ascending point index (the reference's is rstar's traversal order)."""
+    ascending point index (the reference's is rstar's traversal order).  mirror = False (with cull = False): the graph
+    stays on the device only (BAProblem.export_device hands it to the Level-0 launchers)."""
     layout = ("grid", num_cameras_per_block, num_points_per_block, num_blocks, block_length, block_inset, camera_height, point_height)
-    return _visibility_problem(layout, max_dist, True, block_length, block_inset, cull, device, host_candidates)
+    return _visibility_problem(layout, max_dist, True, block_length, block_inset, cull, device, host_candidates, mirror)
 
 
 def synthetic_line(num_cameras, num_points, length, point_offset, camera_height, point_height, max_dist,

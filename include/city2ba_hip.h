@@ -23,6 +23,10 @@
  *   camblk  derived per-camera record, C2B_CAMBLK_DOUBLES doubles (256 bytes; allocate the table 256-byte aligned
  *           so that a record's first 128-byte line is exactly what projection needs):
  *           R row-major[9] | t[3] | f,k1,k2 | J_l(w) row-major[9] | center[3] | pad[5].
+ *   cen4    the cameras' centres alone, [n_cam][4] doubles (x y z 0: 32-byte rows like pts4; 16-byte aligned), written
+ *           by the same launch that derives camblk.  What the statistics read: 32 bytes per camera instead of a
+ *           128-byte line of the 256-byte record (84.5 MB instead of 148.7 MB per pass at --blocks 128).  Optional
+ *           everywhere: NULL = "not kept" (the statistics then read the centre field of camblk).
  *   Jacobian (NOT in the reference; build-defined): residual r = project(project_world(X))
  *           - uv_obs (sign of src/baproblem.rs:273).  Jc[n_obs][2][9] row-major, columns in
  *           to_vec order (w0 w1 w2 t0 t1 t2 f k1 k2); Jp[n_obs][2][3] (d/dX).
@@ -81,10 +85,12 @@ int c2b_workspace_selfcheck(const void *workspace, void *stream, int64_t *nonzer
 int c2b_cameras_from_bal(const double *bal9, int64_t n_cam, double *cam15, void *stream);
 /* SnavelyCamera::to_vec / to_rodrigues (src/baproblem.rs:93-102, 189-202) */
 int c2b_cameras_to_bal(const double *cam15, int64_t n_cam, double *bal9, void *stream);
-/* derive camblk from the in-memory state; Jacobian columns refer to w = to_rodrigues(R) */
-int c2b_cameras_prepare_state(const double *cam15, int64_t n_cam, double *camblk, void *stream);
-/* derive camblk from 9-vectors; R = from_rodrigues(w), Jacobian columns refer to that w */
-int c2b_cameras_prepare_bal(const double *bal9, int64_t n_cam, double *camblk, void *stream);
+/* derive camblk (and, when cen4 != NULL, the compact centre table) from the in-memory state; Jacobian columns refer
+ * to w = to_rodrigues(R).  Run it again after anything moved the cameras (c2b_add_drift*, c2b_add_noise_entities,
+ * c2b_add_sin_noise, c2b_cameras_transform mutate cam15, the truth state): both tables are derived data. */
+int c2b_cameras_prepare_state(const double *cam15, int64_t n_cam, double *camblk, double *cen4, void *stream);
+/* derive camblk (and cen4) from 9-vectors; R = from_rodrigues(w), Jacobian columns refer to that w */
+int c2b_cameras_prepare_bal(const double *bal9, int64_t n_cam, double *camblk, double *cen4, void *stream);
 /* Camera::from_position_direction (src/baproblem.rs:153-159): pos [n][3], dir [n][9] col-major */
 int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, int64_t n_cam,
                                         double *cam15, void *stream);
@@ -270,7 +276,7 @@ int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uin
  * (src/noise.rs:75-87) over camera centers ++ points, into stats[C2B_STATS_DOUBLES].  ONE launch: mean, min, max and
  * the origin as the reference folds them, the standard deviation from per-thread (count, mean, M2) triples merged by
  * Chan's pairwise update -- equal to the reference's second pass around the finished mean up to rounding. */
-int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
+int c2b_stats(const double *camblk, const double *cen4 /* may be NULL */, int64_t n_cam, const double *pts4, int64_t n_pts,
               void *workspace, double *stats, void *stream);
 
 /* The same statistics when cameras are sharded over GPUs: this rank holds cameras
@@ -281,10 +287,10 @@ int c2b_stats(const double *camblk, int64_t n_cam, const double *pts4, int64_t n
  * The host sums [0..2] over ranks, takes min / max, picks the smallest [19] (ties: the larger [18], like fold1 at
  * src/noise.rs:80-86) and hands the global mean to pass 2, which leaves the shard's three sums of squared
  * deviations in sumsq3; std = sqrt(sum over ranks / n_entities_global).  city2ba_amd/dist.py: stats_sharded. */
-int c2b_stats_partial_pass1(const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+int c2b_stats_partial_pass1(const double *camblk, const double *cen4, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
                             const double *pts4, int64_t n_pts, int64_t pt_base, int64_t n_entities_global,
                             void *workspace, double *part, void *stream);
-int c2b_stats_partial_pass2(const double *camblk, int64_t n_cam, const double *pts4, int64_t n_pts,
+int c2b_stats_partial_pass2(const double *camblk, const double *cen4, int64_t n_cam, const double *pts4, int64_t n_pts,
                             const double *mean3, void *workspace, double *sumsq3, void *stream);
 /* the host halves of the two steps above (plain CPU arithmetic; every rank computes the same bits from the same
  * gathered rows): shares [world][20] in rank order -> stats[0..2] mean, [6..8] min, [9..11] max, [12..14] extent,
@@ -329,7 +335,7 @@ void c2b_comm_destroy(c2b_comm *c);
  * host combine, pass 2, all-gather, host finish.  camblk = this rank's cameras [cam_base, cam_base + n_cam) of
  * n_cam_global, pts4 = the whole replicated table (rank r reduces its r-th slice).  Collective and synchronous;
  * stats (DEVICE, C2B_STATS_DOUBLES) holds the same bits on every rank when it returns. */
-int c2b_stats_sharded(c2b_comm *c, const double *camblk, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
+int c2b_stats_sharded(c2b_comm *c, const double *camblk, const double *cen4, int64_t n_cam, int64_t cam_base, int64_t n_cam_global,
                       const double *pts4, int64_t n_pts, void *workspace, double *stats, void *stream);
 
 /* add_drift[_normalized] / add_noise on a shard: cam15 holds cameras [cam_base, cam_base + n_cam) and every draw
@@ -615,6 +621,16 @@ int c2b_problem_remove_singletons(c2b_problem *p);                            /*
  * c2b_problem_visibility_pairs_compact / _dense (+ _dense_occlude) becomes the problem's vis_graph. */
 int c2b_problem_adopt_visibility(c2b_problem *p);
 int c2b_problem_download_graph(c2b_problem *p, uint64_t *row_ptr, uint64_t *pt_idx);
+/* Level 1 -> Level 0 without PCIe: copy the resident problem -- or the shard that belongs to the camera range
+ * [cam_lo, cam_hi) (c2b_partition_cameras) -- into DEVICE buffers the caller owns (on the problem's device; any may be
+ * NULL): cam15 [cam_hi - cam_lo][15]; pts4 [n_pts][4] (every point: the table is replicated across shards); row_ptr
+ * [cam_hi - cam_lo + 1] rebased so that row_ptr[0] = 0; pt_idx (u32) and uv of the range's observations.  *obs_lo = the
+ * index of the range's first observation in the whole list (the obs_base of noise draws), *n_obs_slice = how many it
+ * has: call once with NULL buffers to size them.  What a problem born on the device (c2b_problem_synthetic_*_layout +
+ * c2b_problem_visibility_within_distance, c2b_problem_read, c2b_problem_cull) hands to the stateless launchers; the
+ * BAProblem side of it is the move of vis_graph / cameras / points out of the struct (src/baproblem.rs:256-260). */
+int c2b_problem_export_device(c2b_problem *p, int64_t cam_lo, int64_t cam_hi, double *cam15, double *pts4, uint64_t *row_ptr,
+                              uint32_t *pt_idx, double *uv, int64_t *obs_lo, int64_t *n_obs_slice);
 int c2b_problem_visibility_pairs(c2b_problem *p, int64_t n_pairs, const uint32_t *cam_idx,
                                  const uint32_t *pt_idx, double max_dist, double *uv_out,
                                  uint8_t *keep);

@@ -166,3 +166,44 @@ def test_line_layout_on_the_device_equals_the_host_loop(c2b):
         assert np.array_equal(ba.cameras().view(np.uint64), want.view(np.uint64))
         assert np.array_equal(ba.points().view(np.uint64), pts.view(np.uint64))
         ba.close()
+
+
+def test_export_device_hands_the_resident_problem_or_a_camera_range_to_level0(c2b):
+    """r05: c2b_problem_export_device -- Level 1 -> Level 0 without PCIe.  The whole problem and three camera ranges
+    (one of them empty) against the downloaded arrays; the row pointer comes back rebased; a problem without
+    observations exports zeros; a range outside the cameras is refused; and the bench's shard builder (the only caller
+    that skips the host mirrors: synthetic_grid(..., cull=False, mirror=False)) keeps the row pointer the visibility loop
+    returned."""
+    import torch
+    from city2ba_amd import synthetic as S
+    from city2ba_amd._lib import City2baError
+    ba = S.synthetic_grid(10, 10, 4, 20.0, 1.0, 1.0, 1.0, 10.0, False, cull=False)
+    n_cam, n_pts, n_obs = ba.num_cameras(), ba.num_points(), ba.num_observations()
+    row, pt, uv, cams, pts = ba.row_ptr.astype(np.int64), ba.pt_idx.astype(np.int64), ba.observations(), ba.cameras(), ba.points()
+    for lo, hi in ((0, n_cam), (0, 1), (37, 37), (123, 700), (n_cam - 5, n_cam)):
+        ex = ba.export_device(lo, hi)
+        a, b = int(row[lo]), int(row[hi])
+        assert ex["obs_lo"] == a and ex["n_obs"] == b - a
+        assert np.array_equal(ex["row_ptr"].cpu().numpy(), row[lo:hi + 1] - a)
+        assert np.array_equal(ex["pt_idx"].cpu().numpy().astype(np.int64), pt[a:b])
+        assert np.array_equal(ex["uv"].cpu().numpy(), uv[a:b])
+        assert np.array_equal(ex["cam15"].cpu().numpy(), cams[lo:hi])
+        p4 = ex["pts4"].cpu().numpy()
+        assert np.array_equal(p4[:, :3], pts) and p4.shape == (n_pts, 4)
+    with pytest.raises(City2baError):
+        ba.export_device(5, n_cam + 1)
+    with pytest.raises(City2baError):
+        ba.export_device(9, 8)
+    ba.close()
+    # no observations at all
+    e = _empty_problem(c2b, cams[:7], pts[:11])
+    ex = e.export_device()
+    assert ex["n_obs"] == 0 and ex["obs_lo"] == 0 and not ex["row_ptr"].any() and ex["row_ptr"].shape[0] == 8
+    e.close()
+    # the device-only route the bench takes
+    g = S.synthetic_grid(10, 10, 4, 20.0, 1.0, 1.0, 1.0, 10.0, False, cull=False, mirror=False)
+    assert np.array_equal(g._row_ptr.astype(np.int64), row) and g._sizes() == (n_cam, n_pts, n_obs)
+    ex = g.export_device()
+    assert np.array_equal(ex["pt_idx"].cpu().numpy().astype(np.int64), pt) and np.array_equal(ex["uv"].cpu().numpy(), uv)
+    g.close()
+    torch.cuda.synchronize()

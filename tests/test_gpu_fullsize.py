@@ -108,7 +108,7 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     lo = n // 2
     hi = min(lo + 20_000, n)
     cams15 = sh["cam15"].cpu().numpy()
-    pts = sh["pts_host"]
+    pts = np.ascontiguousarray(sh["pts4"][:, :3].cpu().numpy())
     ci_h = ci[lo:hi].cpu().numpy().astype(np.int64)
     c0, c1 = int(ci_h[0]), int(ci_h[-1]) + 1
     counts = np.bincount(ci_h - c0, minlength=c1 - c0)

@@ -194,6 +194,81 @@ def test_sharded_statistics_equal_unsharded():
     assert np.array_equal(one[6:19], whole[6:19]) and np.allclose(one[0:6], whole[0:6], rtol=1e-13, atol=1e-13)
 
 
+def test_compact_centre_table_is_the_record_field_and_the_statistics_do_not_care_which_they_read():
+    """r05: cameras_prepare_* also write cen4 [n_cam][4], the cameras' centres as 32-byte rows (x y z 0), and the
+    statistics read it instead of one 128-byte line of the 256-byte record per camera.  The table holds the bits of the
+    record's centre field; the statistics -- whole, a shard's shares, the sharded entry -- are bit for bit the same whether
+    they read the table or the records (same kernel, same order; only the address differs); both routes against the
+    oracle; the bal9 form writes the same table."""
+    import torch
+    import oracle as O
+    from city2ba_amd import device as D
+    from city2ba_amd import dist as Dist
+    P, dev, cam15, pts4 = _sharded_setup(seed=79)
+    n_cam, n_pts = cam15.shape[0], pts4.shape[0]
+    ws = D.workspace(0, dev)
+    cen = torch.full((n_cam, 4), float("nan"), dtype=torch.float64, device=dev)
+    blk = D.cameras_prepare_state(cam15, centers=cen)
+    assert torch.equal(cen[:, :3], blk[:, 24:27]) and bool((cen[:, 3] == 0).all())
+    assert torch.equal(blk, D.cameras_prepare_state(cam15))                       # the records do not change
+    assert np.allclose(cen[:, :3].cpu().numpy(), O.centers(P["cams15"]), rtol=0, atol=1e-12)
+    bal9 = D.cameras_to_bal(cam15)
+    cen_b = torch.full_like(cen, float("nan"))
+    blk_b = D.cameras_prepare_bal(bal9, centers=cen_b)
+    assert torch.equal(cen_b[:, :3], blk_b[:, 24:27]) and bool((cen_b[:, 3] == 0).all())
+    a = D.stats(blk, pts4, ws).cpu().numpy()
+    b = D.stats(blk, pts4, ws, centers=cen).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert np.allclose(b[0:3], O.mean(P["cams15"], P["pts"]), rtol=1e-12, atol=1e-12)
+    assert np.allclose(b[3:6], O.std(P["cams15"], P["pts"]), rtol=1e-12)
+    o0, idx0 = O.drift_origin(P["cams15"], P["pts"])
+    assert int(b[18]) == idx0 and np.array_equal(b[15:18], o0)
+    # cameras only / points only / a camera range as a shard
+    assert np.array_equal(D.stats(blk, pts4[:0], ws).cpu().numpy(), D.stats(blk, pts4[:0], ws, centers=cen).cpu().numpy())
+    lo, hi = 40, 170
+    sub, sub_c = blk[lo:hi].contiguous(), cen[lo:hi].contiguous()
+    n_ent = n_cam + n_pts
+    p1 = D.stats_partial_pass1(sub, lo, n_cam, pts4[100:900], 100, n_ent, ws).cpu().numpy()
+    p1c = D.stats_partial_pass1(sub, lo, n_cam, pts4[100:900], 100, n_ent, ws, centers=sub_c).cpu().numpy()
+    assert np.array_equal(p1, p1c)
+    mean_d = torch.from_numpy(b[0:3].copy()).to(dev)
+    assert torch.equal(D.stats_partial_pass2(sub, pts4[100:900], mean_d, ws), D.stats_partial_pass2(sub, pts4[100:900], mean_d, ws, centers=sub_c))
+    one = Dist.stats_sharded(blk, 0, n_cam, pts4, ws, centers=cen).cpu().numpy()
+    assert np.array_equal(one, Dist.stats_sharded(blk, 0, n_cam, pts4, ws).cpu().numpy())
+    # a misshapen table is refused before anything is launched
+    with pytest.raises(AssertionError):
+        D.stats(blk, pts4, ws, centers=cen[:-1])
+
+
+def test_origin_search_without_a_square_root_per_entity_keeps_fold1s_rule():
+    """r05: the statistics pass takes sqrt only for entities whose SQUARED distance is within 8 ulps of the square of the
+    thread's best distance.  fold1 (src/noise.rs:80-86) compares rounded distances and keeps the LATER of equals: points
+    whose squared distances differ in the last bits but round to the same distance must still resolve to the later one,
+    wherever in the table (thread, wave, workgroup) the pair sits."""
+    import torch
+    from city2ba_amd import device as D
+    dev = torch.device("cuda", 0)
+    ws = D.workspace(0, dev)
+    rng = np.random.default_rng(5)
+    n = 300_000
+    pts = rng.uniform(5.0, 50.0, size=(n, 3))
+    # two points whose SQUARED distances differ in the last bit and whose distances are the same double
+    x0 = 2.4842827116307444
+    y0 = float(np.sqrt(np.spacing(x0 * x0)))
+    d2a, d2b = x0 * x0, (x0 * x0 + y0 * y0) + 0.0 * 0.0
+    assert d2b > d2a and np.sqrt(d2a) == np.sqrt(d2b)
+    a, b = np.array([x0, 0.0, 0.0]), np.array([x0, y0, 0.0])
+    cam15 = torch.zeros((0, 15), dtype=torch.float64, device=dev)
+    blk = torch.zeros((0, 32), dtype=torch.float64, device=dev)
+    for ia, ib in ((7, 100_000), (100_000, 7), (131_071, 131_072), (299_999, 0), (5, 6)):
+        q = pts.copy()
+        q[ia], q[ib] = a, b
+        d = np.sqrt((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2])
+        want = int(np.flatnonzero(d == d.min())[-1])
+        st = D.stats(blk, D.points_pad(torch.from_numpy(q).to(dev)), ws).cpu().numpy()
+        assert int(st[18]) == want and np.array_equal(st[15:18], q[want])
+
+
 def test_sharded_drift_and_noise_equal_unsharded_row_for_row():
     """Every draw is keyed by the GLOBAL camera index (cam_base + i): perturbing camera shards separately -- each with
     the whole, replicated point table -- gives bit for bit the cameras and points of the unsharded call."""
