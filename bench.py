@@ -27,8 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_FMT = "k_residual_jacobian_l<2, true, 8, true, %d, 1, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; OPL = c2b_jacobian_tiles_per_wave, NTL = c2b_jacobian_stream_policy of the launch
-KERNEL_NAME = KERNEL_FMT % (2, 3)     # the launch the roofline object describes (set in main() from the shard's sizes)
+KERNEL_FMT = "k_residual_jacobian_l<2, true, %d, true, %d, 1, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; WPB, OPL = c2b_jacobian_launch_shape (by the size and by the output set's store rate), NTL = c2b_jacobian_stream_policy of the launch
+KERNEL_NAME = KERNEL_FMT % (8, 2, 3)     # the launch the roofline object describes (set in main() from the shard's sizes)
 
 
 class Watchdog:
@@ -550,15 +550,15 @@ def main():
     ws = D.workspace(n, dev)
     err = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    def kernel_us_in(bufs, reps=10):
-        """mean duration of the step's kernel writing into `bufs`, HIP events on the launch stream"""
+    def kernel_us_in(outputs, reps=10):
+        """mean duration of the step's kernel writing into the placed set `outputs`, HIP events on the launch stream"""
         for _ in range(3):
-            D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], *bufs, 2.0, ws, err)
+            D.residual_jacobian_rows_placed(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], outputs, 2.0, ws, err)
         torch.cuda.synchronize()
         s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_.record()
         for _ in range(reps):
-            D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], *bufs, 2.0, ws, err)
+            D.residual_jacobian_rows_placed(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], outputs, 2.0, ws, err)
         e_.record()
         torch.cuda.synchronize()
         return s_.elapsed_time(e_) / reps * 1e3
@@ -568,10 +568,10 @@ def main():
     # gets), measured here before anything else, and the timed region in the set c2b_jacobian_outputs_alloc keeps after
     # its bounded search -- the same entry point every caller of the C ABI has.  Untimed set-up.
     torch.cuda.empty_cache()
-    first_us = None
+    first_us, first_GBs = None, None
     if rank == 0 and n >= 1_000_000:
-        first, _ = D.alloc_jacobian_outputs(n, dev, max_attempts=1)
-        first_us = kernel_us_in(first)
+        first = D.JacobianOutputs(n, dev, max_attempts=1)
+        first_us, first_GBs = kernel_us_in(first), first.store_GBs
         del first
     outs = D.JacobianOutputs(n, dev, max_attempts=args.placement_attempts)
     (r, Jc, Jp), placement_log, placement_chosen = (outs.r, outs.Jc, outs.Jp), outs.log, outs.chosen
@@ -642,7 +642,9 @@ def main():
     slot = [0]
 
     def kernel(e):
-        D.residual_jacobian_rows(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], r, Jc, Jp, 2.0, ws, e)
+        # c2b_residual_jacobian_rows_placed: the whole list into the placed output set, the workgroup shape chosen by
+        # the store rate c2b_jacobian_outputs_alloc measured for it (c2b_jacobian_launch_shape)
+        D.residual_jacobian_rows_placed(sh["camblk"], sh["pts4"], sh["rows"], sh["pt_idx"], sh["uv"], outs, 2.0, ws, e)
 
     def step_in_line(ev=None):
         if ev is not None:
@@ -869,7 +871,8 @@ def main():
         alg = algorithmic_bytes(n, sh["n_cam_local"], sh["n_pts"])
         achieved = alg / kern_avg_s / 1e9
         policy = D.jacobian_stream_policy(n, sh["n_cam_local"], sh["n_pts"])
-        kernel_name = KERNEL_FMT % (D.jacobian_tiles_per_wave(n), policy)
+        shape = D.jacobian_launch_shape(n, outs.store_GBs)
+        kernel_name = KERNEL_FMT % (shape[0], shape[1], policy)
         traffic, traffic_tag = pmc_traffic(kernel_name) if (world == 1 and args.blocks == 128) else (None, None)
         out = {
             "metric": "million observations/sec (project+Jacobian)",
@@ -904,6 +907,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
+                "launch_shape": "%d threads per workgroup, %d tile%s of 64 observations per wave (c2b_jacobian_launch_shape: by the "
+                                "launch's size and the %s GB/s the output set takes streaming stores at; below 6 300 GB/s the finer "
+                                "grain is 2.3 %% faster, profiles/r05_ab_slow_store.txt)" % (
+                                    shape[0] * 64, shape[1], "" if shape[1] == 1 else "s", ("%.0f" % outs.store_GBs) if outs.store_GBs else "unmeasured"),
                 "stream_policy": {0: "every load cached", 2: "observed uv non-temporal", 3: "observed uv and point index non-temporal"}[policy]
                 + " (c2b_jacobian_stream_policy: tables and streams of this launch against the 256 MB Infinity Cache)",
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -925,6 +932,7 @@ def main():
                 # the same launch writing into the FIRST allocation the library hands out (no search): what a caller
                 # that passes max_attempts = 1 gets on this device
                 "kernel_us_first_allocation": round(first_us, 2) if first_us else None,
+                "store_GBs_first_allocation": round(first_GBs, 1) if first_GBs else None,
                 "frac_first_allocation": round(alg / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if first_us else None,
                 "output_placement": {"store_GBs_per_attempt": placement_log, "attempts": max(1, len(placement_log)),
                                      "note": "c2b_jacobian_outputs_alloc (C ABI): r/Jc/Jp allocations tried until the "

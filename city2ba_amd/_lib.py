@@ -57,6 +57,10 @@ SIGNATURES = {
     "c2b_add_noise_observations_error_sums2_rows": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _u64, _vp, _vp, _vp]),
     "c2b_jacobian_stream_policy": (_int, [_i64, _i64, _i64]),
     "c2b_jacobian_tiles_per_wave": (_int, [_i64]),
+    "c2b_jacobian_launch_shape": (_int, [_i64, _d, _vp, _vp]),
+    "c2b_jacobian_outputs_store_rate": (_int, [_vp, _vp]),
+    "c2b_jacobian_outputs_set_store_rate": (_int, [_vp, _d]),
+    "c2b_residual_jacobian_rows_placed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _d, _vp, _vp, _vp]),
     "c2b_residual_jacobian_rows": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
     "c2b_residual_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _d, _vp, _vp]),
     "c2b_error_sum_finish": (_int, [_vp, _i64, _vp, _vp]),

@@ -128,6 +128,7 @@ inline unsigned *ws_ticket(void *workspace) {
 int g_jac_variant = 0;        // 0 = the shipped kernel
 int g_obs_variant = 308;
 int g_stats_variant = 0;      // 0 = the shipped shape (kStatBlock x kStatBatch)
+int g_stats_grid_cap = kStatGrid;
 
 template <typename K>
 int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
@@ -331,12 +332,30 @@ static int jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts) {
 // 46.4, 4.9 M 166.2 -> 164.3, against 332.5 -> 339.8 at 9.6 M (profiles/r02k_ab_jacobian_tiles_per_wave.txt).
 constexpr int64_t kJacOneTileBelow = 6000000;
 
+// ... and by the store rate of the output set, when the caller knows it (c2b_residual_jacobian_rows_placed: the rate
+// c2b_jacobian_outputs_alloc measured).  MI355X devices / allocations take this launch's streaming stores at ~7.0-7.1
+// TB/s or at ~5.6-5.9 TB/s, and the better shape differs: into a 7.1 TB/s set two tiles per wave in
+// 512-thread workgroups is the fastest (692 us; 256 threads x one tile: 717, +3.6 %); into a 5.7-5.8 TB/s set -- on a
+// device that has nothing faster and on the slow allocations of a mixed one alike -- ONE tile per wave in 256-thread
+// workgroups is (842 against 862 us on a slow-store device, 825 / 845 and 836 / 856 in the slow sets of two mixed ones:
+// -2.3 % every time, 1.06-1.08 x the launch's algorithmic bytes at the set's own store rate instead of 1.08-1.105;
+// profiles/r05_ab_slow_store.txt, r05a/r05c_ab_step_*).  Stores that drain slowly keep a wave's registers and LDS busy
+// longer; the finer grain -- half the observations per wave, a quarter per workgroup -- lets the CU turn over sooner.
+// Between the classes (6.0-6.8 TB/s) nothing was measured: the boundary sits in the middle.
+constexpr double kJacSlowStoreGBs = 6300.0;
+struct JacShape { int wpb, opl; };                // waves per workgroup, tiles of 64 observations per wave
+static JacShape jacobian_shape(int64_t n_obs, double store_GBs) {
+    if (n_obs < kJacOneTileBelow) return {8, 1};
+    if (store_GBs > 0.0 && store_GBs < kJacSlowStoreGBs) return {4, 1};
+    return {8, 2};
+}
+
 // residual + Jacobian; WITH_ERR also folds sum |r|^norm into out_sum (device pointer) in the same launch
 template <bool WITH_ERR>
 int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                     const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
                     double *out_sum, hipStream_t st, const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0,
-                    int64_t n_pts = 0) {
+                    int64_t n_pts = 0, double store_GBs = 0.0) {
     double *block_part = workspace ? reinterpret_cast<double *>(workspace) + kWsBlockPart : nullptr;
     unsigned *ticket = ws_ticket(workspace);
     if (row_ptr) {          // the *_rows entry points
@@ -368,6 +387,13 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
             case 713: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 256 threads, one tile
             case 714: launch_jac_l<WITH_ERR, 8, 2, 1, 4, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // XCD map in chunks of 4 workgroups
             case 715: launch_jac_l<WITH_ERR, 8, 2, 1, 64, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // ... of 64
+            case 716: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;          // 256 threads, one tile, every load cached
+            case 717: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;          // ... uv nt only
+            case 718: launch_jac_l<WITH_ERR, 4, 1, 1, 0, false, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // ... uv requested per tile
+            case 719: launch_jac_l<WITH_ERR, 2, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 128 threads, two tiles
+            case 720: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 1024 threads, one tile
+            case 721: launch_jac_l<WITH_ERR, 4, 1, 1, 64, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 256 threads, one tile, XCD map in chunks of 64
+            case 722: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3, false>(C2B_ROWS_ARGS); return C2B_OK;   // 256 threads, one tile, plain stores
             case 64:                                                                                      // two tiles per wave whatever the size
                 switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
                     case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
@@ -379,7 +405,14 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         }
 #endif
         const int policy = jacobian_stream_policy(n_obs, n_cam, n_pts);
-        if (n_obs < kJacOneTileBelow) {
+        const JacShape shape = jacobian_shape(n_obs, store_GBs);
+        if (shape.wpb == 4) {                                   // a slow-store output set: 256 threads x one tile
+            switch (policy) {
+                case 3: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
+                case 2: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
+                default: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+            }
+        } else if (shape.opl == 1) {
             switch (policy) {
                 case 3: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
                 case 2: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
@@ -440,9 +473,10 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
     return C2B_OK;
 }
 
-inline int stats_grid(int64_t n, int block = kBlock) {
+inline int stats_grid(int64_t n, int block = kBlock, int cap = kStatGrid) {
+    static_assert(kStatGrid <= kRedBlocks, "one record slot per workgroup");
     int grid = (int)((n + block - 1) / block);
-    if (grid > kRedBlocks) grid = kRedBlocks;
+    if (grid > cap) grid = cap;
     return grid < 1 ? 1 : grid;
 }
 
@@ -452,18 +486,25 @@ int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStr
     double *rec = reinterpret_cast<double *>(workspace);
     const ShardMap whole{src.n_cam, 0, src.n_cam, 0};
 #ifdef C2B_TUNE
-#define C2B_STATS_GO(BLOCK, BATCH)                                                                                       \
-    hipLaunchKernelGGL((k_stats_pass1<Src, true, BLOCK, BATCH>), dim3(stats_grid(n, BLOCK)), dim3(BLOCK), 0, st, src, n, \
+#define C2B_STATS_GO(BLOCK, BATCH, PIPE, CHUNK)                                                                          \
+    hipLaunchKernelGGL((k_stats_pass1<Src, true, BLOCK, BATCH, PIPE, CHUNK>), dim3(stats_grid(n, BLOCK, g_stats_grid_cap)), dim3(BLOCK), 0, st, src, n, \
                        (double)n, rec, ws_ticket(workspace), whole, stats);                                              \
     LAUNCH_CHECK();                                                                                                      \
     return C2B_OK
-    switch (g_stats_variant) {                  // workgroup size x entities per thread and trip
-        case 1: C2B_STATS_GO(256, 4);           // the r03 / r04 shape
-        case 2: C2B_STATS_GO(512, 5);
-        case 3: C2B_STATS_GO(512, 8);
-        case 4: C2B_STATS_GO(512, 2);
-        case 5: C2B_STATS_GO(256, 8);
-        case 6: C2B_STATS_GO(512, 3);
+    switch (g_stats_variant) {                  // workgroup size x entities per thread and trip, pipelined?, chunked?
+        case 1: C2B_STATS_GO(256, 4, false, false);           // the r03 / r04 shape
+        case 2: C2B_STATS_GO(512, 4, false, false);
+        case 3: C2B_STATS_GO(256, 4, true, false);
+        case 4: C2B_STATS_GO(512, 4, true, false);
+        case 5: C2B_STATS_GO(256, 2, true, false);
+        case 6: C2B_STATS_GO(512, 2, true, false);
+        case 7: C2B_STATS_GO(256, 4, false, true);
+        case 8: C2B_STATS_GO(256, 4, true, true);
+        case 9: C2B_STATS_GO(512, 4, true, true);
+        case 10: C2B_STATS_GO(256, 2, true, true);
+        case 11: C2B_STATS_GO(512, 2, true, true);
+        case 12: C2B_STATS_GO(256, 8, false, true);
+        case 13: C2B_STATS_GO(256, 3, true, true);
         default: break;
     }
 #undef C2B_STATS_GO
@@ -579,7 +620,12 @@ int64_t c2b_workspace_bytes(int64_t n_obs) {
 // tuning hooks of libcity2ba_hip_tune.so (tools/tune_jac.py, tools/tune_obs.py); absent from the product library
 int c2b_tune_set_jacobian_variant(int v) { g_jac_variant = v; return C2B_OK; }
 int c2b_tune_set_observation_variant(int v) { g_obs_variant = v; return C2B_OK; }
-int c2b_tune_set_stats_variant(int v) { g_stats_variant = v; return C2B_OK; }
+int c2b_tune_set_stats_variant(int v) { g_stats_variant = v % 100; g_stats_grid_cap = v >= 200 ? 1024 : (v >= 100 ? 768 : kStatGrid); return C2B_OK; }
+// hand the time-stamp probe a device buffer of (workgroups x 8) u64 (NULL = off)
+int c2b_tune_set_probe(void *device_buffer) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(device_buffer);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &p, sizeof p) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
+}
 #endif
 
 #include "capi_level0.hpp"

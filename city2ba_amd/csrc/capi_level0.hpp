@@ -350,13 +350,19 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
 }
 
 int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts) { return jacobian_stream_policy(n_obs, n_cam, n_pts); }
-int c2b_jacobian_tiles_per_wave(int64_t n_obs) { return n_obs < kJacOneTileBelow ? 1 : 2; }
+int c2b_jacobian_tiles_per_wave(int64_t n_obs) { return jacobian_shape(n_obs, 0.0).opl; }
+int c2b_jacobian_launch_shape(int64_t n_obs, double store_GBs, int *waves_per_workgroup, int *tiles_per_wave) {
+    const JacShape s = jacobian_shape(n_obs, store_GBs);
+    if (waves_per_workgroup) *waves_per_workgroup = s.wpb;
+    if (tiles_per_wave) *tiles_per_wave = s.opl;
+    return C2B_OK;
+}
 
-int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
-                               const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
-                               int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
-                               double *out_sum, void *stream) {
-    C2B_API_BEGIN
+// store_GBs: the measured streaming-store rate of the set r / Jc / Jp live in (0 = unknown) -> the workgroup shape
+static int rows_jacobian_impl(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
+                              const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
+                              int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
+                              double *out_sum, void *stream, double store_GBs) {
     int rc = check_obs_args("residual_jacobian_rows", camblk, pts4, tiles, pt_idx, n_obs);
     if (!rc) rc = check_rows_args("residual_jacobian_rows", row_ptr, n_cam, tiles, n_obs);
     if (rc) return rc;
@@ -372,13 +378,22 @@ int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t
     const uint32_t *rec = reinterpret_cast<const uint32_t *>(tiles);
     if (workspace) {
         double *dst = out_sum ? out_sum : reinterpret_cast<double *>(workspace) + kWsFinal;
-        rc = launch_jacobian<true>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, dst, S(stream), row_ptr, n_cam, obs_base, n_pts);
+        rc = launch_jacobian<true>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace, dst, S(stream), row_ptr, n_cam, obs_base, n_pts, store_GBs);
     } else {
-        rc = launch_jacobian<false>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr, nullptr, S(stream), row_ptr, n_cam, obs_base, n_pts);
+        rc = launch_jacobian<false>(camblk, pts4, rec, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, nullptr, nullptr, S(stream), row_ptr, n_cam, obs_base, n_pts, store_GBs);
     }
     if (rc) return rc;
     LAUNCH_CHECK();
     return C2B_OK;
+}
+
+int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
+                               const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
+                               int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
+                               double *out_sum, void *stream) {
+    C2B_API_BEGIN
+    return rows_jacobian_impl(camblk, pts4, n_pts, row_ptr, n_cam, tiles, obs_base, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, workspace,
+                              out_sum, stream, 0.0);
     C2B_API_END("residual_jacobian_rows")
 }
 
@@ -467,7 +482,9 @@ int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_stor
     OutSet sets[8];
     auto free_sets = [&]() { for (auto &q : sets) q.free_all(); };
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool measure = n_obs >= 1000000 && max_attempts > 1;      // below that the store rate means nothing
+    // below a million observations the store rate means nothing; above, even a caller that takes the first set
+    // (max_attempts = 1) gets its rate measured (~4 ms): c2b_residual_jacobian_rows_placed picks its workgroup shape by it
+    const bool measure = n_obs >= 1000000;
     if (measure && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) {
         if (e0) (void)hipEventDestroy(e0);
         return fail(C2B_ERR_HIP, "jacobian_outputs_alloc: hipEventCreate failed");
@@ -529,6 +546,39 @@ int c2b_jacobian_outputs_log(const c2b_jacobian_outputs *h, double *store_GBs_pe
     for (int a = 0; a < h->attempts && a < capacity; ++a) store_GBs_per_attempt[a] = h->rate[a];
     if (attempts) *attempts = h->attempts;
     if (chosen) *chosen = h->chosen;
+    return C2B_OK;
+}
+
+// The whole-list launch INTO a placed output set: c2b_residual_jacobian_rows with r / Jc / Jp taken from the handle and
+// the workgroup shape chosen by the store rate c2b_jacobian_outputs_alloc measured for that set (jacobian_shape).
+int c2b_residual_jacobian_rows_placed(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
+                                      const void *tiles, const uint32_t *pt_idx, const double *uv_obs, int64_t n_obs,
+                                      const c2b_jacobian_outputs *outputs, double norm, void *workspace, double *out_sum, void *stream) {
+    C2B_API_BEGIN
+    if (!outputs) return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows_placed: outputs is NULL");
+    if (outputs->n_obs != n_obs)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows_placed: the output set holds %lld observations, the launch %lld",
+                    (long long)outputs->n_obs, (long long)n_obs);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != outputs->device)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows_placed: the current device (%d) is not the output set's (%d)", cur, outputs->device);
+    const double rate = outputs->chosen >= 0 && outputs->chosen < 8 ? outputs->rate[outputs->chosen] : 0.0;
+    return rows_jacobian_impl(camblk, pts4, n_pts, row_ptr, n_cam, tiles, 0, pt_idx, uv_obs, n_obs, outputs->r, outputs->Jc, outputs->Jp,
+                              norm, workspace, out_sum, stream, rate);
+    C2B_API_END("residual_jacobian_rows_placed")
+}
+
+int c2b_jacobian_outputs_store_rate(const c2b_jacobian_outputs *h, double *store_GBs) {
+    if (!h || !store_GBs) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_store_rate: NULL argument");
+    *store_GBs = h->chosen >= 0 && h->chosen < 8 ? h->rate[h->chosen] : 0.0;
+    return C2B_OK;
+}
+
+// a caller that timed the set itself (or wants a particular shape) replaces the recorded rate; <= 0 = "unknown"
+int c2b_jacobian_outputs_set_store_rate(c2b_jacobian_outputs *h, double store_GBs) {
+    if (!h) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_set_store_rate: NULL handle");
+    if (h->chosen < 0 || h->chosen >= 8) h->chosen = 0;
+    h->rate[h->chosen] = store_GBs > 0.0 ? store_GBs : 0.0;
     return C2B_OK;
 }
 

@@ -553,8 +553,9 @@ int c2b_problem_residual_jacobian_device(c2b_problem *p, int max_attempts, c2b_j
         if (rc) return rc;
     }
     c2b_jacobian_outputs *h = *outputs;
-    rc = c2b_residual_jacobian_rows(p->camblk, p->pts4, p->n_pts, p->rows_ptr, p->n_cam, p->rows_tiles, 0, p->pt_idx, p->uv, p->n_obs,
-                                    h->r, h->Jc, h->Jp, 2.0, p->ws, p->scalar, p->stream);
+    // into the placed set: the workgroup shape follows the store rate measured for it
+    rc = c2b_residual_jacobian_rows_placed(p->camblk, p->pts4, p->n_pts, p->rows_ptr, p->n_cam, p->rows_tiles, p->pt_idx, p->uv, p->n_obs,
+                                           h, 2.0, p->ws, p->scalar, p->stream);
     double sum = 0.0;
     hipError_t e = hipSuccess;
     if (!rc) e = hipMemcpyAsync(&sum, p->scalar, sizeof(double), hipMemcpyDeviceToHost, p->stream);

@@ -22,12 +22,24 @@ namespace c2b {
 
 constexpr int kBlock = 256;          // lanes per workgroup of the per-entity kernels (4 waves)
 constexpr int kWaves = kBlock / 64;
-constexpr int kRedBlocks = 512;      // largest grid of the entity reductions (one record per workgroup in the workspace): 2 per CU.  A/B at 2.6 M entities (r03): 256 / 512 / 768 / 1024 / 2048 / 4096 workgroups -> 35 / 37 / 38 / 40 / 49 / 68 us
+constexpr int kRedBlocks = 1024;     // record slots of the entity reductions in the workspace (the largest grid a variant may use)
+constexpr int kStatGrid = 512;       // largest grid of the entity reductions (one record per workgroup in the workspace): 2 per CU.  A/B at 2.6 M entities (r03): 256 / 512 / 768 / 1024 / 2048 / 4096 workgroups -> 35 / 37 / 38 / 40 / 49 / 68 us
 constexpr int kStatRec = 20;         // doubles per stats partial record (18 used)
 constexpr int kStatBatch = 4;        // entities a thread of the statistics passes loads before it uses any
-constexpr int kStatBlock = 512;      // threads per workgroup of the one-launch statistics pass (k_stats_pass1)
+constexpr int kStatBlock = 256;      // threads per workgroup of the one-launch statistics pass (k_stats_pass1)
+constexpr bool kStatPipe = false;    // next batch's loads in flight while the current one is accumulated
+constexpr bool kStatChunk = false;   // contiguous entities per workgroup instead of grid-strided slabs
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// Tuning build only: a time-stamp probe (tools/tune_stats.py --probe): thread 0 of every workgroup writes the constant-rate
+// wall clock (100 MHz) into slot `k` of its row of a buffer the tool hands over; nothing of it exists in the product library.
+#ifdef C2B_TUNE
+__device__ unsigned long long *g_probe = nullptr;
+#define C2B_PROBE(k) do { if (g_probe != nullptr && threadIdx.x == 0) g_probe[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define C2B_PROBE(k) do { } while (0)
+#endif
 
 // ---- XCD-aware tile map (bijective for any n_tiles; cdna guide T1) -----------------------
 C2B_DEV int64_t xcd_tile(int64_t bid, int64_t n_tiles) {
@@ -1123,35 +1135,96 @@ C2B_DEV void stat_merge(StatRec &a, const StatRec &b) {
         a.cnt = tot;
     }
 }
-// all 64 lanes -> lane 0 (shuffle tree, fixed order).  Field by field, so that only one partner value is live at a time
-// (materialising the partner's whole record cost 149 VGPRs and two waves per SIMD of occupancy).
-template <bool STD>
-C2B_DEV void stat_wave_reduce(StatRec &r) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { r.s[k] = wave_sum(r.s[k]); r.mn[k] = wave_min(r.mn[k]); r.mx[k] = wave_max(r.mx[k]); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Best o;
-        o.d = __shfl_down(r.best.d, off, 64);
-        o.i = __shfl_down(r.best.i, off, 64);
-        r.best = best_merge(r.best, o);
+// all 64 lanes -> lane 0 (shuffle trees, fixed order), field by field.
+// The moments (r05): NOT Chan's update level by level -- six dependent IEEE divisions per tree, and the workgroup's waves
+// then merged one after the other by thread 0 with one more each: measured, these reductions were ~11 of the pass's 29 us
+// (512-thread workgroups, four more serial merges at both levels, cost 7 us more than 256-thread ones whatever the
+// loop's shape, profiles/r05a_ab_stats_shapes.txt).  Instead the textbook combination of partial (count, mean, M2)
+// triples in one step:  N = sum n_i;  mean = sum n_i mean_i / N;  M2 = sum (M2_i + n_i (mean_i - mean)^2)  -- the
+// deviations are taken from the COMBINED mean, so it is as well conditioned as Chan's pairwise form (both equal the
+// reference's second pass around the finished mean up to rounding; tested at 1e-12) and costs seven wave sums, one
+// reciprocal and two broadcasts.
+C2B_DEV double wave_bcast0(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// LANES (a power of two <= 64): how many leading lanes hold records; the tree starts at LANES / 2.
+// LEVEL-MAJOR: at every level all the fields' partner values are requested first and combined afterwards.  A lane
+// shuffle on gfx9 is a ds_bpermute -- a round trip through the LDS crossbar of ~100 cycles -- so sixteen field-by-field
+// trees of six dependent shuffles each cost ~7 us per workgroup (measured with the tuning build's time-stamp probe, r05:
+// the two block reductions were 14 of the pass's 33 us); a level's shuffles issued back to back overlap their latencies.
+// The value `OFF` lanes further down the wave (OFF a power of two), as far as a reduction TO LANE 0 needs it: lanes
+// whose partner lies in another row of 16 get their own value back for OFF < 16 (their sums are never read).  OFF < 16
+// is a DPP row shift -- register to register at vector-ALU rate -- where __shfl_down is a ds_bpermute through the LDS
+// crossbar, ~100 cycles of latency and contended by every wave of the CU that reduces at the same moment (the block
+// reduction of 4 waves: 3.9 us with bpermutes at every level, time-stamp probe, r05).
+template <int OFF>
+C2B_DEV double lane_down(double v) {
+    if constexpr (OFF >= 16) {
+        return __shfl_down(v, OFF, 64);
+    } else {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + OFF, 0xf, 0xf, false);     // row_shl:OFF -- lane i reads lane i + OFF of its row
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + OFF, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
     }
+}
+// one level of the reduction: all the fields' partner values first, then the combinations (level-major: the shuffles of
+// a level overlap their latencies; field by field, sixteen trees of six dependent shuffles cost ~7 us per workgroup)
+template <bool STD, int OFF>
+C2B_DEV void stat_level1(StatRec &r, double &tn, double (&cm)[3]) {
+    double s[3], mn[3], mx[3], oc = 0.0, ocm[3] = {0.0, 0.0, 0.0};
+    Best o;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s[k] = lane_down<OFF>(r.s[k]); mn[k] = lane_down<OFF>(r.mn[k]); mx[k] = lane_down<OFF>(r.mx[k]); }
+    o.d = lane_down<OFF>(r.best.d);
+    o.i = lane_down<OFF>(r.best.i);
     if (STD) {
+        oc = lane_down<OFF>(tn);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {                    // Chan's update, exactly as stat_merge writes it
-            const double ocnt = __shfl_down(r.cnt, off, 64);
-            const double tot = r.cnt + ocnt;
-            const double f = tot > 0.0 ? ocnt / tot : 0.0;
-            const double w = r.cnt * f;
+        for (int k = 0; k < 3; ++k) ocm[k] = lane_down<OFF>(cm[k]);
+    }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double delta = __shfl_down(r.mu[k], off, 64) - r.mu[k];
-                const double om2 = __shfl_down(r.m2[k], off, 64);
-                r.mu[k] = r.mu[k] + delta * f;
-                r.m2[k] = (r.m2[k] + om2) + (delta * delta) * w;
-            }
-            r.cnt = tot;
+    for (int k = 0; k < 3; ++k) { r.s[k] += s[k]; r.mn[k] = fmin(r.mn[k], mn[k]); r.mx[k] = fmax(r.mx[k], mx[k]); }
+    r.best = best_merge(r.best, o);
+    if (STD) {
+        tn += oc;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cm[k] += ocm[k];
+    }
+    if constexpr (OFF > 1) stat_level1<STD, OFF / 2>(r, tn, cm);
+}
+template <int OFF>
+C2B_DEV void stat_level2(double (&q)[3]) {
+    double oq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) oq[k] = lane_down<OFF>(q[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] += oq[k];
+    if constexpr (OFF > 1) stat_level2<OFF / 2>(q);
+}
+// LANES (a power of two, 2 ... 64): how many leading lanes hold records; the tree starts at LANES / 2 -> lane 0.
+template <bool STD, int LANES = 64>
+C2B_DEV void stat_wave_reduce(StatRec &r) {
+    static_assert(LANES >= 2 && LANES <= 64 && (LANES & (LANES - 1)) == 0, "a power of two");
+    // phase 1: sums, extremes, the origin candidate, the count and the count-weighted means
+    double tn = r.cnt, cm[3] = {r.cnt * r.mu[0], r.cnt * r.mu[1], r.cnt * r.mu[2]};
+    stat_level1<STD, LANES / 2>(r, tn, cm);
+    if (STD) {
+        // phase 2: every lane's M2 moved to the combined mean (lane 0 holds the totals), then summed
+        const double n_all = wave_bcast0(tn);
+        const double inv = n_all > 0.0 ? 1.0 / n_all : 0.0;
+        double mean[3], q[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mean[k] = wave_bcast0(cm[k]) * inv;
+            const double d = r.mu[k] - mean[k];
+            q[k] = r.m2[k] + r.cnt * (d * d);
         }
+        stat_level2<LANES / 2>(q);
+        r.cnt = n_all;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.mu[k] = mean[k]; r.m2[k] = q[k]; }
     }
 }
 C2B_DEV void stat_to_lds(const StatRec &r, double *o) {
@@ -1167,44 +1240,114 @@ C2B_DEV StatRec stat_from(const double *o) {
     return r;
 }
 
-// the workgroup's WAVES waves (one record each, on lane 0) -> one record on thread 0, waves in order
+// the workgroup's WAVES waves -> one record on thread 0: every wave reduces to its lane 0, the WAVES wave records go
+// through LDS to the first lanes of wave 0, which reduces them the same way (lanes beyond WAVES hold the identity)
 template <bool STD, int WAVES = kWaves>
 C2B_DEV StatRec stat_block_reduce(StatRec r, double (*sh)[kStatRec]) {
+    static_assert(WAVES <= 64, "one lane of wave 0 per wave");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     stat_wave_reduce<STD>(r);
     __syncthreads();
     if (lane == 0) stat_to_lds(r, sh[wave]);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        r = stat_from(sh[0]);
-#pragma unroll 1                                                  // one record live at a time (unrolled, eight records' loads are hoisted and spill)
-        for (int w = 1; w < WAVES; ++w) stat_merge<STD>(r, stat_from(sh[w]));
+    if (wave == 0) {                                             // wave-uniform
+        r = stat_empty();
+        if (lane < WAVES) r = stat_from(sh[lane]);
+        stat_wave_reduce<STD, WAVES>(r);                          // log2(WAVES) levels
     }
     return r;
 }
 
+// One batch of a thread's entities into the running record: mean sums, min / max, the origin search, and (STD) the
+// batch's own (count, mean, M2) triple merged by Chan's update.  j0 + u * step = the entity index, valid while < lim.
+template <bool STD, int BATCH, bool FULL>
+C2B_DEV void stat_accumulate_impl(StatRec &a, double &best_thr, const double (&x)[BATCH], const double (&y)[BATCH],
+                                  const double (&z)[BATCH], int64_t j0, int64_t step, int64_t lim, double inv_num) {
+    double c = 0.0, bs[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+        const int64_t j = j0 + u * step;
+        if (FULL || j < lim) {
+            a.s[0] += x[u] * inv_num; a.s[1] += y[u] * inv_num; a.s[2] += z[u] * inv_num;
+            a.mn[0] = fmin(a.mn[0], x[u]); a.mn[1] = fmin(a.mn[1], y[u]); a.mn[2] = fmin(a.mn[2], z[u]);
+            a.mx[0] = fmax(a.mx[0], x[u]); a.mx[1] = fmax(a.mx[1], y[u]); a.mx[2] = fmax(a.mx[2], z[u]);
+            const double d2 = dot3(x[u], y[u], z[u], x[u], y[u], z[u]);
+            if (d2 <= best_thr) {                            // rare after the first few entities of a thread
+                const double d = sqrt(d2);
+                if (a.best.i < 0.0 || d <= a.best.d) {       // j grows within a thread: an equal distance is the later entity
+                    a.best.d = d; a.best.i = (double)j;
+                    best_thr = (d * d) * (1.0 + 0x1.0p-49);
+                }
+            }
+            if (STD) { c += 1.0; bs[0] += x[u]; bs[1] += y[u]; bs[2] += z[u]; }
+        }
+    }
+    if (STD && (FULL || c > 0.0)) {                          // the batch's own triple (two passes over registers), then Chan
+        StatRec bt = stat_empty();
+        const double ic = 1.0 / c;
+        bt.cnt = c;
+        bt.mu[0] = bs[0] * ic; bt.mu[1] = bs[1] * ic; bt.mu[2] = bs[2] * ic;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            if (FULL || j0 + u * step < lim) {
+                const double dx = x[u] - bt.mu[0], dy = y[u] - bt.mu[1], dz = z[u] - bt.mu[2];
+                bt.m2[0] += dx * dx; bt.m2[1] += dy * dy; bt.m2[2] += dz * dz;
+            }
+        }
+        const double tot = a.cnt + c, f = c / tot;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double delta = bt.mu[k] - a.mu[k];
+            a.mu[k] = a.mu[k] + delta * f;
+            a.m2[k] = (a.m2[k] + bt.m2[k]) + (delta * delta) * (a.cnt * f);
+        }
+        a.cnt = tot;
+    }
+}
+// a batch whose last entity is in range (all but a thread's last trip) skips the per-entity range checks
+template <bool STD, int BATCH>
+C2B_DEV void stat_accumulate(StatRec &a, double &best_thr, const double (&x)[BATCH], const double (&y)[BATCH],
+                             const double (&z)[BATCH], int64_t j0, int64_t step, int64_t lim, double inv_num) {
+    if (j0 + (BATCH - 1) * step < lim) stat_accumulate_impl<STD, BATCH, true>(a, best_thr, x, y, z, j0, step, lim, inv_num);
+    else stat_accumulate_impl<STD, BATCH, false>(a, best_thr, x, y, z, j0, step, lim, inv_num);
+}
+
 // stats[0..2]=mean, [6..8]=min, [9..11]=max, [12..14]=dim, [15..17]=origin (re-read by index), [18]=origin's GLOBAL
-// index (map).  STD (the unsharded call): [3..5]=std, [19]=|std| from the Chan triples, all in this one launch.  !STD (a
-// shard's share, c2b_stats_partial_pass1): [19]=the origin's distance (compared across ranks), no moments.
+// index (map).  STD (the unsharded call): [3..5]=std, [19]=|std| from the (count, mean, M2) triples, all in this one
+// launch.  !STD (a shard's share, c2b_stats_partial_pass1): [19]=the origin's distance (compared across ranks), no moments.
 // rec: gridDim.x records of kStatRec doubles in the workspace.
 //
-// Shape (r05).  BLOCK = 512 threads and at most kRedBlocks = 512 workgroups: two workgroups = 16 waves per CU, four per
-// SIMD (128 VGPRs: __launch_bounds__(BLOCK, 4)), where r03's 256-thread workgroups left two waves per SIMD to hide a
-// dependent batch of loads each -- and the fold's cost does not grow, because it is per RECORD (one per workgroup).
-// The origin search no longer takes a square root per entity: fold1 (src/noise.rs:80-86) compares the ROUNDED distances
+// Where its time goes (r05, the tuning build's time-stamp probe at --blocks 128, 2.64 M entities, profiles/r05g_*): the
+// entity loop moves its 84.5 MB (32 bytes per entity since the compact centre table; 148.7 MB before) in ~11 us --
+// 7.7 TB/s, and no faster with twice the workgroups, 512-thread workgroups, a software pipeline or contiguous chunks per
+// workgroup: a bandwidth figure, not a latency one -- and everything else is a chain of fixed latencies: ~1 us until
+// the last workgroup has started, the workgroup's reduction (3.3 us), the record's publication and the arrival count
+// (1 us), and in the workgroup that arrives last the records (1.8 us), their reduction (3.1 us) and the results (0.8 us).
+// Those reductions were 7.4 + 6.6 us while every level of every field's shuffle tree was a dependent ds_bpermute with an
+// IEEE division in Chan's update (stat_wave_reduce): 33 -> 25 us for the pass.  512-thread workgroups (4 waves per SIMD
+// instead of 2) make the loop no faster and both reductions slower (8 wave records through LDS): 256 threads ship.
+//
+// The origin search takes no square root per entity: fold1 (src/noise.rs:80-86) compares the ROUNDED distances
 // sqrt(x.x), so the exact rule "the latest entity among those whose rounded distance is smallest" is kept by comparing
 // the squared distance with a threshold just above the square of the thread's current best distance -- 8 ulps above,
 // where 1 would do: sqrt is monotone, so a squared distance beyond it cannot round to a distance <= the best -- and only
 // an entity under the threshold (a handful per thread: the running minimum of a sequence improves O(log n) times) takes
 // the square root and the exact comparison.  NaN coordinates never become the origin (the reference's fold would let
 // the LAST NaN win; not reproduced, like every NaN rule of the reductions).
-template <typename Src, bool STD, int BLOCK = kStatBlock, int BATCH = kStatBatch>
+//
+// PIPE: the loads of a thread's NEXT batch are issued before the current batch is accumulated (clamped, so that every
+// trip issues the same number of loads and the wait in front of the arithmetic is a count, not "everything") -- a trip
+// then costs the longer of a memory round trip and its ~400 vector instructions instead of their sum.
+// CHUNK: workgroup b owns the contiguous entities [b * per, (b + 1) * per) (a thread's batch is BLOCK apart) instead of
+// every gridDim.x-th slab of the whole table (a thread's batch gridDim.x * BLOCK apart).
+template <typename Src, bool STD, int BLOCK = kStatBlock, int BATCH = kStatBatch, bool PIPE = kStatPipe, bool CHUNK = kStatChunk>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(Src src, int64_t n, double num, double *__restrict__ rec,
                                                        unsigned *__restrict__ ticket, ShardMap map,
                                                        double *__restrict__ stats) {
     constexpr int WAVES = BLOCK / 64;
     __shared__ double sh[WAVES + 1][kStatRec];
     unsigned magic = 0u;
+    C2B_PROBE(0);
     if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
     StatRec a = stat_empty();
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
@@ -1215,56 +1358,43 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
     // one reciprocal instead of divided (three IEEE divides per entity were a third of this pass's instructions).  The
     // sums are tree-ordered already, so the last bits differ from the sequential fold either way (tested at 1e-12).
     const double inv_num = 1.0 / num;
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride * BATCH) {
-        double x[BATCH], y[BATCH], z[BATCH];
+    int64_t first, step, lim;                               // this thread's entities: first, first + step, ... while < lim
+    if (CHUNK) {
+        const int64_t per = ((n + gridDim.x - 1) / gridDim.x + BLOCK - 1) / BLOCK * BLOCK;
+        first = (int64_t)blockIdx.x * per + threadIdx.x;
+        step = BLOCK;
+        lim = (int64_t)(blockIdx.x + 1) * per < n ? (int64_t)(blockIdx.x + 1) * per : n;
+    } else {
+        first = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        step = (int64_t)gridDim.x * BLOCK;
+        lim = n;
+    }
+    auto load = [&](int64_t j0, double (&x)[BATCH], double (&y)[BATCH], double (&z)[BATCH]) {
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int64_t j = i + u * stride;
-            src.get(j < n ? j : n - 1, x[u], y[u], z[u]);
+            const int64_t j = j0 + u * step;
+            src.get(j < lim ? j : n - 1, x[u], y[u], z[u]);
         }
-        double c = 0.0, bs[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const int64_t j = i + u * stride;
-            if (j < n) {
-                a.s[0] += x[u] * inv_num; a.s[1] += y[u] * inv_num; a.s[2] += z[u] * inv_num;
-                a.mn[0] = fmin(a.mn[0], x[u]); a.mn[1] = fmin(a.mn[1], y[u]); a.mn[2] = fmin(a.mn[2], z[u]);
-                a.mx[0] = fmax(a.mx[0], x[u]); a.mx[1] = fmax(a.mx[1], y[u]); a.mx[2] = fmax(a.mx[2], z[u]);
-                const double d2 = dot3(x[u], y[u], z[u], x[u], y[u], z[u]);
-                if (d2 <= best_thr) {                            // rare after the first few entities of a thread
-                    const double d = sqrt(d2);
-                    if (a.best.i < 0.0 || d <= a.best.d) {       // j grows within a thread: an equal distance is the later entity
-                        a.best.d = d; a.best.i = (double)j;
-                        best_thr = (d * d) * (1.0 + 0x1.0p-49);
-                    }
-                }
-                if (STD) { c += 1.0; bs[0] += x[u]; bs[1] += y[u]; bs[2] += z[u]; }
-            }
+    };
+    if (PIPE) {
+        double x0[BATCH], y0[BATCH], z0[BATCH], x1[BATCH], y1[BATCH], z1[BATCH];
+        if (first < lim) load(first, x0, y0, z0);
+        for (int64_t i = first; i < lim; i += 2 * step * BATCH) {          // two trips per iteration: the register sets swap roles
+            load(i + step * BATCH, x1, y1, z1);                            // past the end: clamped re-reads, not accumulated
+            stat_accumulate<STD, BATCH>(a, best_thr, x0, y0, z0, i, step, lim, inv_num);
+            load(i + 2 * step * BATCH, x0, y0, z0);
+            stat_accumulate<STD, BATCH>(a, best_thr, x1, y1, z1, i + step * BATCH, step, lim, inv_num);
         }
-        if (STD) {                                           // the batch's own triple (two passes over registers), then Chan
-            StatRec bt = stat_empty();
-            const double ic = 1.0 / c;                       // i < n: the batch holds at least one entity
-            bt.cnt = c;
-            bt.mu[0] = bs[0] * ic; bt.mu[1] = bs[1] * ic; bt.mu[2] = bs[2] * ic;
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                if (i + u * stride < n) {
-                    const double dx = x[u] - bt.mu[0], dy = y[u] - bt.mu[1], dz = z[u] - bt.mu[2];
-                    bt.m2[0] += dx * dx; bt.m2[1] += dy * dy; bt.m2[2] += dz * dz;
-                }
-            }
-            const double tot = a.cnt + c, f = c / tot;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double delta = bt.mu[k] - a.mu[k];
-                a.mu[k] = a.mu[k] + delta * f;
-                a.m2[k] = (a.m2[k] + bt.m2[k]) + (delta * delta) * (a.cnt * f);
-            }
-            a.cnt = tot;
+    } else {
+        for (int64_t i = first; i < lim; i += step * BATCH) {
+            double x[BATCH], y[BATCH], z[BATCH];
+            load(i, x, y, z);
+            stat_accumulate<STD, BATCH>(a, best_thr, x, y, z, i, step, lim, inv_num);
         }
     }
+    C2B_PROBE(1);
     a = stat_block_reduce<STD, WAVES>(a, sh);
+    C2B_PROBE(2);
     if (threadIdx.x == 0) {
         double t[kStatRec];
         stat_to_lds(a, t);
@@ -1273,6 +1403,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
         for (int k = 0; k < (STD ? 18 : 11); ++k) __hip_atomic_store(o + k, t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_waitcnt(0);
         const bool last = ticket_arrive(ticket, magic);
+        C2B_PROBE(3);
         if (magic != kTicketMagic) {
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
             for (int k = 0; k < 20; ++k) stats[k] = nan;
@@ -1295,7 +1426,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
         }
         stat_merge<STD>(f, g);
     }
+    C2B_PROBE(4);
     f = stat_block_reduce<STD, WAVES>(f, sh);
+    C2B_PROBE(5);
     if (threadIdx.x != 0) return;
     double x = 0, y = 0, z = 0;
     if (f.best.i >= 0.0) src.get((int64_t)f.best.i, x, y, z);
@@ -1315,6 +1448,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
     } else {
         stats[19] = f.best.i >= 0.0 ? f.best.d : inf;
     }
+    C2B_PROBE(6);
 }
 
 // pass 2 (sharded statistics only since r03): sums of squared deviations from mean3.  RAW: leave the three sums in

@@ -206,6 +206,23 @@ def jacobian_tiles_per_wave(n_obs):
     return int(L.lib().c2b_jacobian_tiles_per_wave(int(n_obs)))
 
 
+def jacobian_launch_shape(n_obs, store_GBs=0.0):
+    """(waves per workgroup, tiles of 64 observations per wave) of a residual_jacobian_rows launch of this size into an
+    output set that takes streaming stores at store_GBs (0 = unknown)"""
+    w, t = C.c_int(0), C.c_int(0)
+    L.check(L.lib().c2b_jacobian_launch_shape(int(n_obs), float(store_GBs), C.byref(w), C.byref(t)))
+    return w.value, t.value
+
+
+def residual_jacobian_rows_placed(camblk, pts4, rows, pt_idx, uv, outputs, norm=2.0, ws=None, out_sum=None):
+    """residual_jacobian_rows over the whole list into a placed output set (JacobianOutputs): the launch takes the
+    workgroup shape that suits the store rate measured for that set"""
+    L.check(L.lib().c2b_residual_jacobian_rows_placed(_p(camblk), _p(pts4), pts4.shape[0], _p(rows.row_ptr), rows.n_cam, _p(rows.tiles),
+                                                      _p(pt_idx), _p(uv), rows.n_obs, outputs.handle, float(norm), _p(ws), _p(out_sum),
+                                                      _stream()))
+    return out_sum
+
+
 def residual_jacobian(camblk, pts4, cam_idx, pt_idx, uv, r, Jc, Jp, norm=2.0, ws=None):
     """ws != None -> the same launch also folds sum |r|^norm into ws (see error_sum_finish)."""
     L.check(L.lib().c2b_residual_jacobian(_p(camblk), _p(pts4), _p(cam_idx), _p(pt_idx), _p(uv), cam_idx.shape[0],
@@ -278,8 +295,11 @@ class JacobianOutputs:
         rates = (C.c_double * 8)()
         na, ch = C.c_int(0), C.c_int(-1)
         L.check(L.lib().c2b_jacobian_outputs_log(own.h, rates, 8, C.byref(na), C.byref(ch)))
-        self.log = [round(rates[i], 1) for i in range(na.value)] if n_obs >= 1_000_000 and max_attempts > 1 else []
+        self.log = [round(rates[i], 1) for i in range(na.value)] if n_obs >= 1_000_000 else []
         self.chosen = ch.value
+        sr = C.c_double(0.0)
+        L.check(L.lib().c2b_jacobian_outputs_store_rate(own.h, C.byref(sr)))
+        self.store_GBs = sr.value                                # of the kept set (0: not measured)
         n = max(int(n_obs), 0)
         if n == 0:
             self.r, self.Jc, self.Jp = (torch.empty((0, k), dtype=torch.float64, device=dev) for k in (2, 18, 6))
@@ -291,6 +311,11 @@ class JacobianOutputs:
     @property
     def handle(self):
         return self._own.h
+
+    def set_store_rate(self, store_GBs):
+        """replace the rate the library measured (residual_jacobian_rows_placed chooses its launch shape by it)"""
+        L.check(L.lib().c2b_jacobian_outputs_set_store_rate(self._own.h, float(store_GBs)))
+        self.store_GBs = max(float(store_GBs), 0.0)
 
 
 def alloc_jacobian_outputs(n_obs, device, max_attempts=8, fast_store_GBs=7000.0):

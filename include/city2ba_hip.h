@@ -175,6 +175,11 @@ int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts);
  * (diagnostic: names the kernel instance a launch of this size runs; results do not depend on it, the rounding of
  * the folded error sum does, like on any other change of the grid) */
 int c2b_jacobian_tiles_per_wave(int64_t n_obs);
+/* ... and the full shape -- waves of 64 per workgroup, tiles per wave -- of a launch of n_obs observations into an output
+ * set that takes streaming stores at store_GBs (GB/s; 0 = unknown): 8 x 1 below ~6 M observations; above, 8 x 2, or
+ * 4 x 1 when the set is one of the slow-store kind (< 6.3 TB/s; c2b_residual_jacobian_rows_placed).  Diagnostic, like
+ * the two above: results do not depend on the shape. */
+int c2b_jacobian_launch_shape(int64_t n_obs, double store_GBs, int *waves_per_workgroup, int *tiles_per_wave);
 int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
                                int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
@@ -201,8 +206,9 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
  * depending only on which allocation its outputs live in; nothing visible from user space
  * predicts it, so this entry allocates a set, times the kernel's own store pattern into it (~4 ms), keeps it if it
  * streams at fast_store_GBs (<= 0: 7000) or better and otherwise holds it and tries again, at most max_attempts
- * (clamped to 1..8) times; the best set wins, the others are freed before it returns.  max_attempts = 1, or n_obs
- * < 10^6, allocates without measuring.  An attempt that runs out of memory ends the search with the best set so far.
+ * (clamped to 1..8) times; the best set wins, the others are freed before it returns.  max_attempts = 1 takes the
+ * first set (its rate is still measured: c2b_residual_jacobian_rows_placed chooses its workgroup shape by it); n_obs
+ * < 10^6 allocates without measuring.  An attempt that runs out of memory ends the search with the best set so far.
  * Synchronises `stream`.  The handle owns the memory until c2b_jacobian_outputs_free.
  * (No reference counterpart: the Jacobian itself is build-defined; a Rust host holds the handle next to its
  * device mirror, INTEGRATION.md.) */
@@ -213,7 +219,20 @@ int c2b_jacobian_outputs_pointers(const c2b_jacobian_outputs *h, double **r, dou
 /* store rate (GB/s) measured for every attempt, how many there were, and which one was kept */
 int c2b_jacobian_outputs_log(const c2b_jacobian_outputs *h, double *store_GBs_per_attempt, int capacity, int *attempts,
                              int *chosen);
+/* the kept set's measured store rate in GB/s (0: not measured) */
+int c2b_jacobian_outputs_store_rate(const c2b_jacobian_outputs *h, double *store_GBs);
+/* replace it: for a caller that timed the set itself, or wants one particular launch shape (<= 0: "unknown") */
+int c2b_jacobian_outputs_set_store_rate(c2b_jacobian_outputs *h, double store_GBs);
 void c2b_jacobian_outputs_free(c2b_jacobian_outputs *h);
+/* c2b_residual_jacobian_rows over the WHOLE list (obs_base = 0, n_obs = the set's observation count) INTO a placed set:
+ * r / Jc / Jp are the handle's arrays, and the launch takes the workgroup shape that is fastest for stores of the speed
+ * measured for that set (c2b_jacobian_launch_shape: 256-thread workgroups with one tile per wave into a slow-store
+ * set, 2.3 % faster there; 512 threads x two tiles otherwise).  Same results, bit for bit, under either shape; the
+ * folded sum's rounding follows the grid, as always.  The current device must be the set's. */
+int c2b_residual_jacobian_rows_placed(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr,
+                                      int64_t n_cam, const void *tiles, const uint32_t *pt_idx, const double *uv_obs,
+                                      int64_t n_obs, const c2b_jacobian_outputs *outputs, double norm, void *workspace,
+                                      double *out_sum, void *stream);
 
 /* Calibration (measurement aids, no reference counterpart; used by bench.py in the same process as the timed run so
  * that a slow device can be told from a slow kernel).  _store_pattern writes a fill pattern over r [n][2], Jc [n][18],

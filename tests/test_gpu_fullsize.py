@@ -52,6 +52,26 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     torch.cuda.synchronize()
     assert e_one.item() == e_fused.item()
     assert torch.equal(r_b, r) and torch.equal(Jc_b, Jc) and torch.equal(Jp_b, Jp)
+    # r05: the launch INTO a placed output set picks its workgroup shape by the set's store rate (512 threads x two tiles, or
+    # 256 threads x one tile into a slow-store set above 6 M observations): same r / Jc / Jp under either, the folded sum
+    # to rounding (another grid), and each shape reproduces its own sum
+    outs = D.JacobianOutputs(n, dev, max_attempts=1)
+    assert (outs.store_GBs > 1000.0) == (n >= 1_000_000)
+    sums = {}
+    for rate in (5700.0, 7100.0, 0.0):
+        outs.set_store_rate(rate)
+        assert D.jacobian_launch_shape(n, rate) == ((8, 1) if n < 6_000_000 else ((4, 1) if 0 < rate < 6300 else (8, 2)))
+        outs.r.fill_(float("nan")); outs.Jc.fill_(float("nan")); outs.Jp.fill_(float("nan"))
+        for _ in range(2):
+            D.residual_jacobian_rows_placed(camblk, pts4, rows, pi, uv, outs, 2.0, ws, e_one)
+            torch.cuda.synchronize()
+            assert sums.setdefault(rate, e_one.item()) == e_one.item()
+        assert torch.equal(outs.r, r) and torch.equal(outs.Jc, Jc) and torch.equal(outs.Jp, Jp)
+        assert abs(e_one.item() - e_fused.item()) <= 1e-13 * e_fused.item()
+    assert sums[7100.0] == sums[0.0] == e_fused.item()
+    with pytest.raises(Exception):
+        D.residual_jacobian_rows_placed(camblk, pts4, rows, pi, uv, D.JacobianOutputs(n + 64, dev, max_attempts=1), 2.0, ws, e_one)
+    del outs
     if blocks == 32:
         # every cache policy of the once-read streams writes the same bits.  n_pts only sizes the working set for
         # that choice (c2b_jacobian_stream_policy), so claiming more points than there are selects the other kernels.

@@ -36,6 +36,8 @@ VARIANTS = {
     701: "1 tile/wave", 702: "3 tiles/wave", 703: "256 thr, 2 tiles/wave", 704: "256 thr, 4 tiles/wave",
     713: "256 thr, 1 tile/wave", 705: "uv requested per tile", 706: "plain stores", 712: "1 tile/wave, plain stores",
     707: "every load cached", 708: "idx nt only", 709: "uv nt only", 714: "XCD map in chunks of 4", 715: "XCD map in chunks of 64",
+    716: "256 thr, 1 tile, every load cached", 717: "256 thr, 1 tile, uv nt only", 718: "256 thr, 1 tile, uv per tile",
+    719: "128 thr, 2 tiles/wave", 720: "1024 thr, 1 tile/wave", 721: "256 thr, 1 tile, XCD chunks of 64", 722: "256 thr, 1 tile, plain stores",
 }
 
 ap = argparse.ArgumentParser()
@@ -44,6 +46,7 @@ ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--sets", type=int, default=8)
 ap.add_argument("--require", default="any")
+ap.add_argument("--slowest-only", action="store_true", help="A/B in the slowest set only")
 ap.add_argument("--variants", default=",".join(str(v) for v in VARIANTS))
 a = ap.parse_args()
 variants = [int(v) for v in a.variants.split(",")]
@@ -96,6 +99,11 @@ def run(v, r, Jc, Jp):
 
 order = sorted(range(len(sets)), key=lambda k: sets[k][0])
 picks = [("slowest set", order[0])] + ([("fastest set", order[-1])] if order[-1] != order[0] else [])
+mid = [k for k in order[1:-1] if 6100.0 <= sets[k][0] <= 6700.0]
+if mid:
+    picks.insert(1, ("a set in between", mid[len(mid) // 2]))
+if a.slowest_only:
+    picks = picks[:1]
 keep = {k for _, k in picks}
 for k in range(len(sets)):                         # the others go back to the allocator
     if k not in keep:
