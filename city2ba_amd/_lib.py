@@ -153,6 +153,10 @@ SIGNATURES = {
     "c2b_ply_write": (_int, [C.c_char_p, _i64, _vp, _i64, _vp, _vp, _vp]),
     "c2b_problem_create": (_int, [_int, C.POINTER(_vp)]),
     "c2b_problem_destroy": (None, [_vp]),
+    "c2b_problem_options_init": (None, [_vp]),
+    "c2b_problem_set_options": (_int, [_vp, _vp]),
+    "c2b_problem_get_options": (_int, [_vp, _vp]),
+    "c2b_host_set_io_threads": (None, [_int]),
     "c2b_problem_upload": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "c2b_problem_upload_bal": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "c2b_problem_synthetic_grid_layout": (_int, [_vp, _i64, _i64, _i64, _d, _d, _d, _d]),

@@ -22,6 +22,38 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+class ProblemOptions(C.Structure):
+    """c2b_problem_options (include/city2ba_hip.h): which of two equivalent routes a problem's calls take and how many
+    host threads they may use -- arguments of the C ABI, not environment variables"""
+    _fields_ = [("host_text", C.c_int32), ("text_device_strict", C.c_int32), ("read_threads", C.c_int32), ("io_threads", C.c_int32),
+                ("rank_sort_max_row", C.c_int32), ("reserved", C.c_int32), ("text_device_min_bytes", C.c_int64)]
+
+
+_OPTION_NAMES = ("host_text", "text_device_strict", "read_threads", "io_threads", "rank_sort_max_row", "text_device_min_bytes")
+_new_problem_options = {}        # what set_default_options changed: applied to every BAProblem made afterwards
+
+
+def set_default_options(**kw):
+    """options every BAProblem made from now on starts with (BAProblem.set_options changes one problem).  The classmethod
+    constructors read files before a caller can reach the new object, so tests choose the parser this way.
+    host_text, text_device_strict: bool; read_threads, io_threads, rank_sort_max_row: 0 = the library's default;
+    text_device_min_bytes: -1 = the library's default (65 536)."""
+    for k in kw:
+        if k not in _OPTION_NAMES:
+            raise TypeError("unknown option %r (one of %s)" % (k, ", ".join(_OPTION_NAMES)))
+    _new_problem_options.update(kw)
+
+
+def reset_default_options():
+    _new_problem_options.clear()
+
+
+def set_host_io_threads(n):
+    """c2b_host_set_io_threads: threads of the host text formatter / parser for read_bal / write_bal and for problems
+    whose options leave io_threads at 0 (n < 1: the library's default -- the usable cores, at most 16)"""
+    L.lib().c2b_host_set_io_threads(int(n))
+
+
 class BAProblem:
     """cameras + points + vis_graph (CSR) resident on one MI355X.
 
@@ -34,6 +66,25 @@ class BAProblem:
         L.check(L.lib().c2b_problem_create(int(device), C.byref(self._h)))
         self._row_ptr = np.zeros(1, dtype=np.uint64)
         self._pt_idx = np.zeros(0, dtype=np.uint64)
+        if _new_problem_options:
+            self.set_options(**_new_problem_options)
+
+    def options(self):
+        """this problem's c2b_problem_options as a dict"""
+        o = ProblemOptions()
+        L.check(L.lib().c2b_problem_get_options(self._h, C.byref(o)))
+        return {k: getattr(o, k) for k in _OPTION_NAMES}
+
+    def set_options(self, **kw):
+        """c2b_problem_set_options: change the named options of this problem (see set_default_options for the names)"""
+        o = ProblemOptions()
+        L.check(L.lib().c2b_problem_get_options(self._h, C.byref(o)))
+        for k, v in kw.items():
+            if k not in _OPTION_NAMES:
+                raise TypeError("unknown option %r (one of %s)" % (k, ", ".join(_OPTION_NAMES)))
+            setattr(o, k, int(v))
+        L.check(L.lib().c2b_problem_set_options(self._h, C.byref(o)))
+        return self
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -371,7 +422,10 @@ class BAProblem:
     def from_file(cls, path, device=0, fmt=None):
         """BAProblem::from_file (src/baproblem.rs:697-706) straight into the resident problem (c2b_problem_read): a .bbal is
         streamed to the device and decoded there (byte order, index / uv split, range checks, from_vec); .bal text is
-        parsed by the host.  fmt None = by extension, "text", "binary"."""
+        tokenised and parsed on the device too (every number correctly rounded), except files smaller than the option
+        text_device_min_bytes (default 64 KiB), files the device parser declines (NaN, more than 19 digits, glued
+        numbers) and everything under the option host_text, which go through the host parser and an upload -- the same
+        resident state either way.  fmt None = by extension, "text", "binary"."""
         self = cls(device)
         L.check(L.lib().c2b_problem_read(self._h, str(path).encode(), _FORMATS[fmt]))
         return self._refresh_graph()
@@ -386,7 +440,8 @@ class BAProblem:
 
     def write(self, path, fmt=None):
         """BAProblem::write (src/baproblem.rs:768-785) straight from the resident problem: a .bbal image is assembled on
-        the device (to_vec, counts, byte order) and only its bytes cross PCIe; .bal text is formatted by the host"""
+        the device (to_vec, counts, byte order) and only its bytes cross PCIe; so is .bal text (shortest round-trip
+        decimals formatted on the device); the option host_text selects the host formatter over a download: same bytes"""
         L.check(L.lib().c2b_problem_write(self._h, str(path).encode(), _FORMATS[fmt]))
 
     def write_text(self, path):                     # src/baproblem.rs:709-733

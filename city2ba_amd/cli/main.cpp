@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <random>
@@ -112,6 +113,25 @@ Args parse(int argc, char **argv, int first, const std::vector<std::string> &fla
         }
     }
     return a;
+}
+
+// The library takes its behaviour switches as c2b_problem_options, not from the environment; this program -- a caller of
+// the C ABI like any other -- keeps its environment variables (README.md) and turns them into those options for every
+// problem it makes.
+static int env_int(const char *name, int dflt) { const char *v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
+static bool env_on(const char *name) { const char *v = std::getenv(name); return v && *v && std::strcmp(v, "0") != 0; }
+static int create_problem(int device, c2b_problem **out) {
+    const int rc = c2b_problem_create(device, out);
+    if (rc) return rc;
+    c2b_problem_options o;
+    c2b_problem_options_init(&o);
+    o.host_text = env_on("C2B_HOST_TEXT");
+    o.text_device_strict = env_on("C2B_TEXT_DEVICE_STRICT");
+    o.read_threads = std::max(0, std::min(64, env_int("C2B_READ_THREADS", 0)));
+    o.io_threads = std::max(0, std::min(64, env_int("C2B_IO_THREADS", 0)));
+    o.rank_sort_max_row = std::max(0, env_int("C2B_RANK_SORT_MAX_ROW", 0));
+    if (const char *v = std::getenv("C2B_TEXT_DEVICE_MIN_BYTES")) o.text_device_min_bytes = (int64_t)std::strtoll(v, nullptr, 10);
+    return c2b_problem_set_options(*out, &o);
 }
 
 // C2B_TIMING=1: wall time of each phase on stderr
@@ -230,7 +250,7 @@ int run_synthetic(int argc, char **argv) {
     lay.inset = a.f("block-inset", 1); lay.L = a.f("block-length", 20);
     PhaseTimer timer;
     c2b_problem *p = nullptr;
-    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    ck(create_problem((int)a.i("device", 0), &p));
     timer.mark("problem_create (HIP runtime start)");
     generate_cull_write(p, lay, a.f("max-dist", 10), a.positional[0], timer);
     c2b_problem_destroy(p);
@@ -248,7 +268,7 @@ int run_synthetic_line(int argc, char **argv) {
     lay.cam_h = a.f("camera-height", 1); lay.pt_h = a.f("point-height", 1);
     PhaseTimer timer;
     c2b_problem *p = nullptr;
-    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    ck(create_problem((int)a.i("device", 0), &p));
     timer.mark("problem_create (HIP runtime start)");
     generate_cull_write(p, lay, a.f("max-dist", 10), a.positional[0], timer);
     c2b_problem_destroy(p);
@@ -325,7 +345,7 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
                 std::vector<uint64_t> rp((size_t)nc + 1);
                 for (int64_t c = 0; c <= nc; ++c) rp[(size_t)c] = row_ptr[(size_t)(lo + c)] - o0;
                 c2b_problem *p = nullptr;
-                ck(c2b_problem_create(devs[(size_t)k], &p));
+                ck(create_problem(devs[(size_t)k], &p));
                 ck(c2b_problem_upload_bal(p, nc, bal9.data() + 9 * lo, n_pts, pts.data(), rp.data(), pt_idx.data() + o0, uv.data() + 2 * o0));
                 ck(c2b_problem_set_shard(p, lo, n_cam, (int64_t)o0));
                 c2b_comm *comm = comms[(size_t)k];
@@ -400,7 +420,7 @@ int run_noise_sharded(const Args &a, uint64_t seed, int64_t n_cam, int64_t n_pts
         // the reference reports the error AFTER the correspondences were scrambled: one more sharded pass would need a
         // re-upload; the single-GPU evaluation of the final arrays gives the same number
         c2b_problem *p = nullptr;
-        ck(c2b_problem_create(devs[0], &p));
+        ck(create_problem(devs[0], &p));
         ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
         ck(c2b_problem_total_reprojection_errors_l1_l2(p, &err[2], &err[3]));
         c2b_problem_destroy(p);
@@ -428,7 +448,7 @@ int run_noise(int argc, char **argv) {
     if (!reshapes_any && !(a.f("mismatch-chance", 0.0) > 0.0) && !a.has("gpus") && !a.has("devices") && !std::getenv("C2B_HOST_IO")) {
         PhaseTimer timer;
         c2b_problem *p = nullptr;
-        ck(c2b_problem_create((int)a.i("device", 0), &p));
+        ck(create_problem((int)a.i("device", 0), &p));
         timer.mark("problem_create (HIP runtime start)");
         ck(c2b_problem_read(p, a.positional[0].c_str(), -1));
         timer.mark("read (c2b_problem_read: decoded on the device)");
@@ -476,7 +496,7 @@ int run_noise(int argc, char **argv) {
         return run_noise_sharded(a, seed, n_cam, n_pts, n_obs, bal9, pts, pts_cap, uv, row_ptr, pt_idx);
 
     c2b_problem *p = nullptr;
-    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    ck(create_problem((int)a.i("device", 0), &p));
     ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
     double l1, l2;
     ck(c2b_problem_total_reprojection_errors_l1_l2(p, &l1, &l2));        // src/bin/city2ba.rs:283-287: both norms, one pass
@@ -749,7 +769,7 @@ int run_ply(int argc, char **argv) {
     ck(c2b_bal_copy(f, bal9.data(), pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
     c2b_bal_close(f);
     c2b_problem *p = nullptr;
-    ck(c2b_problem_create((int)a.i("device", 0), &p));
+    ck(create_problem((int)a.i("device", 0), &p));
     ck(c2b_problem_upload_bal(p, n_cam, bal9.data(), n_pts, pts.data(), row_ptr.data(), pt_idx.data(), uv.data()));
     std::vector<double> centers((size_t)n_cam * 3 + 1);
     ck(c2b_problem_centers(p, centers.data()));
@@ -810,6 +830,7 @@ int main(int argc, char **argv) {
         return argc < 2 ? 1 : 0;
     }
     const std::string sub = argv[1];
+    c2b_host_set_io_threads(env_int("C2B_IO_THREADS", 0));               // the handle-less host entries (c2b_bal_read / _write)
     for (int k = 2; k < argc; ++k)
         if (!std::strcmp(argv[k], "--help") || !std::strcmp(argv[k], "-h")) {
             const char *h = subcommand_help(sub);

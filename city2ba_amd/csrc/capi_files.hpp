@@ -2,11 +2,6 @@
 // words (cell_kernels.hpp: k_bbal_*) and the .bal decimal text (text_kernels.hpp + decimal.hpp) are assembled / taken
 // apart on the device; the host only moves bytes between the file and pinned memory (image_to_file, file_to_device).
 // Part of the one translation unit of the C ABI: included by capi_problem.hpp, never compiled or included on its own.
-static bool env_flag(const char *name) {
-    const char *v = std::getenv(name);
-    return v && *v && std::strcmp(v, "0") != 0;
-}
-
 // decimal.hpp's tables on the device: computed once on the host, copied once per device
 static int device_dec_tables(int device, const c2b_dec::Tables **out) {
     static std::mutex mu;
@@ -101,7 +96,7 @@ static int image_to_file(const char *path, const void *dev, size_t bytes) {
 // BAProblem::write (src/baproblem.rs:768-785) of the RESIDENT problem.  `.bbal` (format 1): the file image is assembled
 // on the device (cell_kernels.hpp: k_bbal_*: to_vec of every camera, the per-camera counts, the byte order) and leaves
 // through a ring of pinned slots (image_to_file) -- the host touches no observation.  `.bal` (format 0): the same, the
-// image being text (text_kernels.hpp: shortest round-trip decimals on the device; C2B_HOST_TEXT=1 = the host formatter of
+// image being text (text_kernels.hpp: shortest round-trip decimals on the device; options.host_text = the host formatter of
 // csrc/host_baproblem.hpp over a download, the same bytes).  format -1: by extension, like the reference.
 int c2b_problem_write(c2b_problem *p, const char *path, int format) {
     C2B_API_BEGIN
@@ -111,11 +106,16 @@ int c2b_problem_write(c2b_problem *p, const char *path, int format) {
     int rc = bal_format(path, format, &binary);
     if (rc) return rc;
     const int64_t n_cam = p->n_cam, n_pts = p->n_pts, n_obs = p->n_obs;
-    if (!p->bal_valid) {                                     // to_vec (src/baproblem.rs:189-202) of the current state
+    if (!p->bal_valid && !p->bal9_fresh) {                   // to_vec (src/baproblem.rs:189-202) of the current state
         rc = c2b_cameras_to_bal(p->cam15, n_cam, p->bal9, p->stream);
         if (rc) return rc;
+        // bal9 now holds to_vec of the cameras: the next write / download of the unmodified problem skips the pass.  NOT
+        // bal_valid: that flag makes bal9 the truth (R re-derived as from_rodrigues(w), last bits apart from the state's
+        // R), and writing a file must not move a single projection.
+        p->bal9_fresh = true;
     }
-    if (!binary && env_flag("C2B_HOST_TEXT")) {             // the host formatter over a download (rounds 1-3's route)
+    const c2b_host::IoThreadsScope io_scope(p->opt.io_threads);
+    if (!binary && p->opt.host_text) {                       // the host formatter over a download (rounds 1-3's route)
         std::vector<double> bal9((size_t)n_cam * 9 + 1), pts((size_t)n_pts * 3 + 1), uv((size_t)n_obs * 2 + 1);
         std::vector<uint64_t> row_ptr((size_t)n_cam + 1), pt_idx((size_t)n_obs + 1);
         if (n_cam) HIP_TRY(hipMemcpyAsync(bal9.data(), p->bal9, sizeof(double) * 9 * (size_t)n_cam, hipMemcpyDeviceToHost, p->stream));
@@ -215,10 +215,10 @@ static int device_parse_tables(int device, const c2b_dec::ParseTables **out) {
 // `bytes` of an open file -> device memory through a ring of pinned slots: a few reader threads pread() chunk k into
 // slot k % kSlots (reads of one file from the page cache run in parallel, unlike buffered writes), this thread sends the
 // slots to the device in order.  0 = ok, 1 = copy failed, 2 = read failed, 3 = no resources.
-static int file_to_device(int fd, size_t bytes, char *dev) {
+static int file_to_device(int fd, size_t bytes, char *dev, int read_threads = 0) {
     constexpr size_t kChunk = (size_t)8 << 20;
     int kSlots = 6, kReaders = 3;
-    if (const char *ev = std::getenv("C2B_READ_THREADS")) { kReaders = std::max(1, std::atoi(ev)); kSlots = 2 * kReaders; }
+    if (read_threads > 0) { kReaders = read_threads; kSlots = 2 * kReaders; }
     const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
     char *pin = nullptr;
     if (hipHostMalloc((void **)&pin, kChunk * kSlots, hipHostMallocDefault) != hipSuccess) return 3;
@@ -299,8 +299,7 @@ static int read_text_device(c2b_problem *p, const char *path, bool *handled) {
     if (fd < 0) return C2B_OK;                                // the host path words the error
     struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
     const off_t end = ::lseek(fd, 0, SEEK_END);
-    size_t min_bytes = (size_t)64 << 10;
-    if (const char *ev = std::getenv("C2B_TEXT_DEVICE_MIN_BYTES")) min_bytes = (size_t)std::strtoull(ev, nullptr, 10);
+    const size_t min_bytes = p->opt.text_device_min_bytes >= 0 ? (size_t)p->opt.text_device_min_bytes : (size_t)64 << 10;
     if (end < 6 || (size_t)end < min_bytes || (uint64_t)end >= ((uint64_t)1 << 32)) return C2B_OK;
     const size_t bytes = (size_t)end;
     // the three counts, from the first bytes
@@ -346,7 +345,7 @@ static int read_text_device(c2b_problem *p, const char *path, bool *handled) {
     if (e == hipSuccess) e = hipMemsetAsync(t_pts.ptr, 0, np ? 32 * (size_t)np : 16, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? C2B_ERR_OOM : C2B_ERR_HIP, "problem_read: %s", hipGetErrorString(e));
-    const int io = file_to_device(fd, bytes, raw.as<char>());
+    const int io = file_to_device(fd, bytes, raw.as<char>(), p->opt.read_threads);
     if (io == 1) return fail(C2B_ERR_HIP, "problem_read: host-to-device copy failed");
     if (io) return C2B_OK;                                   // unreadable: the host path says so
     hipLaunchKernelGGL(k_text_count_tokens, dim3((unsigned)n_tiles), dim3(kTextTile), 0, st, (const char *)raw.as<char>(), (int64_t)bytes, cnt.as<uint32_t>());
@@ -435,18 +434,19 @@ static int read_text_device(c2b_problem *p, const char *path, bool *handled) {
 // counts (the only part of the format that must be read in order); the per-observation decoding -- byte order, index
 // range checks, the split into index and uv arrays -- and from_vec of every camera run on the device.  `.bal`: tokenised
 // and parsed on the device (read_text_device above); whatever that declines goes through the host parser and an ordinary
-// upload (C2B_HOST_TEXT=1: always).  format: -1 by extension, 0 text, 1 binary.
+// upload (options.host_text: always).  format: -1 by extension, 0 text, 1 binary.
 int c2b_problem_read(c2b_problem *p, const char *path, int format) {
     C2B_API_BEGIN
     if (!p || !path) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_read: NULL argument");
     bool binary = false;
     int rc = bal_format(path, format, &binary);
     if (rc) return rc;
-    if (!binary && !env_flag("C2B_HOST_TEXT")) {
+    const c2b_host::IoThreadsScope io_scope(p->opt.io_threads);
+    if (!binary && !p->opt.host_text) {
         bool handled = false;
         rc = read_text_device(p, path, &handled);
         if (rc || handled) return rc;
-        if (env_flag("C2B_TEXT_DEVICE_STRICT"))              // tests: make sure the device path is the one that ran
+        if (p->opt.text_device_strict)                       // tests: make sure the device path is the one that ran
             return fail(C2B_ERR_INVALID_ARGUMENT, "problem_read: the device parser declined %s", path);
     }
     if (!binary) {
@@ -572,6 +572,9 @@ int c2b_problem_read(c2b_problem *p, const char *path, int format) {
 
     rc = alloc_problem(p, (int64_t)n_cam, (int64_t)n_pts, (int64_t)n_obs);
     if (rc) return rc;
+    // From here on the handle owns freshly allocated, still undecoded arrays: every way out but the last one drops them,
+    // so that a failed read leaves "nothing uploaded" behind and never a problem that passes NEED_UPLOADED with garbage.
+    struct DropUnlessDone { c2b_problem *q; bool done = false; ~DropUnlessDone() { if (!done) { (void)hipStreamSynchronize(q->stream); free_buffers(q); } } } guard{p};
     hipStream_t st = p->stream;
     DevBuf d_row, d_bad;
     e = d_row.alloc(sizeof(uint64_t) * (size_t)(n_cam + 1));
@@ -594,10 +597,8 @@ int c2b_problem_read(c2b_problem *p, const char *path, int format) {
     uint32_t bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, d_bad.ptr, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (bad) {
-        free_buffers(p);
-        return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "Binary parse error: point index out of range");
-    }
+    if (bad) return fail(C2B_ERR_INDEX_OUT_OF_RANGE, "Binary parse error: point index out of range");
+    guard.done = true;
     p->bal_valid = true;
     p->blk_valid = false;
     return C2B_OK;

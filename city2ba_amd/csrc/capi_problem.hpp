@@ -17,8 +17,10 @@ struct c2b_problem {
     // this problem as ONE SHARD of a larger one (c2b_problem_set_shard): its cameras are [shard_cam_base, + n_cam) of
     // shard_n_cam_global (< 0: not a shard), its first observation is observation shard_obs_base of the whole list
     int64_t shard_cam_base = 0, shard_n_cam_global = -1, shard_obs_base = 0;
+    c2b_problem_options opt{0, 0, 0, 0, 0, 0, -1};   // c2b_problem_set_options; survives uploads / reads (it is the handle's, not the data's)
     bool bal_valid = false;     // bal9 still describes the cameras (no mutation since upload_bal)
     bool blk_valid = false;     // camblk matches cam15 (and bal_valid mode)
+    bool bal9_fresh = false;    // !bal_valid, but bal9 holds to_vec of the current cameras (the last write / download_bal computed it)
     // the row structure of the observation list for the *_rows launchers, rebuilt on demand after the list changed
     uint64_t *rows_ptr = nullptr;
     void *rows_tiles = nullptr;
@@ -59,8 +61,25 @@ static void free_buffers(c2b_problem *p) {
     p->cam_idx = p->pt_idx = nullptr;
     p->ws = nullptr; p->stats = p->scalar = nullptr;
     p->n_cam = p->n_pts = p->n_obs = 0;
-    p->bal_valid = p->blk_valid = false;
+    p->bal_valid = p->blk_valid = p->bal9_fresh = false;
 }
+
+void c2b_problem_options_init(c2b_problem_options *o) {
+    if (o) *o = c2b_problem_options{0, 0, 0, 0, 0, 0, -1};
+}
+int c2b_problem_set_options(c2b_problem *p, const c2b_problem_options *o) {
+    if (!p || !o) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_set_options: NULL argument");
+    if (o->read_threads < 0 || o->read_threads > 64 || o->io_threads < 0 || o->io_threads > 64 || o->rank_sort_max_row < 0 || o->reserved != 0)
+        return fail(C2B_ERR_INVALID_ARGUMENT, "problem_set_options: thread counts must be in [0, 64], rank_sort_max_row >= 0, reserved 0");
+    p->opt = *o;
+    return C2B_OK;
+}
+int c2b_problem_get_options(const c2b_problem *p, c2b_problem_options *o) {
+    if (!p || !o) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_get_options: NULL argument");
+    *o = p->opt;
+    return C2B_OK;
+}
+void c2b_host_set_io_threads(int n) { c2b_host::io_threads_setting().store(n < 1 ? 0 : (n > 64 ? 64 : n), std::memory_order_relaxed); }
 
 int c2b_problem_create(int device, c2b_problem **out) {
     C2B_API_BEGIN
@@ -298,10 +317,11 @@ int c2b_problem_download_bal(c2b_problem *p, double *bal9) {
     NEED_UPLOADED(p, "problem_download_bal");
     if (!bal9) return fail(C2B_ERR_INVALID_ARGUMENT, "problem_download_bal: bal9 is NULL");
     if (!p->n_cam) return C2B_OK;
-    if (!p->bal_valid) {
+    if (!p->bal_valid && !p->bal9_fresh) {
         // to_vec (src/baproblem.rs:189-202) of the current state
         int rc = c2b_cameras_to_bal(p->cam15, p->n_cam, p->bal9, p->stream);
         if (rc) return rc;
+        p->bal9_fresh = true;
     }
     HIP_TRY(hipMemcpyAsync(bal9, p->bal9, sizeof(double) * 9 * p->n_cam, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -835,6 +855,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
     drop_rows(p);
     p->n_cam = nc; p->n_pts = np; p->n_obs = no;
     p->blk_valid = false;                                     // camblk is rebuilt on demand from the gathered cameras
+    p->bal9_fresh = false;                                    // (bal9 was gathered only when it was the truth)
     return C2B_OK;
 }
 
@@ -1151,8 +1172,9 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
         // for a radius that makes one camera see tens of thousands of points.  Beyond `long_row` entries the rows are sorted on the
         // host instead (threads over cameras) -- a path for odd inputs, not a fast one; such problems belong to the dense
         // sweep (c2b_problem_visibility_dense).
-        uint32_t long_row = 8192;
-        if (const char *ev = std::getenv("C2B_RANK_SORT_MAX_ROW")) long_row = (uint32_t)std::max(1, std::atoi(ev));
+        // (2 048: a lane of the rank sort then makes at most 64 k dependent compares -- ~0.1 ms per row-wave; at the 8 192 of
+        // round 4 a scene with thousands of cameras seeing several thousand points each was a multi-second cliff)
+        const uint32_t long_row = p->opt.rank_sort_max_row > 0 ? (uint32_t)p->opt.rank_sort_max_row : 2048u;
         if (longest <= long_row) {
             hipLaunchKernelGGL(k_rows_rank_sort, dim3(cam_blocks), dim3(kCellWPB * 64), 0, st, (const uint64_t *)row64.as<uint64_t>(), n_cam,
                                (const uint32_t *)tmp_pt.as<uint32_t>(), (const double2 *)tmp_uv.as<double2>(), out_pt.as<uint32_t>(),
@@ -1169,9 +1191,7 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e == hipSuccess) {
                 const int T = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<int64_t>(1, n_cam));
-                std::vector<std::thread> th;
-                for (int t = 0; t < T; ++t)
-                    th.emplace_back([&, t]() {
+                c2b_host::run_threads(T, [&](int t) {
                         std::vector<uint32_t> order;
                         for (int64_t c = n_cam * t / T; c < n_cam * (t + 1) / T; ++c) {
                             const size_t b = (size_t)rp[(size_t)c], k = (size_t)(rp[(size_t)c + 1] - rp[(size_t)c]);
@@ -1185,7 +1205,6 @@ int c2b_problem_visibility_within_distance(c2b_problem *p, double max_dist, int 
                             }
                         }
                     });
-                for (auto &x : th) x.join();
                 e = hipMemcpyAsync(out_pt.ptr, hq.data(), 4 * w, hipMemcpyHostToDevice, st);
                 if (e == hipSuccess) e = hipMemcpyAsync(out_uv.ptr, hv.data(), 16 * w, hipMemcpyHostToDevice, st);
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1494,7 +1513,7 @@ int c2b_problem_visibility_dense_fetch(c2b_problem *p, uint64_t *pt_idx, double 
     C2B_API_END("problem_visibility_dense_fetch")
 }
 
-static void cameras_mutated(c2b_problem *p) { p->bal_valid = false; p->blk_valid = false; }
+static void cameras_mutated(c2b_problem *p) { p->bal_valid = false; p->blk_valid = false; p->bal9_fresh = false; }
 
 int c2b_problem_add_drift(c2b_problem *p, double strength, double angle_strength, double std, const double dir[3],
                           uint64_t seed) {

@@ -184,9 +184,38 @@ inline Graph cull(const Graph &g, bool faithful, int mode = 0) {
 }
 
 // ---- .bal / .bbal -----------------------------------------------------------------------------------
-// threads of the text formatter / parser: the usable cores (at most 16), or C2B_IO_THREADS
+// fn(0) ... fn(n - 1), one per thread (fn(0) on the caller), all joined before it returns.  Starting a thread can fail
+// (std::system_error, EAGAIN under a container's pids limit): the indices that got no thread then run on the caller, and
+// the threads that did start are joined whatever happens -- unwinding past a joinable std::thread is std::terminate, which
+// would take the embedding process down where the C ABI promises a status code.
+template <typename F>
+inline void run_threads(int n, F &&fn) {
+    std::vector<std::thread> th;
+    struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } join_all{th};
+    th.reserve(n > 1 ? (size_t)(n - 1) : 0);
+    int started = 1;
+    for (; started < n; ++started) {
+        try { th.emplace_back([&fn, started]() { fn(started); }); }
+        catch (const std::system_error &) { break; }
+    }
+    if (n > 0) fn(0);
+    for (int k = started; k < n; ++k) fn(k);
+}
+
+// threads of the text formatter / parser: what the calling problem's options ask for (c2b_problem_options.io_threads,
+// in force on this thread for the duration of its call), else the process-wide setting (c2b_host_set_io_threads), else the
+// usable cores, at most 16.  No environment variable: a caller of the C ABI sets these through the ABI.
+inline std::atomic<int> &io_threads_setting() { static std::atomic<int> v{0}; return v; }
+inline int &io_threads_of_this_call() { static thread_local int v = 0; return v; }
+struct IoThreadsScope {                              // RAII: a problem's own thread count while one of its calls runs
+    int saved;
+    explicit IoThreadsScope(int n) : saved(io_threads_of_this_call()) { if (n > 0) io_threads_of_this_call() = n; }
+    ~IoThreadsScope() { io_threads_of_this_call() = saved; }
+};
 inline int io_threads() {
-    if (const char *e = std::getenv("C2B_IO_THREADS")) { const int v = std::atoi(e); if (v >= 1) return std::min(v, 64); }
+    int v = io_threads_of_this_call();
+    if (v < 1) v = io_threads_setting().load(std::memory_order_relaxed);
+    if (v >= 1) return std::min(v, 64);
     return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
 }
 
@@ -276,8 +305,17 @@ inline bool write_text(const char *path, const Graph &g, std::string *err, int n
             }
         };
         std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
-        for (int64_t k = 0; k < n_tasks; ++k) {
+        // whatever happens below, the workers are told to stop and joined (a joinable thread must never be unwound past)
+        struct StopAndJoin {
+            std::vector<std::thread> &v; std::mutex &m; std::condition_variable &c; bool &stop;
+            ~StopAndJoin() { { std::lock_guard<std::mutex> lk(m); stop = true; } c.notify_all(); for (auto &t : v) if (t.joinable()) t.join(); }
+        } stop_and_join{pool, mu, cv, stop};
+        try { for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker); }
+        catch (const std::system_error &) { }               // fewer workers than asked for; none at all: this thread formats
+        if (pool.empty()) {
+            std::string s;
+            for (int64_t k = 0; k < n_tasks && ok; ++k) { format_task(k, s); ok = std::fwrite(s.data(), 1, s.size(), f) == s.size(); }
+        } else for (int64_t k = 0; k < n_tasks; ++k) {
             std::string s;
             {
                 std::unique_lock<std::mutex> lk(mu);
@@ -289,12 +327,6 @@ inline bool write_text(const char *path, const Graph &g, std::string *err, int n
             written = k + 1;
             cv.notify_all();
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv.notify_all();
-        for (auto &t : pool) t.join();
     }
     ok = (std::fclose(f) == 0) && ok;
     if (!ok) *err = std::string("write failed: ") + path;
@@ -503,11 +535,7 @@ inline bool read_text(const char *path, Graph &g, std::string *err, int n_thread
             p = q;
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int k = 0; k < T; ++k) th.emplace_back([&, k]() { uint64_t c = 0; for_tokens(k, [&](const char *, const char *) { ++c; }); n_tok[(size_t)k] = c; });
-        for (auto &t : th) t.join();
-    }
+    run_threads(T, [&](int k) { uint64_t c = 0; for_tokens(k, [&](const char *, const char *) { ++c; }); n_tok[(size_t)k] = c; });
     std::vector<uint64_t> tok0((size_t)T + 1, 0);
     for (int k = 0; k < T; ++k) tok0[(size_t)k + 1] = tok0[(size_t)k] + n_tok[(size_t)k];
     // header: the first three tokens, wherever they are
@@ -538,9 +566,7 @@ inline bool read_text(const char *path, Graph &g, std::string *err, int n_thread
     std::atomic<int> irregular{0};
     const uint64_t obs_end = 3 + 4 * no, cam_end = obs_end + 9 * nc;
     {
-        std::vector<std::thread> th;
-        for (int k = 0; k < T; ++k)
-            th.emplace_back([&, k]() {
+        run_threads(T, [&](int k) {
                 uint64_t gi = tok0[(size_t)k];
                 for_tokens(k, [&](const char *a, const char *b) {
                     const uint64_t i = gi++;
@@ -567,7 +593,6 @@ inline bool read_text(const char *path, Graph &g, std::string *err, int n_thread
                     if (q != b) irregular = 1;
                 });
             });
-        for (auto &t : th) t.join();
     }
     if (irregular) { g = Graph(); return read_text_sequential(buf, g, err); }
     // BAProblem::new: asserts then per-camera push in file order

@@ -412,10 +412,7 @@ inline void poisson_unit_square(int64_t n_target, std::mt19937_64 &rng, std::vec
             }
         };
         if (T > 1) {
-            std::vector<std::thread> th;
-            for (int t = 1; t < T; ++t) th.emplace_back(draw_and_test, nb_ * t / T, nb_ * (t + 1) / T);
-            draw_and_test(0, nb_ / T);
-            for (auto &q : th) q.join();
+            run_threads(T, [&](int t) { draw_and_test(nb_ * t / T, nb_ * (t + 1) / T); });
         } else {
             draw_and_test(0, nb_);
         }
@@ -470,11 +467,7 @@ inline void cameras_poisson(const std::vector<float> &tri9, int64_t num_points, 
     };
     const int T = (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), std::max<int64_t>(1, n_s / 2048));
     if (T <= 1) cast_range(0, n_s);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back(cast_range, n_s * t / T, n_s * (t + 1) / T);
-        for (auto &x : th) x.join();
-    }
+    else run_threads(T, [&](int t) { cast_range(n_s * t / T, n_s * (t + 1) / T); });
     std::vector<double> positions;
     for (int64_t i = 0; i < n_s; ++i)
         if (hit[(size_t)i]) positions.insert(positions.end(), &hit_pos[3 * (size_t)i], &hit_pos[3 * (size_t)i] + 3);
@@ -590,12 +583,9 @@ inline bool world_points_uniform(const std::vector<float> &tri9, const double *c
                 ok[(size_t)i] = near_camera(p) ? 1 : 0;
             }
         };
-        std::vector<std::thread> pool;
         const int64_t per = (chunk + n_threads - 1) / n_threads;
-        for (unsigned t = 1; t < n_threads; ++t)
-            if ((int64_t)t * per < chunk) pool.emplace_back(work, (int64_t)t * per, std::min(chunk, (int64_t)(t + 1) * per));
-        work(0, std::min(chunk, per));
-        for (auto &th : pool) th.join();
+        run_threads((int)std::min<int64_t>(n_threads, (chunk + per - 1) / std::max<int64_t>(per, 1)),
+                    [&](int t) { work((int64_t)t * per, std::min(chunk, (int64_t)(t + 1) * per)); });
         for (int64_t i = 0; i < chunk && (int64_t)(pts.size() / 3) < num_points && fail < fail_threshold; ++i) {
             if (ok[(size_t)i]) pts.insert(pts.end(), &cand[3 * (size_t)i], &cand[3 * (size_t)i] + 3);
             else ++fail;

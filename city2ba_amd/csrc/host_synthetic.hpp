@@ -238,10 +238,7 @@ inline void candidate_pairs(const double *centers, const double *pts, int64_t n_
             }
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
+    run_threads(n_threads, work);
     size_t total = 0;
     for (auto &P : part) total += P.cam.size();
     out->cam.reserve(total);

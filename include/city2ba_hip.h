@@ -563,6 +563,31 @@ typedef struct c2b_problem c2b_problem;
 int c2b_problem_create(int device, c2b_problem **out);
 void c2b_problem_destroy(c2b_problem *p);
 
+/* Behaviour switches of a problem's calls -- which of two equivalent routes a call takes, and how many host threads it
+ * may use.  They are ARGUMENTS, set through the ABI per problem: the library reads no environment variable for them
+ * (rounds 1-4 did: invisible to, and not settable per call by, a host that binds this header).  Every route gives the
+ * same files and the same resident state; the switches exist for tests, comparisons and odd inputs.
+ * c2b_problem_options_init writes the defaults; set_options replaces all of them (get, change, set to change one). */
+typedef struct c2b_problem_options {
+    int32_t host_text;              /* != 0: .bal text formatted / parsed by the host code over a download / an upload
+                                       (c2b_problem_write / _read; default 0 = on the device) */
+    int32_t text_device_strict;     /* != 0: a text file the device parser declines is an ERROR instead of going to the host
+                                       parser (tests: proves which parser ran; default 0) */
+    int32_t read_threads;           /* reader threads of c2b_problem_read's pinned ring (0 = default: 3) */
+    int32_t io_threads;             /* threads of the host text formatter / parser when this problem's calls use it
+                                       (0 = default: c2b_host_set_io_threads, else the usable cores, at most 16) */
+    int32_t rank_sort_max_row;      /* c2b_problem_visibility_within_distance: rows longer than this are sorted on the host
+                                       (0 = default: 2048) */
+    int32_t reserved;               /* 0 */
+    int64_t text_device_min_bytes;  /* text files smaller than this go to the host parser (< 0 = default: 65536) */
+} c2b_problem_options;
+void c2b_problem_options_init(c2b_problem_options *o);
+int c2b_problem_set_options(c2b_problem *p, const c2b_problem_options *o);
+int c2b_problem_get_options(const c2b_problem *p, c2b_problem_options *o);
+/* process-wide: threads of the host text formatter / parser for the handle-less entries (c2b_bal_read / _write) and for
+ * problems that do not say (n < 1 = default: the usable cores, at most 16) */
+void c2b_host_set_io_threads(int n);
+
 /* BAProblem::from_visibility (src/baproblem.rs:360-376): validates like its asserts */
 int c2b_problem_upload(c2b_problem *p, int64_t n_cam, const double *cams15, int64_t n_pts,
                        const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx,

@@ -20,6 +20,18 @@ def golden():
 
 
 @pytest.fixture(autouse=True)
+def _library_options_are_back_to_their_defaults_after_every_test():
+    """tests choose routes through the ABI's options (city2ba_amd.set_default_options / set_host_io_threads); whatever one
+    changed does not leak into the next"""
+    yield
+    mod = sys.modules.get("city2ba_amd.baproblem")
+    if mod is not None:
+        mod.reset_default_options()
+        if getattr(sys.modules.get("city2ba_amd._lib"), "_lib", None) is not None:
+            mod.set_host_io_threads(0)
+
+
+@pytest.fixture(autouse=True)
 def _fold_counters_are_clean_after_every_gpu_test(request):
     """Every in-kernel fold resets the arrival counters of the workspace it ran in (kernels.hpp: ticket_fold); a launch
     that did not would make the next launch on that workspace lose its sum.  Checked after every GPU test, over every

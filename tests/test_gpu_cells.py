@@ -78,9 +78,9 @@ def test_arbitrary_point_clouds_cameras_outside_the_points_and_degenerate_radii(
             assert len(kept) > 500
     # rows longer than the device row sort is meant for take the host sort instead: same result (threshold lowered here)
     want = ba.visibility_within_distance(25.0)
-    monkeypatch.setenv("C2B_RANK_SORT_MAX_ROW", "8")
+    ba.set_options(rank_sort_max_row=8)
     got = ba.visibility_within_distance(25.0)
-    monkeypatch.delenv("C2B_RANK_SORT_MAX_ROW")
+    ba.set_options(rank_sort_max_row=0)
     assert int(np.diff(want[0].astype(np.int64)).max()) > 8
     for x, y in zip(got, want):
         assert np.array_equal(x, y)

@@ -144,9 +144,10 @@ def test_text_image_from_the_device_equals_the_host_formatter(c2b, tmp_path, mon
     dev = open(a, "rb").read()
     assert dev == _host_file(c2b, ba, str(b), None)
     assert dev.count(b"\n") == 1 + n_obs + len(bal9) + len(pts)
-    monkeypatch.setenv("C2B_HOST_TEXT", "1")                  # rounds 1-3's route: download + host formatter
+    ba.set_options(host_text=True)                            # rounds 1-3's route: download + host formatter
+    assert ba.options()["host_text"] == 1
     ba.write(str(h))
-    monkeypatch.delenv("C2B_HOST_TEXT")
+    ba.set_options(host_text=False)
     assert open(h, "rb").read() == dev
     ba.close()
     e = c2b.BAProblem.from_bal(P["bal9"][:5], P["pts"][:40], np.zeros(6, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros((0, 2)))
@@ -174,12 +175,12 @@ def _same_state(a, b):
 def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, monkeypatch):
     """from_file_text (src/baproblem.rs:580-629) on the device (r04: csrc/text_kernels.hpp -- tokens ranked by a scan,
     every number rounded by csrc/decimal.hpp: Clinger's exact case or Eisel-Lemire): the resident state equals the host
-    parser's (strtod) bit for bit.  C2B_TEXT_DEVICE_STRICT makes a file the device declines an error, so these are the
+    parser's (strtod) bit for bit.  the option text_device_strict makes a file the device declines an error, so these are the
     device's own results; files it must decline (NaN, more than 19 digits, glued numbers,
     an index out of range) reach the host parser and come back as its result or its error."""
     from city2ba_amd.baproblem import read_bal, write_bal
     rng = np.random.default_rng(31)
-    monkeypatch.setenv("C2B_TEXT_DEVICE_MIN_BYTES", "0")
+    c2b.set_default_options(text_device_min_bytes=0)
     P = random_problem(61, 700, 9, seed=12, noise=1e-3, empty_every=5)
     uv = P["uv"].copy()
     wild = np.concatenate([rng.integers(0, 2**64, 4000, dtype=np.uint64).view(np.float64),
@@ -189,9 +190,9 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
     uv.ravel()[:min(uv.size, len(wild))] = wild[:min(uv.size, len(wild))]
     path = str(tmp_path / "w.bal")
     write_bal(path, P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], uv)
-    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    c2b.set_default_options(text_device_strict=True)
     a = c2b.BAProblem.from_file(path)                          # the device parsed it (strict)
-    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+    c2b.set_default_options(text_device_strict=False)
     b = c2b.BAProblem.from_bal(*read_bal(path))
     _same_state(a, b)
     assert np.array_equal(a.observations().view(np.uint64), uv.view(np.uint64))          # and the file round-trips exactly
@@ -207,7 +208,7 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
             alt.append(" ".join(("%.17e" % float(x)) if k % 2 else ("000" + x if x[0].isdigit() else x) for k, x in enumerate(t)))
     path2 = str(tmp_path / "alt.bal")
     open(path2, "w").write("\n".join(alt) + "\n\n  trailing tokens are left unread 1 2 3\n")
-    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    c2b.set_default_options(text_device_strict=True)
     a2 = c2b.BAProblem.from_file(path2)
     _same_state(a2, b)
     # what the device must decline
@@ -220,7 +221,7 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
         open(q, "w").write(text)
         with pytest.raises(c2b.City2baError, match="declined"):
             c2b.BAProblem.from_file(q)
-    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+    c2b.set_default_options(text_device_strict=False)
     for name in ("digits", "glued"):                           # ... and the host parser takes them
         q = str(tmp_path / (name + ".bal"))
         x, y = c2b.BAProblem.from_file(q), c2b.BAProblem.from_bal(*read_bal(q))
@@ -244,11 +245,11 @@ def test_text_file_parsed_on_the_device_equals_the_host_parser(c2b, tmp_path, mo
     g = S.synthetic_grid(10, 10, 32, 20.0, 1.0, 1.0, 1.0, 10.0, False)
     path = str(tmp_path / "g.bal")
     g.write(path)
-    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
-    monkeypatch.delenv("C2B_TEXT_DEVICE_MIN_BYTES")
+    c2b.set_default_options(text_device_strict=True)
+    c2b.set_default_options(text_device_min_bytes=-1)
     d = c2b.BAProblem.from_file(path)
-    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
-    monkeypatch.setenv("C2B_HOST_TEXT", "1")
+    c2b.set_default_options(text_device_strict=False)
+    c2b.set_default_options(host_text=True)
     h = c2b.BAProblem.from_file(path)
     _same_state(d, h)
     assert np.array_equal(d.observations(), g.observations()) and np.array_equal(d.cameras_bal(), g.cameras_bal())
@@ -266,7 +267,7 @@ def test_both_file_forms_round_trip_at_the_headline_size(c2b, tmp_path):
     g = S.synthetic_grid(10, 10, 128, 20.0, 1.0, 1.0, 1.0, 10.0, False)
     assert g.num_observations() > 19_000_000
     c2b.noise.add_noise(g, 0.0, 0.0, 0.0, 1e-3, seed=5)       # observations with all their digits
-    os.environ["C2B_TEXT_DEVICE_STRICT"] = "1"
+    c2b.set_default_options(text_device_strict=True)
     try:
         for ext, size in (("bbal", 500_000_000), ("bal", 900_000_000)):
             path = str(tmp_path / ("g128." + ext))
@@ -280,7 +281,7 @@ def test_both_file_forms_round_trip_at_the_headline_size(c2b, tmp_path):
             back.close()
             os.remove(path)
     finally:
-        del os.environ["C2B_TEXT_DEVICE_STRICT"]
+        c2b.set_default_options(text_device_strict=False)
     g.close()
 
 
@@ -304,10 +305,10 @@ def test_text_file_in_any_observation_order_is_sorted_on_the_device(c2b, tmp_pat
         obs = [obs[i] for i in rng.permutation(n_obs)]
     mixed = str(tmp_path / "mixed.bal")
     open(mixed, "w").write("\n".join(lines[:1] + obs + lines[1 + n_obs:]))
-    monkeypatch.setenv("C2B_TEXT_DEVICE_MIN_BYTES", "0")
-    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    c2b.set_default_options(text_device_min_bytes=0)
+    c2b.set_default_options(text_device_strict=True)
     d = c2b.BAProblem.from_file(mixed)
-    monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+    c2b.set_default_options(text_device_strict=False)
     h = c2b.BAProblem.from_bal(*read_bal(mixed))              # the host parser: sequential per-camera push
     _same_state(d, h)
     assert np.array_equal(d.row_ptr, P["row_ptr"])
@@ -320,7 +321,7 @@ def test_text_reader_edge_files_device_and_host_agree(c2b, tmp_path, monkeypatch
     """small and odd files: no observations, nothing at all, no trailing newline, signed zeros, values that overflow /
     underflow -- the device's result is the host parser's; a short file, a bad header, an index out of range, a float
     where an index belongs -- the device declines and the host parser words the error"""
-    monkeypatch.setenv("C2B_TEXT_DEVICE_MIN_BYTES", "0")
+    c2b.set_default_options(text_device_min_bytes=0)
     nine = " ".join(["-1.5e+0"] * 9)
     good = {"empty": "0 0 0\n", "noobs": "1 2 0\n" + " ".join(["0.5"] * 9) + "\n1 2 3\n4 5 6\n",
             "one": "1 1 1\n0 0 0.25 -0.5\n" + "\n".join(["1e-3"] * 9) + "\n1 2 3",
@@ -337,20 +338,20 @@ def test_text_reader_edge_files_device_and_host_agree(c2b, tmp_path, monkeypatch
     for name, text in good.items():
         path = str(tmp_path / (name + ".bal"))
         open(path, "w").write(text)
-        monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+        c2b.set_default_options(text_device_strict=True)
         d = c2b.BAProblem.from_file(path)
-        monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
-        monkeypatch.setenv("C2B_HOST_TEXT", "1")
+        c2b.set_default_options(text_device_strict=False)
+        c2b.set_default_options(host_text=True)
         h = c2b.BAProblem.from_file(path)
-        monkeypatch.delenv("C2B_HOST_TEXT")
+        c2b.set_default_options(host_text=False)
         assert state(d) == state(h), name
         d.close(); h.close()
     for name, (text, words) in bad.items():
         path = str(tmp_path / (name + ".bal"))
         open(path, "w").write(text)
-        monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+        c2b.set_default_options(text_device_strict=True)
         with pytest.raises(c2b.City2baError, match="declined"):
             c2b.BAProblem.from_file(path)
-        monkeypatch.delenv("C2B_TEXT_DEVICE_STRICT")
+        c2b.set_default_options(text_device_strict=False)
         with pytest.raises(c2b.City2baError, match=words):
             c2b.BAProblem.from_file(path)

@@ -17,6 +17,7 @@ from _problems import (grid_cameras_points, grid_candidate_pairs, np_candidate_p
 entry.build()
 from city2ba_amd import _lib as L  # noqa: E402
 from city2ba_amd import synthetic as S  # noqa: E402
+import city2ba_amd as c2b_mod  # noqa: E402
 from city2ba_amd.baproblem import cull_arrays, read_bal, write_bal  # noqa: E402
 
 
@@ -353,7 +354,7 @@ def test_threaded_text_io_equals_the_sequential_forms(tmp_path, monkeypatch):
     bal9, pts = rng.normal(size=(n_cam, 9)), rng.normal(size=(n_pts, 3)) * 1e3
     files = {}
     for t in ("1", "2", "5", "16"):
-        monkeypatch.setenv("C2B_IO_THREADS", t)
+        c2b_mod.set_host_io_threads(int(t))
         path = tmp_path / ("w%s.bal" % t)
         write_bal(path, bal9, pts, row_ptr, pt_idx, uv)
         files[t] = path.read_bytes()
@@ -367,9 +368,9 @@ def test_threaded_text_io_equals_the_sequential_forms(tmp_path, monkeypatch):
     perm = rng.permutation(n)
     shuffled = tmp_path / "shuffled.bal"
     shuffled.write_text("\n".join([text[0]] + [obs[k] for k in perm] + text[1 + n:]))
-    monkeypatch.setenv("C2B_IO_THREADS", "4")
+    c2b_mod.set_host_io_threads(4)
     par = read_bal(shuffled)
-    monkeypatch.setenv("C2B_IO_THREADS", "1")
+    c2b_mod.set_host_io_threads(1)
     seq = read_bal(shuffled)
     for a, b in zip(par, seq):
         assert np.array_equal(a, b)
@@ -384,7 +385,7 @@ def test_threaded_text_io_equals_the_sequential_forms(tmp_path, monkeypatch):
     glued[1 + k] = " ".join(head) + " " + rest.replace(" -", "-", 1)
     gpath = tmp_path / "glued.bal"
     gpath.write_text("\n".join(glued))
-    monkeypatch.setenv("C2B_IO_THREADS", "4")
+    c2b_mod.set_host_io_threads(4)
     got = read_bal(gpath)
     for a, b in zip(got, (bal9, pts, row_ptr, pt_idx, uv)):
         assert np.array_equal(a, b)
