@@ -31,6 +31,64 @@
  *           - uv_obs (sign of src/baproblem.rs:273).  Jc[n_obs][2][9] row-major, columns in
  *           to_vec order (w0 w1 w2 t0 t1 t2 f k1 k2); Jp[n_obs][2][3] (d/dX).
  *
+ * ---- index of entry points by level (tools/abi_index.py) ----
+ *   library (3):
+ *     version, last_error, device_count
+ *   Level 0: workspace, camera records, points, rows (14):
+ *     workspace_bytes, workspace_init, workspace_selfcheck, cameras_from_bal, cameras_to_bal, cameras_prepare_state,
+ *     cameras_prepare_bal, cameras_from_position_direction, project_world, to_world, cameras_transform, points_pad,
+ *     points_unpad, expand_rows
+ *   Level 0: per-observation passes (cam_idx and row-structure forms) (17):
+ *     project, reprojection_error_sum, rows_tiles_bytes, rows_pack, project_rows, reprojection_error_sum_rows,
+ *     visibility_rows, visibility_rows_bits, reprojection_error_sums2_rows, add_noise_observations_error_sums2_rows,
+ *     jacobian_stream_policy, jacobian_tiles_per_wave, jacobian_launch_shape, residual_jacobian_rows,
+ *     residual_jacobian, error_sum_finish, residual_jacobian_sum
+ *   Level 0: Jacobian output sets and calibration (10):
+ *     jacobian_outputs_alloc, jacobian_outputs_pointers, jacobian_outputs_log, jacobian_outputs_store_rate,
+ *     jacobian_outputs_set_store_rate, jacobian_outputs_free, residual_jacobian_rows_placed, calib_store_pattern,
+ *     calib_store_pattern_map, calib_copy
+ *   Level 0: visibility sweeps and occlusion (10):
+ *     visibility_pairs, visibility_dense_tiles, visibility_dense_count, visibility_dense_fill, occlusion_filter,
+ *     bvh_build, bvh_sizes, bvh_copy, bvh_free, occlusion_filter_bvh
+ *   Level 0: statistics (5):
+ *     stats, stats_partial_pass1, stats_partial_pass2, stats_combine_shares, stats_finish_shares
+ *   collectives (RCCL) and sharded Level-0 forms (13):
+ *     comm_backend, comm_unique_id, comm_init_rank, comm_init_all, comm_group_start, comm_group_end, comm_info,
+ *     comm_all_reduce_sum_f64, comm_all_gather_f64, comm_destroy, stats_sharded, add_drift_sharded,
+ *     add_noise_entities_sharded
+ *   Level 0: noise (5):
+ *     add_drift, add_drift_normalized, add_noise_entities, add_noise_observations, add_sin_noise
+ *   f32 extension (7):
+ *     convert_f64_to_f32, convert_f32_to_f64, stats_f32, add_drift_f32, add_drift_normalized_f32,
+ *     add_noise_entities_f32, add_sin_noise_f32
+ *   host-side rows (CPU; never touch the GPU) (39):
+ *     partition_cameras, synthetic_grid_sizes, synthetic_grid_layout, synthetic_line_layout, candidate_pairs,
+ *     pairs_count, pairs_cam_idx, pairs_pt_idx, pairs_free, obj_load, obj_model_count, obj_model_name,
+ *     obj_model_sizes, obj_model_copy, obj_move_to_origin, obj_triangles, obj_free, generate_cameras_path,
+ *     generate_cameras_poisson, generate_cameras_poisson_bvh, modify_intrinsics, generate_world_points, cull,
+ *     largest_connected_component, remove_singletons, add_incorrect_correspondences, drop_features, split_landmarks,
+ *     join_landmarks, bal_read, bal_sizes, bal_copy, bal_close, bal_write, bal_read_as, bal_write_as, format_f64,
+ *     parse_f64, ply_write
+ *   Level 1: a resident BAProblem (46):
+ *     problem_create, problem_destroy, problem_options_init, problem_set_options, problem_get_options,
+ *     host_set_io_threads, problem_upload, problem_upload_bal, problem_synthetic_grid_layout,
+ *     problem_synthetic_line_layout, problem_sizes, problem_download, problem_download_bal, problem_write,
+ *     problem_read, problem_from_position_direction, problem_centers, problem_project,
+ *     problem_total_reprojection_error, problem_total_reprojection_error_sharded,
+ *     problem_total_reprojection_errors_l1_l2, problem_total_reprojection_errors_l1_l2_sharded,
+ *     problem_residual_jacobian, problem_residual_jacobian_device, host_alloc, host_free, problem_stats, problem_cull,
+ *     problem_largest_connected_component, problem_remove_singletons, problem_adopt_visibility,
+ *     problem_download_graph, problem_export_device, problem_visibility_pairs, problem_visibility_pairs_compact,
+ *     problem_visibility_within_distance, problem_generate_world_points, problem_visibility_dense,
+ *     problem_visibility_dense_fetch, problem_visibility_dense_occlude, problem_visibility_dense_occlude_bvh,
+ *     problem_add_drift, problem_add_drift_normalized, problem_add_noise, problem_add_sin_noise,
+ *     problem_add_noise_errors_l1_l2
+ *   Level 1: one shard of a larger problem (6):
+ *     problem_set_shard, problem_stats_sharded, problem_add_drift_sharded, problem_add_noise_sharded,
+ *     problem_add_sin_noise_sharded, problem_add_noise_errors_l1_l2_sharded
+ *   (175 entry points; names above without their c2b_ prefix)
+ * ---- end of index ----
+ *
  * Every function returns C2B_OK or a negative status; c2b_last_error() gives the text.
  * No exception or abort crosses this boundary.  A context/problem is not thread-safe.
  */

@@ -146,3 +146,30 @@ def test_jacobian_stream_policy_follows_the_working_set(c2b):
     assert lib.c2b_jacobian_stream_policy(19_302_494, 660_480, 0) == 0          # unknown point count: cached
     # one rank of eight on the headline problem: its cameras, every point, an eighth of the observations -- all of it fits
     assert lib.c2b_jacobian_stream_policy(19_302_494 // 8, 660_480 // 8, 1_981_440) == 0
+
+
+def test_header_index_lists_every_entry_point_once_and_the_library_reads_no_environment_switch():
+    """VERDICT r04 items 6, 7.  The header's top comment carries an index of the entry points by level, generated by
+    tools/abi_index.py: the block in the header is exactly what the tool prints, and it names every declared function
+    once.  And the library's sources call getenv in ONE place only -- the loader setting C2B_RCCL_LIB: behaviour switches
+    are c2b_problem_options."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import abi_index
+    header = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    block = abi_index.index_block()
+    assert block in header, "run `python tools/abi_index.py --write`"
+    body = header.replace(block, "")
+    declared = re.findall(r"(?m)^\s*(?:const\s+)?\w+\s*\**\s*(c2b_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    listed = re.findall(r"\b([a-z][a-z0-9_]+)\b(?=,|\n| \*/|$)", "\n".join(ln[7:] for ln in block.split("\n") if ln.startswith(" *     ")))
+    assert sorted("c2b_" + n for n in listed) == sorted(declared)
+    assert len(set(declared)) == len(declared)
+    csrc = os.path.join(ROOT, "city2ba_amd", "csrc")
+    uses = []
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hpp", ".hip")):
+            for k, ln in enumerate(open(os.path.join(csrc, name)).read().split("\n")):
+                if "getenv" in ln and not ln.lstrip().startswith("//"):
+                    uses.append((name, k + 1, ln.strip()))
+    assert len(uses) == 1 and uses[0][0] == "comm_rccl.hpp" and "C2B_RCCL_LIB" in uses[0][2], uses
