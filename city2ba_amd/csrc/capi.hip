@@ -621,6 +621,9 @@ int64_t c2b_workspace_bytes(int64_t n_obs) {
 int c2b_tune_set_jacobian_variant(int v) { g_jac_variant = v; return C2B_OK; }
 int c2b_tune_set_observation_variant(int v) { g_obs_variant = v; return C2B_OK; }
 int c2b_tune_set_stats_variant(int v) { g_stats_variant = v % 100; g_stats_grid_cap = v >= 200 ? 1024 : (v >= 100 ? 768 : kStatGrid); return C2B_OK; }
+int c2b_tune_set_stagger(int units_of_64_cycles) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &units_of_64_cycles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
+}
 // hand the time-stamp probe a device buffer of (workgroups x 8) u64 (NULL = off)
 int c2b_tune_set_probe(void *device_buffer) {
     unsigned long long *p = reinterpret_cast<unsigned long long *>(device_buffer);

@@ -35,6 +35,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // Tuning build only: a time-stamp probe (tools/tune_stats.py --probe): thread 0 of every workgroup writes the constant-rate
 // wall clock (100 MHz) into slot `k` of its row of a buffer the tool hands over; nothing of it exists in the product library.
 #ifdef C2B_TUNE
+__device__ int g_stagger = 0;        // k_observations: wave w of a workgroup sleeps w * g_stagger * 64 cycles before its first load
 __device__ unsigned long long *g_probe = nullptr;
 #define C2B_PROBE(k) do { if (g_probe != nullptr && threadIdx.x == 0) g_probe[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -554,6 +555,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
     double eacc = 0.0, eacc1 = 0.0;                                      // MODE_*ERROR12: eacc1 = the L1 sum, eacc = the L2 sum
+#ifdef C2B_TUNE
+    // experiment (r05): do the waves of a workgroup, started in lockstep, serialise on each other's phases?  Stagger them.
+    for (int k = wave * g_stagger; k > 0; --k) __builtin_amdgcn_s_sleep(1);
+#endif
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];
         double4 X[OPL];

@@ -87,6 +87,12 @@ def test_rccl_world_size_one_reproduces_the_plain_run(plain, collective, graph, 
     if collective in ("auto", "c2b"):
         assert cfg["comm_init_ms"] > 0
     assert cfg["watchdog_seconds"] == 60.0
+    # r05: the set-up is the device route (layout + visibility loop on the resident problem, the range exported device to
+    # device): seconds, not the host candidate search's tens of seconds; the line names the device's store class and the
+    # launch shape chosen by it
+    assert 0 < cfg["setup_s"] < 20.0
+    assert out["roofline"]["device_store_class"] in ("slow", "mixed", "fast") and out["roofline"]["kept_set_store_GBs"] > 1000.0
+    assert "threads per workgroup" in out["roofline"]["launch_shape"]
     assert out["config"]["n_observations"] == plain["config"]["n_observations"]
     assert out["config"]["observations_per_rank"] == [plain["config"]["n_observations"]]
     assert out["config"]["total_L2_error"] == plain["config"]["total_L2_error"]      # all_reduce over one rank: identity
@@ -110,6 +116,7 @@ def test_two_ranks_on_one_gpu_exit_cleanly_and_agree(plain):
     rel = abs(out["config"]["total_L2_error"] - plain["config"]["total_L2_error"]) / plain["config"]["total_L2_error"]
     assert rel < 1e-12
     cfg = out["config"]
+    assert 0 < cfg["setup_s"] < 30.0                              # max over the ranks; no second build, no collective inside
     assert cfg["rccl_ranks"] == [2, 2] and cfg["arrangement"] == "in_line"          # gloo stages the scalar through the host
     assert len(cfg["kernel_us_per_rank"]) == 2 and min(cfg["kernel_us_per_rank"]) > 0 and min(cfg["allreduce_us_per_rank"]) > 0
     assert out["ms_per_step"] == cfg["ms_per_step_in_line"] and "ms_per_step_overlapped" not in cfg

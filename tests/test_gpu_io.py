@@ -355,3 +355,43 @@ def test_text_reader_edge_files_device_and_host_agree(c2b, tmp_path, monkeypatch
         c2b.set_default_options(text_device_strict=False)
         with pytest.raises(c2b.City2baError, match=words):
             c2b.BAProblem.from_file(path)
+
+
+def test_problem_options_are_arguments_of_the_abi_not_environment_variables(c2b, tmp_path, monkeypatch):
+    """r05: c2b_problem_options -- defaults, get / set round trip, validation, inheritance by new
+    problems through set_default_options, and the environment variables of rounds 1-4 no longer reach the library."""
+    from city2ba_amd.baproblem import write_bal
+    ba = c2b.BAProblem()
+    dflt = dict(host_text=0, text_device_strict=0, read_threads=0, io_threads=0, rank_sort_max_row=0, text_device_min_bytes=-1)
+    assert ba.options() == dflt
+    ba.set_options(host_text=True, read_threads=5, text_device_min_bytes=123)
+    assert ba.options() == dict(dflt, host_text=1, read_threads=5, text_device_min_bytes=123)
+    with pytest.raises(c2b.City2baError):
+        ba.set_options(read_threads=65)
+    with pytest.raises(c2b.City2baError):
+        ba.set_options(io_threads=-1)
+    with pytest.raises(TypeError):
+        ba.set_options(no_such_option=1)
+    assert ba.options()["read_threads"] == 5                       # a refused set changes nothing
+    ba.close()
+    c2b.set_default_options(text_device_strict=True, io_threads=2)
+    nb = c2b.BAProblem()
+    assert nb.options() == dict(dflt, text_device_strict=1, io_threads=2)
+    nb.close()
+    c2b.reset_default_options()
+    # the old variables are just variables now: with C2B_TEXT_DEVICE_STRICT=1 in the environment a file the device parser
+    # declines (glued numbers) still goes to the host parser, and a strict problem refuses it whatever the environment says
+    P = random_problem(9, 60, 5, seed=3, noise=1e-3)
+    path = str(tmp_path / "p.bal")
+    write_bal(path, P["bal9"], P["pts"], P["row_ptr"], P["pt_idx"], P["uv"])
+    lines = open(path).read().split("\n")
+    lines[1] = lines[1].rsplit(" ", 1)[0] + "-1.5"
+    open(path, "w").write("\n".join(lines))
+    monkeypatch.setenv("C2B_TEXT_DEVICE_STRICT", "1")
+    monkeypatch.setenv("C2B_TEXT_DEVICE_MIN_BYTES", "0")
+    ok = c2b.BAProblem.from_file(path)
+    assert ok.num_observations() == len(P["pt_idx"])
+    ok.close()
+    c2b.set_default_options(text_device_strict=True, text_device_min_bytes=0)
+    with pytest.raises(c2b.City2baError, match="declined"):
+        c2b.BAProblem.from_file(path)
