@@ -272,7 +272,7 @@ class _OutputsHandle:
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
-        if h:
+        if h and L is not None:                              # (at interpreter shutdown the module globals may be gone already)
             L.lib().c2b_jacobian_outputs_free(h)
 
 
