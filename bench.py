@@ -74,6 +74,12 @@ def parse():
     ap.add_argument("--blocks", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--assume-store-GBs", type=float, default=0.0,
+                    help="diagnostic: tell the placed launch that its output set streams at this rate instead of the measured one "
+                         "(c2b_jacobian_outputs_set_store_rate) -- how the counter passes of live_traffic make their child run the "
+                         "parent's kernel instance: under rocprofv3 --pmc the store pattern's own timing is not to be trusted")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two short child passes under rocprofv3 --pmc that measure the step kernel's HBM bytes on this box")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--placement-attempts", type=int, default=8,
                     help="output allocations c2b_jacobian_outputs_alloc may try for streaming-store speed before it keeps "
@@ -435,6 +441,55 @@ def pmc_traffic(kernel_name=None):
         return None, None
 
 
+def live_traffic(kernel_name, blocks, store_GBs):
+    """HBM bytes per launch of the step kernel measured ON THIS BOX, right after the timed region: two child runs of this very
+    script (3 steps, no extras) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- each counter in its own pass with
+    nothing but --kernel-trace beside it, as the guide prescribes -- and the launches of the instance the timed region ran
+    averaged: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the guide's gfx950 correction).  Children, never an exec: this process has
+    initialised the GPU.  Anything going wrong (no rocprofv3, a pass failing or timing out, no row of that instance: the child
+    may land in an output set of another store class and launch the other shape) returns None and the line falls back to the
+    recorded figure.  ~10 s per pass."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3")
+    if not tool:
+        return None, "no rocprofv3 on PATH"
+    want = kernel_name.replace(" ", "")
+    got = {}
+    base = tempfile.mkdtemp(prefix="c2b_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(base, counter)
+            cmd = [tool, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--blocks", str(blocks), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+                   "--placement-attempts", "1", "--assume-store-GBs", "%.1f" % (store_GBs if store_GBs > 0 else 7000.0)]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+            except subprocess.TimeoutExpired:
+                return None, "%s pass timed out" % counter
+            if p.returncode != 0:
+                return None, "%s pass exited %d" % (counter, p.returncode)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and want in row.get("Kernel_Name", "").replace(" ", ""):
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s row of %s (the child launched another instance)" % (counter, kernel_name)
+            got[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    traffic = int((2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024)
+    return traffic, "%d + %d launches" % (got["FETCH_SIZE"][1], got["WRITE_SIZE"][1])
+
+
 def place_inputs(sh, r, Jc, Jp, ws, err):
     """The input arrays come out of build_shard as slices of whatever blocks the caching allocator had at hand; a copy
     in an allocation of its own is sometimes read faster by the very same kernel (tools/probe_placement4.py: 801 ->
@@ -574,6 +629,8 @@ def main():
         first_us, first_GBs = kernel_us_in(first), first.store_GBs
         del first
     outs = D.JacobianOutputs(n, dev, max_attempts=args.placement_attempts)
+    if args.assume_store_GBs > 0.0:
+        outs.set_store_rate(args.assume_store_GBs)
     (r, Jc, Jp), placement_log, placement_chosen = (outs.r, outs.Jc, outs.Jp), outs.log, outs.chosen
     input_placement = place_inputs(sh, r, Jc, Jp, ws, err) if args.place_inputs else {}
 
@@ -919,7 +976,8 @@ def main():
                 # this very command (tools/profile_bench.sh), recorded in profiles/ -- NOT measured in this run
                 "traffic": traffic,
                 "traffic_recorded_at": ("profiles/pmc_latest.json (tag %s): separate rocprofv3 --pmc pass of `python bench.py` on "
-                                        "the kernel instance this run launched; a recorded figure, not this run's" % traffic_tag)
+                                        "the kernel instance this run launched; a recorded figure, not this run's (replaced below by "
+                                        "this box's own measurement when the extras run)" % traffic_tag)
                 if traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg, "observations_per_launch": n,
                 "bytes_per_observation": round(alg / max(n, 1), 2),
@@ -976,6 +1034,18 @@ def main():
             out["roofline"]["kernel_over_same_run_store_floor"] = round(kern_avg_s * 1e6 / cal["same_run_store_floor_us"], 4)
             # the same-run copy moves exactly the launch's algorithmic byte count (read + write)
             out["roofline"]["kernel_over_same_run_copy"] = round(kern_avg_s * 1e6 / cal["same_run_copy_us"], 4)
+        if world == 1 and args.blocks == 128 and not args.no_extras and not args.no_live_traffic:
+            # the counters cannot be collected inside the timed run, but they can be collected on THIS box right after it
+            t_live, how = live_traffic(kernel_name, args.blocks, outs.store_GBs)
+            out["roofline"]["traffic_recorded"] = traffic
+            if t_live is not None:
+                out["roofline"]["traffic"] = t_live
+                out["roofline"]["traffic_over_algorithmic"] = round(t_live / alg, 4)
+                out["roofline"]["traffic_recorded_at"] = ("measured on this box right after the timed region: child runs of this script under "
+                                                          "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, %s of this kernel "
+                                                          "instance; (2 x FETCH_SIZE + WRITE_SIZE) x 1024)" % how)
+            else:
+                out["roofline"]["traffic_live_unavailable"] = how
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sh, args.cpu_seconds)
         else:
