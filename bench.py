@@ -425,20 +425,23 @@ def adversarial_gather(sh, r, Jc, Jp, ws):
 
 
 def pmc_traffic(kernel_name=None):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (profiles/, produced
-    by tools/profile_bench.sh with the guide's gfx950 FETCH_SIZE correction).  PMC counters cannot be collected
-    from inside the timed run, so this is a figure from a SEPARATE run of the same command; it is only reported when
-    the summary names the kernel this build launches, and it carries its tag."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    try:
-        with open(path) as fh:
-            j = json.load(fh)
-        profiled = str((j.get("dominant_kernel") or {}).get("name", "")).replace(" ", "")
-        if (kernel_name or KERNEL_NAME).replace(" ", "") not in profiled:
-            return None, None
-        return j.get("traffic_bytes_per_launch"), j.get("tag")
-    except Exception:
-        return None, None
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary (profiles/pmc_latest*.json,
+    produced by tools/profile_bench.sh with the guide's gfx950 FETCH_SIZE correction; one per kernel instance: the 512 x 2
+    shape of fast-store sets and the 256 x 1 shape of slow-store ones).  A figure from a SEPARATE run of the same
+    command; only reported when a summary names the kernel instance this run launched, and it carries its tag.  With the
+    extras on, the line replaces it by this box's own measurement (live_traffic)."""
+    import glob
+    want = (kernel_name or KERNEL_NAME).replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_latest*.json"))):
+        try:
+            with open(path) as fh:
+                j = json.load(fh)
+            profiled = str((j.get("dominant_kernel") or {}).get("name", "")).replace(" ", "")
+            if want in profiled and j.get("traffic_bytes_per_launch"):
+                return j.get("traffic_bytes_per_launch"), "%s, %s" % (j.get("tag"), os.path.basename(path))
+        except Exception:
+            continue
+    return None, None
 
 
 def live_traffic(kernel_name, blocks, store_GBs):
@@ -975,7 +978,7 @@ def main():
                 # Counters cannot be collected inside a timed run: this is the figure of a SEPARATE rocprofv3 --pmc pass of
                 # this very command (tools/profile_bench.sh), recorded in profiles/ -- NOT measured in this run
                 "traffic": traffic,
-                "traffic_recorded_at": ("profiles/pmc_latest.json (tag %s): separate rocprofv3 --pmc pass of `python bench.py` on "
+                "traffic_recorded_at": ("profiles/ (tag %s): separate rocprofv3 --pmc pass of `python bench.py` on "
                                         "the kernel instance this run launched; a recorded figure, not this run's (replaced below by "
                                         "this box's own measurement when the extras run)" % traffic_tag)
                 if traffic is not None else None,

@@ -239,6 +239,10 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
             case 30208: launch_obs_v<MODE, 2, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // two
             case 30408: launch_obs_v<MODE, 4, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // four
             case 30304: launch_obs_v<MODE, 3, 4, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // three, four waves per workgroup
+            case 30508: launch_obs_v<MODE, 5, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // r05: five tiles per wave
+            case 30608: launch_obs_v<MODE, 6, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // six
+            case 30604: launch_obs_v<MODE, 6, 4, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // six, four waves per workgroup
+            case 30808: launch_obs_v<MODE, 8, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // eight
             default: break;
         }
 #endif
