@@ -55,7 +55,11 @@ def test_hot_path_stays_within_its_floors_at_the_headline_size(capsys):
     store_us = _timed(torch, lambda: D.calib_store_pattern(outs.r, outs.Jc, outs.Jp), 10)
     rate = n * 208 / store_us / 1e3                         # GB/s this set takes the kernel's own stores at
     floor_us = alg / rate / 1e3
-    step_us = _timed(torch, lambda: D.residual_jacobian_rows_placed(*a, sh["uv"], outs, 2.0, ws, err[:1]), 20)
+    # (the fastest of three measurements: a tripwire must not trip on one noisy reading; floor and kernel interleaved)
+    step_us = min(_timed(torch, lambda: D.residual_jacobian_rows_placed(*a, sh["uv"], outs, 2.0, ws, err[:1]), 20) for _ in range(3))
+    store_us = min(store_us, _timed(torch, lambda: D.calib_store_pattern(outs.r, outs.Jc, outs.Jp), 10))
+    rate = n * 208 / store_us / 1e3
+    floor_us = alg / rate / 1e3
     shape = D.jacobian_launch_shape(n, outs.store_GBs)
     out["step"] = {"kernel_us": round(step_us, 1), "store_GBs_of_the_set": round(rate, 1), "store_class": bench.store_class([rate]),
                    "launch_shape_threads_x_tiles": [shape[0] * 64, shape[1]], "algorithmic_floor_us": round(floor_us, 1),
