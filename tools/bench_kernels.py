@@ -136,10 +136,12 @@ t = timed(lambda: D.add_noise_observations(uv2, 0, 1e-6, 7))
 report("add_noise_observations", t, n, n * 32, "obs")
 
 st = torch.empty(20, dtype=torch.float64, device=dev)
+t = timed(lambda: D.stats(camblk, pts4, ws, st, centers=sh["cen4"]))
+report("stats(mean,std,extent,origin) [compact centre table]", t, n_cam + n_pts, n_cam * 24 + n_pts * 24, "entities")
 t = timed(lambda: D.stats(camblk, pts4, ws, st))
-report("stats(mean,std,extent,origin)", t, n_cam + n_pts, 2 * (n_cam * 24 + n_pts * 24), "entities")
-t = timed(lambda: D.cameras_prepare_state(cam15, camblk))
-report("cameras_prepare_state", t, n_cam, n_cam * (120 + 256), "cams")
+report("stats(mean,std,extent,origin) [centres read from camblk]", t, n_cam + n_pts, n_cam * 24 + n_pts * 24, "entities")
+t = timed(lambda: D.cameras_prepare_state(cam15, camblk, centers=sh["cen4"]))
+report("cameras_prepare_state (+ centre table)", t, n_cam, n_cam * (120 + 256 + 32), "cams")
 bal9 = D.cameras_to_bal(cam15)
 t = timed(lambda: D.cameras_to_bal(cam15))
 report("cameras_to_bal", t, n_cam, n_cam * (120 + 72), "cams")
