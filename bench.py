@@ -495,7 +495,7 @@ def live_traffic(kernel_name, blocks, store_GBs):
 
 def place_inputs(sh, r, Jc, Jp, ws, err):
     """The input arrays come out of build_shard as slices of whatever blocks the caching allocator had at hand; a copy
-    in an allocation of its own is sometimes read faster by the very same kernel (tools/probe_placement4.py: 801 ->
+    in an allocation of its own is sometimes read faster by the very same kernel (r02, docs/log_r01_r03.md: 801 ->
     750 us over uv, camblk, pt_idx).  Greedy and empirical: copy one array, time the kernel, keep the copy
     if the kernel got faster.  Untimed set-up; the log goes into roofline.input_placement."""
     import torch
