@@ -348,8 +348,12 @@ constexpr int64_t kJacOneTileBelow = 6000000;
 // Between the classes (6.0-6.8 TB/s) nothing was measured: the boundary sits in the middle.
 constexpr double kJacSlowStoreGBs = 6300.0;
 struct JacShape { int wpb, opl; };                // waves per workgroup, tiles of 64 observations per wave
+// Below ~6 M observations (one tile per wave) the 1 024-thread workgroup -- ONE workgroup of 16 waves per CU instead of two of 8,
+// half the workgroups to dispatch and to fold -- is 1-3.6 % faster than the 512-thread one at a rank's eighth of the headline
+// problem (2.4 M observations: 108.9 / 113.0 us into a 5.4 TB/s set, 100.3 / 101.9 into a 6.1 TB/s one; 4.9 M: 217.5 / 223.1),
+// on two devices, r05 (output sets of this size never reach the 7 TB/s class).
 static JacShape jacobian_shape(int64_t n_obs, double store_GBs) {
-    if (n_obs < kJacOneTileBelow) return {8, 1};
+    if (n_obs < kJacOneTileBelow) return {16, 1};
     if (store_GBs > 0.0 && store_GBs < kJacSlowStoreGBs) return {4, 1};
     return {8, 2};
 }
@@ -416,11 +420,11 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
                 case 2: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
                 default: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
             }
-        } else if (shape.opl == 1) {
+        } else if (shape.opl == 1) {                           // below ~6 M observations: 1 024 threads x one tile
             switch (policy) {
-                case 3: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
-                case 2: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
-                default: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+                case 3: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
+                case 2: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
+                default: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
             }
         } else {
             switch (policy) {
@@ -471,7 +475,7 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
         default: break;
     }
 #endif
-    if (n_obs < kJacOneTileBelow) launch_jac_l<WITH_ERR, 8, 1, 1>(C2B_ARGS);   // shipped: lean form, one tile per wave (= variant 42) ...
+    if (n_obs < kJacOneTileBelow) launch_jac_l<WITH_ERR, 16, 1, 1>(C2B_ARGS);  // shipped: lean form, one tile per wave in 1 024-thread workgroups (the grid of the rows form: same sum bits) ...
     else launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS);                        // ... or two (= variant 40), by size
 #undef C2B_ARGS
     return C2B_OK;

@@ -234,7 +234,7 @@ int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts);
  * the folded error sum does, like on any other change of the grid) */
 int c2b_jacobian_tiles_per_wave(int64_t n_obs);
 /* ... and the full shape -- waves of 64 per workgroup, tiles per wave -- of a launch of n_obs observations into an output
- * set that takes streaming stores at store_GBs (GB/s; 0 = unknown): 8 x 1 below ~6 M observations; above, 8 x 2, or
+ * set that takes streaming stores at store_GBs (GB/s; 0 = unknown): 16 x 1 below ~6 M observations; above, 8 x 2, or
  * 4 x 1 when the set is one of the slow-store kind (< 6.3 TB/s; c2b_residual_jacobian_rows_placed).  Diagnostic, like
  * the two above: results do not depend on the shape. */
 int c2b_jacobian_launch_shape(int64_t n_obs, double store_GBs, int *waves_per_workgroup, int *tiles_per_wave);

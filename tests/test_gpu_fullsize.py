@@ -60,7 +60,7 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     sums = {}
     for rate in (5700.0, 7100.0, 0.0):
         outs.set_store_rate(rate)
-        assert D.jacobian_launch_shape(n, rate) == ((8, 1) if n < 6_000_000 else ((4, 1) if 0 < rate < 6300 else (8, 2)))
+        assert D.jacobian_launch_shape(n, rate) == ((16, 1) if n < 6_000_000 else ((4, 1) if 0 < rate < 6300 else (8, 2)))
         outs.r.fill_(float("nan")); outs.Jc.fill_(float("nan")); outs.Jp.fill_(float("nan"))
         for _ in range(2):
             D.residual_jacobian_rows_placed(camblk, pts4, rows, pi, uv, outs, 2.0, ws, e_one)
