@@ -32,6 +32,7 @@
 #include "kernels.hpp"
 #ifdef C2B_TUNE
 #include "obs_pipeline.hpp"      // persistent pipelined variants: measured slower, tuning library only
+#include "obs_split.hpp"         // r05 experiment: loader wave + compute waves meeting in LDS (projection only)
 #endif
 #include "cull_kernels.hpp"
 #include "cell_kernels.hpp"
@@ -149,6 +150,17 @@ int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
     return (int)g;
 }
 
+// r05 experiment (obs_split.hpp): the projection with one loader wave and seven compute waves per workgroup
+template <int G, int K>
+void launch_project_split(const double *camblk, const double *pts4, const uint32_t *tiles, const uint32_t *pt_idx, int64_t n,
+                          double *uv_out, hipStream_t st, const uint64_t *row_ptr, int64_t n_cam) {
+    static unsigned *err = nullptr;                     // a leak of four bytes per process, tuning library only
+    if (!err) { (void)hipMalloc((void **)&err, 4); (void)hipMemset(err, 0, 4); }
+    const int n_tiles = (int)((n + 63) / 64), n_wg = (n_tiles + 7 * K - 1) / (7 * K);
+    hipLaunchKernelGGL((k_project_split<G, K, true>), dim3((unsigned)n_wg), dim3(512), 0, st, camblk, reinterpret_cast<const double4 *>(pts4),
+                       reinterpret_cast<const uint4 *>(tiles), pt_idx, (int)n, n_wg, reinterpret_cast<double2 *>(uv_out), row_ptr, (int)n_cam, err);
+}
+
 template <int MODE, int WPB>
 void launch_obs_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
@@ -239,6 +251,10 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
             case 30208: launch_obs_v<MODE, 2, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // two
             case 30408: launch_obs_v<MODE, 4, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // four
             case 30304: launch_obs_v<MODE, 3, 4, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // three, four waves per workgroup
+            case 4066: if constexpr (MODE == MODE_PROJECT) { launch_project_split<6, 6>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
+            case 4046: if constexpr (MODE == MODE_PROJECT) { launch_project_split<4, 6>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
+            case 4612: if constexpr (MODE == MODE_PROJECT) { launch_project_split<6, 12>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
+            case 4088: if constexpr (MODE == MODE_PROJECT) { launch_project_split<8, 8>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
             case 30508: launch_obs_v<MODE, 5, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // r05: five tiles per wave
             case 30608: launch_obs_v<MODE, 6, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // six
             case 30604: launch_obs_v<MODE, 6, 4, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // six, four waves per workgroup

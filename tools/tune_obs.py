@@ -85,7 +85,10 @@ jac = (lambda: D.residual_jacobian_sum(camblk, pts4, ci, pi, uv, r_o, Jc_o, Jp_o
 POLICIES = (("shipped", 308), ("all cached", 20308), ("nt stores", 21308), ("nt stores+uv", 22308), ("nt everything", 23308),
             ("shipped policy, 1 tile per wave", 30108), ("shipped policy, 2 tiles", 30208), ("shipped policy, 4 tiles", 30408),
             ("shipped policy, 3 tiles, 4 waves per workgroup", 30304), ("shipped policy, 5 tiles", 30508), ("shipped policy, 6 tiles", 30608),
-            ("shipped policy, 6 tiles, 4 waves per workgroup", 30604), ("shipped policy, 8 tiles", 30808))
+            ("shipped policy, 6 tiles, 4 waves per workgroup", 30604), ("shipped policy, 8 tiles", 30808),
+            # r05 experiment (obs_split.hpp; projection only, the other kinds run the shipped kernel under these numbers):
+            # one loader wave + seven compute waves per workgroup, G tiles per loader batch x K tiles per compute wave
+            ("split: loader + 7 compute waves, G 6 K 6", 4066), ("split, G 4 K 6", 4046), ("split, G 6 K 12", 4612), ("split, G 8 K 8", 4088))
 modes = {}                                        # name -> (kind, callable)
 for k, (idx_fn, rows_fn) in kinds.items():
     for v in variants:
