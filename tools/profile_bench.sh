@@ -11,6 +11,16 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
+# The counter passes must launch the instance the trace pass timed: the launch shape follows the output set's measured store
+# rate (r05), and under --pmc the store pattern's own timing reads differently -- so tell them the rate the trace pass kept.
+RATE=$(python3 -c "
+import json,sys
+for l in open('$OUT/trace.log'):
+    if l.startswith('{') and '\"metric\"' in l:
+        print(json.loads(l)['roofline'].get('kept_set_store_GBs') or 7000.0); break
+else: print(7000.0)" 2>/dev/null || echo 7000.0)
+ARGS="$ARGS --assume-store-GBs $RATE"
+echo "counter passes with --assume-store-GBs $RATE"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc_fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
