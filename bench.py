@@ -968,8 +968,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                 "launch_shape": "%d threads per workgroup, %d tile%s of 64 observations per wave (c2b_jacobian_launch_shape: by the "
-                                "launch's size and the %s GB/s the output set takes streaming stores at; below 6 300 GB/s the finer "
-                                "grain is 2.3 %% faster, profiles/r05_ab_slow_store.txt)" % (
+                                "launch's size and the %s GB/s the output set takes streaming stores at; below 6 300 GB/s 256 x 1, below 6 850 GB/s 1 024 x 1: the finer "
+                                "grain is 1.6-4.4 %% faster, profiles/r05_ab_slow_store.txt, r05p_ab_step_three_classes.txt)" % (
                                     shape[0] * 64, shape[1], "" if shape[1] == 1 else "s", ("%.0f" % outs.store_GBs) if outs.store_GBs else "unmeasured"),
                 "stream_policy": {0: "every load cached", 2: "observed uv non-temporal", 3: "observed uv and point index non-temporal"}[policy]
                 + " (c2b_jacobian_stream_policy: tables and streams of this launch against the 256 MB Infinity Cache)",

@@ -361,8 +361,12 @@ constexpr int64_t kJacOneTileBelow = 6000000;
 // -2.3 % every time, 1.06-1.08 x the launch's algorithmic bytes at the set's own store rate instead of 1.08-1.105;
 // profiles/r05_ab_slow_store.txt, r05a/r05c_ab_step_*).  Stores that drain slowly keep a wave's registers and LDS busy
 // longer; the finer grain -- half the observations per wave, a quarter per workgroup -- lets the CU turn over sooner.
-// Between the classes (6.0-6.8 TB/s) nothing was measured: the boundary sits in the middle.
-constexpr double kJacSlowStoreGBs = 6300.0;
+// Between the classes (sets at 6.2-6.5 TB/s on mixed devices; profiles/r05p_ab_step_three_classes.txt and the two runs
+// before it): 1 024 threads x ONE tile is the best there -- -3.6 / -3.2 / -2.7 % against 512 x 2 at 6.21 / 6.45 / 6.54 TB/s
+// where 256 x 1 gives -4.4 / -1.9 / -1.6 % -- and it is the one shape that is never far off: -1 ... -3.4 % in the slow sets
+// (256 x 1: -2.3 ... -4.4 %), 0 ... +1.8 % in the fast ones (256 x 1: +3.4 ... +3.7 %).  So three shapes by the measured rate:
+constexpr double kJacSlowStoreGBs = 6300.0;       // below: 256 threads x 1 tile
+constexpr double kJacFastStoreGBs = 6850.0;       // below: 1 024 threads x 1 tile; at or above (or unknown): 512 threads x 2 tiles
 struct JacShape { int wpb, opl; };                // waves per workgroup, tiles of 64 observations per wave
 // Below ~6 M observations (one tile per wave) the 1 024-thread workgroup -- ONE workgroup of 16 waves per CU instead of two of 8,
 // half the workgroups to dispatch and to fold -- is 1-3.6 % faster than the 512-thread one at a rank's eighth of the headline
@@ -371,6 +375,7 @@ struct JacShape { int wpb, opl; };                // waves per workgroup, tiles 
 static JacShape jacobian_shape(int64_t n_obs, double store_GBs) {
     if (n_obs < kJacOneTileBelow) return {16, 1};
     if (store_GBs > 0.0 && store_GBs < kJacSlowStoreGBs) return {4, 1};
+    if (store_GBs > 0.0 && store_GBs < kJacFastStoreGBs) return {16, 1};
     return {8, 2};
 }
 
@@ -417,6 +422,7 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
             case 719: launch_jac_l<WITH_ERR, 2, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 128 threads, two tiles
             case 720: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 1024 threads, one tile
             case 721: launch_jac_l<WITH_ERR, 4, 1, 1, 64, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 256 threads, one tile, XCD map in chunks of 64
+            case 730: launch_jac_l<WITH_ERR, 16, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 1024 threads, two tiles
             case 722: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3, false>(C2B_ROWS_ARGS); return C2B_OK;   // 256 threads, one tile, plain stores
             case 64:                                                                                      // two tiles per wave whatever the size
                 switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
@@ -436,7 +442,7 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
                 case 2: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
                 default: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
             }
-        } else if (shape.opl == 1) {                           // below ~6 M observations: 1 024 threads x one tile
+        } else if (shape.opl == 1) {                           // below ~6 M observations, or a set between the store classes: 1 024 threads x one tile
             switch (policy) {
                 case 3: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
                 case 2: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;

@@ -234,9 +234,9 @@ int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts);
  * the folded error sum does, like on any other change of the grid) */
 int c2b_jacobian_tiles_per_wave(int64_t n_obs);
 /* ... and the full shape -- waves of 64 per workgroup, tiles per wave -- of a launch of n_obs observations into an output
- * set that takes streaming stores at store_GBs (GB/s; 0 = unknown): 16 x 1 below ~6 M observations; above, 8 x 2, or
- * 4 x 1 when the set is one of the slow-store kind (< 6.3 TB/s; c2b_residual_jacobian_rows_placed).  Diagnostic, like
- * the two above: results do not depend on the shape. */
+ * set that takes streaming stores at store_GBs (GB/s; 0 = unknown): 16 x 1 below ~6 M observations; above, 8 x 2 -- or
+ * 4 x 1 when the set is one of the slow-store kind (< 6.3 TB/s) and 16 x 1 when it lies between the classes (< 6.85 TB/s),
+ * which only c2b_residual_jacobian_rows_placed knows.  Diagnostic, like the two above: results do not depend on the shape. */
 int c2b_jacobian_launch_shape(int64_t n_obs, double store_GBs, int *waves_per_workgroup, int *tiles_per_wave);
 int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,

@@ -58,9 +58,9 @@ def test_synthetic_blocks_properties(blocks, n_expected):
     outs = D.JacobianOutputs(n, dev, max_attempts=1)
     assert (outs.store_GBs > 1000.0) == (n >= 1_000_000)
     sums = {}
-    for rate in (5700.0, 7100.0, 0.0):
+    for rate in (5700.0, 6500.0, 7100.0, 0.0):
         outs.set_store_rate(rate)
-        assert D.jacobian_launch_shape(n, rate) == ((16, 1) if n < 6_000_000 else ((4, 1) if 0 < rate < 6300 else (8, 2)))
+        assert D.jacobian_launch_shape(n, rate) == ((16, 1) if n < 6_000_000 else ((4, 1) if 0 < rate < 6300 else ((16, 1) if 0 < rate < 6850 else (8, 2))))
         outs.r.fill_(float("nan")); outs.Jc.fill_(float("nan")); outs.Jp.fill_(float("nan"))
         for _ in range(2):
             D.residual_jacobian_rows_placed(camblk, pts4, rows, pi, uv, outs, 2.0, ws, e_one)

@@ -38,6 +38,7 @@ VARIANTS = {
     707: "every load cached", 708: "idx nt only", 709: "uv nt only", 714: "XCD map in chunks of 4", 715: "XCD map in chunks of 64",
     716: "256 thr, 1 tile, every load cached", 717: "256 thr, 1 tile, uv nt only", 718: "256 thr, 1 tile, uv per tile",
     719: "128 thr, 2 tiles/wave", 720: "1024 thr, 1 tile/wave", 721: "256 thr, 1 tile, XCD chunks of 64", 722: "256 thr, 1 tile, plain stores",
+    730: "1024 thr, 2 tiles/wave",
 }
 
 ap = argparse.ArgumentParser()
