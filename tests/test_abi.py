@@ -108,6 +108,31 @@ def test_workspace_and_partition_host_helpers(c2b):
     assert b"partition_cameras" in L.c2b_last_error()
 
 
+def test_jacobian_launch_shape_is_host_arithmetic_with_three_classes(c2b):
+    """c2b_jacobian_launch_shape (no GPU): one tile per wave in 1 024-thread workgroups below ~6 M observations; above, by the
+    store rate of the output set -- 256 x 1 below 6.3 TB/s, 1 024 x 1 between 6.3 and 6.85, 512 x 2 at 6.85 or more and when
+    the rate is unknown (0): the table the A/Bs of round 5 produced (profiles/r05_ab_slow_store.txt, r05p_*)."""
+    from city2ba_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    L.c2b_jacobian_launch_shape.argtypes = [C.c_int64, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def shape(n, rate):
+        w, t = C.c_int(0), C.c_int(0)
+        assert L.c2b_jacobian_launch_shape(n, rate, C.byref(w), C.byref(t)) == 0
+        return w.value, t.value
+    big = 19_302_494
+    for rate, want in ((0.0, (8, 2)), (-5.0, (8, 2)), (5700.0, (4, 1)), (6299.9, (4, 1)), (6300.0, (16, 1)), (6500.0, (16, 1)), (6849.9, (16, 1)),
+                       (6850.0, (8, 2)), (7100.0, (8, 2))):
+        assert shape(big, rate) == want, rate
+    for n in (0, 64, 1_225_066, 2_412_824, 5_999_999):
+        for rate in (0.0, 5700.0, 7100.0):
+            assert shape(n, rate) == (16, 1)
+    assert shape(6_000_000, 7100.0) == (8, 2)
+    L.c2b_jacobian_tiles_per_wave.argtypes = [C.c_int64]
+    assert L.c2b_jacobian_tiles_per_wave(big) == 2 and L.c2b_jacobian_tiles_per_wave(2_412_824) == 1
+    assert L.c2b_jacobian_launch_shape(big, 7000.0, None, None) == 0            # either output may be NULL
+
+
 def _exported(path):
     out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
