@@ -1417,8 +1417,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
     }
     __syncthreads();
     if (sh[WAVES][0] == 0.0) return;                   // workgroup-uniform
-    StatRec f = stat_empty();
-    for (unsigned r = threadIdx.x; r < gridDim.x; r += BLOCK) {
+    // the last workgroup: thread t takes records t, t + BLOCK, ...  The first two (all there are at the shipped grid of
+    // 2 x BLOCK workgroups) are loaded together -- one round trip to the L2, not two -- and the first is taken as it
+    // is instead of being merged into an empty record (a division saved on the critical path).
+    auto load_rec = [&](unsigned r) {
         const double *q = rec + (int64_t)r * kStatRec;
         StatRec g = stat_empty();
 #pragma unroll
@@ -1429,7 +1431,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
 #pragma unroll
             for (int k = 0; k < 3; ++k) { g.mu[k] = q[12 + k]; g.m2[k] = q[15 + k]; }
         }
-        stat_merge<STD>(f, g);
+        return g;
+    };
+    StatRec f = stat_empty();
+    if (threadIdx.x < gridDim.x) {
+        const unsigned r1 = threadIdx.x + BLOCK;
+        const StatRec g0 = load_rec(threadIdx.x);
+        const StatRec g1 = load_rec(r1 < gridDim.x ? r1 : threadIdx.x);      // clamped: both loads always issue
+        f = g0;
+        if (r1 < gridDim.x) stat_merge<STD>(f, g1);
+        for (unsigned r = r1 + BLOCK; r < gridDim.x; r += BLOCK) stat_merge<STD>(f, load_rec(r));
     }
     C2B_PROBE(4);
     f = stat_block_reduce<STD, WAVES>(f, sh);
