@@ -654,6 +654,12 @@ int c2b_tune_set_stats_variant(int v) { g_stats_variant = v % 100; g_stats_grid_
 int c2b_tune_set_stagger(int units_of_64_cycles) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &units_of_64_cycles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
 }
+int c2b_tune_set_cam_stride(int doubles) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_stride), &doubles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
+}
+int c2b_tune_set_cam_swizzle(int doubles) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_swz), &doubles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
+}
 // hand the time-stamp probe a device buffer of (workgroups x 8) u64 (NULL = off)
 int c2b_tune_set_probe(void *device_buffer) {
     unsigned long long *p = reinterpret_cast<unsigned long long *>(device_buffer);

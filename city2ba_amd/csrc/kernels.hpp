@@ -36,6 +36,8 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // wall clock (100 MHz) into slot `k` of its row of a buffer the tool hands over; nothing of it exists in the product library.
 #ifdef C2B_TUNE
 __device__ int g_stagger = 0;        // k_observations: wave w of a workgroup sleeps w * g_stagger * 64 cycles before its first load
+__device__ int g_cam_stride = 0;     // k_observations (project / error modes): doubles between camera records (0 = kCamBlk); 16 = a compact table of the light line
+__device__ int g_cam_swz = 0;        // ... doubles added to an ODD camera's record address (16: its light line sits in the second half of its 256 bytes)
 __device__ unsigned long long *g_probe = nullptr;
 #define C2B_PROBE(k) do { if (g_probe != nullptr && threadIdx.x == 0) g_probe[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -556,6 +558,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
     double eacc = 0.0, eacc1 = 0.0;                                      // MODE_*ERROR12: eacc1 = the L1 sum, eacc = the L2 sum
 #ifdef C2B_TUNE
+    const int cam_stride = g_cam_stride ? g_cam_stride : kCamBlk;        // experiment (r05): a compact 128-byte-per-camera table
+    const int cam_swz = g_cam_swz;
+#else
+    constexpr int cam_stride = kCamBlk, cam_swz = 0;
+#endif
+#ifdef C2B_TUNE
     // experiment (r05): do the waves of a workgroup, started in lockstep, serialise on each other's phases?  Stagger them.
     for (int k = wave * g_stagger; k > 0; --k) __builtin_amdgcn_s_sleep(1);
 #endif
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             const int k = ch / CH, j = ch % CH;
             const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
             *reinterpret_cast<d2_t *>(sCam + k * HOT + 2 * j) =
-                *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * kCamBlk + src);
+                *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * cam_stride + src + (((c_first + k) & 1u) ? cam_swz : 0));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                     const int k = ch / CH, j = ch % CH;
                     const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
                     *reinterpret_cast<d2_t *>(sSlow + k * HOT + 2 * j) =
-                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)sIdx[k] * kCamBlk + src);
+                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)sIdx[k] * cam_stride + src + ((sIdx[k] & 1u) ? cam_swz : 0));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""r05 experiment (tuning library): the light passes read only the first 128-byte line of every 256-byte camblk record.
+In a cache indexed by physical address that traffic touches every other line of a 169-MB range -- half the sets -- so does
+a COMPACT table of those lines (128 bytes per camera, contiguous) behave better in the 256-MB Infinity Cache?  project /
+error passes, both tables, back to back and from swept caches, with and without 1.2 GB of unrelated allocations made first
+(another physical placement)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import __graft_entry__ as entry  # noqa: E402
+from city2ba_amd import _lib as L  # noqa: E402
+
+L.LIB_PATH = entry.build_tune()
+import bench  # noqa: E402
+from city2ba_amd import device as D  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ballast-mb", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+raw = C.CDLL(L.LIB_PATH)
+raw.c2b_tune_set_cam_stride.argtypes = [C.c_int]
+raw.c2b_tune_set_cam_swizzle.argtypes = [C.c_int]
+ballast = [torch.empty(64 << 20, dtype=torch.uint8, device=dev) for _ in range(a.ballast_mb // 64)]
+sh = bench.build_shard(argparse.Namespace(blocks=128), 0, 1, dev)
+n = sh["n_obs"]
+ws = D.workspace(n, dev)
+err = torch.zeros(2, dtype=torch.float64, device=dev)
+uv_out = torch.empty_like(sh["uv"])
+ref = torch.empty_like(sh["uv"])
+sweep = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
+compact = sh["camblk"][:, :16].contiguous()
+# the light line of ODD cameras moved into the second half of their 256 bytes: the lines the light passes touch then
+# alternate between even and odd 128-byte line addresses instead of being every other line
+swz = torch.zeros_like(sh["camblk"])
+swz[0::2, :16] = sh["camblk"][0::2, :16]
+swz[1::2, 16:] = sh["camblk"][1::2, :16]
+
+
+def measure(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    warm = s.elapsed_time(e) / 20 * 1e3
+    cold = []
+    for _ in range(5):
+        sweep.sum()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        cold.append(s.elapsed_time(e) * 1e3)
+    return warm, sorted(cold)[2]
+
+
+for tag, table, stride, sw in (("256-byte records", sh["camblk"], 0, 0), ("compact 128-byte rows", compact, 16, 0), ("odd records swizzled", swz, 0, 16),
+                               ("256-byte records", sh["camblk"], 0, 0), ("compact 128-byte rows", compact, 16, 0), ("odd records swizzled", swz, 0, 16)):
+    raw.c2b_tune_set_cam_stride(stride)
+    raw.c2b_tune_set_cam_swizzle(sw)
+    aa = (table, sh["pts4"], sh["rows"], sh["pt_idx"])
+    w, c = measure(lambda: D.project_rows(*aa, uv_out))
+    if stride == 0 and sw == 0:
+        ref.copy_(uv_out)
+    same = bool(torch.equal(uv_out, ref))
+    w2, c2 = measure(lambda: D.reprojection_error_sums2_rows(*aa, sh["uv"], ws, err))
+    print("ballast %4d MB  %-22s project %6.1f / %6.1f us (bits %s)   L1+L2 error %6.1f / %6.1f us   (back to back / caches swept)" % (
+        a.ballast_mb, tag, w, c, same, w2, c2), flush=True)
+raw.c2b_tune_set_cam_stride(0)
+raw.c2b_tune_set_cam_swizzle(0)
