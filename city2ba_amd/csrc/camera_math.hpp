@@ -325,6 +325,7 @@ C2B_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 }
 
 // ---- lean transcendentals for the noise draws ---------------------------------------------------------------------
+// (the ENTITY draws -- normal_pair -- and pow_lean use these; the observation draw moved to tables in r05, further down)
 // k_add_noise_observations is bound by vector issue (SQ counters, profiles/r03d: ACTIVE_INST_VALU 85 % of the SIMDs'
 // cycles, 287 vector instructions per wave of 64 observations), and half of those instructions were the library's
 // log / sincospi / cospi, which carry double-double arithmetic and argument handling this kernel has no use for: its
@@ -394,27 +395,9 @@ C2B_DEV void sincos_kernel(double x, double &sn, double &cs) {
     cs = fma(z * z, pc, fma(-0.5, z, 1.0));
 }
 
-// (cos, sin) of the angle w * 2^-32 turns: nearest quarter turn k, remainder in [-1/8, 1/8) turns exactly, the kernels
-// on 2 pi * remainder, then the quarter-turn rotation
-C2B_DEV void sincos_turns32(uint32_t w, double &sn, double &cs) {
-    const uint32_t k = (w + 0x20000000u) >> 30;                       // 0 .. 4
-    const int32_t rem = (int32_t)(w - (k << 30));                     // [-2^29, 2^29)
-    double s, c;
-    sincos_kernel((double)rem * (6.283185307179586476925286766559 * 0x1.0p-32), s, c);
-    const bool swap = (k & 1u) != 0;
-    const double a = swap ? s : c, b = swap ? c : s;                  // k odd: cos = -/+ sin, sin = +/- cos
-    cs = ((k + 1u) & 2u) ? -a : a;                                    // k = 1, 2: cos negated
-    sn = (k & 2u) ? -b : b;                                           // k = 2, 3: sin negated
-}
-C2B_DEV double cos_turns32(uint32_t w) {
-    double s, c;
-    sincos_turns32(w, s, c);
-    return c;
-}
-
 // (sin, cos) of 2 pi u for u in [0, 1) given as a double (a 53-bit fraction of a turn): 4u, its nearest integer and the
 // remainder are all exact in double arithmetic, so the reduction to [-pi/4, pi/4] costs one rounding (the product with
-// pi/2), like sincos_turns32
+// pi/2)
 C2B_DEV void sincos_turns(double u, double &sn, double &cs) {
     const double t = 4.0 * u, kf = rint(t);
     const int k = (int)kf;                                            // 0 .. 4
@@ -448,6 +431,7 @@ C2B_DEV void normal_pair(uint64_t seed, uint32_t stream, uint64_t entity, uint32
 // Philox2x32-10 (Salmon et al., SC'11; Random123's philox2x32_R(10, ...)): one 32 x 32 -> 64 multiply per round where
 // Philox4x32 has two -- the multiplies run at a quarter of the vector rate, and with its xors Philox4x32-10 was 42 % of
 // the observation-noise kernel's issue cycles (19 v_mad_u64_u32 + 40 v_xor of 214 vector instructions, r03 ISA).
+// (gfx950 has no v_xor3_b32 -- the assembler rejects it --, so a round is one multiply and two xors.)
 C2B_DEV void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t out[2]) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
@@ -460,19 +444,87 @@ C2B_DEV void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t out[2]
     out[0] = c0; out[1] = c1;
 }
 
+// ---- the observation draw's tables (r05) ---------------------------------------------------------------------------
+// SQ counters (profiles/r05h_light_sq.json) put the two observation-noise passes at 69-75 % vector issue, 186 of their
+// instructions being this draw; 80 of those were three sine / cosine polynomials and a logarithm with its division.  Both
+// angles are 16-bit fractions of a turn and the logarithm's argument has 32 significant bits, so: (cos, sin)(2 pi a / 65536) =
+// the angle-sum of two 256-entry tables (high byte, low byte: two fused multiply-adds each), and ln through 128 intervals
+// of the mantissa (r = z / c - 1 by one FMA against the tabled 1 / c, a degree-7 series in |r| < 2^-7, the tabled ln c) --
+// the form of ARM's optimised-routines log, with the two intervals touching z = 1 given c = 1 so that draws next to u = 1
+// keep their relative accuracy.  640 16-byte entries (tools/gen_noise_tables.py: correctly rounded from 60 digits,
+// tests/test_noise_tables.py), staged in LDS by the workgroup.  Against glibc: directions within 1.2e-16 absolute,
+// -2 ln u within 3 ulps, its square root within 2.3e-16 relative (tests/test_gpu_parity.py pins the draw at 1e-13).
+constexpr int kNoiseTab = 640;                 // double2 entries: 10 240 bytes
+constexpr int kNoiseTabLog = 512;
+typedef double tab2_t __attribute__((ext_vector_type(2)));      // (the class type double2 cannot be read through an LDS-typed pointer)
+__device__ const tab2_t g_noise_tab[kNoiseTab] = {
+#include "noise_tables.inc"
+};
+typedef const __attribute__((address_space(3))) tab2_t *lds_tab;
+
+// every thread of the workgroup calls this, then a workgroup barrier
+C2B_DEV void noise_tab_stage(tab2_t *sTab, int tid, int n_threads) {
+    for (int i = tid; i < kNoiseTab; i += n_threads) sTab[i] = g_noise_tab[i];
+}
+
+// -2 ln(x) for a normal x in (0, 1]
+C2B_DEV double m2log_tab(double x, lds_tab tab) {
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const uint32_t tmp = hi - 0x3FE60000u;                                // x = z 2^k, z in [0.6875, 1.375)
+    const uint32_t i = (tmp >> 13) & 127u;
+    const int k = (int32_t)tmp >> 20;
+    const double z = __hiloint2double((int)(hi - (tmp & 0xFFF00000u)), __double2loint(x));
+    const tab2_t e = tab[kNoiseTabLog + i];                               // (1 / c, -2 ln c)
+    const double r = fma(z, e.x, -1.0), kd = (double)k;
+    // -2 ln(1 + r) = -2 r + r^2 (1 + r (-2/3 + r (1/2 + r (-2/5 + r (1/3 - 2/7 r)))))
+    double p = fma(r, -2.0 / 7.0, 1.0 / 3.0);
+    p = fma(r, p, -2.0 / 5.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, -2.0 / 3.0);
+    p = fma(r, p, 1.0);
+    const double head = fma(kd, -2.0 * 6.93147180369123816490e-01, e.y);   // k ln2_hi is exact (ln2_hi ends in 21 zero bits)
+    const double tail = fma(kd, -2.0 * 1.90821492927058770002e-10, -2.0 * r);
+    return head + fma(r * r, p, tail);
+}
+
+// sqrt(x) for x = 0 or a normal x >= 2^-40 (what m2log_tab returns): hardware estimate of 1 / sqrt(x), one coupled
+// Goldschmidt step, two residual corrections -- without the scaling and class tests the library's sqrt carries for
+// subnormal and infinite arguments
+C2B_DEV double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
+// (cos, sin) of a / 65536 turns, a < 65536
+C2B_DEV void sincos_turns16(uint32_t a, lds_tab tab, double &cs, double &sn) {
+    const tab2_t A = tab[a >> 8], B = tab[256 + (a & 255u)];
+    cs = fma(A.x, B.x, -(A.y * B.y));
+    sn = fma(A.y, B.x, A.x * B.y);
+}
+
 // add_noise's observation draw (src/noise.rs:152-170: a uniformly distributed unit 2-vector times Normal(0, std)) from
 // ONE Philox2x32-10 block (r04; rounds 1-2 spent two Philox4x32 blocks here, r03 one): counter = the observation's global
 // index, its high word xor-ed with the seed's high word; key = the seed's low word.  Word 0 -> the radius uniform
 // u1 = (w0 + 1) 2^-32 in (0, 1] (the magnitude's tail ends at sqrt(-2 ln 2^-32) = 6.7 sigma); word 1, high half -> the
 // Box-Muller angle, low half -> the direction (16-bit fractions of a turn each).  The normalised Gaussian pair of
 // unit_random has a uniform direction and its radius cancels, so only the direction is drawn.  The CPU restatement
-// under oracle/ reads the same bits.  c, s = the direction; returns the standard normal z.
-C2B_DEV double obs_noise_draw(uint64_t seed, uint64_t observation, double &c, double &s) {
+// under oracle/ reads the same bits (and evaluates them with libm).  c, s = the direction; returns the standard normal z.
+// `tab` = the workgroup's LDS copy of g_noise_tab.
+C2B_DEV double obs_noise_draw(uint64_t seed, uint64_t observation, lds_tab tab, double &c, double &s) {
     uint32_t o[2];
     philox2x32_10((uint32_t)observation, (uint32_t)(observation >> 32) ^ (uint32_t)(seed >> 32), (uint32_t)seed, o);
     const double u1 = fma((double)o[0], 0x1.0p-32, 0x1.0p-32);          // exact: (w0 + 1) 2^-32
-    sincos_turns32(o[1] << 16, s, c);
-    return sqrt(-2.0 * log_unit(u1)) * cos_turns32(o[1] & 0xffff0000u);
+    sincos_turns16(o[1] & 0xffffu, tab, c, s);
+    double ca, sa;
+    sincos_turns16(o[1] >> 16, tab, ca, sa);
+    return sqrt_pos(m2log_tab(u1, tab)) * ca;
 }
 
 }  // namespace c2b

@@ -1090,8 +1090,9 @@ int c2b_add_noise_observations(double *uv, int64_t n_obs, int64_t obs_base, doub
     if (!(observations_std >= 0.0)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise: standard deviations must be >= 0");
     if (!n_obs) return C2B_OK;
     if (!aligned16(uv)) return fail(C2B_ERR_INVALID_ARGUMENT, "add_noise_observations: uv must be 16-byte aligned");
-    hipLaunchKernelGGL(k_add_noise_observations, dim3(blocks_for(n_obs)), dim3(kBlock), 0, S(stream),
-                       reinterpret_cast<double2 *>(uv), n_obs, obs_base, observations_std, seed);
+    const int64_t n_tiles = (n_obs + 63) / 64, wgs = (n_tiles + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(k_add_noise_observations, dim3((unsigned)std::min<int64_t>(wgs, kNoiseGrid)), dim3(kBlock), 0, S(stream),
+                       reinterpret_cast<double2 *>(uv), n_obs, n_tiles, obs_base, observations_std, seed);
     LAUNCH_CHECK();
     return C2B_OK;
     C2B_API_END("add_noise_observations")

@@ -552,7 +552,23 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     constexpr int HOT = VIS ? 20 : kCamLight;
     constexpr int CH = HOT / 2;                                           // 16-byte chunks per camera
     constexpr int kPerWave = 2 * kCamW * HOT + 8;                        // staged cameras | slow-path slots | picked ids
-    __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kPerWave];
+    // MODE_NOISE_ERROR12: the draw's tables (camera_math.hpp: g_noise_tab, 10 KB) behind the camera tiles
+    constexpr int kTabDoubles = MODE == MODE_NOISE_ERROR12 ? 2 * kNoiseTab : 0;
+    __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kPerWave + kTabDoubles];
+    tab2_t *sTab = reinterpret_cast<tab2_t *>(sCamAll + WPB * kPerWave);
+    // The table's entries are REQUESTED first and written to LDS only after this wave's own index / point / camera loads are on
+    // their way (vector-memory results return in order, so the table costs the workgroup no round trip of its own); the
+    // workgroup barrier sits right before the arithmetic -- once per wave, in either branch of the wave-uniform `base < n`.
+    constexpr int kTabTrips = MODE == MODE_NOISE_ERROR12 ? (kNoiseTab + WPB * 64 - 1) / (WPB * 64) : 0;
+    tab2_t tabv[kTabTrips > 0 ? kTabTrips : 1];
+    if (MODE == MODE_NOISE_ERROR12) {
+        static_assert((WPB * kPerWave) % 2 == 0, "the table's 16-byte entries start on a 16-byte boundary");
+#pragma unroll
+        for (int k = 0; k < kTabTrips; ++k) {
+            const int i = (int)threadIdx.x + k * WPB * 64;
+            tabv[k] = g_noise_tab[i < kNoiseTab ? i : 0];
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
@@ -597,6 +613,14 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (MODE == MODE_NOISE_ERROR12) {
+#pragma unroll
+            for (int k = 0; k < kTabTrips; ++k) {
+                const int i = (int)threadIdx.x + k * WPB * 64;
+                if (i < kNoiseTab) sTab[i] = tabv[k];
+            }
+            __syncthreads();
+        }
 
 #pragma unroll
         for (int t = 0; t < OPL; ++t) {
@@ -674,7 +698,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 if (MODE == MODE_NOISE_ERROR12) {
                     // k_add_noise_observations' arithmetic, operation for operation (the stored uv is bit-identical)
                     double c, s;
-                    const double z = obs_noise_draw(seed, (uint64_t)(obs_base + (valid ? o : n - 1)), c, s);
+                    const double z = obs_noise_draw(seed, (uint64_t)(obs_base + (valid ? o : n - 1)), (lds_tab)sTab, c, s);
                     const double r = 0.0 + norm * z;
                     ob.x = ob.x + c * r;
                     ob.y = ob.y + s * r;
@@ -685,6 +709,14 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 eacc += valid ? abs_pow_k<NORM_2>(du, 2.0) + abs_pow_k<NORM_2>(dv, 2.0) : 0.0;
             }
         }
+    }
+    else if (MODE == MODE_NOISE_ERROR12) {                               // a wave past the end: its share of the table, the same barrier
+#pragma unroll
+        for (int k = 0; k < kTabTrips; ++k) {
+            const int i = (int)threadIdx.x + k * WPB * 64;
+            if (i < kNoiseTab) sTab[i] = tabv[k];
+        }
+        __syncthreads();
     }
     if (MODE == MODE_ERROR) ticket_fold(wave_sum(eacc), sCamAll, block_part, ticket, out_sum);
     if (MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) {
@@ -1669,21 +1701,32 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ c
 }
 
 // add_noise observations, src/noise.rs:152-170
-__global__ __launch_bounds__(kBlock) void k_add_noise_observations(double2 *__restrict__ uv, int64_t n,
+// One Philox block per observation (camera_math.hpp: obs_noise_draw): the direction (cos, sin)(2 pi u) of unit_random's
+// pair -- its radius cancels in the normalisation, so neither it nor the normalisation (sqrt + two divides) is evaluated --
+// and the Box-Muller magnitude.  r05: the draw reads its logarithm and its angles from tables a workgroup stages in LDS once
+// (10 KB), so a workgroup walks many tiles of 64 observations (grid-stride, at most kNoiseGrid workgroups) instead of one
+// thread per observation: 104 vector instructions per tile where r04 had 186.
+constexpr int kNoiseGrid = 2048;               // 8 workgroups of 4 waves per CU
+__global__ __launch_bounds__(kBlock) void k_add_noise_observations(double2 *__restrict__ uv, int64_t n, int64_t n_tiles,
                                                                   int64_t obs_base, double observations_std,
                                                                   uint64_t seed) {
-    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (o >= n) return;
-    // One Philox block per observation (camera_math.hpp: obs_noise_draw): the direction
-    // (cos, sin)(2 pi u) of unit_random's pair -- its radius cancels in the normalisation, so neither it nor the
-    // normalisation (sqrt + two divides) is evaluated -- and the Box-Muller magnitude.
-    double c, s;
-    const double z = obs_noise_draw(seed, (uint64_t)(o + obs_base), c, s);
-    const double r = 0.0 + observations_std * z;
-    double2 v = uv[o];
-    v.x = v.x + c * r;
-    v.y = v.y + s * r;
-    uv[o] = v;
+    __shared__ __attribute__((aligned(16))) tab2_t sTab[kNoiseTab];
+    noise_tab_stage(sTab, threadIdx.x, kBlock);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kWaves = kBlock / 64;
+    for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += (int64_t)gridDim.x * kWaves) {
+        const int64_t o = t * 64 + lane;
+        if (o < n) {
+            double2 v = uv[o];
+            double c, s;
+            const double z = obs_noise_draw(seed, (uint64_t)(o + obs_base), (lds_tab)sTab, c, s);
+            const double r = 0.0 + observations_std * z;
+            v.x = v.x + c * r;
+            v.y = v.y + s * r;
+            uv[o] = v;
+        }
+    }
 }
 
 // add_sin_noise, src/noise.rs:388-416
