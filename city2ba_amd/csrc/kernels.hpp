@@ -1844,7 +1844,7 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
         const double4 p = pv[j] ? pts4[p0 + j] : make_double4(1e300, 1e300, 1e300, 0);
         X[j] = p.x; Y[j] = p.y; Z[j] = p.z;
     }
-    const double m2 = max_dist * max_dist;
+    const double m2 = max_dist > 0.0 ? max_dist * max_dist : 0.0;          // a negative or NaN max_dist passes nothing (`magnitude() < max_dist`)
     const double m2_lo = m2 * (1.0 - 0x1.0p-50), m2_hi = m2 * (1.0 + 0x1.0p-50);
 
     const int64_t c_begin = (int64_t)blockIdx.y * cams_per_chunk;
