@@ -660,6 +660,15 @@ int c2b_tune_set_cam_stride(int doubles) {
 int c2b_tune_set_cam_swizzle(int doubles) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_swz), &doubles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
 }
+// experiment (r05): the step kernel's store geometry under store cache policy `pol` (kernels.hpp: store16_pol)
+int c2b_tune_store_pattern_policy(int64_t n_obs, double *r, double *Jc, double *Jp, int pol, void *stream) {
+    const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define C2B_POL(P) case P: hipLaunchKernelGGL((k_store_pattern_pol<P>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); break
+    switch (pol) { C2B_POL(0); C2B_POL(1); C2B_POL(2); C2B_POL(3); C2B_POL(4); C2B_POL(5); C2B_POL(6); C2B_POL(7); default: return C2B_ERR_INVALID_ARGUMENT; }
+#undef C2B_POL
+    return hipGetLastError() == hipSuccess ? C2B_OK : C2B_ERR_HIP;
+}
 // hand the time-stamp probe a device buffer of (workgroups x 8) u64 (NULL = off)
 int c2b_tune_set_probe(void *device_buffer) {
     unsigned long long *p = reinterpret_cast<unsigned long long *>(device_buffer);

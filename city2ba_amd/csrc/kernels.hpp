@@ -2053,6 +2053,39 @@ __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n
     for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
 }
 
+#ifdef C2B_TUNE
+// experiment (r05): the same store geometry under every cache-policy spelling a gfx950 global store has.  The product's
+// non-temporal store is `nt`; sc0 / sc1 are the scope bits (sc1 = agent: the line is written through the XCD's L2).
+// POL: 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 nt sc0, 6 nt sc1, 7 nt sc0 sc1.
+template <int POL>
+C2B_DEV void store16_pol(char *dst, const double2 v) {
+    d2_t t; t.x = v.x; t.y = v.y;
+    if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(t) : "memory");
+}
+template <int POL>
+__global__ __launch_bounds__(512) void k_store_pattern_pol(int64_t n, int64_t n_btiles, double2 *__restrict__ r_out,
+                                                          double *__restrict__ Jc, double *__restrict__ Jp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (xcd_tile(blockIdx.x, n_btiles) * 8 + wave) * 64;
+    if (wave0 + 64 > n) return;
+    const double2 v = make_double2((double)lane, (double)wave);
+    store16_pol<POL>(reinterpret_cast<char *>(r_out + wave0 + lane), v);
+    char *dc = reinterpret_cast<char *>(Jc) + wave0 * 144;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) store16_pol<POL>(dc + (k * 64 + lane) * 16, v);
+    char *dp = reinterpret_cast<char *>(Jp) + wave0 * 48;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) store16_pol<POL>(dp + (k * 64 + lane) * 16, v);
+}
+#endif
+
 // The same store geometry under a selectable workgroup -> tile map (c2b_calib_store_pattern_map): 0 = every XCD streams
 // a contiguous eighth of the arrays (what the kernels do: 8 write fronts per array), 1 = launch order (the whole chip
 // writes inside one moving window), K >= 2 = XCD x takes K consecutive tiles of every group of 8K (xcd_tile_chunked).
