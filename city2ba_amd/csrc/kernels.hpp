@@ -456,8 +456,30 @@ C2B_DEV const double *wave_camera(const double *__restrict__ camblk, uint32_t ci
     return (valid && local < n_staged) ? (sCam + local * HOT) : (camblk + (int64_t)ci * kCamBlk);
 }
 
+#if defined(C2B_TUNE) || defined(C2B_STORE_POL)
+// experiment (r05): the same store geometry under every cache-policy spelling a gfx950 global store has.  The product's
+// non-temporal store is `nt`; sc0 / sc1 are the scope bits (sc1 = agent: the line is written through the XCD's L2).
+// POL: 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 nt sc0, 6 nt sc1, 7 nt sc0 sc1.
+template <int POL>
+C2B_DEV void store16_pol(char *dst, const double2 v) {
+    d2_t t; t.x = v.x; t.y = v.y;
+    if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dst), "v"(t) : "memory");
+    if (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(t) : "memory");
+}
+#endif
+
 template <bool NT>
 C2B_DEV void store16(char *dst, const double2 v) {
+#ifdef C2B_STORE_POL
+    // experiment (r05, tools/probe_store_policy.py --kernel): a build of the library whose non-temporal stores are spelled C2B_STORE_POL
+    if (NT) { store16_pol<C2B_STORE_POL>(dst, v); return; }
+#endif
     if (NT) {
         d2_t t; t.x = v.x; t.y = v.y;
         __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(dst));
@@ -2054,21 +2076,6 @@ __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n
 }
 
 #ifdef C2B_TUNE
-// experiment (r05): the same store geometry under every cache-policy spelling a gfx950 global store has.  The product's
-// non-temporal store is `nt`; sc0 / sc1 are the scope bits (sc1 = agent: the line is written through the XCD's L2).
-// POL: 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 nt sc0, 6 nt sc1, 7 nt sc0 sc1.
-template <int POL>
-C2B_DEV void store16_pol(char *dst, const double2 v) {
-    d2_t t; t.x = v.x; t.y = v.y;
-    if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(t) : "memory");
-}
 template <int POL>
 __global__ __launch_bounds__(512) void k_store_pattern_pol(int64_t n, int64_t n_btiles, double2 *__restrict__ r_out,
                                                           double *__restrict__ Jc, double *__restrict__ Jp) {
