@@ -454,10 +454,11 @@ C2B_DEV void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t out[2]
 // keep their relative accuracy.  640 16-byte entries (tools/gen_noise_tables.py: correctly rounded from 60 digits,
 // tests/test_noise_tables.py), staged in LDS by the workgroup.  Against glibc: directions within 1.2e-16 absolute,
 // -2 ln u within 3 ulps, its square root within 2.3e-16 relative (tests/test_gpu_parity.py pins the draw at 1e-13).
-constexpr int kNoiseTab = 640;                 // double2 entries: 10 240 bytes
+constexpr int kNoiseTab = 640;                 // double2 entries the observation draw stages: 10 240 bytes
 constexpr int kNoiseTabLog = 512;
+constexpr int kPowTab = 704;                   // ... and with the exponential's 128 doubles behind them (pow_tab): 11 264 bytes
 typedef double tab2_t __attribute__((ext_vector_type(2)));      // (the class type double2 cannot be read through an LDS-typed pointer)
-__device__ const tab2_t g_noise_tab[kNoiseTab] = {
+__device__ const tab2_t g_noise_tab[kPowTab] = {
 #include "noise_tables.inc"
 };
 typedef const __attribute__((address_space(3))) tab2_t *lds_tab;
@@ -501,6 +502,31 @@ C2B_DEV double sqrt_pos(double x) {
     g = fma(d, h, g);
     return x == 0.0 ? 0.0 : g;
 }
+
+// exp(x) for |x| < 700: x = (128 e + j) ln2 / 128 + r, |r| <= ln2 / 256; 2^(j / 128) from the table, a degree-5 series in r,
+// the exponent by v_ldexp_f64 (ln2 / 128 in two pieces, the high one short enough for k ln2_hi to be exact)
+C2B_DEV double exp_tab(double x, lds_tab tab) {
+    const double kf = rint(x * 0x1.71547652b82fep+7);
+    double r = fma(-kf, 0x1.62e42fee00000p-8, x);
+    r = fma(-kf, 0x1.a39ef35793c76p-40, r);
+    const int ki = (int)kf;
+    const double T = reinterpret_cast<const __attribute__((address_space(3))) double *>(tab + kNoiseTab)[ki & 127];
+    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+    q = fma(r, q, 0.5);
+    const double p = fma(r * r, q, r);
+    return ldexp(fma(T, p, T), ki >> 7);
+}
+
+// a^y through the two tables for finite a in (2^-1000, 2^1000) with |y ln a| < 600, the library's pow for everything else --
+// pow_lean's contract (relative error ~ |y ln a| ulps) at 38 instead of 70 vector instructions.  `tab` holds kPowTab entries.
+C2B_DEV double pow_tab(double a, double y, lds_tab tab) {
+    const double l = (-0.5 * y) * m2log_tab(a, tab);
+    if (!(a > 0x1.0p-1000 && a < 0x1.0p+1000) || !(l > -600.0 && l < 600.0)) return pow(a, y);
+    return exp_tab(l, tab);
+}
+// |x|^norm for a norm other than 1 and 2 (abs_pow_k<NORM_ANY> with the tables at hand)
+C2B_DEV double abs_pow_tab(double x, double norm, lds_tab tab) { return pow_tab(fabs(x), norm, tab); }
 
 // (cos, sin) of a / 65536 turns, a < 65536
 C2B_DEV void sincos_turns16(uint32_t a, lds_tab tab, double &cs, double &sn) {

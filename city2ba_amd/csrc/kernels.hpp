@@ -574,21 +574,24 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     constexpr int HOT = VIS ? 20 : kCamLight;
     constexpr int CH = HOT / 2;                                           // 16-byte chunks per camera
     constexpr int kPerWave = 2 * kCamW * HOT + 8;                        // staged cameras | slow-path slots | picked ids
-    // MODE_NOISE_ERROR12: the draw's tables (camera_math.hpp: g_noise_tab, 10 KB) behind the camera tiles
-    constexpr int kTabDoubles = MODE == MODE_NOISE_ERROR12 ? 2 * kNoiseTab : 0;
+    // MODE_NOISE_ERROR12: the draw's tables (camera_math.hpp: g_noise_tab, 10 KB) behind the camera tiles; MODE_ERROR with a norm
+    // other than 1 and 2: the same tables + the exponential's (pow_tab, 11 KB)
+    constexpr bool POWTAB = MODE == MODE_ERROR && NK == NORM_ANY;
+    constexpr int kTabN = MODE == MODE_NOISE_ERROR12 ? kNoiseTab : (POWTAB ? kPowTab : 0);
+    constexpr int kTabDoubles = 2 * kTabN;
     __shared__ __attribute__((aligned(16))) double sCamAll[WPB * kPerWave + kTabDoubles];
     tab2_t *sTab = reinterpret_cast<tab2_t *>(sCamAll + WPB * kPerWave);
     // The table's entries are REQUESTED first and written to LDS only after this wave's own index / point / camera loads are on
     // their way (vector-memory results return in order, so the table costs the workgroup no round trip of its own); the
     // workgroup barrier sits right before the arithmetic -- once per wave, in either branch of the wave-uniform `base < n`.
-    constexpr int kTabTrips = MODE == MODE_NOISE_ERROR12 ? (kNoiseTab + WPB * 64 - 1) / (WPB * 64) : 0;
+    constexpr int kTabTrips = (kTabN + WPB * 64 - 1) / (WPB * 64);
     tab2_t tabv[kTabTrips > 0 ? kTabTrips : 1];
-    if (MODE == MODE_NOISE_ERROR12) {
+    if (kTabN > 0) {
         static_assert((WPB * kPerWave) % 2 == 0, "the table's 16-byte entries start on a 16-byte boundary");
 #pragma unroll
         for (int k = 0; k < kTabTrips; ++k) {
             const int i = (int)threadIdx.x + k * WPB * 64;
-            tabv[k] = g_noise_tab[i < kNoiseTab ? i : 0];
+            tabv[k] = g_noise_tab[i < kTabN ? i : 0];
         }
     }
     const int lane = threadIdx.x & 63;
@@ -635,11 +638,11 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (MODE == MODE_NOISE_ERROR12) {
+        if (kTabN > 0) {
 #pragma unroll
             for (int k = 0; k < kTabTrips; ++k) {
                 const int i = (int)threadIdx.x + k * WPB * 64;
-                if (i < kNoiseTab) sTab[i] = tabv[k];
+                if (i < kTabN) sTab[i] = tabv[k];
             }
             __syncthreads();
         }
@@ -715,7 +718,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             } else if (MODE == MODE_PROJECT) {
                 if (valid) store16<NTS>(reinterpret_cast<char *>(uv_out + o), make_double2(p.u, p.v));
             } else if (MODE == MODE_ERROR) {
-                eacc += valid ? abs_pow_k<NK>(p.u - ob.x, norm) + abs_pow_k<NK>(p.v - ob.y, norm) : 0.0;
+                if (POWTAB) eacc += valid ? abs_pow_tab(p.u - ob.x, norm, (lds_tab)sTab) + abs_pow_tab(p.v - ob.y, norm, (lds_tab)sTab) : 0.0;
+                else eacc += valid ? abs_pow_k<NK>(p.u - ob.x, norm) + abs_pow_k<NK>(p.v - ob.y, norm) : 0.0;
             } else {
                 if (MODE == MODE_NOISE_ERROR12) {
                     // k_add_noise_observations' arithmetic, operation for operation (the stored uv is bit-identical)
@@ -732,11 +736,11 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             }
         }
     }
-    else if (MODE == MODE_NOISE_ERROR12) {                               // a wave past the end: its share of the table, the same barrier
+    else if (kTabN > 0) {                                                // a wave past the end: its share of the table, the same barrier
 #pragma unroll
         for (int k = 0; k < kTabTrips; ++k) {
             const int i = (int)threadIdx.x + k * WPB * 64;
-            if (i < kNoiseTab) sTab[i] = tabv[k];
+            if (i < kTabN) sTab[i] = tabv[k];
         }
         __syncthreads();
     }

@@ -152,6 +152,21 @@ def test_total_reprojection_error(c2b, norm):
     assert abs(got - want) / want < 1e-12
 
 
+@pytest.mark.parametrize("norm", [0.5, 1.25, 4.0, 7.3])
+def test_total_reprojection_error_unusual_norms(c2b, norm):
+    """norms other than 1 and 2 go through the table logarithm / exponential (camera_math.hpp: pow_tab, r05); residuals that
+    are exactly zero (their power is 0, not NaN) and tiny ones included"""
+    P = random_problem(120, 2500, 11, seed=23, noise=1e-2, empty_every=7)
+    ba = _upload(c2b, P)
+    uv = np.array(P["uv"], copy=True)
+    exact = ba.project()
+    uv[::5] = exact[::5]                              # every fifth residual exactly zero
+    uv[1::5] = exact[1::5] + 1e-300                   # ... and a few far below the table path's range check
+    want = O.total_reprojection_error(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], uv, norm)
+    got = c2b.BAProblem.from_visibility(P["cams15"], P["pts"], P["row_ptr"], P["pt_idx"], uv).total_reprojection_error(norm)
+    assert np.isfinite(got) and abs(got - want) / want < 1e-12
+
+
 def test_zero_error_by_construction_on_gpu(c2b):
     """observations written from the device's own project() => error exactly 0."""
     P = random_problem(100, 2000, 10, seed=13)

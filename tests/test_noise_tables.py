@@ -27,7 +27,7 @@ def test_committed_file_is_what_the_generator_writes():
 
 def test_entries_are_correctly_rounded():
     t = _table()
-    assert t.shape == (640, 2)
+    assert t.shape == (704, 2)
     mp.mp.dps = 50
     for h in (0, 1, 63, 64, 65, 128, 200, 255):
         assert t[h, 0] == float(mp.cospi(mp.mpf(h) / 128)) and t[h, 1] == float(mp.sinpi(mp.mpf(h) / 128))
@@ -85,3 +85,30 @@ def test_table_algorithm_against_exact_arithmetic():
         assert abs(got - want) <= 4e-16 * abs(want), (w, float(got), float(want))
     z, k, i = _z_of(1.0)                                   # w = 2^32 - 1: u = 1, the draw's magnitude is exactly zero
     assert (z, k, i) == (1.0, 0, 80)
+
+
+def test_exponential_table_and_series():
+    """entries [640, 704): 2^(j / 128) as 128 consecutive doubles, correctly rounded; camera_math.hpp: exp_tab's reduction and
+    degree-5 series restated in exact arithmetic stay within 2e-16 (relative) of exp(x)"""
+    t = _table()[640:].reshape(-1)
+    assert t.shape == (128,)
+    mp.mp.dps = 40
+    for j in (0, 1, 2, 63, 64, 127):
+        assert t[j] == float(mp.power(2, mp.mpf(j) / 128))
+    assert t[0] == 1.0 and np.all(np.diff(t) > 0)
+    hi, lo, inv = float.fromhex("0x1.62e42fee00000p-8"), float.fromhex("0x1.a39ef35793c76p-40"), float.fromhex("0x1.71547652b82fep+7")
+    assert abs(mp.mpf(hi) + mp.mpf(lo) - mp.log(2) / 128) < mp.mpf(2) ** -90 and Fraction(hi) * (1 << 17) * (1 << 40) % 1 == 0
+    rng = np.random.default_rng(9)
+    for x in list(rng.uniform(-600, 600, 200)) + [0.0, 1e-9, -1e-9, 599.9, -599.9]:
+        kf = round(float(x) * inv)
+        r = Fraction(float(x)) - kf * Fraction(hi) - kf * Fraction(lo)
+        assert abs(r) < Fraction(28, 10000)
+        q = Fraction(1, 120) * r + Fraction(1, 24)
+        q = q * r + Fraction(1, 6)
+        q = q * r + Fraction(1, 2)
+        p = r * r * q + r
+        T = Fraction(float(t[kf & 127]))
+        got = T * (1 + p)
+        got = mp.mpf(got.numerator) / got.denominator * mp.power(2, kf >> 7)
+        want = mp.exp(mp.mpf(float(x)))
+        assert abs(got - want) <= 2e-16 * want, (x, float(got / want - 1))
