@@ -239,6 +239,9 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
     // the next call finds them there) and is non-temporal where it is not (visibility, Jacobian: 256 B per camera).
     // (the fused observation noise reads and rewrites uv exactly once: both directions bypass the caches)
     constexpr int kNTL = (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) ? 2 : ((MODE == MODE_VISIBILITY || MODE == MODE_VISIBILITY_BITS) ? 1 : 0);
+    // the fused noise pass holds the draw's table entries and the camera chunks in flight at once: left alone the allocator takes
+    // 68 registers (7 waves per SIMD, one workgroup per CU less); told to leave room for 8 waves it fits 64 without scratch
+    constexpr int kMinW = MODE == MODE_NOISE_ERROR12 ? 8 : 1;
     if (row_ptr) {          // the *_rows entry points: cam_idx = the tile records of c2b_rows_pack
 #define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base, seed
 #ifdef C2B_TUNE
@@ -262,7 +265,7 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
             default: break;
         }
 #endif
-        launch_obs_v<MODE, 3, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS);
+        launch_obs_v<MODE, 3, 8, kMinW, false, true, true, kNTL>(C2B_ROWS_ARGS);
 #undef C2B_ROWS_ARGS
         return C2B_OK;
     }
@@ -284,7 +287,7 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
         default: break;
     }
 #endif
-    launch_obs_v<MODE, 3, 8, 1, false, false, true, kNTL>(C2B_ARGS);    // shipped (308): three tiles of 64 per wave
+    launch_obs_v<MODE, 3, 8, kMinW, false, false, true, kNTL>(C2B_ARGS);    // shipped (308): three tiles of 64 per wave
 #undef C2B_ARGS
     return C2B_OK;
 }

@@ -414,20 +414,29 @@ template <int OPL>
 C2B_DEV void rows_cameras(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ row_ptr, int n_cam, int base,
                           int n, int64_t obs_base, int lane, uint32_t (&ci)[OPL]) {
     const int last_tile = (n - 1) >> 6;
+    // The records are wave-uniform, so they arrive by scalar loads -- ALL of them requested before any is looked at, each as
+    // one 16-byte load (r05: the compiler had split every record into its flag word and, behind the branch on it, its mask:
+    // 2 x OPL dependent scalar round trips at the head of every wave, in front of the gathers that need the camera ids).
+    uint4 rec[OPL];
+    int tis[OPL];
 #pragma unroll
     for (int t = 0; t < OPL; ++t) {
-        int ti = (base >> 6) + t;
-        ti = ti < last_tile ? ti : last_tile;
-        const uint4 rec = tiles[ti];
-        if (rec.z & 0x80000000u) {                                       // wave-uniform: an empty list inside this tile
-            int o = ti * 64 + lane;
+        const int ti = (base >> 6) + t;
+        tis[t] = ti < last_tile ? ti : last_tile;
+        rec[t] = tiles[tis[t]];
+    }
+#pragma unroll
+    for (int t = 0; t < OPL; ++t) {
+        // bits 1..63 of the mask, moved down one place: mbcnt counts the set bits BELOW a lane (evaluated unconditionally, so
+        // that the whole record is needed before the branch)
+        const uint32_t lo = (rec[t].x >> 1) | (rec[t].y << 31), hi = rec[t].y >> 1;
+        uint32_t c = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, rec[t].z));
+        if (rec[t].z & 0x80000000u) {                                    // wave-uniform: an empty list inside this tile
+            int o = tis[t] * 64 + lane;
             o = o < n ? o : n - 1;
-            ci[t] = csr_search(row_ptr, n_cam, (uint64_t)(obs_base + o));
-        } else {
-            // bits 1..63 of the mask, moved down one place: mbcnt counts the set bits BELOW a lane
-            const uint32_t lo = (rec.x >> 1) | (rec.y << 31), hi = rec.y >> 1;
-            ci[t] = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, rec.z));
+            c = csr_search(row_ptr, n_cam, (uint64_t)(obs_base + o));
         }
+        ci[t] = c;
     }
 }
 
@@ -619,10 +628,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             pi[t] = (NTL & 1) ? __builtin_nontemporal_load(pt_idx + o) : pt_idx[o];
         }
         if (CSR) rows_cameras<OPL>(reinterpret_cast<const uint4 *>(cam_idx), row_ptr, n_cam, base, n, 0, lane, ci);
-#pragma unroll
-        for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
 
-        // wave-private camera tile covering all OPL tiles: cameras ci[0](lane 0) .. ci[OPL-1](lane 63) on sorted input
+        // wave-private camera tile covering all OPL tiles: cameras ci[0](lane 0) .. ci[OPL-1](lane 63) on sorted input.
+        // r05: its (at most kStageTrips x 64) 16-byte chunks are REQUESTED here, all at once and -- in the row-structure form,
+        // where the camera ids come from scalar records -- before this wave waits for its point indices; they go to LDS after
+        // the point gathers are on their way.  (Before: a load -> wait -> LDS-write loop behind the gathers, whose second trip,
+        // taken whenever the wave's tiles touch more than 64 / CH cameras, was a round trip of its own.)
         double *sCam = sCamAll + wave * kPerWave;
         double *sSlow = sCam + kCamW * HOT;
         uint32_t *sIdx = reinterpret_cast<uint32_t *>(sSlow + kCamW * HOT);
@@ -630,22 +641,34 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         const uint32_t c_last = __builtin_amdgcn_readlane(ci[OPL - 1], 63);
         uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
         if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
-        for (int ch = lane; ch < (int)n_staged * CH; ch += 64) {
-            const int k = ch / CH, j = ch % CH;
-            const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
-            *reinterpret_cast<d2_t *>(sCam + k * HOT + 2 * j) =
-                *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * cam_stride + src + (((c_first + k) & 1u) ? cam_swz : 0));
+        constexpr int kStageTrips = (kCamW * CH + 63) / 64;
+        d2_t camv[kStageTrips];
+#pragma unroll
+        for (int q = 0; q < kStageTrips; ++q) {
+            const int ch = lane + q * 64;
+            if (ch < (int)n_staged * CH) {
+                const int k = ch / CH, j = ch % CH;
+                const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
+                camv[q] = *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * cam_stride + src + (((c_first + k) & 1u) ? cam_swz : 0));
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (kTabN > 0) {
+        if (kTabN > 0) {                                                 // the table's entries were requested first: they are here first
 #pragma unroll
             for (int k = 0; k < kTabTrips; ++k) {
                 const int i = (int)threadIdx.x + k * WPB * 64;
                 if (i < kTabN) sTab[i] = tabv[k];
             }
-            __syncthreads();
         }
+#pragma unroll
+        for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
+#pragma unroll
+        for (int q = 0; q < kStageTrips; ++q) {
+            const int ch = lane + q * 64;
+            if (ch < (int)n_staged * CH) *reinterpret_cast<d2_t *>(sCam + (ch / CH) * HOT + 2 * (ch % CH)) = camv[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (kTabN > 0) __syncthreads();
 
 #pragma unroll
         for (int t = 0; t < OPL; ++t) {
