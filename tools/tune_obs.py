@@ -45,6 +45,8 @@ ws = D.workspace(n, dev)
 err = torch.zeros(1, dtype=torch.float64, device=dev)
 camblk, pts4, ci, pi, uv, rows = sh["camblk"], sh["pts4"], sh["cam_idx"], sh["pt_idx"], sh["uv"], sh["rows"]
 uv_out = torch.empty_like(uv)
+uv_noise = uv.clone()
+err2 = torch.zeros(2, dtype=torch.float64, device=dev)
 keep = torch.empty(n, dtype=torch.uint8, device=dev)
 if a.place:
     (r_o, Jc_o, Jp_o), log = D.alloc_jacobian_outputs(n, dev)
@@ -78,6 +80,9 @@ kinds = {
                  lambda: D.reprojection_error_sum_rows(camblk, pts4, rows, pi, uv, 2.0, ws, err)),
     "visibility": (lambda: D.visibility_pairs(camblk, pts4, ci, pi, 10.0, uv_out, keep),
                    lambda: D.visibility_rows(camblk, pts4, rows, pi, 10.0, uv_out, keep)),
+    # r05: observation noise + L1 + L2 in one pass (rows form only; its sums depend on the grid, so no bit comparison)
+    "noise_L1L2": (lambda: D.add_noise_observations_error_sums2_rows(camblk, pts4, rows, pi, uv_noise, 0, 1e-9, 7, ws, err2),
+                   lambda: D.add_noise_observations_error_sums2_rows(camblk, pts4, rows, pi, uv_noise, 0, 1e-9, 7, ws, err2)),
 }
 jac = (lambda: D.residual_jacobian_sum(camblk, pts4, ci, pi, uv, r_o, Jc_o, Jp_o, 2.0, ws, err),
        lambda: D.residual_jacobian_rows(camblk, pts4, rows, pi, uv, r_o, Jc_o, Jp_o, 2.0, ws, err))
@@ -113,6 +118,8 @@ def snapshot(kind):
         return (uv_out.clone().view(torch.int64), keep.clone())
     if kind == "error_L2":
         return (err.clone(),)
+    if kind == "noise_L1L2":
+        return ()
     return (r_o.clone(), Jc_o[::97].clone(), Jp_o[::89].clone(), err.clone())
 
 
