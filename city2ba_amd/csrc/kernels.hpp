@@ -616,6 +616,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
 #ifdef C2B_TUNE
     // experiment (r05): do the waves of a workgroup, started in lockstep, serialise on each other's phases?  Stagger them.
     for (int k = wave * g_stagger; k > 0; --k) __builtin_amdgcn_s_sleep(1);
+    // ... or do the WORKGROUPS that share a CU convoy (all four in their load phase, then all four computing)?  A negative
+    // g_stagger delays the first generation's workgroups by their presumed slot on the CU (blockIdx / 256) x |g_stagger| x 64 cycles.
+    if (g_stagger < 0 && blockIdx.x < 1024)
+        for (int k = (int)((blockIdx.x >> 8) & 3u) * -g_stagger; k > 0; --k) __builtin_amdgcn_s_sleep(1);
 #endif
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];

@@ -72,6 +72,10 @@ for name in ("project_rows", "error_sums2_rows", "noise+error_sums2_rows", "visi
         raw.c2b_tune_set_stagger(K)
         w, c = measure(cases(idx["real"])[name])
         print("%-24s stagger %2d x 64 cycles per wave index: warm %6.1f us  cold %6.1f us" % (name, K, w, c), flush=True)
+    for K in (-12, -25, -50, -100, -200):                      # workgroup-slot stagger of the first generation (r05)
+        raw.c2b_tune_set_stagger(K)
+        w, c = measure(cases(idx["real"])[name])
+        print("%-24s first-generation workgroups delayed by slot x %3d x 64 cycles: warm %6.1f us  cold %6.1f us" % (name, -K, w, c), flush=True)
     raw.c2b_tune_set_stagger(0)
     for kind in ("all zero", "consecutive"):
         w, c = measure(cases(idx[kind])[name])
