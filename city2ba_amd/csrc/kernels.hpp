@@ -40,8 +40,15 @@ __device__ int g_cam_stride = 0;     // k_observations (project / error modes): 
 __device__ int g_cam_swz = 0;        // ... doubles added to an ODD camera's record address (16: its light line sits in the second half of its 256 bytes)
 __device__ unsigned long long *g_probe = nullptr;
 #define C2B_PROBE(k) do { if (g_probe != nullptr && threadIdx.x == 0) g_probe[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+// k_observations' variant (tools/probe_wave_phases.py): the stamps of wave 0 stay in scalar registers until the wave ends (a store per
+// stamp would sit in the wave's own memory counter); OBS_ARRIVED waits for everything requested so far, at points where the code
+// needs those results next anyway
+#define OBS_STAMP(k) do { if (probing) tp[k] = wall_clock64(); } while (0)
+#define OBS_ARRIVED() do { if (probing) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define C2B_PROBE(k) do { } while (0)
+#define OBS_STAMP(k) do { } while (0)
+#define OBS_ARRIVED() do { } while (0)
 #endif
 
 // ---- XCD-aware tile map (bijective for any n_tiles; cdna guide T1) -----------------------
@@ -608,6 +615,9 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
     double eacc = 0.0, eacc1 = 0.0;                                      // MODE_*ERROR12: eacc1 = the L1 sum, eacc = the L2 sum
 #ifdef C2B_TUNE
+    const bool probing = g_probe != nullptr;
+    unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    OBS_STAMP(0);
     const int cam_stride = g_cam_stride ? g_cam_stride : kCamBlk;        // experiment (r05): a compact 128-byte-per-camera table
     const int cam_swz = g_cam_swz;
 #else
@@ -632,6 +642,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             pi[t] = (NTL & 1) ? __builtin_nontemporal_load(pt_idx + o) : pt_idx[o];
         }
         if (CSR) rows_cameras<OPL>(reinterpret_cast<const uint4 *>(cam_idx), row_ptr, n_cam, base, n, 0, lane, ci);
+        OBS_STAMP(1);                                                    // the tile records are here (camera ids known)
 
         // wave-private camera tile covering all OPL tiles: cameras ci[0](lane 0) .. ci[OPL-1](lane 63) on sorted input.
         // r05: its (at most kStageTrips x 64) 16-byte chunks are REQUESTED here, all at once and -- in the row-structure form,
@@ -663,6 +674,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 if (i < kTabN) sTab[i] = tabv[k];
             }
         }
+        OBS_ARRIVED();
+        OBS_STAMP(2);                                                    // the point indices (and the camera chunks) are here
 #pragma unroll
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
 #pragma unroll
@@ -673,6 +686,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (kTabN > 0) __syncthreads();
+        OBS_ARRIVED();
+        OBS_STAMP(3);                                                    // the points are here: arithmetic starts
 
 #pragma unroll
         for (int t = 0; t < OPL; ++t) {
@@ -761,7 +776,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 eacc1 += valid ? abs_pow_k<NORM_1>(du, 1.0) + abs_pow_k<NORM_1>(dv, 1.0) : 0.0;
                 eacc += valid ? abs_pow_k<NORM_2>(du, 2.0) + abs_pow_k<NORM_2>(dv, 2.0) : 0.0;
             }
+            OBS_STAMP(4 + (t < 2 ? t : 2));                              // tile t's results are on their way out
         }
+        OBS_ARRIVED();
+        OBS_STAMP(7);                                                    // ... and acknowledged
     }
     else if (kTabN > 0) {                                                // a wave past the end: its share of the table, the same barrier
 #pragma unroll
@@ -771,6 +789,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         }
         __syncthreads();
     }
+#ifdef C2B_TUNE
+    if (probing && threadIdx.x == 0)
+        for (int k = 0; k < 8; ++k) g_probe[(size_t)blockIdx.x * 8 + k] = tp[k];
+#endif
     if (MODE == MODE_ERROR) ticket_fold(wave_sum(eacc), sCamAll, block_part, ticket, out_sum);
     if (MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) {
         const double w[2] = {wave_sum(eacc1), wave_sum(eacc)};            // out_sum[0] = L1, out_sum[1] = L2
