@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(kBlock) void k_add_noise_entities(T *__restrict__ c
 // pair -- its radius cancels in the normalisation, so neither it nor the normalisation (sqrt + two divides) is evaluated --
 // and the Box-Muller magnitude.  r05: the draw reads its logarithm and its angles from tables a workgroup stages in LDS once
 // (10 KB), so a workgroup walks many tiles of 64 observations (grid-stride, at most kNoiseGrid workgroups) instead of one
-// thread per observation: 104 vector instructions per tile where r04 had 186.
+// thread per observation: 95 vector instructions per tile (SQ_INSTS_VALU) where r04 had 186.
 constexpr int kNoiseGrid = 2048;               // 8 workgroups of 4 waves per CU
 __global__ __launch_bounds__(kBlock) void k_add_noise_observations(double2 *__restrict__ uv, int64_t n, int64_t n_tiles,
                                                                   int64_t obs_base, double observations_std,
