@@ -81,9 +81,12 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two short child passes under rocprofv3 --pmc that measure the step kernel's HBM bytes on this box")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--placement-attempts", type=int, default=8,
+    ap.add_argument("--placement-attempts", type=int, default=48,
                     help="output allocations c2b_jacobian_outputs_alloc may try for streaming-store speed before it keeps "
-                         "the best (1 = take the first; the line always ALSO reports the kernel in the first allocation)")
+                         "the best (1 = take the first; the line always ALSO reports the kernel in the first allocation).  "
+                         "r05: 48, not 8 -- where in the device memory a set lies decides its store rate, every device mapped "
+                         "has 8-12 fast sets among 60 consecutive ones but not always among the first eight "
+                         "(tools/probes/vram_store_map.py, profiles/r05ao); the rejects are held only during the search")
     ap.add_argument("--place-inputs", action="store_true",
                     help="also re-place the input arrays by measured kernel time (bench-only experiment, off by default)")
     ap.add_argument("--collective", choices=("auto", "c2b", "torch"), default="auto",

@@ -443,14 +443,19 @@ int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
 // space predicts it, so the placement is chosen by measurement: allocate, time the kernel's own store pattern
 // (~0.6 ms per repetition), keep the set if it streams at fast_store_GBs or better, otherwise HOLD it (so that the
 // allocator cannot hand the same memory back) and try again; the best of max_attempts wins, the rest are freed.
-// Held memory is bounded (max_attempts <= 8 sets of 208 B per observation) and an out-of-memory attempt ends the
-// search with the best set so far instead of failing.
+// r05 (tools/probes/vram_store_map.py, profiles/r05ao): the rate belongs to WHERE in the device memory a set lies -- of 56-60
+// consecutive 4-GB sets of a fresh process 8-12 stream at 7.0-7.2 TB/s on every one of 17 devices mapped, in windows that
+// recur with a period of ~64 GiB, the rest at 5.6-5.9 -- so a search that goes deep enough finds a fast set on devices whose
+// first eight sets (32 GB: the search depth of rounds 2-4) are all slow.  Hence up to kMaxPlacementAttempts.
+// Held memory is bounded (max_attempts sets of 208 B per observation, and never more than three quarters of the memory that
+// was free at the call) and an out-of-memory attempt ends the search with the best set so far instead of failing.
+constexpr int kMaxPlacementAttempts = 64;
 struct c2b_jacobian_outputs {
     int device = 0;
     int64_t n_obs = 0;
     double *r = nullptr, *Jc = nullptr, *Jp = nullptr;
     int attempts = 0, chosen = -1;
-    double rate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double rate[kMaxPlacementAttempts] = {};
 };
 
 namespace {
@@ -473,13 +478,21 @@ int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_stor
     if (!out || n_obs < 0 || n_obs >= ((int64_t)1 << 31)) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_alloc: bad arguments");
     *out = nullptr;
     if (max_attempts < 1) max_attempts = 1;
-    if (max_attempts > 8) max_attempts = 8;
+    if (max_attempts > kMaxPlacementAttempts) max_attempts = kMaxPlacementAttempts;
     if (!(fast_store_GBs > 0.0)) fast_store_GBs = 7000.0;
     hipStream_t st = S(stream);
     std::unique_ptr<c2b_jacobian_outputs> h(new c2b_jacobian_outputs);
     HIP_TRY(hipGetDevice(&h->device));
     h->n_obs = n_obs;
-    OutSet sets[8];
+    if (max_attempts > 1) {                            // the rejects are HELD during the search: at most 3/4 of what is free now
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t set_b = (size_t)(n_obs > 0 ? n_obs : 1) * 208;
+            const size_t fit = free_b / 4 * 3 / set_b;
+            if ((size_t)max_attempts > fit) max_attempts = fit < 1 ? 1 : (int)fit;
+        }
+    }
+    std::vector<OutSet> sets((size_t)max_attempts);
     auto free_sets = [&]() { for (auto &q : sets) q.free_all(); };
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // below a million observations the store rate means nothing; above, even a caller that takes the first set

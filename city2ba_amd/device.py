@@ -292,9 +292,9 @@ class JacobianOutputs:
                                                            C.byref(own.h)))
         r, jc, jp = C.c_void_p(), C.c_void_p(), C.c_void_p()
         L.check(L.lib().c2b_jacobian_outputs_pointers(own.h, C.byref(r), C.byref(jc), C.byref(jp)))
-        rates = (C.c_double * 8)()
+        rates = (C.c_double * 64)()
         na, ch = C.c_int(0), C.c_int(-1)
-        L.check(L.lib().c2b_jacobian_outputs_log(own.h, rates, 8, C.byref(na), C.byref(ch)))
+        L.check(L.lib().c2b_jacobian_outputs_log(own.h, rates, 64, C.byref(na), C.byref(ch)))
         self.log = [round(rates[i], 1) for i in range(na.value)] if n_obs >= 1_000_000 else []
         self.chosen = ch.value
         sr = C.c_double(0.0)

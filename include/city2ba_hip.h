@@ -264,7 +264,9 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
  * depending only on which allocation its outputs live in; nothing visible from user space
  * predicts it, so this entry allocates a set, times the kernel's own store pattern into it (~4 ms), keeps it if it
  * streams at fast_store_GBs (<= 0: 7000) or better and otherwise holds it and tries again, at most max_attempts
- * (clamped to 1..8) times; the best set wins, the others are freed before it returns.  max_attempts = 1 takes the
+ * (clamped to 1..64, and to what fits three quarters of the free device memory) times; the best set wins, the others are
+ * freed before it returns.  (r05: fast sets exist on every device mapped -- 8-12 of 60 consecutive 4-GB sets -- but not always among
+ * the first eight: a depth of 32-48 finds one.)  max_attempts = 1 takes the
  * first set (its rate is still measured: c2b_residual_jacobian_rows_placed chooses its workgroup shape by it); n_obs
  * < 10^6 allocates without measuring.  An attempt that runs out of memory ends the search with the best set so far.
  * Synchronises `stream`.  The handle owns the memory until c2b_jacobian_outputs_free.
