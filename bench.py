@@ -662,7 +662,10 @@ def main():
         first = D.JacobianOutputs(n, dev, max_attempts=1)
         first_us, first_GBs = kernel_us_in(first), first.store_GBs
         del first
-    outs = D.JacobianOutputs(n, dev, max_attempts=args.placement_attempts)
+    # (a rank's shard of a few million observations: its sets' fast class is 6.7-7.0 TB/s, so the search stops at 6.8; ranks that
+    # SHARE a device in a rehearsal must not each hold tens of GB of rejects)
+    attempts = min(args.placement_attempts, 8) if os.environ.get("C2B_SHARE_GPU") == "1" else args.placement_attempts
+    outs = D.JacobianOutputs(n, dev, max_attempts=attempts, fast_store_GBs=7000.0 if n >= 6_000_000 else 6800.0)
     if args.assume_store_GBs > 0.0:
         outs.set_store_rate(args.assume_store_GBs)
     (r, Jc, Jp), placement_log, placement_chosen = (outs.r, outs.Jc, outs.Jp), outs.log, outs.chosen

@@ -447,9 +447,14 @@ int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
 // consecutive 4-GB sets of a fresh process 8-12 stream at 7.0-7.2 TB/s on every one of 17 devices mapped, in windows that
 // recur with a period of ~64 GiB, the rest at 5.6-5.9 -- so a search that goes deep enough finds a fast set on devices whose
 // first eight sets (32 GB: the search depth of rounds 2-4) are all slow.  Hence up to kMaxPlacementAttempts.
-// Held memory is bounded (max_attempts sets of 208 B per observation, and never more than three quarters of the memory that
-// was free at the call) and an out-of-memory attempt ends the search with the best set so far instead of failing.
+// The windows are several GB wide also for small sets (0.5-GB sets of a rank's eighth: 5.3-5.6 TB/s outside, 6.7-7.0 inside, the
+// first window 6-37 GB into the memory by device), so a search over sets smaller than kPlacementStride skips ahead: after a
+// rejected set it allocates -- and holds, untouched -- a filler that brings the step to kPlacementStride bytes.
+// Held memory is bounded (max_attempts steps of max(208 B per observation, kPlacementStride), and never more than three
+// quarters of the memory that was free at the call) and an out-of-memory attempt ends the search with the best set so far
+// instead of failing.
 constexpr int kMaxPlacementAttempts = 64;
+constexpr size_t kPlacementStride = (size_t)2 << 30;
 struct c2b_jacobian_outputs {
     int device = 0;
     int64_t n_obs = 0;
@@ -488,12 +493,18 @@ int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_stor
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t set_b = (size_t)(n_obs > 0 ? n_obs : 1) * 208;
-            const size_t fit = free_b / 4 * 3 / set_b;
+            const size_t fit = free_b / 4 * 3 / (set_b > kPlacementStride ? set_b : kPlacementStride);
             if ((size_t)max_attempts > fit) max_attempts = fit < 1 ? 1 : (int)fit;
         }
     }
     std::vector<OutSet> sets((size_t)max_attempts);
-    auto free_sets = [&]() { for (auto &q : sets) q.free_all(); };
+    std::vector<void *> fillers;
+    const size_t set_bytes = (size_t)(n_obs > 0 ? n_obs : 1) * 208;
+    auto free_sets = [&]() {
+        for (auto &q : sets) q.free_all();
+        for (void *f : fillers) (void)hipFree(f);
+        fillers.clear();
+    };
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // below a million observations the store rate means nothing; above, even a caller that takes the first set
     // (max_attempts = 1) gets its rate measured (~4 ms): c2b_residual_jacobian_rows_placed picks its workgroup shape by it
@@ -531,6 +542,11 @@ int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_stor
         // measured rate differs by noise, and the kernel's own time does not follow differences that small
         if (best < 0 || h->rate[a] > h->rate[best] * 1.02) best = a;
         if (h->rate[a] >= fast_store_GBs) break;
+        if (set_bytes < kPlacementStride && a + 1 < max_attempts) {       // skip ahead: the next set starts a stride further on
+            void *f = nullptr;
+            if (hipMalloc(&f, kPlacementStride - set_bytes) == hipSuccess) fillers.push_back(f);
+            else { (void)hipGetLastError(); break; }                      // memory is full: the best so far is it
+        }
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
@@ -575,7 +591,7 @@ int c2b_residual_jacobian_rows_placed(const double *camblk, const double *pts4, 
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != outputs->device)
         return fail(C2B_ERR_INVALID_ARGUMENT, "residual_jacobian_rows_placed: the current device (%d) is not the output set's (%d)", cur, outputs->device);
-    const double rate = outputs->chosen >= 0 && outputs->chosen < 8 ? outputs->rate[outputs->chosen] : 0.0;
+    const double rate = outputs->chosen >= 0 && outputs->chosen < kMaxPlacementAttempts ? outputs->rate[outputs->chosen] : 0.0;
     return rows_jacobian_impl(camblk, pts4, n_pts, row_ptr, n_cam, tiles, 0, pt_idx, uv_obs, n_obs, outputs->r, outputs->Jc, outputs->Jp,
                               norm, workspace, out_sum, stream, rate);
     C2B_API_END("residual_jacobian_rows_placed")
@@ -583,14 +599,14 @@ int c2b_residual_jacobian_rows_placed(const double *camblk, const double *pts4, 
 
 int c2b_jacobian_outputs_store_rate(const c2b_jacobian_outputs *h, double *store_GBs) {
     if (!h || !store_GBs) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_store_rate: NULL argument");
-    *store_GBs = h->chosen >= 0 && h->chosen < 8 ? h->rate[h->chosen] : 0.0;
+    *store_GBs = h->chosen >= 0 && h->chosen < kMaxPlacementAttempts ? h->rate[h->chosen] : 0.0;
     return C2B_OK;
 }
 
 // a caller that timed the set itself (or wants a particular shape) replaces the recorded rate; <= 0 = "unknown"
 int c2b_jacobian_outputs_set_store_rate(c2b_jacobian_outputs *h, double store_GBs) {
     if (!h) return fail(C2B_ERR_INVALID_ARGUMENT, "jacobian_outputs_set_store_rate: NULL handle");
-    if (h->chosen < 0 || h->chosen >= 8) h->chosen = 0;
+    if (h->chosen < 0 || h->chosen >= kMaxPlacementAttempts) h->chosen = 0;
     h->rate[h->chosen] = store_GBs > 0.0 ? store_GBs : 0.0;
     return C2B_OK;
 }

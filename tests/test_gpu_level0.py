@@ -381,3 +381,27 @@ def test_level1_jacobian_left_on_the_device_equals_the_host_output_entry():
     assert s0 == 0.0 and o0.r.shape == (0, 2)
     for b in (ba, e):
         b.close()
+
+
+@pytest.mark.gpu
+def test_output_placement_searches_deep_and_returns_what_it_held():
+    """c2b_jacobian_outputs_alloc (r05): up to 64 attempts; sets smaller than the 2-GiB stride are followed by a held filler so that the
+    search moves through the device memory; every reject and filler is freed before the call returns; the kept set's rate is what
+    c2b_jacobian_outputs_store_rate reports also when it is the 9th or a later attempt."""
+    import torch
+    from city2ba_amd import device as D
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    n = 1_200_000                                                  # >= 10^6: measured; 250 MB per set
+    free0 = torch.cuda.mem_get_info()[0]
+    o = D.JacobianOutputs(n, dev, max_attempts=12, fast_store_GBs=1e9)      # an unreachable rate: all 12 attempts are made
+    assert len(o.log) == 12 and 0 <= o.chosen < 12 and all(r > 1000.0 for r in o.log)
+    assert o.store_GBs == pytest.approx(o.log[o.chosen], rel=1e-3) and o.log[o.chosen] >= 0.98 * max(o.log)
+    o.r.fill_(1.0); o.Jc.fill_(2.0); o.Jp.fill_(3.0)
+    torch.cuda.synchronize()
+    assert float(o.Jc.sum().item()) == 2.0 * n * 18
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held < 2 * n * 208 + (64 << 20), held                    # the kept set (+ allocator granularity), not twelve strides
+    late = D.JacobianOutputs(n, dev, max_attempts=64, fast_store_GBs=1e9)
+    assert 1 <= len(late.log) <= 64 and late.store_GBs > 0.0
+    del o, late
