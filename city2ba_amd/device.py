@@ -281,7 +281,7 @@ class JacobianOutputs:
     (include/city2ba_hip.h).  .r / .Jc / .Jp are torch views of the handle's memory; .log = store
     GB/s of every attempt, .chosen = the attempt kept."""
 
-    def __init__(self, n_obs, device, max_attempts=8, fast_store_GBs=7000.0, _handle=None):
+    def __init__(self, n_obs, device, max_attempts=32, fast_store_GBs=7000.0, _handle=None):
         own = self._own = _OutputsHandle()
         dev = torch.device(device)
         if _handle is not None:                                  # a set the library allocated (c2b_problem_residual_jacobian_device)
@@ -318,7 +318,7 @@ class JacobianOutputs:
         self.store_GBs = max(float(store_GBs), 0.0)
 
 
-def alloc_jacobian_outputs(n_obs, device, max_attempts=8, fast_store_GBs=7000.0):
+def alloc_jacobian_outputs(n_obs, device, max_attempts=32, fast_store_GBs=7000.0):
     """((r, Jc, Jp), log): the output arrays of residual_jacobian*, placed for streaming stores by the library
     (c2b_jacobian_outputs_alloc -- every caller of the C ABI gets the same placement, not just this wrapper)."""
     out = JacobianOutputs(n_obs, device, max_attempts, fast_store_GBs)
