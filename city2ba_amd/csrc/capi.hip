@@ -660,6 +660,9 @@ int c2b_tune_set_stagger(int units_of_64_cycles) {
 int c2b_tune_set_cam_stride(int doubles) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_stride), &doubles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
 }
+int c2b_tune_set_cam_block(int log2_cameras) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_block), &log2_cameras, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
+}
 int c2b_tune_set_cam_swizzle(int doubles) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_swz), &doubles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
 }

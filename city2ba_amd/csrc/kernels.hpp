@@ -38,6 +38,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 __device__ int g_stagger = 0;        // k_observations: wave w of a workgroup sleeps w * g_stagger * 64 cycles before its first load
 __device__ int g_cam_stride = 0;     // k_observations (project / error modes): doubles between camera records (0 = kCamBlk); 16 = a compact table of the light line
 __device__ int g_cam_swz = 0;        // ... doubles added to an ODD camera's record address (16: its light line sits in the second half of its 256 bytes)
+__device__ int g_cam_block = 0;      // ... log2 B (0 = off): BLOCKED table -- the light lines of B consecutive cameras contiguous (B x 128 bytes), their heavy lines behind them
 __device__ unsigned long long *g_probe = nullptr;
 #define C2B_PROBE(k) do { if (g_probe != nullptr && threadIdx.x == 0) g_probe[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 // k_observations' variant (tools/probe_wave_phases.py): the stamps of wave 0 stay in scalar registers until the wave ends (a store per
@@ -553,6 +554,12 @@ C2B_DEV int xcd_tile32(int bid, int n_tiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// doubles from the table's start to camera c's light line (product: c * kCamBlk; the tuning build's layouts: kernels.hpp top)
+C2B_DEV int64_t cam_row(int64_t c, int stride, int swz, int log2_block) {
+    if (log2_block > 0) return ((c >> log2_block) << log2_block) * kCamBlk + (c & ((1 << log2_block) - 1)) * 16;
+    return c * stride + ((c & 1) ? swz : 0);
+}
+
 // MINW = waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument)
 // Chunked XCD map: consecutive workgroups go round-robin over the 8 XCDs; XCD x takes K consecutive tile-blocks of
 // every super-tile of 8K, so each XCD's L2 sees K neighbouring blocks (camera / point reuse) while the whole chip writes
@@ -619,9 +626,9 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     OBS_STAMP(0);
     const int cam_stride = g_cam_stride ? g_cam_stride : kCamBlk;        // experiment (r05): a compact 128-byte-per-camera table
-    const int cam_swz = g_cam_swz;
+    const int cam_swz = g_cam_swz, cam_block = g_cam_block;
 #else
-    constexpr int cam_stride = kCamBlk, cam_swz = 0;
+    constexpr int cam_stride = kCamBlk, cam_swz = 0, cam_block = 0;
 #endif
 #ifdef C2B_TUNE
     // experiment (r05): do the waves of a workgroup, started in lockstep, serialise on each other's phases?  Stagger them.
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             if (ch < (int)n_staged * CH) {
                 const int k = ch / CH, j = ch % CH;
                 const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
-                camv[q] = *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * cam_stride + src + (((c_first + k) & 1u) ? cam_swz : 0));
+                camv[q] = *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)(c_first + k), cam_stride, cam_swz, cam_block) + src);
             }
         }
         if (kTabN > 0) {                                                 // the table's entries were requested first: they are here first
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                     const int k = ch / CH, j = ch % CH;
                     const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
                     *reinterpret_cast<d2_t *>(sSlow + k * HOT + 2 * j) =
-                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)sIdx[k] * cam_stride + src + ((sIdx[k] & 1u) ? cam_swz : 0));
+                        *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)sIdx[k], cam_stride, cam_swz, cam_block) + src);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -27,6 +27,7 @@ dev = torch.device("cuda", 0)
 raw = C.CDLL(L.LIB_PATH)
 raw.c2b_tune_set_cam_stride.argtypes = [C.c_int]
 raw.c2b_tune_set_cam_swizzle.argtypes = [C.c_int]
+raw.c2b_tune_set_cam_block.argtypes = [C.c_int]
 ballast = [torch.empty(64 << 20, dtype=torch.uint8, device=dev) for _ in range(a.ballast_mb // 64)]
 sh = bench.build_shard(argparse.Namespace(blocks=128), 0, 1, dev)
 n = sh["n_obs"]
@@ -66,8 +67,27 @@ def measure(fn):
     return warm, sorted(cold)[2]
 
 
-for tag, table, stride, sw in (("256-byte records", sh["camblk"], 0, 0), ("compact 128-byte rows", compact, 16, 0), ("odd records swizzled", swz, 0, 16),
-                               ("256-byte records", sh["camblk"], 0, 0), ("compact 128-byte rows", compact, 16, 0), ("odd records swizzled", swz, 0, 16)):
+# PAIRS (end of r05): the light lines of cameras 2k and 2k + 1 next to each other (256 contiguous bytes), their heavy lines behind them -- a layout
+# that keeps camblk[n_cam][32] and every signature; does the Infinity Cache's granularity stop at 256 bytes?
+pair = torch.zeros_like(sh["camblk"])
+n_even = pair[0::2].shape[0]
+pair[0::2, :16] = sh["camblk"][0::2, :16]
+pair[0::2, 16:][: sh["camblk"][1::2].shape[0]] = sh["camblk"][1::2, :16]
+def blocked(lb):
+    """the light lines of 2^lb consecutive cameras contiguous, their heavy lines behind them; camblk[n_cam][32] keeps its size"""
+    B = 1 << lb
+    nc = sh["camblk"].shape[0] // B * B                     # whole blocks (the tail keeps the record layout: not exercised, the grid has 660 480 = 64 x 10 320 cameras)
+    t = sh["camblk"].clone()
+    v = sh["camblk"][:nc].view(-1, B, 32)
+    t[:nc] = torch.cat((v[:, :, :16], v[:, :, 16:]), dim=1).reshape(nc, 32)
+    return t
+
+
+for tag, table, stride, sw, lb in (("256-byte records", sh["camblk"], 0, 0, 0), ("compact 128-byte rows", compact, 16, 0, 0), ("light lines in pairs", pair, 0, -16, 0),
+                                   ("blocks of 8 cameras", blocked(3), 0, 0, 3), ("blocks of 64 cameras", blocked(6), 0, 0, 6), ("blocks of 512 cameras", blocked(9), 0, 0, 9),
+                                   ("256-byte records", sh["camblk"], 0, 0, 0), ("compact 128-byte rows", compact, 16, 0, 0),
+                                   ("blocks of 8 cameras", blocked(3), 0, 0, 3), ("blocks of 64 cameras", blocked(6), 0, 0, 6), ("blocks of 512 cameras", blocked(9), 0, 0, 9)):
+    raw.c2b_tune_set_cam_block(lb)
     raw.c2b_tune_set_cam_stride(stride)
     raw.c2b_tune_set_cam_swizzle(sw)
     aa = (table, sh["pts4"], sh["rows"], sh["pt_idx"])
@@ -80,3 +100,4 @@ for tag, table, stride, sw in (("256-byte records", sh["camblk"], 0, 0), ("compa
         a.ballast_mb, tag, w, c, same, w2, c2), flush=True)
 raw.c2b_tune_set_cam_stride(0)
 raw.c2b_tune_set_cam_swizzle(0)
+raw.c2b_tune_set_cam_block(0)
