@@ -27,8 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_FMT = "k_residual_jacobian_l<2, true, %d, true, %d, 1, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; WPB, OPL = c2b_jacobian_launch_shape (by the size and by the output set's store rate), NTL = c2b_jacobian_stream_policy of the launch
-KERNEL_NAME = KERNEL_FMT % (8, 2, 3)     # the launch the roofline object describes (set in main() from the shard's sizes)
+KERNEL_FMT = "k_residual_jacobian_l<2, true, %d, true, %d, %d, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; WPB, OPL = c2b_jacobian_launch_shape (by the size and by the output set's store rate), NTL = c2b_jacobian_stream_policy of the launch
+KERNEL_NAME = KERNEL_FMT % (8, 2, 4, 3)     # the launch the roofline object describes (set in main() from the shard's sizes)
 
 
 class Watchdog:
@@ -550,7 +550,7 @@ def place_inputs(sh, r, Jc, Jp, ws, err):
     best = log["kernel_us_before"]
     for name in ("uv", "camblk", "pt_idx", "pts4"):
         old = sh[name]
-        sh[name] = old.clone()
+        sh[name] = D.camblk_clone(old) if name == "camblk" else old.clone()
         t = kernel_us()
         if t < best * 0.995:
             log[name] = round(t, 1)
@@ -966,7 +966,7 @@ def main():
         achieved = alg / kern_avg_s / 1e9
         policy = D.jacobian_stream_policy(n, sh["n_cam_local"], sh["n_pts"])
         shape = D.jacobian_launch_shape(n, outs.store_GBs)
-        kernel_name = KERNEL_FMT % (shape[0], shape[1], policy)
+        kernel_name = KERNEL_FMT % (shape[0], shape[1], 4 if shape[1] == 2 else 1, policy)     # (MINW: 4 with two tiles per wave, capi.hip: launch_jac_l)
         traffic, traffic_tag = pmc_traffic(kernel_name) if (world == 1 and args.blocks == 128) else (None, None)
         out = {
             "metric": "million observations/sec (project+Jacobian)",

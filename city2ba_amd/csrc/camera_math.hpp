@@ -21,8 +21,32 @@ namespace c2b {
 // centre.  (28-double records straddled lines: 1.75 lines per camera for the first 128 bytes.)
 constexpr int kCamBlk = 32;       // doubles per camblk record (C2B_CAMBLK_DOUBLES)
 constexpr int kCamHot = 24;       // leading doubles the per-observation kernels stage in LDS
-// camblk offsets
+// camblk offsets (of the logical 32-double record)
 constexpr int kR = 0, kT = 9, kIntr = 12, kJl = 15, kCenter = 24;
+
+// r05 (end of the round): WHERE the record's two lines sit.  The table is blocked in groups of kCamGroup = 8 cameras: a group's
+// eight light lines (record doubles 0..15: R, t, intrinsics, J_l[0]) are contiguous (1 KB), its eight heavy lines (doubles 16..31:
+// J_l[1..8], centre, pad) follow (1 KB).  The passes that need projection only then touch contiguous kilobytes and skip as many,
+// instead of one 128-byte line of every 256: interleaved records cost the 256-MB Infinity Cache their whole 169 MB (it keeps more
+// than the touched line), so the light passes' 230 MB of inputs thrashed it or not by where the arrays happened to lie -- 78 us
+// or 90-112 us for the same projection pass back to back, by device (profiles/r05ar).  Measured layouts: blocks of 8 -> 78-80 us on
+// every device; pairs (256 B + 256 B) and blocks of 64 (8 KB + 8 KB) -> 105-118 everywhere (those strides switch address-hash
+// bits and halve the cache slices in use); blocks of 512 -> like the interleaved records.  The table keeps its shape --
+// C2B_CAMBLK_DOUBLES per camera -- but holds WHOLE groups: allocate it for n_cam rounded up to a multiple of 8 cameras
+// (cam_table_doubles); a table is prepared for its own cameras, never sliced by camera.
+constexpr int kCamGroup = 8;
+__host__ __device__ inline int64_t cam_light_at(int64_t c) { return (c >> 3) * (int64_t)(kCamGroup * kCamBlk) + (c & 7) * 16; }
+__host__ __device__ inline int64_t cam_heavy_at(int64_t c) { return cam_light_at(c) + kCamGroup * 16; }
+// record double j / 16-byte chunk j2 of camera c, as an offset in doubles from the table's start
+__host__ __device__ inline int64_t cam_at(int64_t c, int j) { return j < 16 ? cam_light_at(c) + j : cam_heavy_at(c) + (j - 16); }
+__host__ __device__ inline int64_t cam_chunk_at(int64_t c, int j2) { return j2 < 8 ? cam_light_at(c) + 2 * j2 : cam_heavy_at(c) + 2 * (j2 - 8); }
+__host__ __device__ inline int64_t cam_table_doubles(int64_t n_cam) { return ((n_cam + kCamGroup - 1) / kCamGroup * kCamGroup) * (int64_t)kCamBlk; }
+// a camera's record read in place (global memory): rec[j] = record double j.  project_obs takes it like a pointer.
+struct CamRec {
+    const double *light, *heavy;
+    __device__ __forceinline__ CamRec(const double *camblk, int64_t c) : light(camblk + cam_light_at(c)), heavy(camblk + cam_heavy_at(c)) {}
+    __device__ __forceinline__ double operator[](int j) const { return j < 16 ? light[j] : heavy[j - 16]; }
+};
 
 constexpr double kEps = 2.220446049250313e-16;   // f64::EPSILON
 constexpr double kPi = 3.14159265358979323846;

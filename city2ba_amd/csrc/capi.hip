@@ -319,9 +319,18 @@ void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
                   const uint64_t *row_ptr = nullptr, int64_t n_cam = 0, int64_t obs_base = 0) {
+    // Two tiles per wave sit at the edge of 128 registers: the blocked camera table's address arithmetic tipped the allocator to 134
+    // (three waves per SIMD, one workgroup per CU).  With the error sum the instance is told to leave room for four waves and stays
+    // at 128 without scratch (tests/test_isa_pins.py); WITHOUT the sum the cap would spill 20 bytes, so a launch that wants no sum
+    // takes the one-tile shape of the same workgroup count per CU instead (0 ... 2 % behind in fast output sets, nothing to fold).
+    if constexpr (!WITH_ERR && WPB == 8 && OPL == 2 && MINW == 1) {
+        launch_jac_l<WITH_ERR, 16, 1, MINW, XK, OBUP, CSR, NTL, NTS>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket,
+                                                                     out_sum, st, row_ptr, n_cam, obs_base);
+    } else {
     const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
+    constexpr int kMinW = (MINW == 1 && OPL == 2) ? 4 : MINW;
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, NTS, OPL, MINW, XK, OBUP, CSR, NTL>), dim3((unsigned)btiles),        \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, NTS, OPL, kMinW, XK, OBUP, CSR, NTL>), dim3((unsigned)btiles),        \
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
                        reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum, row_ptr, (int)n_cam, obs_base)
@@ -330,6 +339,7 @@ void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_
     else if (norm == 1.0) C2B_GO(NORM_1);
     else C2B_GO(NORM_ANY);
 #undef C2B_GO
+    }
 }
 
 // Which of the Jacobian launch's once-read streams bypass the caches (0 none, 2 the observed uv, 3 uv and point index).

@@ -129,7 +129,7 @@ static int alloc_problem(c2b_problem *p, int64_t n_cam, int64_t n_pts, int64_t n
     auto dalloc = [&](void **q, size_t bytes) -> hipError_t { return hipMalloc(q, bytes ? bytes : 16); };
     HIP_TRY(dalloc((void **)&p->cam15, sizeof(double) * 15 * n_cam));
     HIP_TRY(dalloc((void **)&p->bal9, sizeof(double) * 9 * n_cam));
-    HIP_TRY(dalloc((void **)&p->camblk, sizeof(double) * kCamBlk * n_cam));
+    HIP_TRY(dalloc((void **)&p->camblk, sizeof(double) * (size_t)cam_table_doubles(n_cam)));      // whole groups of 8 cameras
     HIP_TRY(dalloc((void **)&p->cen4, sizeof(double) * 4 * n_cam));
     HIP_TRY(dalloc((void **)&p->pts4, sizeof(double) * 4 * n_pts));
     HIP_TRY(dalloc((void **)&p->uv, sizeof(double) * 2 * n_obs));
@@ -826,7 +826,7 @@ static int cull_impl(c2b_problem *p, int faithful, int mode) {
     DevBuf n_cam15, n_bal9, n_camblk, n_cen4, n_pts4, n_uv, n_ws;
     if (e == hipSuccess) {
         A(n_cam15, sizeof(double) * 15 * (size_t)nc); A(n_bal9, sizeof(double) * 9 * (size_t)nc);
-        A(n_camblk, sizeof(double) * kCamBlk * (size_t)nc); A(n_cen4, sizeof(double) * 4 * (size_t)nc); A(n_pts4, sizeof(double) * 4 * (size_t)np);
+        A(n_camblk, sizeof(double) * (size_t)cam_table_doubles(nc)); A(n_cen4, sizeof(double) * 4 * (size_t)nc); A(n_pts4, sizeof(double) * 4 * (size_t)np);
         A(n_uv, sizeof(double) * 2 * (size_t)no); A(n_ws, (size_t)c2b_workspace_bytes(no));
     }
     if (e == hipSuccess && c2b_workspace_init(n_ws.ptr, st) != C2B_OK) e = hipErrorUnknown;

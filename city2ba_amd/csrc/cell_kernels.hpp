@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kCellWPB * 64) void k_cells_visibility(
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t)blockIdx.x * kCellWPB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (c >= n_cam) return;                                              // wave-uniform; no workgroup barrier below
-    const double *cam = camblk + c * kCamBlk;                            // wave-uniform address: scalar loads
+    const CamRec cam(camblk, c);                                         // wave-uniform addresses: scalar loads
     const double gx = cam[kCenter], gy = cam[kCenter + 1], gz = cam[kCenter + 2];
     const int ccx = cell_coord(gx, g.x0, g.inv_cs, g.ncx), ccz = cell_coord(gz, g.z0, g.inv_cs, g.ncz);
     const double r2 = max_dist * max_dist;

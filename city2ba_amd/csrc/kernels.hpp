@@ -318,13 +318,15 @@ __global__ __launch_bounds__(kBlock) void k_cameras_prepare(const double *__rest
         __builtin_amdgcn_wave_barrier();
         int nv = n_wave - h * 32;
         nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
-        double *dst = camblk + (wave0 + h * 32) * kCamBlk;
+        // the blocked table (camera_math.hpp: groups of 8 cameras, light lines then heavy lines) is written front to back: chunk ch
+        // of these four groups is line (ch >> 6 & 1) of camera (ch >> 7) * 8 + (ch >> 3 & 7), its 16 bytes number (ch & 7)
+        double *dst = camblk + (wave0 + h * 32) * kCamBlk;               // wave0 + h * 32 is a multiple of 8: a group's start
 #pragma unroll
         for (int it = 0; it < 8; ++it) {                                 // 32 records x 16 chunks of 16 bytes = 512 chunks
-            const int ch = it * 64 + lane, rec = ch >> 4, part = ch & 15;
+            const int ch = it * 64 + lane, rec = (ch >> 7) * 8 + ((ch >> 3) & 7), part = ((ch >> 6) & 1) * 8 + (ch & 7);
             if (rec < nv) {
                 const double *q = slab + rec * kStride + 2 * part;
-                *reinterpret_cast<double2 *>(dst + rec * kCamBlk + 2 * part) = make_double2(q[0], q[1]);
+                *reinterpret_cast<double2 *>(dst + 2 * ch) = make_double2(q[0], q[1]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -455,24 +457,6 @@ C2B_DEV void rows_cameras(const uint4 *__restrict__ tiles, const uint64_t *__res
 // than kCamW cameras in 64 observations) read global memory instead: correct, just slower.
 constexpr int kCamW = 12;                      // cameras staged per wave
 
-template <int HOT>
-C2B_DEV const double *wave_camera(const double *__restrict__ camblk, uint32_t ci, bool valid, int n_wave, int lane,
-                                  double *sCam) {
-    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci);
-    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci, n_wave - 1, 64));
-    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
-    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
-    for (int ch = lane; ch < (int)n_staged * (HOT / 2); ch += 64) {
-        const int k = ch / (HOT / 2), j = ch % (HOT / 2);
-        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
-        *reinterpret_cast<double2 *>(sCam + k * HOT + 2 * j) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t local = ci - c_first;
-    return (valid && local < n_staged) ? (sCam + local * HOT) : (camblk + (int64_t)ci * kCamBlk);
-}
-
 #if defined(C2B_TUNE) || defined(C2B_STORE_POL)
 // experiment (r05): the same store geometry under every cache-policy spelling a gfx950 global store has.  The product's
 // non-temporal store is `nt`; sc0 / sc1 are the scope bits (sc1 = agent: the line is written through the XCD's L2).
@@ -554,10 +538,16 @@ C2B_DEV int xcd_tile32(int bid, int n_tiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// doubles from the table's start to camera c's light line (product: c * kCamBlk; the tuning build's layouts: kernels.hpp top)
-C2B_DEV int64_t cam_row(int64_t c, int stride, int swz, int log2_block) {
-    if (log2_block > 0) return ((c >> log2_block) << log2_block) * kCamBlk + (c & ((1 << log2_block) - 1)) * 16;
-    return c * stride + ((c & 1) ? swz : 0);
+// doubles from the table's start to chunk j of a camera's staged row: chunks 0..7 = its light line, 8.. = its centre (the
+// visibility predicate's; heavy line, record doubles 24..).  The tuning build's other layouts (kernels.hpp top) apply to the
+// light line only.
+C2B_DEV int64_t cam_row(int64_t c, int j, int stride, int swz, int log2_block) {
+    if (j >= kCamLight / 2) return cam_heavy_at(c) + (kCenter - 16) + 2 * (j - kCamLight / 2);
+#ifdef C2B_TUNE
+    if (log2_block > 0) return ((c >> log2_block) << log2_block) * kCamBlk + (c & ((1 << log2_block) - 1)) * 16 + 2 * j;
+    if (stride != kCamBlk || swz != 0) return c * stride + ((c & 1) ? swz : 0) + 2 * j;
+#endif
+    return cam_light_at(c) + 2 * j;
 }
 
 // MINW = waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument)
@@ -670,8 +660,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             const int ch = lane + q * 64;
             if (ch < (int)n_staged * CH) {
                 const int k = ch / CH, j = ch % CH;
-                const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
-                camv[q] = *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)(c_first + k), cam_stride, cam_swz, cam_block) + src);
+                camv[q] = *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)(c_first + k), j, cam_stride, cam_swz, cam_block));
             }
         }
         if (kTabN > 0) {                                                 // the table's entries were requested first: they are here first
@@ -734,9 +723,8 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 __builtin_amdgcn_wave_barrier();
                 for (int ch = lane; ch < ns * CH; ch += 64) {
                     const int k = ch / CH, j = ch % CH;
-                    const int src = j < kCamLight / 2 ? 2 * j : kCenter + 2 * (j - kCamLight / 2);
                     *reinterpret_cast<d2_t *>(sSlow + k * HOT + 2 * j) =
-                        *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)sIdx[k], cam_stride, cam_swz, cam_block) + src);
+                        *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)sIdx[k], j, cam_stride, cam_swz, cam_block));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -915,7 +903,7 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
     if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
     for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
         const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
-        const double2 v = *reinterpret_cast<const double2 *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+        const double2 v = *reinterpret_cast<const double2 *>(camblk + cam_chunk_at((int64_t)(c_first + k), j));
         *reinterpret_cast<double2 *>(sCam + k * kCamHot + 2 * j) = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -938,8 +926,10 @@ __global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
         if (LDSCAM && __builtin_amdgcn_ballot_w64(valid[t] && !in_tile) == 0ull) {
             jacobian_obs<ABL>(sCam + (in_tile ? local : 0u) * kCamHot, X[t], ob[t], r0, r1, jc, jp);
         } else {
-            const double *cam = in_tile ? (sCam + local * kCamHot) : (camblk + (int64_t)ci[t] * kCamBlk);
-            jacobian_obs<ABL>(cam, X[t], ob[t], r0, r1, jc, jp);
+            double rec[kCamHot];                                               // (a lane whose camera is not staged: its record by value)
+#pragma unroll
+            for (int j = 0; j < kCamHot; ++j) rec[j] = in_tile ? sCam[local * kCamHot + j] : camblk[cam_at((int64_t)ci[t], j)];
+            jacobian_obs<ABL>(static_cast<const double *>(rec), X[t], ob[t], r0, r1, jc, jp);
         }
 
         // residual: 16 B per lane, already coalesced
@@ -1057,10 +1047,14 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
         const uint32_t c_last = __builtin_amdgcn_readlane(ci[OPL - 1], 63);
         uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
         if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
+        // (addresses as a wave-uniform base -- the group of the first staged camera -- plus a 32-bit lane offset: the blocked table's
+        // two-level index costs no 64-bit vector arithmetic, which this kernel has no registers for)
+        const double *cam_base = camblk + (int64_t)(c_first >> 3) * (kCamGroup * kCamBlk);
+        const int c_in_group = (int)(c_first & 7u);
         for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
-            const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
-            *reinterpret_cast<d2_t *>(sCam + k * kCamHot + 2 * j) =
-                *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+            const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2), cg = c_in_group + k;
+            const int off = (cg >> 3) * (kCamGroup * kCamBlk) + (cg & 7) * 16 + (j < 8 ? 2 * j : kCamGroup * 16 + 2 * (j - 8));
+            *reinterpret_cast<d2_t *>(sCam + k * kCamHot + 2 * j) = *reinterpret_cast<const d2_t *>(cam_base + off);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1088,7 +1082,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
                 for (int ch = lane; ch < ns * (kCamHot / 2); ch += 64) {
                     const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
                     *reinterpret_cast<d2_t *>(sSlow + k * kCamHot + 2 * j) =
-                        *reinterpret_cast<const d2_t *>(camblk + (int64_t)sIdx[k] * kCamBlk + 2 * j);
+                        *reinterpret_cast<const d2_t *>(camblk + cam_chunk_at((int64_t)sIdx[k], j));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1164,15 +1158,16 @@ struct SrcBlk {                                  // f64: camera centres + pts4
     // next to camblk (cen4[n_cam][4], 32-byte rows like pts4: stride 4) -- or, for a caller that kept none, the centre
     // field inside the 256-byte camblk records (stride kCamBlk: a whole 128-byte line fetched per camera for 24 useful
     // bytes -- 148.7 MB per pass over the --blocks 128 entities where the compact table moves 84.5, r04f / r05).
-    const double *cen; int64_t cen_stride; const double4 *pts; int64_t n_cam;
+    const double *cen; int64_t cen_stride; const double4 *pts; int64_t n_cam;      // cen_stride 4: the centre table; 0: camblk itself
     static SrcBlk make(const double *camblk, const double *cen4, const double *pts4, int64_t n_cam) {
-        return SrcBlk{cen4 ? cen4 : camblk + kCenter, cen4 ? 4 : kCamBlk, reinterpret_cast<const double4 *>(pts4), n_cam};
+        return SrcBlk{cen4 ? cen4 : camblk, cen4 ? 4 : 0, reinterpret_cast<const double4 *>(pts4), n_cam};
     }
     // branch-free: both kinds of entity are three consecutive doubles at a 16-byte aligned address, so the address is
     // selected and the loads are unconditional -- a thread's batch of loads then issues back to back (with a branch per
     // entity every arm ended in s_waitcnt vmcnt(0) and the batch was serial again)
     C2B_DEV void get(int64_t i, double &x, double &y, double &z) const {
-        const double *c = i < n_cam ? cen + i * cen_stride : reinterpret_cast<const double *>(pts + (i - n_cam));
+        const double *c = i < n_cam ? (cen_stride ? cen + i * cen_stride : cen + cam_heavy_at(i) + (kCenter - 16))
+                                    : reinterpret_cast<const double *>(pts + (i - n_cam));
         const double2 xy = *reinterpret_cast<const double2 *>(c);
         x = xy.x; y = xy.y; z = c[2];
     }
@@ -1936,7 +1931,7 @@ __global__ __launch_bounds__(kDenseWPB * 64) void k_visibility_dense(
     // that has a candidate falls into the per-point path below.  tile_counts is zeroed by the launcher, so only
     // non-empty (camera, tile) cells are written.
     auto camera_step = [&](const int64_t c) {
-        const double *cam = camblk + c * kCamBlk;
+        const CamRec cam(camblk, c);
         const double cx = cam[kCenter], cy = cam[kCenter + 1], cz = cam[kCenter + 2];
         double d2[kDensePPL];
         bool cand = false;
@@ -2267,7 +2262,7 @@ __global__ __launch_bounds__(kBlock) void k_occlusion(const double *__restrict__
     const bool valid = i < n;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, tfar = -1.0f;
     if (valid) {
-        const double *c = camblk + (int64_t)cam_idx[i] * kCamBlk + kCenter;
+        const double *c = camblk + cam_heavy_at((int64_t)cam_idx[i]) + (kCenter - 16);
         const double4 p = pts4[pt_idx[i]];
         const double ex = p.x - c[0], ey = p.y - c[1], ez = p.z - c[2];        // point - camera.center()
         const double mag = sqrt(dot3(ex, ey, ez, ex, ey, ez));
@@ -2331,7 +2326,7 @@ __global__ __launch_bounds__(kBlock) void k_occlusion_bvh(const double *__restri
                                                          uint8_t *__restrict__ keep, uint32_t *__restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const double *c = camblk + (int64_t)cam_idx[i] * kCamBlk + kCenter;
+    const double *c = camblk + cam_heavy_at((int64_t)cam_idx[i]) + (kCenter - 16);
     const double4 p = pts4[pt_idx[i]];
     const double ex = p.x - c[0], ey = p.y - c[1], ez = p.z - c[2];
     const double mag = sqrt(dot3(ex, ey, ez, ex, ey, ez));

@@ -72,7 +72,7 @@ C2B_DEV void pipe_issue_gather(PipeSet &S, int lane, const double *__restrict__ 
     const int nch = (int)ns * (HOT / 2);
     const int ch = lane < nch ? lane : nch - 1;        // always load (static VM count); the LDS write is predicated
     const int k = ch / (HOT / 2), j = ch % (HOT / 2);
-    S.cs = *reinterpret_cast<const d2_t *>(camblk + (int64_t)(c_first + k) * kCamBlk + 2 * j);
+    S.cs = *reinterpret_cast<const d2_t *>(camblk + cam_chunk_at((int64_t)(c_first + k), j));
 }
 
 template <int HOT>
@@ -161,7 +161,7 @@ C2B_DEV void pipe_jacobian_tile(const PipeSet &S, int tile, int n_wave, int lane
         __builtin_amdgcn_wave_barrier();
         if (lane < kCamHot / 2)
             *reinterpret_cast<d2_t *>(const_cast<double *>(sCam) + 2 * lane) =
-                *reinterpret_cast<const d2_t *>(camblk + (int64_t)c_first * kCamBlk + 2 * lane);
+                *reinterpret_cast<const d2_t *>(camblk + cam_chunk_at((int64_t)c_first, lane));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -317,7 +317,7 @@ C2B_DEV void pipe_light_tile(const PipeSet &S, int tile, int n_wave, int lane, c
         __builtin_amdgcn_wave_barrier();
         if (lane < hot / 2)
             *reinterpret_cast<d2_t *>(const_cast<double *>(sCam) + 2 * lane) =
-                *reinterpret_cast<const d2_t *>(camblk + (int64_t)c_first * kCamBlk + 2 * lane);
+                *reinterpret_cast<const d2_t *>(camblk + cam_chunk_at((int64_t)c_first, lane));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

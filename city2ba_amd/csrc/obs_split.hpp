@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512) void k_project_split(
                 uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
                 if (n_staged > (uint32_t)kSplitCams) n_staged = kSplitCams;
                 if (lane < (int)n_staged * 8) {
-                    const char *row = reinterpret_cast<const char *>(camblk + (int64_t)(c_first + (lane >> 3)) * kCamBlk) + (lane & 7) * 16;
+                    const char *row = reinterpret_cast<const char *>(camblk + cam_light_at((int64_t)(c_first + (lane >> 3)))) + (lane & 7) * 16;
                     __builtin_amdgcn_global_load_lds((glb_vptr)row, (lds_vptr)(slot + kSplitRows), 16, 0, 0);
                 }
                 reinterpret_cast<uint32_t *>(slot + kSplitCi)[lane] = ci;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void k_project_split(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // this wave's LDS reads are done
         if (lane == 0) flag_store(&done[s], gen);
         if (__builtin_amdgcn_ballot_w64(valid && !in) != 0) {              // rare: more cameras than staged / an empty list inside
-            const Proj q = project_obs((glb_cptr)(camblk + (int64_t)ci * kCamBlk), xy.x, xy.y, zw.x);
+            const Proj q = project_obs(CamRec(camblk, (int64_t)ci), xy.x, xy.y, zw.x);
             if (!in) p = q;
         }
         if (valid) store16<NTS>(reinterpret_cast<char *>(uv_out + o), make_double2(p.u, p.v));

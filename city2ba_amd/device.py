@@ -82,11 +82,40 @@ def centers_table(n_cam, device):
     return torch.empty((n_cam, 4), dtype=torch.float64, device=device)
 
 
+def camblk_table(n_cam, device):
+    """an uninitialised camblk for n_cam cameras: [n_cam][CAMBLK_DOUBLES] to look at, but its storage holds WHOLE groups of 8
+    cameras (the table is blocked: a group's eight light lines, then its eight heavy lines -- include/city2ba_hip.h), so the
+    last group's heavy lines have somewhere to go when n_cam is not a multiple of 8.  Never slice or clone it by camera."""
+    n = int(n_cam)
+    flat = torch.empty(((n + 7) // 8 * 8) * L.CAMBLK_DOUBLES, dtype=torch.float64, device=device)
+    return flat[: n * L.CAMBLK_DOUBLES].view(n, L.CAMBLK_DOUBLES)
+
+
+def camblk_records(camblk):
+    """the table's logical records, [n_cam][CAMBLK_DOUBLES] (R 9, t 3, intrinsics 3, J_l 9, centre 3, pad), as a COPY taken out of
+    the blocked layout -- for looking at; the kernels take the table itself"""
+    n = camblk.shape[0]
+    g = (n + 7) // 8
+    flat = torch.as_strided(camblk, (g * 8 * L.CAMBLK_DOUBLES,), (1,))
+    v = flat.view(g, 2, 8, 16)
+    return torch.cat((v[:, 0], v[:, 1]), dim=-1).reshape(g * 8, L.CAMBLK_DOUBLES)[:n].clone()
+
+
+def camblk_clone(camblk):
+    """a copy of a prepared camblk in storage of its own (with the slack of the last group: camblk_table)"""
+    n = camblk.shape[0]
+    out = camblk_table(n, camblk.device)
+    whole = ((n + 7) // 8 * 8) * L.CAMBLK_DOUBLES
+    out.untyped_storage()                                       # (same dtype / device; copy the whole groups, slack included)
+    torch.as_strided(out, (whole,), (1,)).copy_(torch.as_strided(camblk, (whole,), (1,)))
+    return out
+
+
 def cameras_prepare_state(cam15, out=None, centers=None):
     """camblk from the in-memory cameras; `centers` (centers_table) also receives every camera's centre"""
     _chk(cam15, torch.float64, "cam15")
     n = cam15.shape[0]
-    blk = out if out is not None else torch.empty((n, L.CAMBLK_DOUBLES), dtype=torch.float64, device=cam15.device)
+    blk = out if out is not None else camblk_table(n, cam15.device)
     L.check(L.lib().c2b_cameras_prepare_state(_p(cam15), n, _p(blk), _pn(centers, n), _stream()))
     return blk
 
@@ -94,7 +123,7 @@ def cameras_prepare_state(cam15, out=None, centers=None):
 def cameras_prepare_bal(bal9, out=None, centers=None):
     _chk(bal9, torch.float64, "bal9")
     n = bal9.shape[0]
-    blk = out if out is not None else torch.empty((n, L.CAMBLK_DOUBLES), dtype=torch.float64, device=bal9.device)
+    blk = out if out is not None else camblk_table(n, bal9.device)
     L.check(L.lib().c2b_cameras_prepare_bal(_p(bal9), n, _p(blk), _pn(centers, n), _stream()))
     return blk
 

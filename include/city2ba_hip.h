@@ -20,9 +20,14 @@
  *           camera-major: row_ptr[n_cam+1] (u64), pt_idx[n_obs] (u64 host / u32 device),
  *           uv[n_obs][2].  cam_idx[n_obs] (u32) is the COO expansion of row_ptr, i.e. the
  *           camera column of a .bal observation line (src/baproblem.rs:718-722).
- *   camblk  derived per-camera record, C2B_CAMBLK_DOUBLES doubles (256 bytes; allocate the table 256-byte aligned
- *           so that a record's first 128-byte line is exactly what projection needs):
- *           R row-major[9] | t[3] | f,k1,k2 | J_l(w) row-major[9] | center[3] | pad[5].
+ *   camblk  derived per-camera record, C2B_CAMBLK_DOUBLES doubles (256 bytes):
+ *           R row-major[9] | t[3] | f,k1,k2 | J_l(w) row-major[9] | center[3] | pad[5] -- two 128-byte lines, the first of which
+ *           is exactly what projection needs.  The TABLE is blocked in groups of C2B_CAMBLK_GROUP = 8 cameras (r05): a group's
+ *           eight first lines are contiguous (1 KB), its eight second lines follow (1 KB) -- the projection-only passes then
+ *           touch whole kilobytes instead of every other line, which the 256-MB Infinity Cache needs to hold their inputs
+ *           (DESIGN.md section 3.1).  ALLOCATE IT FOR WHOLE GROUPS: C2B_CAMBLK_DOUBLES * (n_cam rounded up to a multiple of 8)
+ *           doubles, 256-byte aligned; a table is written by c2b_cameras_prepare_* for its own n_cam cameras (camera c of the
+ *           call = row c of the table) and is never sliced or copied by camera range -- a shard prepares its own.
  *   cen4    the cameras' centres alone, [n_cam][4] doubles (x y z 0: 32-byte rows like pts4; 16-byte aligned), written
  *           by the same launch that derives camblk.  What the statistics read: 32 bytes per camera instead of a
  *           128-byte line of the 256-byte record (84.5 MB instead of 148.7 MB per pass at --blocks 128).  Optional
@@ -110,6 +115,7 @@ extern "C" {
 #define C2B_ERR_RCCL                -6  /* a collective failed, or RCCL could not be loaded */
 
 #define C2B_CAMBLK_DOUBLES 32
+#define C2B_CAMBLK_GROUP 8          /* cameras per group of the blocked table: allocate C2B_CAMBLK_DOUBLES * ((n_cam + 7) / 8 * 8) doubles */
 #define C2B_STATS_DOUBLES  20  /* mean[3] std[3] min[3] max[3] dim[3] origin[3] origin_idx |std| */
 
 const char *c2b_version(void);

@@ -153,9 +153,10 @@ def test_bvh_filter_equals_all_triangles_filter(c2b):
     B, L, inset = 6, 20.0, 1.0
     pos, dirs, gpts = S.grid_layout(B, 10, 10, L, inset, 1.0, 1.0)
     cam15 = D.cameras_from_position_direction(torch.from_numpy(pos).to(dev), torch.from_numpy(dirs).to(dev))
-    camblk = D.cameras_prepare_state(cam15)
+    cen4 = D.centers_table(cam15.shape[0], dev)
+    camblk = D.cameras_prepare_state(cam15, centers=cen4)       # (camblk is blocked by groups of 8 cameras: the centres come from their table)
     pts4 = D.points_pad(torch.from_numpy(gpts).to(dev))
-    ci, pi = S.candidate_pairs(camblk[:, 24:27].cpu().numpy(), gpts, 10.0)
+    ci, pi = S.candidate_pairs(cen4[:, :3].cpu().numpy().copy(), gpts, 10.0)
     ci_d, pi_d = torch.from_numpy(ci.astype(np.int32)).to(dev), torch.from_numpy(pi.astype(np.int32)).to(dev)
     boxes = []
     for bx in range(B):

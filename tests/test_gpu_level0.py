@@ -209,13 +209,14 @@ def test_compact_centre_table_is_the_record_field_and_the_statistics_do_not_care
     ws = D.workspace(0, dev)
     cen = torch.full((n_cam, 4), float("nan"), dtype=torch.float64, device=dev)
     blk = D.cameras_prepare_state(cam15, centers=cen)
-    assert torch.equal(cen[:, :3], blk[:, 24:27]) and bool((cen[:, 3] == 0).all())
-    assert torch.equal(blk, D.cameras_prepare_state(cam15))                       # the records do not change
+    rec = D.camblk_records(blk)                                                   # (the table is blocked by groups of 8 cameras)
+    assert torch.equal(cen[:, :3], rec[:, 24:27]) and bool((cen[:, 3] == 0).all())
+    assert torch.equal(rec, D.camblk_records(D.cameras_prepare_state(cam15)))     # the records do not change
     assert np.allclose(cen[:, :3].cpu().numpy(), O.centers(P["cams15"]), rtol=0, atol=1e-12)
     bal9 = D.cameras_to_bal(cam15)
     cen_b = torch.full_like(cen, float("nan"))
     blk_b = D.cameras_prepare_bal(bal9, centers=cen_b)
-    assert torch.equal(cen_b[:, :3], blk_b[:, 24:27]) and bool((cen_b[:, 3] == 0).all())
+    assert torch.equal(cen_b[:, :3], D.camblk_records(blk_b)[:, 24:27]) and bool((cen_b[:, 3] == 0).all())
     a = D.stats(blk, pts4, ws).cpu().numpy()
     b = D.stats(blk, pts4, ws, centers=cen).cpu().numpy()
     assert np.array_equal(a, b)
@@ -226,7 +227,7 @@ def test_compact_centre_table_is_the_record_field_and_the_statistics_do_not_care
     # cameras only / points only / a camera range as a shard
     assert np.array_equal(D.stats(blk, pts4[:0], ws).cpu().numpy(), D.stats(blk, pts4[:0], ws, centers=cen).cpu().numpy())
     lo, hi = 40, 170
-    sub, sub_c = blk[lo:hi].contiguous(), cen[lo:hi].contiguous()
+    sub, sub_c = D.cameras_prepare_state(cam15[lo:hi].contiguous()), cen[lo:hi].contiguous()      # a shard's table is PREPARED for its cameras, not sliced
     n_ent = n_cam + n_pts
     p1 = D.stats_partial_pass1(sub, lo, n_cam, pts4[100:900], 100, n_ent, ws).cpu().numpy()
     p1c = D.stats_partial_pass1(sub, lo, n_cam, pts4[100:900], 100, n_ent, ws, centers=sub_c).cpu().numpy()

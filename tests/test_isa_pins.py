@@ -43,7 +43,7 @@ def test_every_shipped_kernel_has_no_scratch_no_spills_no_flat(isa):
 
 def test_headline_kernel_resources(isa):
     _, _, rows = isa
-    jac = [r for r in rows if r["name"].startswith("k_residual_jacobian_l<2, true, 8, true, 2, 1, 0, true, true, 3>")]
+    jac = [r for r in rows if r["name"].startswith("k_residual_jacobian_l<2, true, 8, true, 2, 4, 0, true, true, 3>")]
     assert len(jac) == 1
     assert jac[0]["vgpr"] <= 128 and jac[0]["lds"] <= 80 * 1024       # 4 waves per SIMD, two workgroups per CU
 

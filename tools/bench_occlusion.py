@@ -50,9 +50,10 @@ def main():
     B, L, inset = a.blocks, 20.0, 1.0
     pos, dirs, pts = S.grid_layout(B, 10, 10, L, inset, 1.0, 1.0)
     cam15 = D.cameras_from_position_direction(torch.from_numpy(pos).to(dev), torch.from_numpy(dirs).to(dev))
-    camblk = D.cameras_prepare_state(cam15)
+    cen4 = D.centers_table(cam15.shape[0], dev)
+    camblk = D.cameras_prepare_state(cam15, centers=cen4)
     pts4 = D.points_pad(torch.from_numpy(pts).to(dev))
-    centers = camblk[:, 24:27].cpu().numpy()
+    centers = cen4[:, :3].cpu().numpy().copy()
     out = {"blocks": B, "cameras": len(pos), "points": len(pts)}
     for name, occl in (("all", False), ("hits_building", True)):
         ci, pi = S.candidate_pairs(centers, pts, a.max_dist, occlusion=occl, block_length=L, block_inset=inset)
