@@ -38,7 +38,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 __device__ int g_stagger = 0;        // k_observations: wave w of a workgroup sleeps w * g_stagger * 64 cycles before its first load
 __device__ int g_cam_stride = 0;     // k_observations (project / error modes): doubles between camera records (0 = kCamBlk); 16 = a compact table of the light line
 __device__ int g_cam_swz = 0;        // ... doubles added to an ODD camera's record address (16: its light line sits in the second half of its 256 bytes)
-__device__ int g_cam_block = 0;      // ... log2 B (0 = off): BLOCKED table -- the light lines of B consecutive cameras contiguous (B x 128 bytes), their heavy lines behind them
+__device__ int g_cam_block = 0;      // ... log2 B (0 = the product's table, -1 = interleaved 256-byte records): BLOCKED table -- the light lines of B consecutive cameras contiguous (B x 128 bytes), their heavy lines behind them
 __device__ unsigned long long *g_probe = nullptr;
 #define C2B_PROBE(k) do { if (g_probe != nullptr && threadIdx.x == 0) g_probe[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 // k_observations' variant (tools/probe_wave_phases.py): the stamps of wave 0 stay in scalar registers until the wave ends (a store per
@@ -545,7 +545,7 @@ C2B_DEV int64_t cam_row(int64_t c, int j, int stride, int swz, int log2_block) {
     if (j >= kCamLight / 2) return cam_heavy_at(c) + (kCenter - 16) + 2 * (j - kCamLight / 2);
 #ifdef C2B_TUNE
     if (log2_block > 0) return ((c >> log2_block) << log2_block) * kCamBlk + (c & ((1 << log2_block) - 1)) * 16 + 2 * j;
-    if (stride != kCamBlk || swz != 0) return c * stride + ((c & 1) ? swz : 0) + 2 * j;
+    if (log2_block < 0 || stride != kCamBlk || swz != 0) return c * stride + ((c & 1) ? swz : 0) + 2 * j;     // (-1: the interleaved records of rounds 1-5)
 #endif
     return cam_light_at(c) + 2 * j;
 }
