@@ -35,17 +35,24 @@ constexpr int kR = 0, kT = 9, kIntr = 12, kJl = 15, kCenter = 24;
 // C2B_CAMBLK_DOUBLES per camera -- but holds WHOLE groups: allocate it for n_cam rounded up to a multiple of 8 cameras
 // (cam_table_doubles); a table is prepared for its own cameras, never sliced by camera.
 constexpr int kCamGroup = 8;
-__host__ __device__ inline int64_t cam_light_at(int64_t c) { return (c >> 3) * (int64_t)(kCamGroup * kCamBlk) + (c & 7) * 16; }
-__host__ __device__ inline int64_t cam_heavy_at(int64_t c) { return cam_light_at(c) + kCamGroup * 16; }
+// A group's 256 doubles: [0, 128) eight light lines (record doubles 0..15) | [128, 192) eight J_l tails (doubles 16..23, 64 bytes each)
+// | [192, 224) eight centres (doubles 24..27: x y z 0, 32 bytes each) | [224, 256) the rest of the pad (doubles 28..31).  So the Jacobian
+// kernel touches the first 1.5 KB of a group, the visibility predicate 1 KB + 256 bytes, projection 1 KB -- not 2 KB each.
+__host__ __device__ inline int cam_in_group_at(int k, int j) {          // record double j of the group's k-th camera, from the group's start
+    return j < 16 ? k * 16 + j : (j < 24 ? 128 + k * 8 + (j - 16) : (j < 28 ? 192 + k * 4 + (j - 24) : 224 + k * 4 + (j - 28)));
+}
+__host__ __device__ inline int64_t cam_group_at(int64_t c) { return (c >> 3) * (int64_t)(kCamGroup * kCamBlk); }
+__host__ __device__ inline int64_t cam_light_at(int64_t c) { return cam_group_at(c) + (c & 7) * 16; }
+__host__ __device__ inline int64_t cam_center_at(int64_t c) { return cam_group_at(c) + 192 + (c & 7) * 4; }     // 3 doubles, 32-byte aligned
 // record double j / 16-byte chunk j2 of camera c, as an offset in doubles from the table's start
-__host__ __device__ inline int64_t cam_at(int64_t c, int j) { return j < 16 ? cam_light_at(c) + j : cam_heavy_at(c) + (j - 16); }
-__host__ __device__ inline int64_t cam_chunk_at(int64_t c, int j2) { return j2 < 8 ? cam_light_at(c) + 2 * j2 : cam_heavy_at(c) + 2 * (j2 - 8); }
+__host__ __device__ inline int64_t cam_at(int64_t c, int j) { return cam_group_at(c) + cam_in_group_at((int)(c & 7), j); }
+__host__ __device__ inline int64_t cam_chunk_at(int64_t c, int j2) { return cam_at(c, 2 * j2); }
 __host__ __device__ inline int64_t cam_table_doubles(int64_t n_cam) { return ((n_cam + kCamGroup - 1) / kCamGroup * kCamGroup) * (int64_t)kCamBlk; }
 // a camera's record read in place (global memory): rec[j] = record double j.  project_obs takes it like a pointer.
 struct CamRec {
-    const double *light, *heavy;
-    __device__ __forceinline__ CamRec(const double *camblk, int64_t c) : light(camblk + cam_light_at(c)), heavy(camblk + cam_heavy_at(c)) {}
-    __device__ __forceinline__ double operator[](int j) const { return j < 16 ? light[j] : heavy[j - 16]; }
+    const double *group; int k;
+    __device__ __forceinline__ CamRec(const double *camblk, int64_t c) : group(camblk + cam_group_at(c)), k((int)(c & 7)) {}
+    __device__ __forceinline__ double operator[](int j) const { return group[cam_in_group_at(k, j)]; }
 };
 
 constexpr double kEps = 2.220446049250313e-16;   // f64::EPSILON

@@ -318,12 +318,15 @@ __global__ __launch_bounds__(kBlock) void k_cameras_prepare(const double *__rest
         __builtin_amdgcn_wave_barrier();
         int nv = n_wave - h * 32;
         nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
-        // the blocked table (camera_math.hpp: groups of 8 cameras, light lines then heavy lines) is written front to back: chunk ch
-        // of these four groups is line (ch >> 6 & 1) of camera (ch >> 7) * 8 + (ch >> 3 & 7), its 16 bytes number (ch & 7)
+        // the blocked table (camera_math.hpp: groups of 8 cameras -- light lines, J_l tails, centres, pad) is written front to back:
+        // chunk w of a group's 128 is chunk `part` of its camera `r8`
         double *dst = camblk + (wave0 + h * 32) * kCamBlk;               // wave0 + h * 32 is a multiple of 8: a group's start
 #pragma unroll
         for (int it = 0; it < 8; ++it) {                                 // 32 records x 16 chunks of 16 bytes = 512 chunks
-            const int ch = it * 64 + lane, rec = (ch >> 7) * 8 + ((ch >> 3) & 7), part = ((ch >> 6) & 1) * 8 + (ch & 7);
+            const int ch = it * 64 + lane, w = ch & 127;
+            const int r8 = w < 64 ? w >> 3 : (w < 96 ? (w - 64) >> 2 : ((w & 15) >> 1));
+            const int part = w < 64 ? w & 7 : (w < 96 ? 8 + (w & 3) : (w < 112 ? 12 : 14) + (w & 1));
+            const int rec = (ch >> 7) * 8 + r8;
             if (rec < nv) {
                 const double *q = slab + rec * kStride + 2 * part;
                 *reinterpret_cast<double2 *>(dst + 2 * ch) = make_double2(q[0], q[1]);
@@ -542,7 +545,7 @@ C2B_DEV int xcd_tile32(int bid, int n_tiles) {
 // visibility predicate's; heavy line, record doubles 24..).  The tuning build's other layouts (kernels.hpp top) apply to the
 // light line only.
 C2B_DEV int64_t cam_row(int64_t c, int j, int stride, int swz, int log2_block) {
-    if (j >= kCamLight / 2) return cam_heavy_at(c) + (kCenter - 16) + 2 * (j - kCamLight / 2);
+    if (j >= kCamLight / 2) return cam_center_at(c) + 2 * (j - kCamLight / 2);
 #ifdef C2B_TUNE
     if (log2_block > 0) return ((c >> log2_block) << log2_block) * kCamBlk + (c & ((1 << log2_block) - 1)) * 16 + 2 * j;
     if (log2_block < 0 || stride != kCamBlk || swz != 0) return c * stride + ((c & 1) ? swz : 0) + 2 * j;     // (-1: the interleaved records of rounds 1-5)
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
         const int c_in_group = (int)(c_first & 7u);
         for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
             const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2), cg = c_in_group + k;
-            const int off = (cg >> 3) * (kCamGroup * kCamBlk) + (cg & 7) * 16 + (j < 8 ? 2 * j : kCamGroup * 16 + 2 * (j - 8));
+            const int off = (cg >> 3) * (kCamGroup * kCamBlk) + cam_in_group_at(cg & 7, 2 * j);
             *reinterpret_cast<d2_t *>(sCam + k * kCamHot + 2 * j) = *reinterpret_cast<const d2_t *>(cam_base + off);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1166,7 +1169,7 @@ struct SrcBlk {                                  // f64: camera centres + pts4
     // selected and the loads are unconditional -- a thread's batch of loads then issues back to back (with a branch per
     // entity every arm ended in s_waitcnt vmcnt(0) and the batch was serial again)
     C2B_DEV void get(int64_t i, double &x, double &y, double &z) const {
-        const double *c = i < n_cam ? (cen_stride ? cen + i * cen_stride : cen + cam_heavy_at(i) + (kCenter - 16))
+        const double *c = i < n_cam ? (cen_stride ? cen + i * cen_stride : cen + cam_center_at(i))
                                     : reinterpret_cast<const double *>(pts + (i - n_cam));
         const double2 xy = *reinterpret_cast<const double2 *>(c);
         x = xy.x; y = xy.y; z = c[2];
@@ -2262,7 +2265,7 @@ __global__ __launch_bounds__(kBlock) void k_occlusion(const double *__restrict__
     const bool valid = i < n;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, tfar = -1.0f;
     if (valid) {
-        const double *c = camblk + cam_heavy_at((int64_t)cam_idx[i]) + (kCenter - 16);
+        const double *c = camblk + cam_center_at((int64_t)cam_idx[i]);
         const double4 p = pts4[pt_idx[i]];
         const double ex = p.x - c[0], ey = p.y - c[1], ez = p.z - c[2];        // point - camera.center()
         const double mag = sqrt(dot3(ex, ey, ez, ex, ey, ez));
@@ -2326,7 +2329,7 @@ __global__ __launch_bounds__(kBlock) void k_occlusion_bvh(const double *__restri
                                                          uint8_t *__restrict__ keep, uint32_t *__restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const double *c = camblk + cam_heavy_at((int64_t)cam_idx[i]) + (kCenter - 16);
+    const double *c = camblk + cam_center_at((int64_t)cam_idx[i]);
     const double4 p = pts4[pt_idx[i]];
     const double ex = p.x - c[0], ey = p.y - c[1], ez = p.z - c[2];
     const double mag = sqrt(dot3(ex, ey, ez, ex, ey, ez));

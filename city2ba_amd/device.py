@@ -84,8 +84,8 @@ def centers_table(n_cam, device):
 
 def camblk_table(n_cam, device):
     """an uninitialised camblk for n_cam cameras: [n_cam][CAMBLK_DOUBLES] to look at, but its storage holds WHOLE groups of 8
-    cameras (the table is blocked: a group's eight light lines, then its eight heavy lines -- include/city2ba_hip.h), so the
-    last group's heavy lines have somewhere to go when n_cam is not a multiple of 8.  Never slice or clone it by camera."""
+    cameras (the table is blocked: a group's eight light lines, then its J_l tails, centres and pad -- include/city2ba_hip.h), so the
+    last group's later parts have somewhere to go when n_cam is not a multiple of 8.  Never slice or clone it by camera."""
     n = int(n_cam)
     flat = torch.empty(((n + 7) // 8 * 8) * L.CAMBLK_DOUBLES, dtype=torch.float64, device=device)
     return flat[: n * L.CAMBLK_DOUBLES].view(n, L.CAMBLK_DOUBLES)
@@ -96,9 +96,9 @@ def camblk_records(camblk):
     the blocked layout -- for looking at; the kernels take the table itself"""
     n = camblk.shape[0]
     g = (n + 7) // 8
-    flat = torch.as_strided(camblk, (g * 8 * L.CAMBLK_DOUBLES,), (1,))
-    v = flat.view(g, 2, 8, 16)
-    return torch.cat((v[:, 0], v[:, 1]), dim=-1).reshape(g * 8, L.CAMBLK_DOUBLES)[:n].clone()
+    flat = torch.as_strided(camblk, (g * 8 * L.CAMBLK_DOUBLES,), (1,)).view(g, 256)
+    parts = (flat[:, :128].reshape(g, 8, 16), flat[:, 128:192].reshape(g, 8, 8), flat[:, 192:224].reshape(g, 8, 4), flat[:, 224:].reshape(g, 8, 4))
+    return torch.cat(parts, dim=-1).reshape(g * 8, L.CAMBLK_DOUBLES)[:n].clone()
 
 
 def camblk_clone(camblk):

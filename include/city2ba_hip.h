@@ -23,9 +23,10 @@
  *   camblk  derived per-camera record, C2B_CAMBLK_DOUBLES doubles (256 bytes):
  *           R row-major[9] | t[3] | f,k1,k2 | J_l(w) row-major[9] | center[3] | pad[5] -- two 128-byte lines, the first of which
  *           is exactly what projection needs.  The TABLE is blocked in groups of C2B_CAMBLK_GROUP = 8 cameras (r05): a group's
- *           eight first lines are contiguous (1 KB), its eight second lines follow (1 KB) -- the projection-only passes then
- *           touch whole kilobytes instead of every other line, which the 256-MB Infinity Cache needs to hold their inputs
- *           (DESIGN.md section 3.1).  ALLOCATE IT FOR WHOLE GROUPS: C2B_CAMBLK_DOUBLES * (n_cam rounded up to a multiple of 8)
+ *           eight first lines are contiguous (1 KB), then its eight J_l tails (64 bytes each), its eight centres (32 bytes
+ *           each) and the pad -- the projection-only passes then touch whole kilobytes instead of every other line (and the
+ *           Jacobian 1.5 KB, the visibility predicate 1.25 KB of every 2), which the 256-MB Infinity Cache needs to hold their
+ *           inputs.  ALLOCATE IT FOR WHOLE GROUPS: C2B_CAMBLK_DOUBLES * (n_cam rounded up to a multiple of 8)
  *           doubles, 256-byte aligned; a table is written by c2b_cameras_prepare_* for its own n_cam cameras (camera c of the
  *           call = row c of the table) and is never sliced or copied by camera range -- a shard prepares its own.
  *   cen4    the cameras' centres alone, [n_cam][4] doubles (x y z 0: 32-byte rows like pts4; 16-byte aligned), written
