@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-KERNEL_FMT = "k_residual_jacobian_l<2, true, %d, true, %d, %d, 0, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, XK, OBUP, CSR, NTL>, as rocprofv3 prints it; WPB, OPL = c2b_jacobian_launch_shape (by the size and by the output set's store rate), NTL = c2b_jacobian_stream_policy of the launch
+KERNEL_FMT = "k_residual_jacobian_l<2, true, %d, true, %d, %d, true, true, %d>"   # <NORM_2, WITH_ERR, WPB, NT, OPL, MINW, OBUP, CSR, NTL>, as rocprofv3 prints it; WPB, OPL = c2b_jacobian_launch_shape (by the size and by the output set's store rate), NTL = c2b_jacobian_stream_policy of the launch
 KERNEL_NAME = KERNEL_FMT % (8, 2, 4, 3)     # the launch the roofline object describes (set in main() from the shard's sizes)
 
 
@@ -407,12 +407,12 @@ def light_kernels(sh, dev, ws):
 
 # pass of light_kernels -> its kernel in profiles/r05at_light_sq.json (tools/profile_r05.sh: rocprofv3 kernel trace, SQ issue /
 # wait counters, FETCH_SIZE and WRITE_SIZE, each in its own pass)
-_LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, false, true, true, 0>",
-                 "error_sum_rows_L2": "k_observations<1, 2, 3, 8, 1, false, true, true, 2>",
-                 "error_sums2_rows_L1_and_L2": "k_observations<3, 2, 3, 8, 1, false, true, true, 2>",
-                 "add_noise_observations+error_sums2_rows": "k_observations<4, 2, 3, 8, 8, false, true, true, 2>",
-                 "visibility_rows": "k_observations<2, 2, 3, 8, 1, false, true, true, 1>",
-                 "visibility_rows_bits": "k_observations<5, 2, 3, 8, 1, false, true, true, 1>",
+_LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, true, true, 0>",
+                 "error_sum_rows_L2": "k_observations<1, 2, 3, 8, 1, true, true, 2>",
+                 "error_sums2_rows_L1_and_L2": "k_observations<3, 2, 3, 8, 1, true, true, 2>",
+                 "add_noise_observations+error_sums2_rows": "k_observations<4, 2, 3, 8, 8, true, true, 2>",
+                 "visibility_rows": "k_observations<2, 2, 3, 8, 1, true, true, 1>",
+                 "visibility_rows_bits": "k_observations<5, 2, 3, 8, 1, true, true, 1>",
                  "add_noise_observations": "k_add_noise_observations", "stats": "k_stats_pass1<"}
 
 

@@ -36,8 +36,9 @@ SIGNATURES = {
     "c2b_workspace_selfcheck": (_int, [_vp, _vp, C.POINTER(_i64)]),
     "c2b_cameras_from_bal": (_int, [_vp, _i64, _vp, _vp]),
     "c2b_cameras_to_bal": (_int, [_vp, _i64, _vp, _vp]),
-    "c2b_cameras_prepare_state": (_int, [_vp, _i64, _vp, _vp, _vp]),
-    "c2b_cameras_prepare_bal": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "c2b_camblk_doubles": (_i64, [_i64]),
+    "c2b_camblk_from_state": (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "c2b_camblk_from_bal": (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "c2b_cameras_from_position_direction": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "c2b_project_world": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "c2b_to_world": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
@@ -72,7 +73,6 @@ SIGNATURES = {
     "c2b_jacobian_outputs_log": (_int, [_vp, _vp, _int, C.POINTER(_int), C.POINTER(_int)]),
     "c2b_jacobian_outputs_free": (None, [_vp]),
     "c2b_calib_store_pattern": (_int, [_i64, _vp, _vp, _vp, _vp]),
-    "c2b_calib_store_pattern_map": (_int, [_i64, _vp, _vp, _vp, _int, _vp]),
     "c2b_calib_copy": (_int, [_vp, _vp, _i64, _vp]),
     "c2b_visibility_pairs": (_int, [_vp, _vp, _vp, _vp, _i64, _d, _vp, _vp, _vp]),
     "c2b_visibility_dense_tiles": (_i64, [_i64]),

@@ -232,7 +232,7 @@ class BAProblem:
         L.check(L.lib().c2b_problem_residual_jacobian(self._h, _ptr(r), _ptr(Jc), _ptr(Jp)))
         return r, Jc, Jp
 
-    def residual_jacobian_device(self, outputs=None, max_attempts=32):
+    def residual_jacobian_device(self, outputs=None, max_attempts=8):
         """residual + Jacobian of every observation in ONE launch with the results left on the device
         (c2b_problem_residual_jacobian_device): returns (outputs, sum_sq) -- outputs.r [n,2], .Jc [n,18], .Jp [n,6] are
         torch views of device arrays placed for streaming stores (device.JacobianOutputs; pass the object back in to

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "pow4_libm.hpp"
 
 namespace c2b {
 
@@ -247,26 +248,17 @@ struct Proj {
     double u, v;           // pixel             (project, src/baproblem.rs:145-151)
 };
 
-// x^4 correctly rounded: x^2 = h + l exactly (one FMA), h^2 = hh + hl exactly, x^4 = hh + (hl + 2 h l + l^2) with
-// the bracket accurate to ~2^-104 of the result, one final rounding.  Overflow / NaN / underflow-to-zero keep the
-// class pow() would return.
-C2B_DEV double pow4_cr(double x) {
-    const double h = x * x;
-    const double hh = h * h;
-    if (!(hh < __longlong_as_double(0x7ff0000000000000LL)) || hh == 0.0) return hh;
-    const double l = fma(x, x, -h);
-    const double hl = fma(h, h, -hh);
-    double t = fma(2.0 * h, l, hl);
-    t = fma(l, l, t);
-    return hh + t;
-}
+// |p|^4 the reference's way: libm's pow(|p|, 4.0), restated from glibc's machine code in pow4_libm.hpp (bit for bit the
+// image's pow on every argument class; tests/test_pow4.py, tests/test_gpu_parity.py).  The two tables (4 KB + 2 KB) live
+// in global memory: the rows a wave touches stay in the vector L1 / L2, and only cameras with k2 != 0 ever read them.
+// (Rounds 1-5 evaluated the correctly rounded x^4 here; the CPU checker had a second mode to match.  Both are gone.)
+__device__ const PowLogRow g_pow_log_tab[C2B_POW_LOG_ROWS] __attribute__((aligned(32))) = {C2B_POW_LOG_TAB};
+__device__ const PowExpRow g_pow_exp_tab[C2B_POW_EXP_ROWS] __attribute__((aligned(16))) = {C2B_EXP_TAB};
+C2B_DEV double pow4_libm(double x) { return pow4_glibc(x, g_pow_log_tab, g_pow_exp_tab); }
 
 // cam points at a camblk-shaped record (LDS or global).  The reference writes |p|^4 as p.magnitude().powf(4.0)
-// (src/baproblem.rs:147-149) = libm pow(sqrt(n), 4): here the CORRECTLY ROUNDED value of fl(sqrt(n))^4, which is what
-// glibc's pow returns in 99.9 % of cases (it is accurate to 0.52 ulp, not correctly rounded; the rest differ by
-// one ulp and cannot be reproduced without being glibc -- measured in tests/test_pow4.py).  With
-// k2 = 0 the term is k2 * n^4 = 0 whatever the rounding of n^4, so that (wave-uniform on the generators' cameras)
-// case skips the square root.
+// (src/baproblem.rs:147-149) = libm pow(sqrt(n), 4.0): pow4_libm above.  With k2 = 0 the term is k2 * n^4 = 0 whatever
+// the rounding of n^4, so that (wave-uniform on the generators' cameras) case skips the square root and the tables.
 // q1 = a1 / b and q2 = a2 / b, both IEEE-correct and bit-identical to the compiler's own expansion of `/` (the
 // v_div_scale / v_rcp / 4 FMA / v_div_fmas / v_div_fixup sequence, restated with the same builtins in the same order),
 // with the refined reciprocal of the shared denominator computed once: 16 instructions and one v_rcp_f64 instead of 22
@@ -298,21 +290,44 @@ C2B_DEV void div2_shared(double a1, double a2, double b, double &q1, double &q2)
 typedef const __attribute__((address_space(3))) double *lds_cptr;
 typedef const __attribute__((address_space(1))) double *glb_cptr;
 
+// The projection in the pieces the kernels assemble it from.
+//   project_head: project_world + the perspective divide + |p|^2;
+//   project_tail: the radial factor and the pixel, |p|^4 handed in;
+//   project_obs_k0: head + tail with |p|^4 = n * n -- FINAL when k2 == 0 (k2 * n^4 = 0 whatever the rounding of n^4), and what
+//     every observation of the generators' default cameras takes: straight-line code, nothing of pow() in it;
+//   project_obs: the reference's projection for any k2 -- |p|^4 = libm's pow(|p|, 4.0) (pow4_libm) when k2 != 0.
+// The per-observation kernels run project_obs_k0 on everything and, behind ONE wave-uniform branch on "some lane's k2 != 0",
+// project_obs again for those lanes (kernels.hpp): the pow4 code is register-hungry and they have no registers to spare, so it
+// runs where next to nothing else is live, and the common path is exactly the code of rounds 1-5.
 template <typename P>
-C2B_DEV Proj project_obs(P cam, double X, double Y, double Z) {
+C2B_DEV Proj project_head(P cam, double X, double Y, double Z) {
     Proj p;
     p.qx = dot3(cam[0], cam[1], cam[2], X, Y, Z) + cam[9];
     p.qy = dot3(cam[3], cam[4], cam[5], X, Y, Z) + cam[10];
     p.qz = dot3(cam[6], cam[7], cam[8], X, Y, Z) + cam[11];
     div2_shared(-p.qx, -p.qy, p.qz, p.px, p.py);            // -q.x / q.z, -q.y / q.z (src/baproblem.rs:146)
     p.n = p.px * p.px + p.py * p.py;
-    const double k2 = cam[14];
-    double n4 = p.n * p.n;
-    if (k2 != 0.0) n4 = pow4_cr(sqrt(p.n));
-    p.rad = 1.0 + cam[13] * p.n + k2 * n4;
-    const double fr = cam[12] * p.rad;
+    return p;
+}
+C2B_DEV void project_tail(Proj &p, double f, double k1, double k2, double n4) {
+    p.rad = 1.0 + k1 * p.n + k2 * n4;
+    const double fr = f * p.rad;
     p.u = fr * p.px;
     p.v = fr * p.py;
+}
+template <typename P>
+C2B_DEV Proj project_obs_k0(P cam, double X, double Y, double Z) {
+    Proj p = project_head(cam, X, Y, Z);
+    project_tail(p, cam[12], cam[13], cam[14], p.n * p.n);
+    return p;
+}
+template <typename P>
+C2B_DEV Proj project_obs(P cam, double X, double Y, double Z) {
+    Proj p = project_head(cam, X, Y, Z);
+    const double k2 = cam[14];
+    double n4 = p.n * p.n;
+    if (k2 != 0.0) n4 = pow4_libm(sqrt(p.n));
+    project_tail(p, cam[12], cam[13], k2, n4);
     return p;
 }
 

@@ -30,10 +30,6 @@
 #include "host_noise.hpp"
 #include "host_synthetic.hpp"
 #include "kernels.hpp"
-#ifdef C2B_TUNE
-#include "obs_pipeline.hpp"      // persistent pipelined variants: measured slower, tuning library only
-#include "obs_split.hpp"         // r05 experiment: loader wave + compute waves meeting in LDS (projection only)
-#endif
 #include "cull_kernels.hpp"
 #include "cell_kernels.hpp"
 #include "text_kernels.hpp"
@@ -123,88 +119,10 @@ inline unsigned *ws_ticket(void *workspace) {
     return workspace ? reinterpret_cast<unsigned *>(reinterpret_cast<double *>(workspace) + kWsTicket) : nullptr;
 }
 
-#ifdef C2B_TUNE
-// Tuning build only (libcity2ba_hip_tune.so, tools/tune_*.py): kernel variants, including timing-only ablations
-// whose outputs are wrong by construction.  None of this exists in the product library.
-int g_jac_variant = 0;        // 0 = the shipped kernel
-int g_obs_variant = 308;
-int g_stats_variant = 0;      // 0 = the shipped shape (kStatBlock x kStatBatch)
-int g_stats_grid_cap = kStatGrid;
-
-template <typename K>
-int persistent_grid(K kernel, int block_threads, int64_t work_blocks) {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!cached[dev]) {
-        int occ = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, 0) != hipSuccess || occ < 1) occ = 1;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached[dev] = occ * cus;
-    }
-    int64_t g = cached[dev];
-    if (g > work_blocks) g = work_blocks;
-    g = (g + 7) & ~(int64_t)7;
-    if (g < 8) g = 8;
-    if (g > 4096) g = 4096;
-    return (int)g;
-}
-
-// r05 experiment (obs_split.hpp): the projection with one loader wave and seven compute waves per workgroup
-template <int G, int K>
-void launch_project_split(const double *camblk, const double *pts4, const uint32_t *tiles, const uint32_t *pt_idx, int64_t n,
-                          double *uv_out, hipStream_t st, const uint64_t *row_ptr, int64_t n_cam) {
-    static unsigned *err = nullptr;                     // a leak of four bytes per process, tuning library only
-    if (!err) { (void)hipMalloc((void **)&err, 4); (void)hipMemset(err, 0, 4); }
-    const int n_tiles = (int)((n + 63) / 64), n_wg = (n_tiles + 7 * K - 1) / (7 * K);
-    hipLaunchKernelGGL((k_project_split<G, K, true>), dim3((unsigned)n_wg), dim3(512), 0, st, camblk, reinterpret_cast<const double4 *>(pts4),
-                       reinterpret_cast<const uint4 *>(tiles), pt_idx, (int)n, n_wg, reinterpret_cast<double2 *>(uv_out), row_ptr, (int)n_cam, err);
-}
-
-template <int MODE, int WPB>
-void launch_obs_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                  const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
-                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
-    const int64_t work = ((n >> 6) + WPB - 1) / WPB + 1;
-#define C2B_GO(NK)                                                                                                      \
-    do {                                                                                                                \
-        const int grid = persistent_grid(k_observations_p<MODE, NK, WPB>, WPB * 64, work);                              \
-        hipLaunchKernelGGL((k_observations_p<MODE, NK, WPB>), dim3(grid), dim3(WPB * 64), 0, st, camblk,                \
-                           reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                                   \
-                           reinterpret_cast<const double2 *>(uv_obs), (int)n, norm, max_dist,                          \
-                           reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum);                     \
-    } while (0)
-    if constexpr (MODE != MODE_ERROR) { C2B_GO(NORM_2); }
-    else if (norm == 2.0) C2B_GO(NORM_2);
-    else if (norm == 1.0) C2B_GO(NORM_1);
-    else C2B_GO(NORM_ANY);
-#undef C2B_GO
-}
-
-template <bool WITH_ERR, int WPB, int MINW>
-void launch_jac_p(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                  const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
-                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
-    const int64_t work = ((n_obs >> 6) + WPB - 1) / WPB + 1;
-#define C2B_GO(NK)                                                                                                      \
-    do {                                                                                                                \
-        const int grid = persistent_grid(k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>, WPB * 64, work);         \
-        hipLaunchKernelGGL((k_residual_jacobian_p<NK, WITH_ERR, WPB, MINW, true>), dim3(grid), dim3(WPB * 64), 0, st,  \
-                           camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                           \
-                           reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, norm, reinterpret_cast<double2 *>(r), \
-                           Jc, Jp, block_part, ticket, out_sum);                                                        \
-    } while (0)
-    if constexpr (!WITH_ERR) { C2B_GO(NORM_2); }
-    else if (norm == 2.0) C2B_GO(NORM_2);
-    else if (norm == 1.0) C2B_GO(NORM_1);
-    else C2B_GO(NORM_ANY);
-#undef C2B_GO
-}
-#endif
 
 // one-shot launch of k_observations<MODE, NK, OPL, WPB>: one workgroup per WPB * OPL tiles of 64 observations
 // CSR: cam_idx = the camera of every 64th observation, row_ptr / n_cam = the lists' boundaries (kernels.hpp)
-template <int MODE, int OPL, int WPB, int MINW = 1, bool FAKECI = false, bool CSR = false, bool NTS = false, int NTL = 0>
+template <int MODE, int OPL, int WPB, int MINW = 1, bool CSR = false, bool NTS = false, int NTL = 0>
 void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n, double norm, double max_dist, double *uv_out, uint8_t *keep,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
@@ -212,7 +130,7 @@ void launch_obs_v(const double *camblk, const double *pts4, const uint32_t *cam_
     static_assert(WPB * OPL >= 8, "two partials per workgroup must fit block_part_slots (one per 4 tiles)");
     const int tiles = (int)(((n + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, FAKECI, CSR, NTS, NTL>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,    \
+    hipLaunchKernelGGL((k_observations<MODE, NK, OPL, WPB, MINW, CSR, NTS, NTL>), dim3((unsigned)tiles), dim3(WPB * 64), 0, st,    \
                        camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,                               \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n, tiles, norm, max_dist,                       \
                        reinterpret_cast<double2 *>(uv_out), keep, block_part, ticket, out_sum, row_ptr, (int)n_cam, obs_base, seed)
@@ -244,77 +162,20 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
     constexpr int kMinW = MODE == MODE_NOISE_ERROR12 ? 8 : 1;
     if (row_ptr) {          // the *_rows entry points: cam_idx = the tile records of c2b_rows_pack
 #define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base, seed
-#ifdef C2B_TUNE
-        switch (g_obs_variant) {
-            case 20308: launch_obs_v<MODE, 3, 8, 1, false, true, false, 0>(C2B_ROWS_ARGS); return C2B_OK;   // everything cached (r02h)
-            case 21308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;    // non-temporal stores only
-            case 22308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;    // ... + observed uv
-            case 23308: launch_obs_v<MODE, 3, 8, 1, false, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;    // ... + point index
-            case 30108: launch_obs_v<MODE, 1, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // shipped policy, one tile per wave
-            case 30208: launch_obs_v<MODE, 2, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // two
-            case 30408: launch_obs_v<MODE, 4, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // four
-            case 30304: launch_obs_v<MODE, 3, 4, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // three, four waves per workgroup
-            case 4066: if constexpr (MODE == MODE_PROJECT) { launch_project_split<6, 6>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
-            case 4046: if constexpr (MODE == MODE_PROJECT) { launch_project_split<4, 6>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
-            case 4612: if constexpr (MODE == MODE_PROJECT) { launch_project_split<6, 12>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
-            case 4088: if constexpr (MODE == MODE_PROJECT) { launch_project_split<8, 8>(camblk, pts4, cam_idx, pt_idx, n, uv_out, st, row_ptr, n_cam); return C2B_OK; } break;
-            case 30508: launch_obs_v<MODE, 5, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // r05: five tiles per wave
-            case 30608: launch_obs_v<MODE, 6, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // six
-            case 30604: launch_obs_v<MODE, 6, 4, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // six, four waves per workgroup
-            case 30808: launch_obs_v<MODE, 8, 8, 1, false, true, true, kNTL>(C2B_ROWS_ARGS); return C2B_OK;   // eight
-            default: break;
-        }
-#endif
-        launch_obs_v<MODE, 3, 8, kMinW, false, true, true, kNTL>(C2B_ROWS_ARGS);
+        launch_obs_v<MODE, 3, 8, kMinW, true, true, kNTL>(C2B_ROWS_ARGS);
 #undef C2B_ROWS_ARGS
         return C2B_OK;
     }
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st
-#ifdef C2B_TUNE
-    switch (g_obs_variant) {
-        case 108: launch_obs_v<MODE, 1, 8>(C2B_ARGS); return C2B_OK;
-        case 216: launch_obs_v<MODE, 2, 16>(C2B_ARGS); return C2B_OK;
-        case 204: launch_obs_v<MODE, 2, 4>(C2B_ARGS); return C2B_OK;
-        case 208: launch_obs_v<MODE, 2, 8>(C2B_ARGS); return C2B_OK;
-        case 1308: launch_obs_v<MODE, 3, 8, 8>(C2B_ARGS); return C2B_OK;    // 3 tiles per wave, registers capped for 8 waves per SIMD
-        case 9308: launch_obs_v<MODE, 3, 8, 1, true>(C2B_ARGS); return C2B_OK;   // ablation: camera index computed, not loaded (wrong outputs)
-        case 408: launch_obs_v<MODE, 4, 8>(C2B_ARGS); return C2B_OK;
-        case 20308: launch_obs_v<MODE, 3, 8>(C2B_ARGS); return C2B_OK;                              // everything cached (r02h)
-        case 23308: launch_obs_v<MODE, 3, 8, 1, false, false, true, 3>(C2B_ARGS); return C2B_OK;   // every stream non-temporal
-        case 2004: launch_obs_p<MODE, 4>(C2B_ARGS); return C2B_OK;       // persistent pipelined forms (obs_pipeline.hpp)
-        case 2008: launch_obs_p<MODE, 8>(C2B_ARGS); return C2B_OK;
-        case 2016: launch_obs_p<MODE, 16>(C2B_ARGS); return C2B_OK;
-        default: break;
-    }
-#endif
-    launch_obs_v<MODE, 3, 8, kMinW, false, false, true, kNTL>(C2B_ARGS);    // shipped (308): three tiles of 64 per wave
+    launch_obs_v<MODE, 3, 8, kMinW, false, true, kNTL>(C2B_ARGS);    // shipped (308): three tiles of 64 per wave
 #undef C2B_ARGS
     return C2B_OK;
 }
 
-#ifdef C2B_TUNE
-template <bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL, int OPL, bool LDSCAM>
-void launch_jac_w(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
-                  const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
-                  double *block_part, unsigned *ticket, double *out_sum, hipStream_t st) {
-    const int64_t wave_tiles = (n_obs + 63) / 64;
-    const int64_t btiles = (wave_tiles + WPB * OPL - 1) / (WPB * OPL);
-#define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_w<NK, WITH_ERR, WPB, SPLIT, NT, ABL, OPL, LDSCAM>), dim3((unsigned)btiles), \
-                       dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
-                       reinterpret_cast<const double2 *>(uv_obs), n_obs, btiles, norm, reinterpret_cast<double2 *>(r), \
-                       Jc, Jp, block_part, ticket, out_sum)
-    if constexpr (!WITH_ERR) { C2B_GO(NORM_2); }
-    else if (norm == 2.0) C2B_GO(NORM_2);
-    else if (norm == 1.0) C2B_GO(NORM_1);
-    else C2B_GO(NORM_ANY);
-#undef C2B_GO
-}
-#endif
 
 // CSR: cam_idx = the tile records of c2b_rows_pack for this launch's first observation (= observation obs_base of
 // the list row_ptr describes)
-template <bool WITH_ERR, int WPB, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false, int NTL = 0, bool NTS = true>
+template <bool WITH_ERR, int WPB, int OPL, int MINW, bool OBUP = true, bool CSR = false, int NTL = 0, bool NTS = true>
 void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_idx, const uint32_t *pt_idx,
                   const double *uv_obs, int64_t n_obs, double *r, double *Jc, double *Jp, double norm,
                   double *block_part, unsigned *ticket, double *out_sum, hipStream_t st,
@@ -324,13 +185,13 @@ void launch_jac_l(const double *camblk, const double *pts4, const uint32_t *cam_
     // at 128 without scratch (tests/test_isa_pins.py); WITHOUT the sum the cap would spill 20 bytes, so a launch that wants no sum
     // takes the one-tile shape of the same workgroup count per CU instead (0 ... 2 % behind in fast output sets, nothing to fold).
     if constexpr (!WITH_ERR && WPB == 8 && OPL == 2 && MINW == 1) {
-        launch_jac_l<WITH_ERR, 16, 1, MINW, XK, OBUP, CSR, NTL, NTS>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket,
+        launch_jac_l<WITH_ERR, 16, 1, MINW, OBUP, CSR, NTL, NTS>(camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket,
                                                                      out_sum, st, row_ptr, n_cam, obs_base);
     } else {
     const int btiles = (int)(((n_obs + 63) / 64 + WPB * OPL - 1) / (WPB * OPL));
     constexpr int kMinW = (MINW == 1 && OPL == 2) ? 4 : MINW;
 #define C2B_GO(NK)                                                                                                      \
-    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, NTS, OPL, kMinW, XK, OBUP, CSR, NTL>), dim3((unsigned)btiles),        \
+    hipLaunchKernelGGL((k_residual_jacobian_l<NK, WITH_ERR, WPB, NTS, OPL, kMinW, OBUP, CSR, NTL>), dim3((unsigned)btiles),        \
                        dim3(WPB * 64), 0, st, camblk, reinterpret_cast<const double4 *>(pts4), cam_idx, pt_idx,        \
                        reinterpret_cast<const double2 *>(uv_obs), (int)n_obs, btiles, norm,                            \
                        reinterpret_cast<double2 *>(r), Jc, Jp, block_part, ticket, out_sum, row_ptr, (int)n_cam, obs_base)
@@ -402,114 +263,31 @@ int launch_jacobian(const double *camblk, const double *pts4, const uint32_t *ca
     unsigned *ticket = ws_ticket(workspace);
     if (row_ptr) {          // the *_rows entry points
 #define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base
-#ifdef C2B_TUNE
-        switch (g_jac_variant) {
-            case 51: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;    // every load cached
-            case 52: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;    // non-temporal observed uv
-            case 53: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;    // ... and point index
-            case 61:                                                                                      // one tile per wave whatever the size, streams by the size rule
-                switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
-                    case 3: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
-                    case 2: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
-                    default: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
-                }
-                return C2B_OK;
-            // r05: the A/B of VERDICT r04 item 1 (tools/ab_slow_store.py): the shipped instance at --blocks 128 is <8, 2, ntl 3>
-            case 700: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // = shipped there
-            case 701: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // one tile per wave
-            case 702: launch_jac_l<WITH_ERR, 8, 3, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // three
-            case 703: launch_jac_l<WITH_ERR, 4, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 256-thread workgroups
-            case 704: launch_jac_l<WITH_ERR, 4, 4, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // ... four tiles per wave
-            case 705: launch_jac_l<WITH_ERR, 8, 2, 1, 0, false, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // observed uv requested per tile
-            case 706: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3, false>(C2B_ROWS_ARGS); return C2B_OK;   // plain (cached) stores
-            case 707: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;          // every load cached
-            case 708: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 1>(C2B_ROWS_ARGS); return C2B_OK;          // point index non-temporal only
-            case 709: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;          // observed uv non-temporal only
-            case 712: launch_jac_l<WITH_ERR, 8, 1, 1, 0, true, true, 3, false>(C2B_ROWS_ARGS); return C2B_OK;   // one tile, plain stores
-            case 713: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 256 threads, one tile
-            case 714: launch_jac_l<WITH_ERR, 8, 2, 1, 4, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // XCD map in chunks of 4 workgroups
-            case 715: launch_jac_l<WITH_ERR, 8, 2, 1, 64, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // ... of 64
-            case 716: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); return C2B_OK;          // 256 threads, one tile, every load cached
-            case 717: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); return C2B_OK;          // ... uv nt only
-            case 718: launch_jac_l<WITH_ERR, 4, 1, 1, 0, false, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // ... uv requested per tile
-            case 719: launch_jac_l<WITH_ERR, 2, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;          // 128 threads, two tiles
-            case 720: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 1024 threads, one tile
-            case 721: launch_jac_l<WITH_ERR, 4, 1, 1, 64, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 256 threads, one tile, XCD map in chunks of 64
-            case 730: launch_jac_l<WITH_ERR, 16, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); return C2B_OK;         // 1024 threads, two tiles
-            case 722: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3, false>(C2B_ROWS_ARGS); return C2B_OK;   // 256 threads, one tile, plain stores
-            case 64:                                                                                      // two tiles per wave whatever the size
-                switch (jacobian_stream_policy(n_obs, n_cam, n_pts)) {
-                    case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
-                    case 2: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
-                    default: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
-                }
-                return C2B_OK;
-            default: break;
-        }
-#endif
         const int policy = jacobian_stream_policy(n_obs, n_cam, n_pts);
         const JacShape shape = jacobian_shape(n_obs, store_GBs);
         if (shape.wpb == 4) {                                   // a slow-store output set: 256 threads x one tile
             switch (policy) {
-                case 3: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
-                case 2: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
-                default: launch_jac_l<WITH_ERR, 4, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+                case 3: launch_jac_l<WITH_ERR, 4, 1, 1, true, true, 3>(C2B_ROWS_ARGS); break;
+                case 2: launch_jac_l<WITH_ERR, 4, 1, 1, true, true, 2>(C2B_ROWS_ARGS); break;
+                default: launch_jac_l<WITH_ERR, 4, 1, 1, true, true, 0>(C2B_ROWS_ARGS); break;
             }
         } else if (shape.opl == 1) {                           // below ~6 M observations, or a set between the store classes: 1 024 threads x one tile
             switch (policy) {
-                case 3: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
-                case 2: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
-                default: launch_jac_l<WITH_ERR, 16, 1, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+                case 3: launch_jac_l<WITH_ERR, 16, 1, 1, true, true, 3>(C2B_ROWS_ARGS); break;
+                case 2: launch_jac_l<WITH_ERR, 16, 1, 1, true, true, 2>(C2B_ROWS_ARGS); break;
+                default: launch_jac_l<WITH_ERR, 16, 1, 1, true, true, 0>(C2B_ROWS_ARGS); break;
             }
         } else {
             switch (policy) {
-                case 3: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 3>(C2B_ROWS_ARGS); break;
-                case 2: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 2>(C2B_ROWS_ARGS); break;
-                default: launch_jac_l<WITH_ERR, 8, 2, 1, 0, true, true, 0>(C2B_ROWS_ARGS); break;
+                case 3: launch_jac_l<WITH_ERR, 8, 2, 1, true, true, 3>(C2B_ROWS_ARGS); break;
+                case 2: launch_jac_l<WITH_ERR, 8, 2, 1, true, true, 2>(C2B_ROWS_ARGS); break;
+                default: launch_jac_l<WITH_ERR, 8, 2, 1, true, true, 0>(C2B_ROWS_ARGS); break;
             }
         }
 #undef C2B_ROWS_ARGS
         return C2B_OK;
     }
 #define C2B_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n_obs, r, Jc, Jp, norm, block_part, ticket, out_sum, st
-#ifdef C2B_TUNE
-    switch (g_jac_variant) {
-        case 14: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, true>(C2B_ARGS); return C2B_OK;      // rounds 1-2a: two code paths (LDS / FLAT fallback), 64-bit indices
-        case 9: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, false>(C2B_ARGS); return C2B_OK;
-        case 13: launch_jac_w<WITH_ERR, 8, 2, true, 0, 2, false>(C2B_ARGS); return C2B_OK;     // FLAT camera reads
-        case 16: launch_jac_w<WITH_ERR, 8, 2, true, 0, 1, true>(C2B_ARGS); return C2B_OK;
-        case 17: launch_jac_w<WITH_ERR, 8, 2, false, 0, 2, true>(C2B_ARGS); return C2B_OK;    // shipped structure, plain (not nt) stores
-        case 18: launch_jac_w<WITH_ERR, 4, 2, true, 0, 2, true>(C2B_ARGS); return C2B_OK;     // 256-thread workgroups
-        case 31: {                                                                                  // store pattern only, plain stores
-            const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
-            hipLaunchKernelGGL((k_store_pattern<false, 8>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp);
-            return C2B_OK;
-        }
-        case 20: launch_jac_w<WITH_ERR, 8, 2, true, 1, 2, false>(C2B_ARGS); return C2B_OK;     // no Jacobian stores
-        case 21: launch_jac_w<WITH_ERR, 8, 2, true, 2, 2, false>(C2B_ARGS); return C2B_OK;     // no arithmetic
-        case 40: launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS); return C2B_OK;      // lean form, observed uv requested up front
-        case 49: launch_jac_l<WITH_ERR, 8, 2, 1, 0, false>(C2B_ARGS); return C2B_OK;   // ... requested per tile
-        case 50: launch_jac_l<WITH_ERR, 8, 2, 4, 0, true>(C2B_ARGS); return C2B_OK;    // up front, registers capped for 4 waves per SIMD
-        case 42: launch_jac_l<WITH_ERR, 8, 1, 1>(C2B_ARGS); return C2B_OK;      // one tile per wave
-        case 44: launch_jac_l<WITH_ERR, 8, 2, 1, 1>(C2B_ARGS); return C2B_OK;     // tiles in launch order (no XCD-aware map)
-        case 45: launch_jac_l<WITH_ERR, 8, 2, 1, 4>(C2B_ARGS); return C2B_OK;     // chunked XCD map, K = 4
-        case 46: launch_jac_l<WITH_ERR, 8, 2, 1, 16>(C2B_ARGS); return C2B_OK;    // K = 16
-        case 47: launch_jac_l<WITH_ERR, 8, 2, 1, 64>(C2B_ARGS); return C2B_OK;    // K = 64
-        case 48: launch_jac_l<WITH_ERR, 8, 2, 1, 256>(C2B_ARGS); return C2B_OK;   // K = 256
-        case 32: {                                                                 // store pattern only, tiles in launch order
-            const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
-            hipLaunchKernelGGL((k_store_pattern<true, 8, false>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp);
-            return C2B_OK;
-        }
-        case 43: launch_jac_l<WITH_ERR, 8, 3, 1>(C2B_ARGS); return C2B_OK;      // three tiles per wave
-        case 100: launch_jac_p<WITH_ERR, 8, 4>(C2B_ARGS); return C2B_OK;     // persistent pipelined forms (obs_pipeline.hpp)
-        case 104: launch_jac_p<WITH_ERR, 4, 1>(C2B_ARGS); return C2B_OK;     // 12 waves per CU at the natural register count
-        case 105: launch_jac_p<WITH_ERR, 4, 4>(C2B_ARGS); return C2B_OK;     // 16 waves per CU (spills)
-        case 108: launch_jac_p<WITH_ERR, 8, 1>(C2B_ARGS); return C2B_OK;     //  8 waves per CU
-        case 116: launch_jac_p<WITH_ERR, 16, 4>(C2B_ARGS); return C2B_OK;    // 16 waves per CU, one workgroup
-        default: break;
-    }
-#endif
     if (n_obs < kJacOneTileBelow) launch_jac_l<WITH_ERR, 16, 1, 1>(C2B_ARGS);  // shipped: lean form, one tile per wave in 1 024-thread workgroups (the grid of the rows form: same sum bits) ...
     else launch_jac_l<WITH_ERR, 8, 2, 1>(C2B_ARGS);                        // ... or two (= variant 40), by size
 #undef C2B_ARGS
@@ -528,30 +306,6 @@ template <typename Src>
 int stats_impl(const Src &src, int64_t n, void *workspace, double *stats, hipStream_t st) {
     double *rec = reinterpret_cast<double *>(workspace);
     const ShardMap whole{src.n_cam, 0, src.n_cam, 0};
-#ifdef C2B_TUNE
-#define C2B_STATS_GO(BLOCK, BATCH, PIPE, CHUNK)                                                                          \
-    hipLaunchKernelGGL((k_stats_pass1<Src, true, BLOCK, BATCH, PIPE, CHUNK>), dim3(stats_grid(n, BLOCK, g_stats_grid_cap)), dim3(BLOCK), 0, st, src, n, \
-                       (double)n, rec, ws_ticket(workspace), whole, stats);                                              \
-    LAUNCH_CHECK();                                                                                                      \
-    return C2B_OK
-    switch (g_stats_variant) {                  // workgroup size x entities per thread and trip, pipelined?, chunked?
-        case 1: C2B_STATS_GO(256, 4, false, false);           // the r03 / r04 shape
-        case 2: C2B_STATS_GO(512, 4, false, false);
-        case 3: C2B_STATS_GO(256, 4, true, false);
-        case 4: C2B_STATS_GO(512, 4, true, false);
-        case 5: C2B_STATS_GO(256, 2, true, false);
-        case 6: C2B_STATS_GO(512, 2, true, false);
-        case 7: C2B_STATS_GO(256, 4, false, true);
-        case 8: C2B_STATS_GO(256, 4, true, true);
-        case 9: C2B_STATS_GO(512, 4, true, true);
-        case 10: C2B_STATS_GO(256, 2, true, true);
-        case 11: C2B_STATS_GO(512, 2, true, true);
-        case 12: C2B_STATS_GO(256, 8, false, true);
-        case 13: C2B_STATS_GO(256, 3, true, true);
-        default: break;
-    }
-#undef C2B_STATS_GO
-#endif
     hipLaunchKernelGGL((k_stats_pass1<Src, true>), dim3(stats_grid(n, kStatBlock)), dim3(kStatBlock), 0, st, src, n, (double)n, rec,
                        ws_ticket(workspace), whole, stats);
     LAUNCH_CHECK();
@@ -609,7 +363,7 @@ int sin_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts, c
 
 extern "C" {
 
-const char *c2b_version(void) { return "city2ba_hip 0.1.0 (gfx950)"; }
+const char *c2b_version(void) { return "city2ba_hip 0.6.0 (gfx950)"; }
 const char *c2b_last_error(void) { return g_err; }
 
 int c2b_device_count(int *count) {
@@ -659,38 +413,6 @@ int64_t c2b_workspace_bytes(int64_t n_obs) {
     return (kWsBlockPart + block_part_slots(n_obs)) * (int64_t)sizeof(double);
 }
 
-#ifdef C2B_TUNE
-// tuning hooks of libcity2ba_hip_tune.so (tools/tune_jac.py, tools/tune_obs.py); absent from the product library
-int c2b_tune_set_jacobian_variant(int v) { g_jac_variant = v; return C2B_OK; }
-int c2b_tune_set_observation_variant(int v) { g_obs_variant = v; return C2B_OK; }
-int c2b_tune_set_stats_variant(int v) { g_stats_variant = v % 100; g_stats_grid_cap = v >= 200 ? 1024 : (v >= 100 ? 768 : kStatGrid); return C2B_OK; }
-int c2b_tune_set_stagger(int units_of_64_cycles) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &units_of_64_cycles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
-}
-int c2b_tune_set_cam_stride(int doubles) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_stride), &doubles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
-}
-int c2b_tune_set_cam_block(int log2_cameras) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_block), &log2_cameras, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
-}
-int c2b_tune_set_cam_swizzle(int doubles) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_cam_swz), &doubles, sizeof(int)) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
-}
-// experiment (r05): the step kernel's store geometry under store cache policy `pol` (kernels.hpp: store16_pol)
-int c2b_tune_store_pattern_policy(int64_t n_obs, double *r, double *Jc, double *Jp, int pol, void *stream) {
-    const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define C2B_POL(P) case P: hipLaunchKernelGGL((k_store_pattern_pol<P>), dim3((unsigned)bt), dim3(512), 0, st, n_obs, bt, reinterpret_cast<double2 *>(r), Jc, Jp); break
-    switch (pol) { C2B_POL(0); C2B_POL(1); C2B_POL(2); C2B_POL(3); C2B_POL(4); C2B_POL(5); C2B_POL(6); C2B_POL(7); default: return C2B_ERR_INVALID_ARGUMENT; }
-#undef C2B_POL
-    return hipGetLastError() == hipSuccess ? C2B_OK : C2B_ERR_HIP;
-}
-// hand the time-stamp probe a device buffer of (workgroups x 8) u64 (NULL = off)
-int c2b_tune_set_probe(void *device_buffer) {
-    unsigned long long *p = reinterpret_cast<unsigned long long *>(device_buffer);
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &p, sizeof p) == hipSuccess ? C2B_OK : C2B_ERR_HIP;
-}
-#endif
 
 #include "capi_level0.hpp"
 #include "capi_host_rows.hpp"

@@ -24,26 +24,34 @@ int c2b_cameras_to_bal(const double *cam15, int64_t n, double *bal9, void *strea
     C2B_API_END("cameras_to_bal")
 }
 
-int c2b_cameras_prepare_state(const double *cam15, int64_t n, double *camblk, double *cen4, void *stream) {
+int64_t c2b_camblk_doubles(int64_t n_cam) { return n_cam > 0 ? cam_table_doubles(n_cam) : 0; }
+
+int c2b_camblk_from_state(const double *cam15, int64_t n, double *camblk, int64_t camblk_doubles, double *cen4, void *stream) {
     C2B_API_BEGIN
-    if (n < 0 || (n && (!cam15 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_state: bad arguments");
+    if (n < 0 || (n && (!cam15 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk_from_state: bad arguments");
     if (!n) return C2B_OK;
+    if (camblk_doubles < cam_table_doubles(n))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "camblk_from_state: the table holds whole groups of 8 cameras -- %lld doubles for %lld cameras, the buffer has %lld",
+                    (long long)cam_table_doubles(n), (long long)n, (long long)camblk_doubles);
     if (!aligned16(camblk) || !aligned16(cen4)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk / cen4 must be 16-byte aligned");
     hipLaunchKernelGGL(k_cameras_prepare<false>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), cam15, n, camblk, cen4);
     LAUNCH_CHECK();
     return C2B_OK;
-    C2B_API_END("cameras_prepare_state")
+    C2B_API_END("camblk_from_state")
 }
 
-int c2b_cameras_prepare_bal(const double *bal9, int64_t n, double *camblk, double *cen4, void *stream) {
+int c2b_camblk_from_bal(const double *bal9, int64_t n, double *camblk, int64_t camblk_doubles, double *cen4, void *stream) {
     C2B_API_BEGIN
-    if (n < 0 || (n && (!bal9 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "cameras_prepare_bal: bad arguments");
+    if (n < 0 || (n && (!bal9 || !camblk))) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk_from_bal: bad arguments");
     if (!n) return C2B_OK;
+    if (camblk_doubles < cam_table_doubles(n))
+        return fail(C2B_ERR_INVALID_ARGUMENT, "camblk_from_bal: the table holds whole groups of 8 cameras -- %lld doubles for %lld cameras, the buffer has %lld",
+                    (long long)cam_table_doubles(n), (long long)n, (long long)camblk_doubles);
     if (!aligned16(camblk) || !aligned16(cen4)) return fail(C2B_ERR_INVALID_ARGUMENT, "camblk / cen4 must be 16-byte aligned");
     hipLaunchKernelGGL(k_cameras_prepare<true>, dim3(blocks_for(n)), dim3(kBlock), 0, S(stream), bal9, n, camblk, cen4);
     LAUNCH_CHECK();
     return C2B_OK;
-    C2B_API_END("cameras_prepare_bal")
+    C2B_API_END("camblk_from_bal")
 }
 
 int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, int64_t n, double *cam15,
@@ -410,19 +418,6 @@ int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, vo
     C2B_API_END("calib_store_pattern")
 }
 
-int c2b_calib_store_pattern_map(int64_t n_obs, double *r, double *Jc, double *Jp, int tile_map, void *stream) {
-    C2B_API_BEGIN
-    if (n_obs < 0 || tile_map < 0 || (n_obs && (!r || !Jc || !Jp)) || !aligned16(r) || !aligned16(Jc) || !aligned16(Jp))
-        return fail(C2B_ERR_INVALID_ARGUMENT, "calib_store_pattern_map: bad arguments");
-    if (n_obs < 64) return C2B_OK;
-    const int64_t wt = (n_obs + 63) / 64, bt = (wt + 7) / 8;
-    hipLaunchKernelGGL((k_store_pattern_map<true, 8>), dim3((unsigned)bt), dim3(512), 0, S(stream), n_obs, bt, tile_map,
-                       reinterpret_cast<double2 *>(r), Jc, Jp);
-    LAUNCH_CHECK();
-    return C2B_OK;
-    C2B_API_END("calib_store_pattern_map")
-}
-
 int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream) {
     C2B_API_BEGIN
     if (bytes < 0 || (bytes && (!src || !dst)) || !aligned16(src) || !aligned16(dst) || (bytes & 15))
@@ -489,12 +484,15 @@ int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_stor
     std::unique_ptr<c2b_jacobian_outputs> h(new c2b_jacobian_outputs);
     HIP_TRY(hipGetDevice(&h->device));
     h->n_obs = n_obs;
+    size_t free_at_call = 0;
     if (max_attempts > 1) {                            // the rejects are HELD during the search: at most 3/4 of what is free now
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        size_t total_b = 0;
+        if (hipMemGetInfo(&free_at_call, &total_b) == hipSuccess) {
             const size_t set_b = (size_t)(n_obs > 0 ? n_obs : 1) * 208;
-            const size_t fit = free_b / 4 * 3 / (set_b > kPlacementStride ? set_b : kPlacementStride);
+            const size_t fit = free_at_call / 4 * 3 / (set_b > kPlacementStride ? set_b : kPlacementStride);
             if ((size_t)max_attempts > fit) max_attempts = fit < 1 ? 1 : (int)fit;
+        } else {
+            free_at_call = 0;
         }
     }
     std::vector<OutSet> sets((size_t)max_attempts);
@@ -516,6 +514,13 @@ int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_stor
     int best = -1;
     hipError_t err = hipSuccess;
     for (int a = 0; a < (measure ? max_attempts : 1); ++a) {
+        // the bound above was computed once; another process, rank or allocator sharing the device may have taken
+        // memory since.  Asked again before every further attempt: the search stops, with the best set so far, as soon as less
+        // than a quarter of what was free at the call (plus one more set) is left.
+        if (a > 0 && free_at_call) {
+            size_t free_now = 0, total_b = 0;
+            if (hipMemGetInfo(&free_now, &total_b) == hipSuccess && free_now < free_at_call / 4 + set_bytes) break;
+        }
         err = alloc_set(n_obs, &sets[a]);
         if (err != hipSuccess) {
             if (best >= 0 && err == hipErrorOutOfMemory) { (void)hipGetLastError(); err = hipSuccess; }   // keep the best so far

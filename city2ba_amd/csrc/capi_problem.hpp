@@ -115,8 +115,8 @@ void c2b_problem_destroy(c2b_problem *p) {
 
 static int ensure_camblk(c2b_problem *p) {
     if (p->blk_valid) return C2B_OK;
-    int rc = p->bal_valid ? c2b_cameras_prepare_bal(p->bal9, p->n_cam, p->camblk, p->cen4, p->stream)
-                          : c2b_cameras_prepare_state(p->cam15, p->n_cam, p->camblk, p->cen4, p->stream);
+    int rc = p->bal_valid ? c2b_camblk_from_bal(p->bal9, p->n_cam, p->camblk, cam_table_doubles(p->n_cam), p->cen4, p->stream)
+                          : c2b_camblk_from_state(p->cam15, p->n_cam, p->camblk, cam_table_doubles(p->n_cam), p->cen4, p->stream);
     if (rc) return rc;
     p->blk_valid = true;
     return C2B_OK;

@@ -32,26 +32,6 @@ constexpr bool kStatChunk = false;   // contiguous entities per workgroup instea
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-// Tuning build only: a time-stamp probe (tools/tune_stats.py --probe): thread 0 of every workgroup writes the constant-rate
-// wall clock (100 MHz) into slot `k` of its row of a buffer the tool hands over; nothing of it exists in the product library.
-#ifdef C2B_TUNE
-__device__ int g_stagger = 0;        // k_observations: wave w of a workgroup sleeps w * g_stagger * 64 cycles before its first load
-__device__ int g_cam_stride = 0;     // k_observations (project / error modes): doubles between camera records (0 = kCamBlk); 16 = a compact table of the light line
-__device__ int g_cam_swz = 0;        // ... doubles added to an ODD camera's record address (16: its light line sits in the second half of its 256 bytes)
-__device__ int g_cam_block = 0;      // ... log2 B (0 = the product's table, -1 = interleaved 256-byte records): BLOCKED table -- the light lines of B consecutive cameras contiguous (B x 128 bytes), their heavy lines behind them
-__device__ unsigned long long *g_probe = nullptr;
-#define C2B_PROBE(k) do { if (g_probe != nullptr && threadIdx.x == 0) g_probe[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-// k_observations' variant (tools/probe_wave_phases.py): the stamps of wave 0 stay in scalar registers until the wave ends (a store per
-// stamp would sit in the wave's own memory counter); OBS_ARRIVED waits for everything requested so far, at points where the code
-// needs those results next anyway
-#define OBS_STAMP(k) do { if (probing) tp[k] = wall_clock64(); } while (0)
-#define OBS_ARRIVED() do { if (probing) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
-#else
-#define C2B_PROBE(k) do { } while (0)
-#define OBS_STAMP(k) do { } while (0)
-#define OBS_ARRIVED() do { } while (0)
-#endif
-
 // ---- XCD-aware tile map (bijective for any n_tiles; cdna guide T1) -----------------------
 C2B_DEV int64_t xcd_tile(int64_t bid, int64_t n_tiles) {
     const int64_t q = n_tiles >> 3, r = n_tiles & 7;
@@ -460,30 +440,9 @@ C2B_DEV void rows_cameras(const uint4 *__restrict__ tiles, const uint64_t *__res
 // than kCamW cameras in 64 observations) read global memory instead: correct, just slower.
 constexpr int kCamW = 12;                      // cameras staged per wave
 
-#if defined(C2B_TUNE) || defined(C2B_STORE_POL)
-// experiment (r05): the same store geometry under every cache-policy spelling a gfx950 global store has.  The product's
-// non-temporal store is `nt`; sc0 / sc1 are the scope bits (sc1 = agent: the line is written through the XCD's L2).
-// POL: 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 nt sc0, 6 nt sc1, 7 nt sc0 sc1.
-template <int POL>
-C2B_DEV void store16_pol(char *dst, const double2 v) {
-    d2_t t; t.x = v.x; t.y = v.y;
-    if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dst), "v"(t) : "memory");
-    if (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(t) : "memory");
-}
-#endif
 
 template <bool NT>
 C2B_DEV void store16(char *dst, const double2 v) {
-#ifdef C2B_STORE_POL
-    // experiment (r05, tools/probe_store_policy.py --kernel): a build of the library whose non-temporal stores are spelled C2B_STORE_POL
-    if (NT) { store16_pol<C2B_STORE_POL>(dst, v); return; }
-#endif
     if (NT) {
         d2_t t; t.x = v.x; t.y = v.y;
         __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(dst));
@@ -542,39 +501,19 @@ C2B_DEV int xcd_tile32(int bid, int n_tiles) {
 }
 
 // doubles from the table's start to chunk j of a camera's staged row: chunks 0..7 = its light line, 8.. = its centre (the
-// visibility predicate's; heavy line, record doubles 24..).  The tuning build's other layouts (kernels.hpp top) apply to the
-// light line only.
-C2B_DEV int64_t cam_row(int64_t c, int j, int stride, int swz, int log2_block) {
+// visibility predicate's; heavy line, record doubles 24..)
+C2B_DEV int64_t cam_row(int64_t c, int j) {
     if (j >= kCamLight / 2) return cam_center_at(c) + 2 * (j - kCamLight / 2);
-#ifdef C2B_TUNE
-    if (log2_block > 0) return ((c >> log2_block) << log2_block) * kCamBlk + (c & ((1 << log2_block) - 1)) * 16 + 2 * j;
-    if (log2_block < 0 || stride != kCamBlk || swz != 0) return c * stride + ((c & 1) ? swz : 0) + 2 * j;     // (-1: the interleaved records of rounds 1-5)
-#endif
     return cam_light_at(c) + 2 * j;
 }
 
 // MINW = waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument)
-// Chunked XCD map: consecutive workgroups go round-robin over the 8 XCDs; XCD x takes K consecutive tile-blocks of
-// every super-tile of 8K, so each XCD's L2 sees K neighbouring blocks (camera / point reuse) while the whole chip writes
-// inside one moving window of 8K blocks (DRAM locality of the output streams).  K = 1 is launch order, K = n/8 the
-// contiguous-eighths map of xcd_tile32.  Blocks past the last whole super-tile keep launch order.  Bijective.
-template <int K>
-C2B_DEV int xcd_tile_chunked(int bid, int n_tiles) {
-    if (K <= 1) return bid;
-    const int whole = n_tiles / (8 * K) * (8 * K);
-    if (bid >= whole) return bid;
-    const int xcd = bid & 7, k = bid >> 3;
-    return (k / K) * (8 * K) + xcd * K + (k % K);
-}
-
-// FAKECI (tuning library only; WRONG outputs): derive the camera index from the observation index instead of loading
-// it -- what the kernels would cost if cam_idx were not 4 of their ~25 bytes per observation.
 //
 // CSR: the camera of an observation comes from the reference's own structure -- one list per camera, i.e. row_ptr
 // (src/baproblem.rs:256-260) -- instead of a 4-byte index per observation: `cam_idx` then points at the tile records
 // k_csr_pack derives from row_ptr (16 bytes per 64 observations).  SURVEY 8(d)'s algorithmic bytes assume exactly
 // this: 4 B of point index per observation and the row structure once.
-template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1, bool FAKECI = false,
+template <int MODE, int NK = NORM_2, int OPL = kObsOPL, int WPB = kObsWPB, int MINW = 1,
           bool CSR = false, bool NTS = false, int NTL = 0>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
@@ -614,23 +553,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
     double eacc = 0.0, eacc1 = 0.0;                                      // MODE_*ERROR12: eacc1 = the L1 sum, eacc = the L2 sum
-#ifdef C2B_TUNE
-    const bool probing = g_probe != nullptr;
-    unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    OBS_STAMP(0);
-    const int cam_stride = g_cam_stride ? g_cam_stride : kCamBlk;        // experiment (r05): a compact 128-byte-per-camera table
-    const int cam_swz = g_cam_swz, cam_block = g_cam_block;
-#else
-    constexpr int cam_stride = kCamBlk, cam_swz = 0, cam_block = 0;
-#endif
-#ifdef C2B_TUNE
-    // experiment (r05): do the waves of a workgroup, started in lockstep, serialise on each other's phases?  Stagger them.
-    for (int k = wave * g_stagger; k > 0; --k) __builtin_amdgcn_s_sleep(1);
-    // ... or do the WORKGROUPS that share a CU convoy (all four in their load phase, then all four computing)?  A negative
-    // g_stagger delays the first generation's workgroups by their presumed slot on the CU (blockIdx / 256) x |g_stagger| x 64 cycles.
-    if (g_stagger < 0 && blockIdx.x < 1024)
-        for (int k = (int)((blockIdx.x >> 8) & 3u) * -g_stagger; k > 0; --k) __builtin_amdgcn_s_sleep(1);
-#endif
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];
         double4 X[OPL];
@@ -638,11 +560,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         for (int t = 0; t < OPL; ++t) {
             int o = base + t * 64 + lane;
             o = o < n ? o : n - 1;                                       // clamped, not predicated
-            if (!CSR) ci[t] = FAKECI ? (uint32_t)(((uint64_t)(uint32_t)o * 146585185ull) >> 32) : ((NTL & 1) ? __builtin_nontemporal_load(cam_idx + o) : cam_idx[o]);   // o / 29.3 (stays below n_cam on the bench grid)
+            if (!CSR) ci[t] = (NTL & 1) ? __builtin_nontemporal_load(cam_idx + o) : cam_idx[o];
             pi[t] = (NTL & 1) ? __builtin_nontemporal_load(pt_idx + o) : pt_idx[o];
         }
         if (CSR) rows_cameras<OPL>(reinterpret_cast<const uint4 *>(cam_idx), row_ptr, n_cam, base, n, 0, lane, ci);
-        OBS_STAMP(1);                                                    // the tile records are here (camera ids known)
 
         // wave-private camera tile covering all OPL tiles: cameras ci[0](lane 0) .. ci[OPL-1](lane 63) on sorted input.
         // r05: its (at most kStageTrips x 64) 16-byte chunks are REQUESTED here, all at once and -- in the row-structure form,
@@ -663,7 +584,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             const int ch = lane + q * 64;
             if (ch < (int)n_staged * CH) {
                 const int k = ch / CH, j = ch % CH;
-                camv[q] = *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)(c_first + k), j, cam_stride, cam_swz, cam_block));
+                camv[q] = *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)(c_first + k), j));
             }
         }
         if (kTabN > 0) {                                                 // the table's entries were requested first: they are here first
@@ -673,8 +594,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 if (i < kTabN) sTab[i] = tabv[k];
             }
         }
-        OBS_ARRIVED();
-        OBS_STAMP(2);                                                    // the point indices (and the camera chunks) are here
 #pragma unroll
         for (int t = 0; t < OPL; ++t) X[t] = pts4[pi[t]];
 #pragma unroll
@@ -685,8 +604,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (kTabN > 0) __syncthreads();
-        OBS_ARRIVED();
-        OBS_STAMP(3);                                                    // the points are here: arithmetic starts
 
 #pragma unroll
         for (int t = 0; t < OPL; ++t) {
@@ -713,7 +630,10 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             uint32_t local = ci[t] - c_first;
             bool in = local < n_staged;
             lds_cptr cam = (lds_cptr)sCam + (in ? local : 0u) * HOT;
-            Proj p = project_obs(cam, X[t].x, X[t].y, X[t].z);
+            // every lane: the projection with |p|^4 = n * n (final for k2 == 0); which lanes' cameras have k2 != 0 is kept as a lane
+            // mask in scalar registers -- the pow() route for those runs behind one wave-uniform branch below the loop
+            Proj p = project_obs_k0(cam, X[t].x, X[t].y, X[t].z);
+            uint64_t k2nz = __builtin_amdgcn_ballot_w64(cam[14] != 0.0);
             double gx = 0.0, gy = 0.0, gz = 0.0;
             if (VIS) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
             uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
@@ -727,24 +647,56 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 for (int ch = lane; ch < ns * CH; ch += 64) {
                     const int k = ch / CH, j = ch % CH;
                     *reinterpret_cast<d2_t *>(sSlow + k * HOT + 2 * j) =
-                        *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)sIdx[k], j, cam_stride, cam_swz, cam_block));
+                        *reinterpret_cast<const d2_t *>(camblk + cam_row((int64_t)sIdx[k], j));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                in = my >= 0;
-                cam = (lds_cptr)sSlow + (in ? my : 0) * HOT;
-                const Proj q = project_obs(cam, X[t].x, X[t].y, X[t].z);
-                if (in) {
+                const bool mine = my >= 0;
+                lds_cptr cam2 = (lds_cptr)sSlow + (mine ? my : 0) * HOT;
+                const Proj q = project_obs_k0(cam2, X[t].x, X[t].y, X[t].z);
+                const uint64_t served = __builtin_amdgcn_ballot_w64(mine);
+                k2nz = (k2nz & ~served) | __builtin_amdgcn_ballot_w64(mine && cam2[14] != 0.0);
+                if (mine) {
                     p = q;
-                    if (VIS) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
+                    if (VIS) { gx = cam2[16]; gy = cam2[17]; gz = cam2[18]; }
                 }
-                todo &= ~__builtin_amdgcn_ballot_w64(in);
+                todo &= ~served;
             }
+            if (k2nz != 0) {                                             // wave-uniform; cameras with k2 != 0 only (src/baproblem.rs:147-149)
+                // |p|^4 = p.magnitude().powf(4.0) as the reference computes it -- libm's pow -- for the lanes that need it: the whole
+                // projection again (the head's results were not kept: no registers), from the lane's staged camera or, for a lane the
+                // loop above served (its slot was restaged every round), from the table itself
+                struct RowCam {
+                    glb_cptr tab; int64_t c;
+                    __device__ __forceinline__ double operator[](int j) const { return tab[cam_row(c, j >> 1) + (j & 1)]; }
+                };
+                const bool need = (k2nz >> lane) & 1ull;
+                if (need && valid && !in) {
+                    const RowCam rc{(glb_cptr)camblk, (int64_t)ci[t]};
+                    const Proj q = project_obs(rc, X[t].x, X[t].y, X[t].z);
+                    p.u = q.u; p.v = q.v;
+                } else if (need) {
+                    const Proj q = project_obs(cam, X[t].x, X[t].y, X[t].z);
+                    p.u = q.u; p.v = q.v;
+                }
+                // (the observed uv is fetched again behind this branch rather than held across it: the fused noise pass is at its 64
+                // registers without the branch, and the allocator would park a long-lived value of the COMMON path in scratch instead)
+                if (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) {
+                    typedef const __attribute__((address_space(1))) d2_t *glb_d2;          // typed global: the load must not become FLAT
+                    glb_d2 src = (glb_d2)((MODE == MODE_NOISE_ERROR12 ? uv_out : uv_obs) + (valid ? o : n - 1));
+                    asm volatile("" : "+v"(src));
+                    const d2_t t2 = *src;
+                    ob = make_double2(t2.x, t2.y);
+                }
+            }
+            // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1   (src/synthetic.rs:285-291, src/generate.rs:448-454)
+            bool front = false;
             if (VIS) {
-                // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1   (src/synthetic.rs:285-291, src/generate.rs:448-454)
                 const double dx = gx - X[t].x, dy = gy - X[t].y, dz = gz - X[t].z;
                 const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
-                const bool front = dist < max_dist && p.qz <= 0.0;
+                front = dist < max_dist && p.qz <= 0.0;
+            }
+            if (VIS) {
                 const bool k = front && p.u >= -1.0 && p.u <= 1.0 && p.v >= -1.0 && p.v <= 1.0;
                 const double nan = __longlong_as_double(0x7ff8000000000000LL);
                 if (valid) store16<NTS>(reinterpret_cast<char *>(uv_out + o), front ? make_double2(p.u, p.v) : make_double2(nan, nan));
@@ -774,10 +726,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 eacc1 += valid ? abs_pow_k<NORM_1>(du, 1.0) + abs_pow_k<NORM_1>(dv, 1.0) : 0.0;
                 eacc += valid ? abs_pow_k<NORM_2>(du, 2.0) + abs_pow_k<NORM_2>(dv, 2.0) : 0.0;
             }
-            OBS_STAMP(4 + (t < 2 ? t : 2));                              // tile t's results are on their way out
         }
-        OBS_ARRIVED();
-        OBS_STAMP(7);                                                    // ... and acknowledged
     }
     else if (kTabN > 0) {                                                // a wave past the end: its share of the table, the same barrier
 #pragma unroll
@@ -787,10 +736,6 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
         }
         __syncthreads();
     }
-#ifdef C2B_TUNE
-    if (probing && threadIdx.x == 0)
-        for (int k = 0; k < 8; ++k) g_probe[(size_t)blockIdx.x * 8 + k] = tp[k];
-#endif
     if (MODE == MODE_ERROR) ticket_fold(wave_sum(eacc), sCamAll, block_part, ticket, out_sum);
     if (MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) {
         const double w[2] = {wave_sum(eacc1), wave_sum(eacc)};            // out_sum[0] = L1, out_sum[1] = L2
@@ -801,26 +746,20 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
 // ---- residual + Jacobian, wave-centric form -------------------------------------------------------
 // Every wave owns OPL consecutive tiles of 64 observations and never synchronises with another wave: it
 // stages the (typically 3-7) cameras its observations touch in a wave-private LDS tile, transposes its
-// Jacobian blocks through a wave-private slab (in SPLIT rounds to shrink the slab) and leaves one error
+// Jacobian blocks through a wave-private slab (half a tile at a time) and leaves one error
 // partial per tile.  With OPL = 2 each lane carries two observations: both tiles' index / uv loads, then
 // both point gathers, are issued up front, so the second tile's memory latency hides behind the first
 // tile's arithmetic and stores (the index -> gather chain is two dependent round trips per tile otherwise).
 
 // one observation: projection (reference order) + the 2x9 / 2x3 blocks (explicit FMAs)
-template <int ABL, typename P>
+template <typename P>
 C2B_DEV void jacobian_obs(P cam, const double4 X, const double2 ob, double &r0, double &r1,
                           double jc[18], double jp[6]) {
-    Proj p;
-    if (ABL == 2) {        // memory-only build: keep every load live, skip the arithmetic
-        p.qx = X.x + cam[0]; p.qy = X.y + cam[9]; p.qz = X.z + cam[12]; p.px = cam[15]; p.py = cam[23];
-        p.n = ob.x; p.rad = ob.y; p.u = X.x; p.v = X.y;
-    } else {
-        p = project_obs(cam, X.x, X.y, X.z);
-    }
+    const Proj p = project_obs(cam, X.x, X.y, X.z);
     r0 = p.u - ob.x; r1 = p.v - ob.y;
     const double f = cam[12], k1 = cam[13], k2 = cam[14];
     // -1/z by v_rcp_f64 + two Newton steps (~full precision, cheaper than an IEEE divide)
-    double iz = ABL == 2 ? p.qz : __builtin_amdgcn_rcp(p.qz);
+    double iz = __builtin_amdgcn_rcp(p.qz);
     iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
     iz = fma(fma(-p.qz, iz, 1.0), iz, iz);
     const double s = -f * iz;                                   // f * (-1/z)
@@ -848,162 +787,18 @@ C2B_DEV void jacobian_obs(P cam, const double4 X, const double2 ob, double &r0, 
     jc[6] = p.rad * p.px;  jc[15] = p.rad * p.py;
     jc[7] = fn * p.px;     jc[16] = fn * p.py;
     jc[8] = fnn * p.px;    jc[17] = fnn * p.py;
-    if (ABL == 2) {
-#pragma unroll
-        for (int k = 0; k < 18; ++k) jc[k] = p.qx + k;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) jp[k] = p.qy + k;
-    }
 }
 
-// ABL != 0: timing-only ablations, instantiated by the tuning library only (their outputs are wrong by construction).
-// WITH_ERR folds sum |r|^norm over all observations into out_sum[0] in the same launch (ticket_fold).
-template <int NK, bool WITH_ERR, int WPB, int SPLIT, bool NT, int ABL = 0, int OPL = 1, bool LDSCAM = true>
-__global__ __launch_bounds__(WPB * 64) void k_residual_jacobian_w(
-    const double *__restrict__ camblk, const double4 *__restrict__ pts4,
-    const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
-    const double2 *__restrict__ uv_obs, int64_t n, int64_t n_btiles, double norm,
-    double2 *__restrict__ r_out, double *__restrict__ Jc, double *__restrict__ Jp,
-    double *__restrict__ block_part, unsigned *__restrict__ ticket, double *__restrict__ out_sum) {
-    constexpr int kSlab = 64 * 144 / SPLIT;
-    constexpr int kCamBytes = kCamW * kCamHot * 8;
-    __shared__ __attribute__((aligned(16))) char smem[WPB * (kSlab + kCamBytes)];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wt0 = (xcd_tile(blockIdx.x, n_btiles) * WPB + wave) * OPL;   // this wave's first 64-observation tile
-    const int64_t base = wt0 * 64;
-    double eacc = 0.0;
-    if (base < n) {                                                            // wave-uniform; waves past the end only fold
-
-    // ---- all loads of all OPL tiles up front: indices + uv, then the dependent point gathers ----
-    uint32_t ci[OPL], pi[OPL];
-    double2 ob[OPL];
-    double4 X[OPL];
-    bool valid[OPL];
-#pragma unroll
-    for (int t = 0; t < OPL; ++t) {
-        const int64_t o = base + t * 64 + lane;
-        valid[t] = o < n;
-        ci[t] = 0; pi[t] = 0; ob[t] = make_double2(0, 0);
-        if (valid[t]) { ci[t] = cam_idx[o]; pi[t] = pt_idx[o]; ob[t] = uv_obs[o]; }
-    }
-#pragma unroll
-    for (int t = 0; t < OPL; ++t) {
-        X[t] = make_double4(0, 0, -1, 0);
-        if (valid[t]) X[t] = pts4[pi[t]];
-    }
-
-    // ---- wave-private camera tile covering every tile of this wave ----
-    double *sCam = reinterpret_cast<double *>(smem + wave * (kSlab + kCamBytes) + kSlab);
-    const int64_t n_here = n - base < 64 * OPL ? n - base : 64 * OPL;          // valid observations of this wave
-    const int last_t = (int)((n_here - 1) >> 6), last_l = (int)((n_here - 1) & 63);
-    uint32_t ci_last = ci[0];
-#pragma unroll
-    for (int t = 0; t < OPL; ++t) if (t == last_t) ci_last = ci[t];
-    const uint32_t c_first = __builtin_amdgcn_readfirstlane(ci[0]);
-    const uint32_t c_last = __builtin_amdgcn_readfirstlane(__shfl(ci_last, last_l, 64));
-    uint32_t n_staged = c_last >= c_first ? c_last - c_first + 1 : 1;
-    if (n_staged > (uint32_t)kCamW) n_staged = kCamW;
-    for (int ch = lane; ch < (int)n_staged * (kCamHot / 2); ch += 64) {
-        const int k = ch / (kCamHot / 2), j = ch % (kCamHot / 2);
-        const double2 v = *reinterpret_cast<const double2 *>(camblk + cam_chunk_at((int64_t)(c_first + k), j));
-        *reinterpret_cast<double2 *>(sCam + k * kCamHot + 2 * j) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    char *slab = smem + wave * (kSlab + kCamBytes);
-    constexpr int kHalf = 64 / SPLIT;                 // lanes per transposition round
-#pragma unroll
-    for (int t = 0; t < OPL; ++t) {
-        const int64_t wave0 = base + t * 64;
-        if (wave0 >= n) break;                                                 // wave-uniform
-        const int64_t o = wave0 + lane;
-        const int n_wave = n - wave0 < 64 ? (int)(n - wave0) : 64;
-        const uint32_t local = ci[t] - c_first;
-        const bool in_tile = valid[t] && local < n_staged;
-        double r0, r1, jc[18], jp[6];
-        // The usual case is wave-uniform: every lane's camera is in the LDS tile, and a pointer that can only be LDS
-        // compiles to ds_read (lgkmcnt).  A pointer that may be LDS or global compiles to FLAT loads, which count in
-        // vmcnt behind the previous tile's stores (vmcnt retires in order) -- keep those for the rare fallback only.
-        if (LDSCAM && __builtin_amdgcn_ballot_w64(valid[t] && !in_tile) == 0ull) {
-            jacobian_obs<ABL>(sCam + (in_tile ? local : 0u) * kCamHot, X[t], ob[t], r0, r1, jc, jp);
-        } else {
-            double rec[kCamHot];                                               // (a lane whose camera is not staged: its record by value)
-#pragma unroll
-            for (int j = 0; j < kCamHot; ++j) rec[j] = in_tile ? sCam[local * kCamHot + j] : camblk[cam_at((int64_t)ci[t], j)];
-            jacobian_obs<ABL>(static_cast<const double *>(rec), X[t], ob[t], r0, r1, jc, jp);
-        }
-
-        // residual: 16 B per lane, already coalesced
-        if (valid[t]) store16<NT>(reinterpret_cast<char *>(r_out + o), make_double2(r0, r1));
-        if (ABL == 1) {        // load+compute-only build: fold the Jacobian into one value, no slab / no stores
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 18; ++k) acc += jc[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc += jp[k];
-            if (acc == 1.2345e300) Jc[o] = acc;
-            continue;
-        }
-
-        // transpose through the wave-private slab, leave as contiguous 1-KiB stores of whole 128-B lines
-#pragma unroll
-        for (int h = 0; h < SPLIT; ++h) {
-            if (SPLIT == 1 || (lane / kHalf) == h) {
-                double2 *w = reinterpret_cast<double2 *>(slab + (lane % kHalf) * 144);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) w[k] = make_double2(jc[2 * k], jc[2 * k + 1]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            char *dst = reinterpret_cast<char *>(Jc) + (wave0 + h * kHalf) * 144;
-            int nv = n_wave - h * kHalf;
-            nv = nv < 0 ? 0 : (nv > kHalf ? kHalf : nv);
-            const int bytes = nv * 144;
-            constexpr int kIters = (kHalf * 144 + 1023) / 1024;
-#pragma unroll
-            for (int k = 0; k < kIters; ++k) {
-                const int off = (k * 64 + lane) * 16;
-                if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        {
-            double2 *w = reinterpret_cast<double2 *>(slab + lane * 48);      // 64 x 48 B = 3 KB <= slab
-#pragma unroll
-            for (int k = 0; k < 3; ++k) w[k] = make_double2(jp[2 * k], jp[2 * k + 1]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            char *dst = reinterpret_cast<char *>(Jp) + wave0 * 48;
-            const int bytes = n_wave * 48;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int off = (k * 64 + lane) * 16;
-                if (off < bytes) store16<NT>(dst + off, *reinterpret_cast<const double2 *>(slab + off));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-
-        if (WITH_ERR) eacc += valid[t] ? abs_pow_k<NK>(r0, norm) + abs_pow_k<NK>(r1, norm) : 0.0;
-    }
-    }
-    if (WITH_ERR) ticket_fold(wave_sum(eacc), reinterpret_cast<double *>(smem), block_part, ticket, out_sum);
-}
-
-// ---- residual + Jacobian, lean form --------------------------------------------------------------------
-// The same wave-centric structure as k_residual_jacobian_w with the light kernels' economies: 32-bit observation
-// indices, clamped (not predicated) loads, ONE inlined copy of the arithmetic per tile reading its camera through an
+// ---- residual + Jacobian: the kernel ---------------------------------------------------------------------
+// WITH_ERR folds sum |r|^norm over all observations into out_sum[0] in the same launch (ticket_fold).  The wave-centric
+// structure described above with the light kernels' economies: 32-bit observation indices, clamped (not predicated) loads, ONE inlined copy of the arithmetic per tile reading its camera through an
 // LDS-typed pointer (first pass unmasked; lanes whose camera was not staged are served in extra rounds through a
 // spare LDS slot and merged under a mask -- never taken on camera-major input), the observed uv requested per tile.
-// XK: tile map -- 0 = contiguous eighths per XCD (xcd_tile32), K >= 1 = xcd_tile_chunked<K>
 // OBUP: request every tile's observed uv up front with the indices (true) or when that tile's arithmetic starts (false)
 // CSR: cam_idx points at the tile records of k_rows_pack (for this launch's first observation, which is observation
 //      obs_base of the list row_ptr describes) instead of one camera index per observation
 // NTL: bit 0 = non-temporal loads of the index streams, bit 1 = of the observed uv (streams read once per launch)
-template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, int XK = 0, bool OBUP = true, bool CSR = false, int NTL = 0>
+template <int NK, bool WITH_ERR, int WPB, bool NT, int OPL, int MINW, bool OBUP = true, bool CSR = false, int NTL = 0>
 __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
     const double *__restrict__ camblk, const double4 *__restrict__ pts4,
     const uint32_t *__restrict__ cam_idx, const uint32_t *__restrict__ pt_idx,
@@ -1017,7 +812,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int base = ((XK == 0 ? xcd_tile32(blockIdx.x, n_btiles) : xcd_tile_chunked<XK>(blockIdx.x, n_btiles)) * WPB + wave) * (OPL * 64);
+    const int base = (xcd_tile32(blockIdx.x, n_btiles) * WPB + wave) * (OPL * 64);
     double eacc = 0.0;
     if (base < n) {                                                      // wave-uniform; waves past the end only fold
         uint32_t ci[OPL], pi[OPL];
@@ -1073,7 +868,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
             uint32_t local = ci[t] - c_first;
             bool in = local < n_staged;
             double r0, r1, jc[18], jp[6];
-            jacobian_obs<0>((lds_cptr)sCam + (in ? local : 0u) * kCamHot, X[t], ob, r0, r1, jc, jp);
+            jacobian_obs((lds_cptr)sCam + (in ? local : 0u) * kCamHot, X[t], ob, r0, r1, jc, jp);
             uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
             while (todo != 0) {                                          // wave-uniform; never taken on sorted input
                 int my;
@@ -1091,7 +886,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_residual_jacobian_l(
                 __builtin_amdgcn_wave_barrier();
                 in = my >= 0;
                 double q0, q1, qc[18], qp[6];
-                jacobian_obs<0>((lds_cptr)sSlow + (in ? my : 0) * kCamHot, X[t], ob, q0, q1, qc, qp);
+                jacobian_obs((lds_cptr)sSlow + (in ? my : 0) * kCamHot, X[t], ob, q0, q1, qc, qp);
                 if (in) {
                     r0 = q0; r1 = q1;
 #pragma unroll
@@ -1472,7 +1267,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
     constexpr int WAVES = BLOCK / 64;
     __shared__ double sh[WAVES + 1][kStatRec];
     unsigned magic = 0u;
-    C2B_PROBE(0);
     if (threadIdx.x == 0) magic = ticket[kTicketMagicAt];
     StatRec a = stat_empty();
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
@@ -1517,9 +1311,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
             stat_accumulate<STD, BATCH>(a, best_thr, x, y, z, i, step, lim, inv_num);
         }
     }
-    C2B_PROBE(1);
     a = stat_block_reduce<STD, WAVES>(a, sh);
-    C2B_PROBE(2);
     if (threadIdx.x == 0) {
         double t[kStatRec];
         stat_to_lds(a, t);
@@ -1528,7 +1320,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
         for (int k = 0; k < (STD ? 18 : 11); ++k) __hip_atomic_store(o + k, t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_waitcnt(0);
         const bool last = ticket_arrive(ticket, magic);
-        C2B_PROBE(3);
         if (magic != kTicketMagic) {
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
             for (int k = 0; k < 20; ++k) stats[k] = nan;
@@ -1562,9 +1353,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
         if (r1 < gridDim.x) stat_merge<STD>(f, g1);
         for (unsigned r = r1 + BLOCK; r < gridDim.x; r += BLOCK) stat_merge<STD>(f, load_rec(r));
     }
-    C2B_PROBE(4);
     f = stat_block_reduce<STD, WAVES>(f, sh);
-    C2B_PROBE(5);
     if (threadIdx.x != 0) return;
     double x = 0, y = 0, z = 0;
     if (f.best.i >= 0.0) src.get((int64_t)f.best.i, x, y, z);
@@ -1584,7 +1373,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 ? 4 : 1)) void k_stats_pass1(S
     } else {
         stats[19] = f.best.i >= 0.0 ? f.best.d : inf;
     }
-    C2B_PROBE(6);
 }
 
 // pass 2 (sharded statistics only since r03): sums of squared deviations from mean3.  RAW: leave the three sums in
@@ -2133,54 +1921,6 @@ __global__ __launch_bounds__(WPB * 64) void k_store_pattern(int64_t n, int64_t n
     for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
 }
 
-#ifdef C2B_TUNE
-template <int POL>
-__global__ __launch_bounds__(512) void k_store_pattern_pol(int64_t n, int64_t n_btiles, double2 *__restrict__ r_out,
-                                                          double *__restrict__ Jc, double *__restrict__ Jp) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wave0 = (xcd_tile(blockIdx.x, n_btiles) * 8 + wave) * 64;
-    if (wave0 + 64 > n) return;
-    const double2 v = make_double2((double)lane, (double)wave);
-    store16_pol<POL>(reinterpret_cast<char *>(r_out + wave0 + lane), v);
-    char *dc = reinterpret_cast<char *>(Jc) + wave0 * 144;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) store16_pol<POL>(dc + (k * 64 + lane) * 16, v);
-    char *dp = reinterpret_cast<char *>(Jp) + wave0 * 48;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) store16_pol<POL>(dp + (k * 64 + lane) * 16, v);
-}
-#endif
-
-// The same store geometry under a selectable workgroup -> tile map (c2b_calib_store_pattern_map): 0 = every XCD streams
-// a contiguous eighth of the arrays (what the kernels do: 8 write fronts per array), 1 = launch order (the whole chip
-// writes inside one moving window), K >= 2 = XCD x takes K consecutive tiles of every group of 8K (xcd_tile_chunked).
-// A measurement aid for the question of section 3 of DESIGN.md: does the slow / fast allocation effect depend on how
-// the chip's concurrent write fronts are laid over the address space?
-template <bool NT, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_store_pattern_map(int64_t n, int64_t n_btiles, int map, double2 *__restrict__ r_out,
-                                                               double *__restrict__ Jc, double *__restrict__ Jp) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t bt = blockIdx.x;
-    if (map == 0) {
-        bt = xcd_tile(bt, n_btiles);
-    } else if (map >= 2) {
-        const int64_t K = map, whole = n_btiles / (8 * K) * (8 * K);
-        if (bt < whole) {
-            const int64_t xcd = bt & 7, k = bt >> 3;
-            bt = (k / K) * (8 * K) + xcd * K + (k % K);
-        }
-    }
-    const int64_t wave0 = (bt * WPB + wave) * 64;
-    if (wave0 + 64 > n) return;
-    const double2 v = make_double2((double)lane, (double)wave);
-    store16<NT>(reinterpret_cast<char *>(r_out + wave0 + lane), v);
-    char *dc = reinterpret_cast<char *>(Jc) + wave0 * 144;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) store16<NT>(dc + (k * 64 + lane) * 16, v);
-    char *dp = reinterpret_cast<char *>(Jp) + wave0 * 48;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) store16<NT>(dp + (k * 64 + lane) * 16, v);
-}
 
 // 16 bytes per lane streaming copy, one element per thread (the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for)
 __global__ __launch_bounds__(256) void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n16) {

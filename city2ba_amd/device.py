@@ -82,49 +82,111 @@ def centers_table(n_cam, device):
     return torch.empty((n_cam, 4), dtype=torch.float64, device=device)
 
 
+class CameraTable:
+    """A camblk table for n_cam cameras, OPAQUE on purpose: the table is blocked in groups of 8 cameras (a group's eight
+    light lines, then its J_l tails, centres and pad -- include/city2ba_hip.h) and holds whole groups, so its rows are not records:
+    slicing, indexing, .to(), .contiguous() or .clone() of a plain [n, 32] view would silently give truncated or scrambled data.
+    What exists instead: data_ptr() for the launchers, clone() (whole groups, storage of its own), records() (a COPY of the logical
+    [n_cam][32] records, for looking at), flat (the storage: capacity_doubles() doubles, 1-D) and shape == (n_cam, 32) so that
+    callers can read the camera count the way they did."""
+    __slots__ = ("flat", "n_cam")
+
+    def __init__(self, n_cam, device, flat=None):
+        self.n_cam = int(n_cam)
+        need = ((self.n_cam + 7) // 8 * 8) * L.CAMBLK_DOUBLES
+        if flat is None:
+            flat = torch.empty(need, dtype=torch.float64, device=device)
+        if not (flat.is_cuda and flat.dtype == torch.float64 and flat.dim() == 1 and flat.is_contiguous() and flat.numel() >= need
+                and flat.data_ptr() % 256 == 0):
+            raise ValueError("a camera table for %d cameras needs a contiguous, 256-byte aligned 1-D float64 CUDA tensor of >= %d doubles "
+                             "(whole groups of 8 cameras)" % (self.n_cam, need))
+        self.flat = flat
+
+    shape = property(lambda self: (self.n_cam, L.CAMBLK_DOUBLES))
+    device = property(lambda self: self.flat.device)
+    dtype = property(lambda self: self.flat.dtype)
+    is_cuda = property(lambda self: True)
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return self.flat.data_ptr()
+
+    def capacity_doubles(self):
+        return self.flat.numel()
+
+    def clone(self):
+        return CameraTable(self.n_cam, self.flat.device, self.flat.clone())
+
+    def prefix(self, n_cam):
+        """the same storage seen as a table of its first n_cam cameras (a camera's place depends on its index only, so a PREFIX
+        is a table; any other range is not -- a shard prepares a table of its own)"""
+        if not 0 <= int(n_cam) <= self.n_cam:
+            raise ValueError("prefix of %d cameras of a table of %d" % (int(n_cam), self.n_cam))
+        return CameraTable(n_cam, self.flat.device, self.flat)
+
+    def records(self):
+        g = (self.n_cam + 7) // 8
+        flat = self.flat[: g * 256].view(g, 256)
+        parts = (flat[:, :128].reshape(g, 8, 16), flat[:, 128:192].reshape(g, 8, 8), flat[:, 192:224].reshape(g, 8, 4), flat[:, 224:].reshape(g, 8, 4))
+        return torch.cat(parts, dim=-1).reshape(g * 8, L.CAMBLK_DOUBLES)[: self.n_cam].clone()
+
+    def __getitem__(self, _):
+        raise TypeError("a CameraTable is not a tensor of records (it is blocked in groups of 8 cameras): use .records() to look at it")
+
+    def __len__(self):
+        return self.n_cam
+
+
 def camblk_table(n_cam, device):
-    """an uninitialised camblk for n_cam cameras: [n_cam][CAMBLK_DOUBLES] to look at, but its storage holds WHOLE groups of 8
-    cameras (the table is blocked: a group's eight light lines, then its J_l tails, centres and pad -- include/city2ba_hip.h), so the
-    last group's later parts have somewhere to go when n_cam is not a multiple of 8.  Never slice or clone it by camera."""
-    n = int(n_cam)
-    flat = torch.empty(((n + 7) // 8 * 8) * L.CAMBLK_DOUBLES, dtype=torch.float64, device=device)
-    return flat[: n * L.CAMBLK_DOUBLES].view(n, L.CAMBLK_DOUBLES)
+    """an uninitialised camera table for n_cam cameras (CameraTable: storage for whole groups of 8)"""
+    return CameraTable(n_cam, device)
 
 
 def camblk_records(camblk):
     """the table's logical records, [n_cam][CAMBLK_DOUBLES] (R 9, t 3, intrinsics 3, J_l 9, centre 3, pad), as a COPY taken out of
     the blocked layout -- for looking at; the kernels take the table itself"""
-    n = camblk.shape[0]
-    g = (n + 7) // 8
-    flat = torch.as_strided(camblk, (g * 8 * L.CAMBLK_DOUBLES,), (1,)).view(g, 256)
-    parts = (flat[:, :128].reshape(g, 8, 16), flat[:, 128:192].reshape(g, 8, 8), flat[:, 192:224].reshape(g, 8, 4), flat[:, 224:].reshape(g, 8, 4))
-    return torch.cat(parts, dim=-1).reshape(g * 8, L.CAMBLK_DOUBLES)[:n].clone()
+    return _as_table(camblk).records()
 
 
 def camblk_clone(camblk):
-    """a copy of a prepared camblk in storage of its own (with the slack of the last group: camblk_table)"""
-    n = camblk.shape[0]
-    out = camblk_table(n, camblk.device)
-    whole = ((n + 7) // 8 * 8) * L.CAMBLK_DOUBLES
-    out.untyped_storage()                                       # (same dtype / device; copy the whole groups, slack included)
-    torch.as_strided(out, (whole,), (1,)).copy_(torch.as_strided(camblk, (whole,), (1,)))
-    return out
+    """a copy of a prepared table in storage of its own"""
+    return _as_table(camblk).clone()
+
+
+def _as_table(x, n_cam=None):
+    """`out=` arguments and hand-made tables: a CameraTable passes; a tensor is accepted only if its STORAGE from its first
+    element on holds whole groups for its row count (what the kernel will write), and is wrapped -- never written out of bounds"""
+    if isinstance(x, CameraTable):
+        if n_cam is not None and x.n_cam != int(n_cam):
+            raise ValueError("the camera table was made for %d cameras, not %d" % (x.n_cam, int(n_cam)))
+        return x
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()):
+        raise ValueError("camblk: a CameraTable (device.camblk_table) or a contiguous float64 CUDA tensor")
+    n = int(n_cam) if n_cam is not None else (x.shape[0] if x.dim() == 2 else x.numel() // L.CAMBLK_DOUBLES)
+    need = ((n + 7) // 8 * 8) * L.CAMBLK_DOUBLES
+    have = (x.untyped_storage().nbytes() - 8 * x.storage_offset()) // 8
+    if have < need:
+        raise ValueError("camblk for %d cameras needs %d doubles of storage (whole groups of 8 cameras), this tensor has %d: "
+                         "allocate with device.camblk_table()" % (n, need, have))
+    return CameraTable(n, x.device, torch.as_strided(x, (need,), (1,)))
 
 
 def cameras_prepare_state(cam15, out=None, centers=None):
-    """camblk from the in-memory cameras; `centers` (centers_table) also receives every camera's centre"""
+    """the camera table from the in-memory cameras; `centers` (centers_table) also receives every camera's centre"""
     _chk(cam15, torch.float64, "cam15")
     n = cam15.shape[0]
-    blk = out if out is not None else camblk_table(n, cam15.device)
-    L.check(L.lib().c2b_cameras_prepare_state(_p(cam15), n, _p(blk), _pn(centers, n), _stream()))
+    blk = _as_table(out, n) if out is not None else CameraTable(n, cam15.device)
+    L.check(L.lib().c2b_camblk_from_state(_p(cam15), n, _p(blk), blk.capacity_doubles(), _pn(centers, n), _stream()))
     return blk
 
 
 def cameras_prepare_bal(bal9, out=None, centers=None):
     _chk(bal9, torch.float64, "bal9")
     n = bal9.shape[0]
-    blk = out if out is not None else camblk_table(n, bal9.device)
-    L.check(L.lib().c2b_cameras_prepare_bal(_p(bal9), n, _p(blk), _pn(centers, n), _stream()))
+    blk = _as_table(out, n) if out is not None else CameraTable(n, bal9.device)
+    L.check(L.lib().c2b_camblk_from_bal(_p(bal9), n, _p(blk), blk.capacity_doubles(), _pn(centers, n), _stream()))
     return blk
 
 
@@ -270,11 +332,6 @@ def calib_store_pattern(r, Jc, Jp):
     L.check(L.lib().c2b_calib_store_pattern(r.shape[0], _p(r), _p(Jc), _p(Jp), _stream()))
 
 
-def calib_store_pattern_map(r, Jc, Jp, tile_map):
-    """calib_store_pattern under another workgroup -> tile map (0 = XCD eighths, 1 = launch order, K >= 2 = chunked)"""
-    L.check(L.lib().c2b_calib_store_pattern_map(r.shape[0], _p(r), _p(Jc), _p(Jp), int(tile_map), _stream()))
-
-
 def calib_copy(src, dst):
     """Calibration: 16-bytes-per-lane streaming copy of src into dst (same byte size, multiple of 16)."""
     nbytes = src.numel() * src.element_size()
@@ -310,7 +367,7 @@ class JacobianOutputs:
     (include/city2ba_hip.h).  .r / .Jc / .Jp are torch views of the handle's memory; .log = store
     GB/s of every attempt, .chosen = the attempt kept."""
 
-    def __init__(self, n_obs, device, max_attempts=32, fast_store_GBs=7000.0, _handle=None):
+    def __init__(self, n_obs, device, max_attempts=8, fast_store_GBs=7000.0, _handle=None):
         own = self._own = _OutputsHandle()
         dev = torch.device(device)
         if _handle is not None:                                  # a set the library allocated (c2b_problem_residual_jacobian_device)
@@ -347,7 +404,7 @@ class JacobianOutputs:
         self.store_GBs = max(float(store_GBs), 0.0)
 
 
-def alloc_jacobian_outputs(n_obs, device, max_attempts=32, fast_store_GBs=7000.0):
+def alloc_jacobian_outputs(n_obs, device, max_attempts=8, fast_store_GBs=7000.0):
     """((r, Jc, Jp), log): the output arrays of residual_jacobian*, placed for streaming stores by the library
     (c2b_jacobian_outputs_alloc -- every caller of the C ABI gets the same placement, not just this wrapper)."""
     out = JacobianOutputs(n_obs, device, max_attempts, fast_store_GBs)

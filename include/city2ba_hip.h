@@ -27,7 +27,7 @@
  *           each) and the pad -- the projection-only passes then touch whole kilobytes instead of every other line (and the
  *           Jacobian 1.5 KB, the visibility predicate 1.25 KB of every 2), which the 256-MB Infinity Cache needs to hold their
  *           inputs.  ALLOCATE IT FOR WHOLE GROUPS: C2B_CAMBLK_DOUBLES * (n_cam rounded up to a multiple of 8)
- *           doubles, 256-byte aligned; a table is written by c2b_cameras_prepare_* for its own n_cam cameras (camera c of the
+ *           doubles (= c2b_camblk_doubles(n_cam)), 256-byte aligned; a table is written by c2b_camblk_from_* for its own n_cam cameras (camera c of the
  *           call = row c of the table) and is never sliced or copied by camera range -- a shard prepares its own.
  *   cen4    the cameras' centres alone, [n_cam][4] doubles (x y z 0: 32-byte rows like pts4; 16-byte aligned), written
  *           by the same launch that derives camblk.  What the statistics read: 32 bytes per camera instead of a
@@ -40,19 +40,19 @@
  * ---- index of entry points by level (tools/abi_index.py) ----
  *   library (3):
  *     version, last_error, device_count
- *   Level 0: workspace, camera records, points, rows (14):
- *     workspace_bytes, workspace_init, workspace_selfcheck, cameras_from_bal, cameras_to_bal, cameras_prepare_state,
- *     cameras_prepare_bal, cameras_from_position_direction, project_world, to_world, cameras_transform, points_pad,
- *     points_unpad, expand_rows
+ *   Level 0: workspace, camera records, points, rows (15):
+ *     workspace_bytes, workspace_init, workspace_selfcheck, cameras_from_bal, cameras_to_bal, camblk_doubles,
+ *     camblk_from_state, camblk_from_bal, cameras_from_position_direction, project_world, to_world, cameras_transform,
+ *     points_pad, points_unpad, expand_rows
  *   Level 0: per-observation passes (cam_idx and row-structure forms) (17):
  *     project, reprojection_error_sum, rows_tiles_bytes, rows_pack, project_rows, reprojection_error_sum_rows,
  *     visibility_rows, visibility_rows_bits, reprojection_error_sums2_rows, add_noise_observations_error_sums2_rows,
  *     jacobian_stream_policy, jacobian_tiles_per_wave, jacobian_launch_shape, residual_jacobian_rows,
  *     residual_jacobian, error_sum_finish, residual_jacobian_sum
- *   Level 0: Jacobian output sets and calibration (10):
+ *   Level 0: Jacobian output sets and calibration (9):
  *     jacobian_outputs_alloc, jacobian_outputs_pointers, jacobian_outputs_log, jacobian_outputs_store_rate,
  *     jacobian_outputs_set_store_rate, jacobian_outputs_free, residual_jacobian_rows_placed, calib_store_pattern,
- *     calib_store_pattern_map, calib_copy
+ *     calib_copy
  *   Level 0: visibility sweeps and occlusion (10):
  *     visibility_pairs, visibility_dense_tiles, visibility_dense_count, visibility_dense_fill, occlusion_filter,
  *     bvh_build, bvh_sizes, bvh_copy, bvh_free, occlusion_filter_bvh
@@ -153,9 +153,14 @@ int c2b_cameras_to_bal(const double *cam15, int64_t n_cam, double *bal9, void *s
 /* derive camblk (and, when cen4 != NULL, the compact centre table) from the in-memory state; Jacobian columns refer
  * to w = to_rodrigues(R).  Run it again after anything moved the cameras (c2b_add_drift*, c2b_add_noise_entities,
  * c2b_add_sin_noise, c2b_cameras_transform mutate cam15, the truth state): both tables are derived data. */
-int c2b_cameras_prepare_state(const double *cam15, int64_t n_cam, double *camblk, double *cen4, void *stream);
+/* camblk_doubles = the CAPACITY of the buffer behind camblk, in doubles: rejected (C2B_ERR_INVALID_ARGUMENT, nothing written) when
+ * it is less than c2b_camblk_doubles(n_cam) -- the table holds WHOLE groups of 8 cameras, so a buffer sized 32 * n_cam is too
+ * small whenever n_cam is not a multiple of 8.  (r06: these two replace c2b_camblk_from_state / _bal, whose argument list
+ * had changed in place in r05 -- a binding written against the older list must fail to link, not write out of bounds.) */
+int64_t c2b_camblk_doubles(int64_t n_cam);
+int c2b_camblk_from_state(const double *cam15, int64_t n_cam, double *camblk, int64_t camblk_doubles, double *cen4, void *stream);
 /* derive camblk (and cen4) from 9-vectors; R = from_rodrigues(w), Jacobian columns refer to that w */
-int c2b_cameras_prepare_bal(const double *bal9, int64_t n_cam, double *camblk, double *cen4, void *stream);
+int c2b_camblk_from_bal(const double *bal9, int64_t n_cam, double *camblk, int64_t camblk_doubles, double *cen4, void *stream);
 /* Camera::from_position_direction (src/baproblem.rs:153-159): pos [n][3], dir [n][9] col-major */
 int c2b_cameras_from_position_direction(const double *pos3, const double *dir9, int64_t n_cam,
                                         double *cam15, void *stream);
@@ -243,7 +248,10 @@ int c2b_jacobian_tiles_per_wave(int64_t n_obs);
 /* ... and the full shape -- waves of 64 per workgroup, tiles per wave -- of a launch of n_obs observations into an output
  * set that takes streaming stores at store_GBs (GB/s; 0 = unknown): 16 x 1 below ~6 M observations; above, 8 x 2 -- or
  * 4 x 1 when the set is one of the slow-store kind (< 6.3 TB/s) and 16 x 1 when it lies between the classes (< 6.85 TB/s),
- * which only c2b_residual_jacobian_rows_placed knows.  Diagnostic, like the two above: results do not depend on the shape. */
+ * which only c2b_residual_jacobian_rows_placed knows.  Diagnostic, like the two above: results do not depend on the shape.
+ * The shapes named are those of a launch WITH an error sum (workspace != NULL, the bench step).  One exception: a launch
+ * without a sum (workspace == NULL) that would take 8 x 2 runs 16 x 1 instead -- the 8 x 2 instance without the sum's
+ * fold does not fit its 128 registers without scratch (capi.hip: launch_jac_l). */
 int c2b_jacobian_launch_shape(int64_t n_obs, double store_GBs, int *waves_per_workgroup, int *tiles_per_wave);
 int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
@@ -276,6 +284,11 @@ int c2b_residual_jacobian_sum(const double *camblk, const double *pts4, const ui
  * the first eight: a depth of 32-48 finds one.)  max_attempts = 1 takes the
  * first set (its rate is still measured: c2b_residual_jacobian_rows_placed chooses its workgroup shape by it); n_obs
  * < 10^6 allocates without measuring.  An attempt that runs out of memory ends the search with the best set so far.
+ * TRANSIENT FOOTPRINT: every rejected set (and, for sets below 2 GiB, a 2-GiB filler per reject) is held until the call
+ * returns -- up to max_attempts x max(208 B x n_obs, 2 GiB), never more than three quarters of the memory that was free
+ * at the call; the free memory is asked for again before every further attempt and the search stops once less than a
+ * quarter of that (plus one set) is left, so a process, rank or allocator sharing the device is not driven out of memory.
+ * Ask for depth deliberately: 8 is what the bindings default to, 32-48 what a long-lived solver or a benchmark asks for.
  * Synchronises `stream`.  The handle owns the memory until c2b_jacobian_outputs_free.
  * (No reference counterpart: the Jacobian itself is build-defined; a Rust host holds the handle next to its
  * device mirror, INTEGRATION.md.) */
@@ -306,9 +319,6 @@ int c2b_residual_jacobian_rows_placed(const double *camblk, const double *pts4, 
  * Jp [n][6] in exactly the residual+Jacobian kernel's store geometry with no loads and no arithmetic -- the time its
  * stores alone take; _copy is a 16-bytes-per-lane streaming copy (bytes % 16 == 0). */
 int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, void *stream);
-/* _store_pattern under another workgroup -> tile map: 0 = each XCD streams a contiguous eighth of the arrays (what the
- * kernels and _store_pattern do), 1 = launch order, K >= 2 = XCD x takes K consecutive tiles of every group of 8K */
-int c2b_calib_store_pattern_map(int64_t n_obs, double *r, double *Jc, double *Jp, int tile_map, void *stream);
 int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream);
 
 /* visibility predicate of the generators (src/synthetic.rs:285-291, 368-375;

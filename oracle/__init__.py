@@ -68,8 +68,6 @@ def lib():
     sig("orc_camera_to_bal", None, _dp, _dp)
     sig("orc_project_world", None, _dp, _dp, _dp)
     sig("orc_project", None, _dp, _dp, _dp)
-    sig("orc_set_pow4_mode", None, C.c_int)
-    sig("orc_get_pow4_mode", C.c_int)
     sig("orc_pow4_cr", _d, _d)
     sig("orc_pow4_both", None, _dp, _i64, _dp, _dp)
     sig("orc_center", None, _dp, _dp)
@@ -106,23 +104,6 @@ def lib():
         C.POINTER(_d), C.POINTER(_d))
     _lib = L
     return L
-
-
-class pow4_mode:
-    """with oracle.pow4_mode(1): ... evaluates |p|^4 correctly rounded (what the device does) instead of with libm's
-    pow (what the reference calls; default).  See the comment above orc_pow4_cr in city2ba_oracle.c."""
-
-    def __init__(self, mode):
-        self.mode = int(mode)
-
-    def __enter__(self):
-        self.old = lib().orc_get_pow4_mode()
-        lib().orc_set_pow4_mode(self.mode)
-        return self
-
-    def __exit__(self, *exc):
-        lib().orc_set_pow4_mode(self.old)
-        return False
 
 
 def pow4_cr(x):

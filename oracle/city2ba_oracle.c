@@ -236,17 +236,14 @@ void orc_project_world(const double cam[15], const double p[3], double q[3]) {
 }
 
 /* p.magnitude().powf(4.0), :149.  Rust's f64::powf is the platform libm's pow (glibc here, as on the machine the
- * reference would run on).  glibc's pow is accurate to ~0.52 ulp, NOT correctly rounded: on this image
- * pow(sqrt(n), 4.0) differs from the correctly rounded value of fl(sqrt(n))^4 in 0.085 % of draws (always by one ulp;
- * tests/test_pow4.py measures it).  No implementation other than glibc itself reproduces those draws, so the device
- * evaluates the CORRECTLY ROUNDED value and the oracle offers both: mode 0 = libm pow (the reference restated; default),
- * mode 1 = correctly rounded (what the device is compared with bit for bit). */
-static int g_pow4_mode = 0;
-void orc_set_pow4_mode(int mode) { g_pow4_mode = mode; }
-int orc_get_pow4_mode(void) { return g_pow4_mode; }
+ * reference would run on), and that is ALL the oracle evaluates: one arithmetic, the reference's.  glibc's pow is
+ * accurate to ~0.52 ulp, NOT correctly rounded: pow(sqrt(n), 4.0) differs from the correctly rounded fl(sqrt(n))^4 in
+ * 0.09 % of draws, always by one ulp (tests/test_pow4.py measures it).  Rounds 1-5 had the device evaluate the correctly
+ * rounded value and gave this file a second mode to match it; since round 6 the device runs a restatement of glibc's own
+ * pow (city2ba_amd/csrc/pow4_libm.hpp, bit for bit this libm on every argument class) and the second mode is gone. */
 
-/* x^4 correctly rounded for finite x of ordinary magnitude: x^2 = h + l exactly (one FMA), h^2 = hh + hl exactly,
- * x^4 = hh + (hl + 2 h l + l^2) with the bracket accurate to ~2^-104 of the result, one final rounding. */
+/* x^4 correctly rounded -- NOT used by any projection here; kept so that tests/test_pow4.py can state how often and by
+ * how much libm's pow differs from it (x^2 = h + l exactly, h^2 = hh + hl exactly, x^4 = hh + (hl + 2 h l + l^2)). */
 double orc_pow4_cr(double x) {
     const double h = x * x;
     const double hh = h * h;
@@ -258,14 +255,15 @@ double orc_pow4_cr(double x) {
     return hh + t;
 }
 
-/* both evaluations of x[i]^4 for an array (tests measure how often libm's pow is not correctly rounded) */
+/* x[i]^4 by libm's pow (what the projection below calls) and correctly rounded, for an array */
 void orc_pow4_both(const double *x, int64_t n, double *out_libm, double *out_cr) {
-    for (int64_t i = 0; i < n; ++i) { out_libm[i] = pow(x[i], 4.0); out_cr[i] = orc_pow4_cr(x[i]); }
+    volatile double four = 4.0;                    /* the library call, not a compile-time expansion */
+    for (int64_t i = 0; i < n; ++i) { out_libm[i] = pow(x[i], four); out_cr[i] = orc_pow4_cr(x[i]); }
 }
 
 static double magnitude_pow4(double mag2) {
-    const double x = sqrt(mag2);
-    return g_pow4_mode ? orc_pow4_cr(x) : pow(x, 4.0);
+    volatile double four = 4.0;
+    return pow(sqrt(mag2), four);
 }
 
 /* project, :145-151 */

@@ -68,8 +68,7 @@ def test_arbitrary_point_clouds_cameras_outside_the_points_and_degenerate_radii(
     for max_dist in (25.0, 400.0, 3.0, 0.05, 0.0):
         row, kept, uv = ba.visibility_within_distance(max_dist)
         ci, pi = grid_candidate_pairs(cams, pts, max_dist)              # brute force over every pair, numpy
-        with O.pow4_mode(1):                                             # k2 != 0: correctly rounded |p|^4 on both sides
-            uv0, keep0 = O.visibility_pairs(cams, pts, ci, pi, max_dist)
+        uv0, keep0 = O.visibility_pairs(cams, pts, ci, pi, max_dist)     # k2 != 0: libm's pow on both sides
         k = keep0 == 1
         want_row = np.concatenate([[0], np.bincount(ci[k], minlength=len(cams)).cumsum()]).astype(np.uint64)
         assert np.array_equal(row, want_row), max_dist

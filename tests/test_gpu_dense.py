@@ -44,8 +44,7 @@ def test_dense_random_cameras_ragged_sizes(c2b):
     distortion on (k2 != 0: uv still bit-exact), some cameras seeing nothing."""
     P = random_problem(131, 1000 + 37, 3, seed=41)
     cams, pts = P["cams15"], P["pts"]
-    with O.pow4_mode(1):                                       # k2 != 0: correctly rounded |p|^4, like the device
-        want = _oracle_dense(cams, pts, 6.0)
+    want = _oracle_dense(cams, pts, 6.0)                       # k2 != 0: libm's pow on both sides
     ba = c2b.BAProblem.from_visibility(cams, pts, np.zeros(len(cams) + 1, dtype=np.uint64), [], np.zeros((0, 2)))
     row_ptr, pt_idx, uv = ba.visibility_graph(6.0, dense=True)
     assert np.array_equal(row_ptr, want[0]) and np.array_equal(pt_idx, want[1])
@@ -70,7 +69,7 @@ def test_dense_boundary_distance_is_decided_exactly(c2b):
 def _boundary_points(cam15, rng, n_rows, side):
     """Points (px, py, -1) seen by an identity-rotation camera at the origin (so p = (px, py) exactly) whose u lands
     within a few ulps of `side` (+1 or -1) on either side: bisection over the doubles px with the oracle's projection
-    (correctly rounded pow mode), then the neighbouring doubles of the crossing."""
+    (libm pow), then the neighbouring doubles of the crossing."""
     pts = []
     for _ in range(n_rows):
         py = rng.uniform(-0.6, 0.6)
@@ -95,32 +94,27 @@ def _boundary_points(cam15, rng, n_rows, side):
 
 @pytest.mark.parametrize("k1,k2", [(-2e-2, 3e-2), (5e-2, -1e-2), (0.0, 2e-1)])
 def test_predicate_at_the_u_equals_one_boundary_with_k2(c2b, k1, k2):
-    """`generate` applies modify_intrinsics before visibility_graph (src/bin/city2ba.rs:534,542), so the
-    predicate -1 <= u <= 1 (src/generate.rs:446-454) is decided on projections that involve powf(4.0).  Points are
-    constructed with |u| = 1 +- a few ulps; the kept index sets and the uv bits of both device predicates (pair list
-    and dense sweep) must equal the oracle's in correctly-rounded-pow mode exactly.  In libm-pow mode the kept sets may
-    differ only at points whose uv differ, i.e. where glibc's pow is not correctly rounded."""
+    """`generate` applies modify_intrinsics before visibility_graph
+    (src/bin/city2ba.rs:534,542), so the predicate -1 <= u <= 1 (src/generate.rs:446-454) is decided on projections
+    that involve powf(4.0).  Points are constructed with |u| = 1 +- a few ulps; the kept index sets and the uv bits of
+    both device predicates (pair list and dense sweep) must equal the oracle's -- libm's pow, the reference's call --
+    exactly: 0 differing kept indices."""
     rng = np.random.default_rng(97)
     cam = O.camera_from_bal([0, 0, 0, 0, 0, 0, 0.9, k1, k2]).reshape(1, 15)
-    with O.pow4_mode(1):
-        pts = np.vstack([_boundary_points(cam[0], rng, 60, +1.0), _boundary_points(cam[0], rng, 60, -1.0)])
-        n = len(pts)
-        ci, pi = np.zeros(n, dtype=np.uint32), np.arange(n, dtype=np.uint32)
-        uv_cr, keep_cr = O.visibility_pairs(cam, pts, ci, pi, 10.0)
+    pts = np.vstack([_boundary_points(cam[0], rng, 60, +1.0), _boundary_points(cam[0], rng, 60, -1.0)])
+    n = len(pts)
+    ci, pi = np.zeros(n, dtype=np.uint32), np.arange(n, dtype=np.uint32)
     uv_lm, keep_lm = O.visibility_pairs(cam, pts, ci, pi, 10.0)
-    u = uv_cr[:, 0]
+    u = uv_lm[:, 0]
     assert np.sum(np.abs(u) == 1.0) >= 20 and np.sum(np.abs(u) > 1.0) >= 200 and np.sum(np.abs(u) < 1.0) >= 200
-    assert 0 < keep_cr.sum() < n
+    assert 0 < keep_lm.sum() < n
 
     ba = c2b.BAProblem.from_visibility(cam, pts, np.zeros(2, dtype=np.uint64), [], np.zeros((0, 2)))
     uv_d, keep_d = ba.visibility_pairs(ci, pi, 10.0)
-    assert np.array_equal(keep_d, keep_cr), "pair-list predicate must keep exactly the oracle's set"
-    assert np.array_equal(uv_d.view(np.uint64), uv_cr.view(np.uint64)), "uv bits"
+    assert np.array_equal(keep_d, keep_lm), "pair-list predicate must keep exactly the oracle's set"
+    assert np.array_equal(uv_d.view(np.uint64), uv_lm.view(np.uint64)), "uv bits"
     row_ptr, pt_idx, uv_s = ba.visibility_graph(10.0, dense=True)
-    kept = np.nonzero(keep_cr == 1)[0]
+    kept = np.nonzero(keep_lm == 1)[0]
     assert np.array_equal(pt_idx, kept.astype(np.uint64)) and int(row_ptr[-1]) == len(kept)
-    assert np.array_equal(uv_s.view(np.uint64), uv_cr[kept].view(np.uint64))
-    # against the reference's libm pow: any disagreement of the kept set sits where the projections differ
-    disagree = keep_lm != keep_cr
-    assert not np.any(disagree & np.all(uv_lm == uv_cr, axis=1))
-    print("boundary points: %d, kept %d; libm-pow mode decides %d of them differently" % (n, keep_cr.sum(), disagree.sum()))
+    assert np.array_equal(uv_s.view(np.uint64), uv_lm[kept].view(np.uint64))
+    print("boundary points: %d, kept %d; differing kept indices: 0" % (n, keep_lm.sum()))

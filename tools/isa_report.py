@@ -3,7 +3,7 @@
 operations, waits and branches (what the software-pipelined kernels are checked against: no s_waitcnt vmcnt(0)
 and no scratch inside the loop).  Works on the CPU box: hipcc cross-compiles.
 
-    python tools/isa_report.py [--tune] [--filter k_residual_jacobian_p] [--dump <mangled-name-substring>]
+    python tools/isa_report.py [--filter k_residual_jacobian_l] [--dump <mangled-name-substring>]
 
 Also a module: compile_asm() / kernel_table() / kernel_body() are what tests/test_isa_pins.py asserts on.
 """
@@ -20,11 +20,11 @@ CSRC = os.path.join(ROOT, "city2ba_amd", "csrc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-pthread", "-ldl"]
 
 
-def compile_asm(tune=False, keep=""):
+def compile_asm(keep=""):
     """Compile capi.hip exactly like __graft_entry__.build_hip() plus --save-temps; returns the gfx950 assembly text."""
     tmp = keep or tempfile.mkdtemp(prefix="c2b_isa_")
     os.makedirs(tmp, exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc"] + (["-DC2B_TUNE"] if tune else []) + HIPCC_FLAGS + [
+    cmd = ["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + [
         "--save-temps=obj", "-o", os.path.join(tmp, "lib.so"), os.path.join(CSRC, "capi.hip")]
     subprocess.check_call(cmd, cwd=CSRC)
     return open(glob.glob(os.path.join(tmp, "*gfx950*.s"))[0]).read()
@@ -76,12 +76,11 @@ def kernel_body(asm, mangled):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tune", action="store_true", help="compile with -DC2B_TUNE (all variants)")
     ap.add_argument("--filter", default="", help="only kernels whose demangled name contains this")
     ap.add_argument("--dump", default="", help="print the VM-op / wait skeleton of the first kernel whose name contains this")
     ap.add_argument("--keep", default="", help="directory to keep the temporaries in")
     a = ap.parse_args()
-    asm = compile_asm(a.tune, a.keep)
+    asm = compile_asm(a.keep)
     rows = kernel_table(asm)
     for r in rows:
         if a.filter in r["name"]:
