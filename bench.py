@@ -86,7 +86,7 @@ def parse():
                          "the best (1 = take the first; the line always ALSO reports the kernel in the first allocation).  "
                          "r05: 48, not 8 -- where in the device memory a set lies decides its store rate, every device mapped "
                          "has 8-12 fast sets among 60 consecutive ones but not always among the first eight "
-                         "(tools/probes/vram_store_map.py, profiles/r05ao); the rejects are held only during the search")
+                         "(profiles/r05ao); the rejects are held only during the search")
     ap.add_argument("--place-inputs", action="store_true",
                     help="also re-place the input arrays by measured kernel time (bench-only experiment, off by default)")
     ap.add_argument("--collective", choices=("auto", "c2b", "torch"), default="auto",
@@ -109,7 +109,7 @@ def parse():
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="diagnostic (1-GPU boxes): replace the collective by a kernel that spins this many microseconds on "
                          "the collective's stream -- what an N-rank all-reduce of that latency would cost the step in line "
-                         "and overlapped (tools/ab_step.sh)")
+                         "and overlapped (profiles/r03h_ab_step.txt)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group, balanced split, all-reduce) even with one rank: "
                          "how tests exercise the RCCL backend on a 1-GPU box")
@@ -405,7 +405,7 @@ def light_kernels(sh, dev, ws):
     return out
 
 
-# pass of light_kernels -> its kernel in profiles/r05at_light_sq.json (tools/profile_r05.sh: rocprofv3 kernel trace, SQ issue /
+# pass of light_kernels -> its kernel in profiles/r05at_light_sq.json (tools/profile_light.sh: rocprofv3 kernel trace, SQ issue /
 # wait counters, FETCH_SIZE and WRITE_SIZE, each in its own pass)
 _LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, true, true, 0>",
                  "error_sum_rows_L2": "k_observations<1, 2, 3, 8, 1, true, true, 2>",

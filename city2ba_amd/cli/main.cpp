@@ -38,6 +38,8 @@
 #include <vector>
 
 #include "../../include/city2ba_hip.h"
+#include "../../include/city2ba_hip_host.h"
+#include "../../include/city2ba_hip_experimental.h"
 
 namespace {
 

@@ -4,6 +4,8 @@
 //   capi_host_rows.hpp host-side rows (CPU C++ behind the same ABI): layouts, candidates, mesh samplers, cull, files
 //   capi_problem.hpp   Level 1: a BAProblem resident on one device (host buffers in / out, synchronous), *_sharded forms
 #include "../../include/city2ba_hip.h"
+#include "../../include/city2ba_hip_host.h"
+#include "../../include/city2ba_hip_experimental.h"
 
 #include <hip/hip_runtime.h>
 

@@ -37,44 +37,38 @@
  *           - uv_obs (sign of src/baproblem.rs:273).  Jc[n_obs][2][9] row-major, columns in
  *           to_vec order (w0 w1 w2 t0 t1 t2 f k1 k2); Jp[n_obs][2][3] (d/dX).
  *
+ * The boundary comes in three headers: THIS one -- Level 0 (stateless launchers over device pointers), the collectives, Level 1
+ * (a resident BAProblem): the stable device boundary; city2ba_hip_host.h -- the host-side rows (CPU C++ of the generators, cull,
+ * file IO: they never touch the GPU); city2ba_hip_experimental.h -- measurement aids, launch diagnostics and the f32 extension,
+ * which may change between rounds.
+ *
  * ---- index of entry points by level (tools/abi_index.py) ----
  *   library (3):
  *     version, last_error, device_count
- *   Level 0: workspace, camera records, points, rows (15):
- *     workspace_bytes, workspace_init, workspace_selfcheck, cameras_from_bal, cameras_to_bal, camblk_doubles,
- *     camblk_from_state, camblk_from_bal, cameras_from_position_direction, project_world, to_world, cameras_transform,
- *     points_pad, points_unpad, expand_rows
- *   Level 0: per-observation passes (cam_idx and row-structure forms) (17):
+ *   Level 0: workspace, camera records, points, rows (14):
+ *     workspace_bytes, workspace_init, cameras_from_bal, cameras_to_bal, camblk_doubles, camblk_from_state,
+ *     camblk_from_bal, cameras_from_position_direction, project_world, to_world, cameras_transform, points_pad,
+ *     points_unpad, expand_rows
+ *   Level 0: per-observation passes (cam_idx and row-structure forms) (15):
  *     project, reprojection_error_sum, rows_tiles_bytes, rows_pack, project_rows, reprojection_error_sum_rows,
  *     visibility_rows, visibility_rows_bits, reprojection_error_sums2_rows, add_noise_observations_error_sums2_rows,
- *     jacobian_stream_policy, jacobian_tiles_per_wave, jacobian_launch_shape, residual_jacobian_rows,
- *     residual_jacobian, error_sum_finish, residual_jacobian_sum
- *   Level 0: Jacobian output sets and calibration (9):
- *     jacobian_outputs_alloc, jacobian_outputs_pointers, jacobian_outputs_log, jacobian_outputs_store_rate,
- *     jacobian_outputs_set_store_rate, jacobian_outputs_free, residual_jacobian_rows_placed, calib_store_pattern,
- *     calib_copy
- *   Level 0: visibility sweeps and occlusion (10):
+ *     jacobian_stream_policy, residual_jacobian_rows, residual_jacobian, error_sum_finish, residual_jacobian_sum
+ *   Level 0: Jacobian output sets and calibration (5):
+ *     jacobian_outputs_alloc, jacobian_outputs_pointers, jacobian_outputs_store_rate, jacobian_outputs_free,
+ *     residual_jacobian_rows_placed
+ *   Level 0: visibility sweeps and occlusion (6):
  *     visibility_pairs, visibility_dense_tiles, visibility_dense_count, visibility_dense_fill, occlusion_filter,
- *     bvh_build, bvh_sizes, bvh_copy, bvh_free, occlusion_filter_bvh
+ *     occlusion_filter_bvh
  *   Level 0: statistics (5):
  *     stats, stats_partial_pass1, stats_partial_pass2, stats_combine_shares, stats_finish_shares
- *   collectives (RCCL) and sharded Level-0 forms (13):
- *     comm_backend, comm_unique_id, comm_init_rank, comm_init_all, comm_group_start, comm_group_end, comm_info,
+ *   collectives (RCCL) and sharded Level-0 forms (12):
+ *     comm_unique_id, comm_init_rank, comm_init_all, comm_group_start, comm_group_end, comm_info,
  *     comm_all_reduce_sum_f64, comm_all_gather_f64, comm_destroy, stats_sharded, add_drift_sharded,
  *     add_noise_entities_sharded
  *   Level 0: noise (5):
  *     add_drift, add_drift_normalized, add_noise_entities, add_noise_observations, add_sin_noise
- *   f32 extension (7):
- *     convert_f64_to_f32, convert_f32_to_f64, stats_f32, add_drift_f32, add_drift_normalized_f32,
- *     add_noise_entities_f32, add_sin_noise_f32
- *   host-side rows (CPU; never touch the GPU) (39):
- *     partition_cameras, synthetic_grid_sizes, synthetic_grid_layout, synthetic_line_layout, candidate_pairs,
- *     pairs_count, pairs_cam_idx, pairs_pt_idx, pairs_free, obj_load, obj_model_count, obj_model_name,
- *     obj_model_sizes, obj_model_copy, obj_move_to_origin, obj_triangles, obj_free, generate_cameras_path,
- *     generate_cameras_poisson, generate_cameras_poisson_bvh, modify_intrinsics, generate_world_points, cull,
- *     largest_connected_component, remove_singletons, add_incorrect_correspondences, drop_features, split_landmarks,
- *     join_landmarks, bal_read, bal_sizes, bal_copy, bal_close, bal_write, bal_read_as, bal_write_as, format_f64,
- *     parse_f64, ply_write
+ *   the shard map (1):
+ *     partition_cameras
  *   Level 1: a resident BAProblem (46):
  *     problem_create, problem_destroy, problem_options_init, problem_set_options, problem_get_options,
  *     host_set_io_threads, problem_upload, problem_upload_bal, problem_synthetic_grid_layout,
@@ -92,7 +86,20 @@
  *   Level 1: one shard of a larger problem (6):
  *     problem_set_shard, problem_stats_sharded, problem_add_drift_sharded, problem_add_noise_sharded,
  *     problem_add_sin_noise_sharded, problem_add_noise_errors_l1_l2_sharded
- *   (175 entry points; names above without their c2b_ prefix)
+ *   -- city2ba_hip.h: 118 entry points --
+ *   city2ba_hip_host.h: host-side rows (CPU; never touch the GPU) (42):
+ *     synthetic_grid_sizes, synthetic_grid_layout, synthetic_line_layout, candidate_pairs, pairs_count, pairs_cam_idx,
+ *     pairs_pt_idx, pairs_free, obj_load, obj_model_count, obj_model_name, obj_model_sizes, obj_model_copy,
+ *     obj_move_to_origin, obj_triangles, obj_free, generate_cameras_path, generate_cameras_poisson,
+ *     generate_cameras_poisson_bvh, modify_intrinsics, generate_world_points, cull, largest_connected_component,
+ *     remove_singletons, add_incorrect_correspondences, drop_features, split_landmarks, join_landmarks, bal_read,
+ *     bal_sizes, bal_copy, bal_close, bal_write, bal_read_as, bal_write_as, format_f64, parse_f64, ply_write,
+ *     bvh_build, bvh_sizes, bvh_copy, bvh_free
+ *   city2ba_hip_experimental.h: diagnostics, calibration, f32 extension (15):
+ *     workspace_selfcheck, comm_backend, jacobian_tiles_per_wave, jacobian_launch_shape, jacobian_outputs_log,
+ *     jacobian_outputs_set_store_rate, calib_store_pattern, calib_copy, convert_f64_to_f32, convert_f32_to_f64,
+ *     stats_f32, add_drift_f32, add_drift_normalized_f32, add_noise_entities_f32, add_sin_noise_f32
+ *   (175 entry points in all; names above without their c2b_ prefix)
  * ---- end of index ----
  *
  * Every function returns C2B_OK or a negative status; c2b_last_error() gives the text.
@@ -142,9 +149,6 @@ int c2b_device_count(int *count);
 int64_t c2b_workspace_bytes(int64_t n_obs);
 /* zero the arrival counters, write the magic: one tiny launch on `stream` (capture-safe) */
 int c2b_workspace_init(void *workspace, void *stream);
-/* Diagnostic: synchronises `stream`, then counts the workspace's non-zero arrival counters.  Zero whenever no launch
- * using it is in flight; anything else means a fold did not complete.  -1: the workspace was never initialised. */
-int c2b_workspace_selfcheck(const void *workspace, void *stream, int64_t *nonzero_words);
 
 /* SnavelyCamera::from_vec / from_rodrigues (src/baproblem.rs:78-90, 180-186) */
 int c2b_cameras_from_bal(const double *bal9, int64_t n_cam, double *cam15, void *stream);
@@ -241,18 +245,6 @@ int c2b_add_noise_observations_error_sums2_rows(const double *camblk, const doub
  * that the camera and point tables stay in them (c2b_jacobian_stream_policy returns that decision: 0 none, 2 uv,
  * 3 uv and index; results are identical under every policy). */
 int c2b_jacobian_stream_policy(int64_t n_obs, int64_t n_cam, int64_t n_pts);
-/* tiles of 64 observations a wave of the residual + Jacobian launch takes: 1 below ~6 M observations, else 2
- * (diagnostic: names the kernel instance a launch of this size runs; results do not depend on it, the rounding of
- * the folded error sum does, like on any other change of the grid) */
-int c2b_jacobian_tiles_per_wave(int64_t n_obs);
-/* ... and the full shape -- waves of 64 per workgroup, tiles per wave -- of a launch of n_obs observations into an output
- * set that takes streaming stores at store_GBs (GB/s; 0 = unknown): 16 x 1 below ~6 M observations; above, 8 x 2 -- or
- * 4 x 1 when the set is one of the slow-store kind (< 6.3 TB/s) and 16 x 1 when it lies between the classes (< 6.85 TB/s),
- * which only c2b_residual_jacobian_rows_placed knows.  Diagnostic, like the two above: results do not depend on the shape.
- * The shapes named are those of a launch WITH an error sum (workspace != NULL, the bench step).  One exception: a launch
- * without a sum (workspace == NULL) that would take 8 x 2 runs 16 x 1 instead -- the 8 x 2 instance without the sum's
- * fold does not fit its 128 registers without scratch (capi.hip: launch_jac_l). */
-int c2b_jacobian_launch_shape(int64_t n_obs, double store_GBs, int *waves_per_workgroup, int *tiles_per_wave);
 int c2b_residual_jacobian_rows(const double *camblk, const double *pts4, int64_t n_pts, const uint64_t *row_ptr, int64_t n_cam,
                                const void *tiles, int64_t obs_base, const uint32_t *pt_idx, const double *uv_obs,
                                int64_t n_obs, double *r, double *Jc, double *Jp, double norm, void *workspace,
@@ -296,13 +288,8 @@ typedef struct c2b_jacobian_outputs c2b_jacobian_outputs;
 int c2b_jacobian_outputs_alloc(int64_t n_obs, int max_attempts, double fast_store_GBs, void *stream,
                                c2b_jacobian_outputs **out);
 int c2b_jacobian_outputs_pointers(const c2b_jacobian_outputs *h, double **r, double **Jc, double **Jp);
-/* store rate (GB/s) measured for every attempt, how many there were, and which one was kept */
-int c2b_jacobian_outputs_log(const c2b_jacobian_outputs *h, double *store_GBs_per_attempt, int capacity, int *attempts,
-                             int *chosen);
 /* the kept set's measured store rate in GB/s (0: not measured) */
 int c2b_jacobian_outputs_store_rate(const c2b_jacobian_outputs *h, double *store_GBs);
-/* replace it: for a caller that timed the set itself, or wants one particular launch shape (<= 0: "unknown") */
-int c2b_jacobian_outputs_set_store_rate(c2b_jacobian_outputs *h, double store_GBs);
 void c2b_jacobian_outputs_free(c2b_jacobian_outputs *h);
 /* c2b_residual_jacobian_rows over the WHOLE list (obs_base = 0, n_obs = the set's observation count) INTO a placed set:
  * r / Jc / Jp are the handle's arrays, and the launch takes the workgroup shape that is fastest for stores of the speed
@@ -314,12 +301,6 @@ int c2b_residual_jacobian_rows_placed(const double *camblk, const double *pts4, 
                                       int64_t n_obs, const c2b_jacobian_outputs *outputs, double norm, void *workspace,
                                       double *out_sum, void *stream);
 
-/* Calibration (measurement aids, no reference counterpart; used by bench.py in the same process as the timed run so
- * that a slow device can be told from a slow kernel).  _store_pattern writes a fill pattern over r [n][2], Jc [n][18],
- * Jp [n][6] in exactly the residual+Jacobian kernel's store geometry with no loads and no arithmetic -- the time its
- * stores alone take; _copy is a 16-bytes-per-lane streaming copy (bytes % 16 == 0). */
-int c2b_calib_store_pattern(int64_t n_obs, double *r, double *Jc, double *Jp, void *stream);
-int c2b_calib_copy(const void *src, void *dst, int64_t bytes, void *stream);
 
 /* visibility predicate of the generators (src/synthetic.rs:285-291, 368-375;
  * src/generate.rs:448-454): keep = |center - p| < max_dist && q.z <= 0 && |u|,|v| <= 1.
@@ -360,10 +341,7 @@ int c2b_occlusion_filter(const double *camblk, const double *pts4, const uint32_
 #define C2B_BVH_NODE_BYTES 64
 #define C2B_BVH_TRI_BYTES 48
 typedef struct c2b_bvh c2b_bvh;
-int c2b_bvh_build(const float *tri9, int64_t n_tri, c2b_bvh **out);
-int c2b_bvh_sizes(const c2b_bvh *b, int64_t *n_nodes, int64_t *n_slots, int *depth);
-int c2b_bvh_copy(const c2b_bvh *b, void *nodes, void *tris, uint32_t *order);
-void c2b_bvh_free(c2b_bvh *b);
+/* (c2b_bvh_build / _sizes / _copy / _free: host-side rows, city2ba_hip_host.h) */
 int c2b_occlusion_filter_bvh(const double *camblk, const double *pts4, const uint32_t *cam_idx,
                              const uint32_t *pt_idx, int64_t n_obs, const void *nodes, int64_t n_nodes,
                              const void *tris, int64_t n_slots, uint8_t *keep, uint32_t *overflow, void *stream);
@@ -408,8 +386,6 @@ int c2b_stats_finish_shares(const double *sumsq, int world, int64_t n_entities_g
  * ===================================================================================== */
 #define C2B_COMM_ID_BYTES 128
 typedef struct c2b_comm c2b_comm;
-/* "RCCL 2.x.y (path)" or "unavailable: ..." */
-const char *c2b_comm_backend(void);
 /* Rank 0 makes the id and hands its C2B_COMM_ID_BYTES bytes to every rank through whatever channel the host has
  * (a file, a pipe, MPI, the torch store); then EVERY rank calls c2b_comm_init_rank with it (collective; makes `device`
  * the calling thread's current device). */
@@ -468,168 +444,10 @@ int c2b_add_sin_noise(double *cam15, int64_t n_cam, double *pts4, int64_t n_pts,
                       double ndir_x, double ndir_y, double ndir_z, double strength,
                       double frequency, void *stream);
 
-/* ---- f32 extension (BASELINE.json configs[4]).  The reference has NO f32 compute path:
- * these run the same kernels over a float state -- cam15 / pts4 stored as float -- with the draws and
- * the statistics kept in f64; results track the f64 path to f32 accuracy (tested at an f32 tolerance). */
-int c2b_convert_f64_to_f32(const double *src, int64_t n, float *dst, void *stream);
-int c2b_convert_f32_to_f64(const float *src, int64_t n, double *dst, void *stream);
-int c2b_stats_f32(const float *cam15, int64_t n_cam, const float *pts4, int64_t n_pts, void *workspace,
-                  double *stats, void *stream);
-int c2b_add_drift_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *origin,
-                      double strength, double angle_strength, double std, double dir_x, double dir_y,
-                      double dir_z, uint64_t seed, void *stream);
-int c2b_add_drift_normalized_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts,
-                                 const double *stats, double strength, double angle_strength,
-                                 double std, uint64_t seed, void *stream);
-int c2b_add_noise_entities_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts,
-                               const double *stats, double translation_std, double rotation_std,
-                               double point_std, uint64_t seed, void *stream);
-int c2b_add_sin_noise_f32(float *cam15, int64_t n_cam, float *pts4, int64_t n_pts, const double *stats,
-                          double dir_x, double dir_y, double dir_z, double ndir_x, double ndir_y,
-                          double ndir_z, double strength, double frequency, void *stream);
 
 /* contiguous camera ranges with ~equal observation counts (host pointers): the multi-GPU
  * shard map.  bounds[n_parts+1]; part k owns cameras [bounds[k], bounds[k+1]). */
 int c2b_partition_cameras(const uint64_t *row_ptr, int64_t n_cam, int n_parts, int64_t *bounds);
-
-/* ===================================================================================== *
- * Host-side generator pieces around the device predicate (HOST pointers, CPU, synchronous).
- * These are the callers either side of the hot path, in C++ because the
- * reference's generator is compiled code; they never touch the GPU.
- * ===================================================================================== */
-
-/* synthetic_grid's camera / point counts: 4*cpb*B*(B+1), 12*ppb*B*(B+1) (src/synthetic.rs:179-258) */
-int c2b_synthetic_grid_sizes(int64_t cameras_per_block, int64_t points_per_block, int64_t blocks,
-                             int64_t *n_cam, int64_t *n_pts);
-/* layout loops of synthetic_grid (src/synthetic.rs:178-258) in the reference's push and arithmetic
- * order: camera positions [n_cam][3], directions [n_cam][9] (col-major Basis3), points [n_pts][3] */
-int c2b_synthetic_grid_layout(int64_t cameras_per_block, int64_t points_per_block, int64_t blocks,
-                              double block_length, double block_inset, double camera_height,
-                              double point_height, double *cam_pos3, double *cam_dir9, double *pts3);
-/* layout of synthetic_line (src/synthetic.rs:323-344) */
-int c2b_synthetic_line_layout(int64_t n_cam, int64_t n_pts, double length, double point_offset,
-                              double camera_height, double point_height, double *cam_pos3,
-                              double *cam_dir9, double *pts3);
-
-/* Candidate (camera, point) pairs for cameras [cam_lo, cam_hi): squared distance from the camera
- * centre <= max_dist^2 (rstar locate_within_distance, src/synthetic.rs:277-280), camera-major,
- * ascending point index per camera; with occlusion != 0, pairs whose sight line crosses a building
- * are dropped (hits_building, src/synthetic.rs:52-124, incl. its end-point quirk at :93). */
-typedef struct c2b_pairs c2b_pairs;
-int c2b_candidate_pairs(const double *centers3, int64_t n_cam, const double *pts3, int64_t n_pts,
-                        double max_dist, int64_t cam_lo, int64_t cam_hi, int occlusion,
-                        double block_length, double block_inset, int n_threads, c2b_pairs **out);
-int64_t c2b_pairs_count(const c2b_pairs *p);
-const uint32_t *c2b_pairs_cam_idx(const c2b_pairs *p);
-const uint32_t *c2b_pairs_pt_idx(const c2b_pairs *p);
-void c2b_pairs_free(c2b_pairs *p);
-
-/* ---- mesh generator (src/generate.rs), host side.  Embree is replaced by brute-force f32 ray / triangle
- * tests; every sampler takes a seed where the reference draws from an unseeded thread_rng(). ---- */
-
-/* tobj::load_obj conventions (tobj 0.1.12): one model per `o`/`g` that owns faces or lines, f32 positions
- * re-indexed per model, polygons fan-triangulated, `l` polylines as index pairs. */
-typedef struct c2b_obj c2b_obj;
-int c2b_obj_load(const char *path, c2b_obj **out);
-int64_t c2b_obj_model_count(const c2b_obj *o);
-const char *c2b_obj_model_name(const c2b_obj *o, int64_t model);
-/* is_lines: 1 when the model is a polyline (indices are segment pairs), 0 for triangles */
-int c2b_obj_model_sizes(const c2b_obj *o, int64_t model, int64_t *n_positions, int64_t *n_indices, int *is_lines);
-int c2b_obj_model_copy(const c2b_obj *o, int64_t model, float *positions3, uint32_t *indices);
-/* move_to_origin (src/generate.rs:484-527), in place, over every model except `skip_model` (-1: none):
- * run_generate (src/bin/city2ba.rs:493-513) takes the --path model out of the list before the move */
-int c2b_obj_move_to_origin(c2b_obj *o, int64_t skip_model);
-/* triangles of every non-polyline model except `skip_model` (-1: none) as packed f32 [n_tri][9];
- * call with tri9 == NULL to get the count */
-int c2b_obj_triangles(const c2b_obj *o, int64_t skip_model, float *tri9, int64_t *n_tri);
-void c2b_obj_free(c2b_obj *o);
-
-/* generate_cameras_path (step_size <= 0, src/generate.rs:109-148) / generate_cameras_path_step (:152-213) along
- * polyline model `path_model`: positions [num_cameras][3], directions [num_cameras][9] (col-major Basis3) */
-int c2b_generate_cameras_path(const c2b_obj *o, int64_t path_model, int64_t num_cameras, double step_size,
-                              uint64_t seed, double *cam_pos3, double *cam_dir9);
-/* generate_cameras_poisson (:217-280) over triangles tri9: Poisson-disk x-z samples, downward ray casts, the
- * `pt[2] < lower_y + ground` filter of :264, random yaw.  *n_out = the number of cameras generated; the first
- * min(*n_out, capacity) are written (same seed => same cameras, so call with capacity 0 to size the buffers). */
-int c2b_generate_cameras_poisson(const float *tri9, int64_t n_tri, int64_t num_points, double height, double ground,
-                                 uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9, int64_t *n_out);
-/* the same with a hierarchy the caller already built over tri9 (c2b_bvh_build) for the downward rays; without one the
- * function builds its own while it throws the darts.  The rays are cast on all host threads, gathered in sample order. */
-int c2b_generate_cameras_poisson_bvh(const float *tri9, int64_t n_tri, const c2b_bvh *bvh, int64_t num_points, double height,
-                                     double ground, uint64_t seed, int64_t capacity, double *cam_pos3, double *cam_dir9,
-                                     int64_t *n_out);
-/* modify_intrinsics (:530-544) */
-int c2b_modify_intrinsics(double *cams15, int64_t n_cam, const double start[3], const double end[3], uint64_t seed);
-/* generate_world_points_uniform (:356-420): area-weighted samples on the triangles that lie within max_dist of
- * some camera centre; fails like the reference's panics (no cameras / too many rejections) */
-int c2b_generate_world_points(const float *tri9, int64_t n_tri, const double *centers3, int64_t n_cam,
-                              int64_t num_points, double max_dist, uint64_t seed, double *pts3, int64_t *n_out);
-
-/* BAProblem::cull (src/baproblem.rs:538-549) = largest_connected_component + remove_singletons to a
- * fixed point, IN PLACE on host arrays (outputs are subsets, so they fit).  Camera rows are opaque
- * `cam_stride` doubles.  On return *n_cam / *n_pts hold the new counts and row_ptr[*n_cam] the new
- * observation count.  faithful != 0 keeps the reference's observation filter at :523 (it indexes the
- * camera-first union-find array with a point index); ties between equally large components go to the one
- * with the smallest member (the reference: HashMap order). */
-int c2b_cull(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
-             uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful);
-/* its two halves as the reference also exposes them: BAProblem::largest_connected_component (:456-534) and
- * BAProblem::remove_singletons (:426-453), one application each, same calling convention */
-int c2b_largest_connected_component(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
-                                    uint64_t *row_ptr, uint64_t *pt_idx, double *uv, int faithful);
-int c2b_remove_singletons(int64_t *n_cam, double *cams, int cam_stride, int64_t *n_pts, double *pts3,
-                          uint64_t *row_ptr, uint64_t *pt_idx, double *uv);
-
-/* noise.rs' index-corruption functions: sequential random reshuffles of the visibility graph, on the host over
- * the flat CSR arrays, IN PLACE, seeded (the reference: thread_rng()).
- * add_incorrect_correspondences (src/noise.rs:180-226): per observation, with probability mismatch_chance, swap
- *   its point index with a distance-weighted partner of the same camera (weights as at :198-206). */
-int c2b_add_incorrect_correspondences(int64_t n_cam, const uint64_t *row_ptr, uint64_t *pt_idx, const double *uv,
-                                      double mismatch_chance, uint64_t seed);
-/* drop_features (:229-251): per camera keep floor(len * keep_fraction) observations of a random shuffle;
- *   rewrites row_ptr and compacts pt_idx / uv. */
-int c2b_drop_features(int64_t n_cam, uint64_t *row_ptr, uint64_t *pt_idx, double *uv, double keep_fraction,
-                      uint64_t seed);
-/* split_landmarks (:255-291): floor(split_fraction * *n_pts) landmarks are duplicated at the end of pts3 (which must
- *   hold pts_capacity >= *n_pts + that many rows) and their observations move to the copy with probability 1/2. */
-int c2b_split_landmarks(int64_t *n_pts, double *pts3, int64_t pts_capacity, int64_t n_obs, uint64_t *pt_idx,
-                        double split_fraction, uint64_t seed);
-/* join_landmarks (:326-378): floor(join_fraction * n_pts) random observations are re-pointed at one of the 10
- *   nearest other landmarks of their landmark. */
-int c2b_join_landmarks(int64_t n_pts, const double *pts3, int64_t n_obs, uint64_t *pt_idx, double join_fraction,
-                       uint64_t seed);
-
-/* BAProblem::from_file (src/baproblem.rs:697-706): ".bal" text / ".bbal" big-endian binary by extension.
- * Cameras come back as 9-vectors (upload them with c2b_problem_upload_bal = from_vec). */
-typedef struct c2b_balfile c2b_balfile;
-int c2b_bal_read(const char *path, c2b_balfile **out);
-int c2b_bal_sizes(const c2b_balfile *f, int64_t *n_cam, int64_t *n_pts, int64_t *n_obs);
-int c2b_bal_copy(const c2b_balfile *f, double *bal9, double *pts3, uint64_t *row_ptr, uint64_t *pt_idx,
-                 double *uv);
-void c2b_bal_close(c2b_balfile *f);
-/* BAProblem::write (src/baproblem.rs:768-785); bal9 = to_vec of every camera (c2b_problem_download_bal) */
-int c2b_bal_write(const char *path, int64_t n_cam, const double *bal9, int64_t n_pts, const double *pts3,
-                  const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv);
-/* the format chosen by the caller instead of by the extension: format 0 = text (from_file_text :580, write_text
- * :709), 1 = binary (from_file_binary :632, write_binary :736), -1 = by extension */
-int c2b_bal_read_as(const char *path, int format, c2b_balfile **out);
-int c2b_bal_write_as(const char *path, int format, int64_t n_cam, const double *bal9, int64_t n_pts,
-                     const double *pts3, const uint64_t *row_ptr, const uint64_t *pt_idx, const double *uv);
-/* one f64 as write_text prints it -- Rust's `{}` (src/baproblem.rs:713-731): the shortest digits that read back to the
- * same double, no exponent, "-0", "NaN", "inf".  n values -> their texts back to back in buf, each followed by '\n';
- * *len = bytes written.  C2B_ERR_INVALID_ARGUMENT if cap is too small (330 bytes per value always suffice).  Host code
- * (csrc/decimal.hpp); the device writer of c2b_problem_write runs the same functions. */
-int c2b_format_f64(int64_t n, const double *values, char *buf, int64_t cap, int64_t *len);
-/* the other direction, as from_file_text reads a number (nom's `double`, i.e. str::parse::<f64>: correctly rounded;
- * src/baproblem.rs:580-629): `text` holds n whitespace-separated tokens; values[i] = token i, status[i] = 0 parsed,
- * 1 a spelling this parser leaves to strtod (anything but [+-]digits[.digits][(e|E)[+-]digits], e.g. "NaN"), 2 more
- * than 19 significant digits or a rounding its 128-bit arithmetic cannot decide (the device reader hands such files to
- * the host parser).  Host code (csrc/decimal.hpp); the device reader of c2b_problem_read runs the same functions. */
-int c2b_parse_f64(const char *text, int64_t len, int64_t n, double *values, int32_t *status);
-/* write_cameras of the `ply` subcommand (src/bin/city2ba.rs:359-439): ASCII PLY with one red vertex per camera
- * centre, one green vertex per point (f32) and one edge per observation (camera, n_cam + point) */
-int c2b_ply_write(const char *path, int64_t n_cam, const double *centers3, int64_t n_pts, const double *pts3,
-                  const uint64_t *row_ptr, const uint64_t *pt_idx);
 
 /* ===================================================================================== *
  * Level 1 -- a BAProblem resident on one device.  Pointers are HOST pointers; calls are

@@ -20,8 +20,15 @@ def c2b():
     return city2ba_amd
 
 
+HEADERS = ("city2ba_hip.h", "city2ba_hip_host.h", "city2ba_hip_experimental.h")     # the stable device boundary, the host-side rows, the rest
+
+
+def _headers_text():
+    return "\n".join(open(os.path.join(ROOT, "include", h)).read() for h in HEADERS)
+
+
 def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    text = _headers_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(c2b_[a-z0-9_]+)\s*\(", text)))
 
@@ -45,6 +52,8 @@ def test_header_is_plain_c_and_links(c2b, tmp_path):
     src.write_text(r'''
 #include <stdio.h>
 #include "city2ba_hip.h"
+#include "city2ba_hip_host.h"
+#include "city2ba_hip_experimental.h"
 int main(void) {
     int64_t n_cam = 0, n_pts = 0;
     int rc = c2b_synthetic_grid_sizes(10, 10, 4, &n_cam, &n_pts);
@@ -66,7 +75,7 @@ int main(void) {
 
 
 def test_header_cites_reference_lines():
-    text = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    text = _headers_text()
     assert len(re.findall(r"src/(baproblem|noise|synthetic|generate)\.rs:\d+", text)) >= 15
 
 
@@ -84,7 +93,7 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "city2ba_oracle" not in src and "orc_" not in src, f
-    assert "oracle" not in open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    assert "oracle" not in _headers_text()
 
 
 def test_workspace_and_partition_host_helpers(c2b):
@@ -144,7 +153,7 @@ def test_product_library_has_no_tuning_hooks_and_no_undeclared_entry_points(c2b)
     no source file carries a tuning island."""
     import re
     import __graft_entry__ as entry
-    header = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", _headers_text(), flags=re.S)
     declared = set(re.findall(r"\b(c2b_[a-z0-9_]+)\s*\(", header))
     product = {s for s in _exported(entry.build_hip()) if s.startswith("c2b_")}
     assert not [s for s in product if "tune" in s], "tuning hooks in the product library"
@@ -188,7 +197,10 @@ def test_header_index_lists_every_entry_point_once_and_the_library_reads_no_envi
     header = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
     block = abi_index.index_block()
     assert block in header, "run `python tools/abi_index.py --write`"
-    body = header.replace(block, "")
+    body = _headers_text().replace(block, "")
+    # the stable device boundary holds at most 120 entry points
+    main_only = re.findall(r"(?m)^\s*(?:const\s+)?\w+\s*\**\s*(c2b_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", header.replace(block, ""), flags=re.S))
+    assert len(main_only) <= 120, len(main_only)
     declared = re.findall(r"(?m)^\s*(?:const\s+)?\w+\s*\**\s*(c2b_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     listed = re.findall(r"\b([a-z][a-z0-9_]+)\b(?=,|\n| \*/|$)", "\n".join(ln[7:] for ln in block.split("\n") if ln.startswith(" *     ")))
     assert sorted("c2b_" + n for n in listed) == sorted(declared)

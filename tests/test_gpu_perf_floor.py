@@ -1,15 +1,22 @@
-"""A performance floor in the GPU suite: refactors cannot regress the hot path silently, and whatever
-MI355X the suite runs on reports what it measured.  `synthetic --blocks 128` (19 302 494 observations):
+"""A performance floor in the GPU suite (tightened per VERDICT r05 item 8 / ADVICE r05): refactors cannot
+regress the hot path silently, and whatever MI355X the suite runs on reports what it measured.  `synthetic --blocks 128`
+(19 302 494 observations):
 
   * the step kernel (residual + 2x(9+3) Jacobian + folded L2 sum, launched into a placed output set so that the launch
-    shape follows the set's store rate) <= 1.15 x the launch's algorithmic bytes at the streaming-store rate THIS device
-    sustains into THAT set, measured in the same process (the device-independent figure of merit: 1.06-1.105 measured on
-    slow-store, mixed and fast-store devices, profiles/r05*_ab_*);
-  * both error norms in one pass, caches swept before every launch <= 1.2 x the recorded 117 us;
-  * the statistics pass, back to back <= 50 us (25-33 us measured since the compact centre table).
+    shape follows the set's store rate) <= 1.10 x the launch's algorithmic bytes at the streaming-store rate THIS device
+    sustains into THAT set, measured in the same process (the device-independent figure of merit: 1.05-1.08 measured on
+    slow-store, mixed and fast-store devices over rounds 5-6);
+  * a rank's EIGHTH of the list (2.41 M observations, what a rank of the 8-GPU run launches) <= 1.25 x its own floor of the
+    same kind (1.08-1.19 measured: ramp, tail and fold weigh a tenth of a 95-us launch);
+  * both error norms in one pass, caches swept before every launch: <= 120 us (110-116 measured on every device of rounds
+    5-6, whatever its store class) AND <= 1.6 x a same-process streaming copy of the pass's algorithmic bytes (the
+    device-relative form ADVICE r05 asked for: 1.25-1.4 measured);
+  * the statistics pass, back to back <= 29 us (25-26 us measured since the compact centre table).
 
-The bounds are regression tripwires with 10-40 % of air, not targets.  The measured figures go to the test log (printed
-past pytest's capture) and, when gpurun_out/ exists, to gpurun_out/perf_floor.json."""
+Tripwires with 4-10 % of air over what five rounds of devices measured -- a 5 % regression of the step kernel trips --,
+not targets.  Every figure is the best of three interleaved measurements, so one noisy reading does not trip them.  The
+measured figures go to the test log (printed past pytest's capture) and, when gpurun_out/ exists, to
+gpurun_out/perf_floor.json."""
 import argparse
 import json
 import os
@@ -65,23 +72,49 @@ def test_hot_path_stays_within_its_floors_at_the_headline_size(capsys):
                    "launch_shape_threads_x_tiles": [shape[0] * 64, shape[1]], "algorithmic_floor_us": round(floor_us, 1),
                    "kernel_over_floor": round(step_us / floor_us, 4), "frac_of_8TBs": round(alg / step_us / 1e3 / 8000.0, 4)}
 
+    # -- a rank's eighth of the list: the launch the 8-GPU run lives on ---------------------------------------------------
+    sh8 = bench.build_shard(argparse.Namespace(blocks=128), 0, 8, dev)
+    n8 = sh8["n_obs"]
+    ws8 = D.workspace(n8, dev)
+    outs8 = D.JacobianOutputs(n8, dev, max_attempts=1)
+    a8 = (sh8["camblk"], sh8["pts4"], sh8["rows"], sh8["pt_idx"])
+    alg8 = bench.algorithmic_bytes(n8, sh8["n_cam_local"], sh8["n_pts"])
+    store8 = min(_timed(torch, lambda: D.calib_store_pattern(outs8.r, outs8.Jc, outs8.Jp), 20) for _ in range(3))
+    step8 = min(_timed(torch, lambda: D.residual_jacobian_rows_placed(*a8, sh8["uv"], outs8, 2.0, ws8, err[:1]), 50) for _ in range(3))
+    floor8 = alg8 / (n8 * 208 / store8 / 1e3) / 1e3
+    shape8 = D.jacobian_launch_shape(n8, outs8.store_GBs)
+    out["step_rank_eighth"] = {"n_observations": n8, "kernel_us": round(step8, 1), "store_GBs_of_the_set": round(n8 * 208 / store8 / 1e3, 1),
+                               "launch_shape_threads_x_tiles": [shape8[0] * 64, shape8[1]], "algorithmic_floor_us": round(floor8, 1),
+                               "kernel_over_floor": round(step8 / floor8, 4)}
+    del outs8, sh8
+
     # -- both norms in one pass, cold ---------------------------------------------------------------------------------
     sweep = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
-    cold = []
-    for _ in range(7):
-        sweep.sum()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        D.reprojection_error_sums2_rows(*a, sh["uv"], ws, err)
-        e.record()
-        torch.cuda.synchronize()
-        cold.append(s.elapsed_time(e) * 1e3)
-    cold_us = sorted(cold)[3]
-    out["error_sums2_rows_L1_and_L2"] = {"us_cold": round(cold_us, 1), "us_back_to_back": round(_timed(torch, lambda: D.reprojection_error_sums2_rows(*a, sh["uv"], ws, err), 20), 1)}
+
+    def cold_median(fn):
+        t = []
+        for _ in range(7):
+            sweep.sum()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            t.append(s.elapsed_time(e) * 1e3)
+        return sorted(t)[3]
+
+    cold_us = min(cold_median(lambda: D.reprojection_error_sums2_rows(*a, sh["uv"], ws, err)) for _ in range(3))
+    # the same-process yardstick: a 16-byte-per-lane streaming copy of the pass's algorithmic bytes (20 B per observation + tables)
+    light_bytes = (n * 20 + sh["n_cam_local"] * 72 + sh["n_pts"] * 24) // 16 * 16
+    src = torch.empty(light_bytes // 8, dtype=torch.float64, device=dev)
+    dst = torch.empty_like(src)
+    copy_us = min(_timed(torch, lambda: D.calib_copy(src, dst), 20) for _ in range(3))
+    out["error_sums2_rows_L1_and_L2"] = {"us_cold": round(cold_us, 1), "us_back_to_back": round(_timed(torch, lambda: D.reprojection_error_sums2_rows(*a, sh["uv"], ws, err), 20), 1),
+                                         "copy_of_its_algorithmic_bytes_us": round(copy_us, 1), "cold_over_copy": round(cold_us / copy_us, 3)}
 
     # -- statistics ---------------------------------------------------------------------------------------------------
     st = torch.empty(20, dtype=torch.float64, device=dev)
-    stats_us = _timed(torch, lambda: D.stats(sh["camblk"], sh["pts4"], ws, st, centers=sh["cen4"]), 50)
+    stats_us = min(_timed(torch, lambda: D.stats(sh["camblk"], sh["pts4"], ws, st, centers=sh["cen4"]), 50) for _ in range(3))
     out["stats"] = {"us_back_to_back": round(stats_us, 1)}
 
     with capsys.disabled():
@@ -91,6 +124,7 @@ def test_hot_path_stays_within_its_floors_at_the_headline_size(capsys):
         with open(os.path.join(d, "perf_floor.json"), "w") as fh:
             json.dump(out, fh, indent=1)
 
-    assert step_us <= 1.15 * floor_us, out["step"]
-    assert cold_us <= 1.2 * 117.0, out["error_sums2_rows_L1_and_L2"]
-    assert stats_us <= 50.0, out["stats"]
+    assert step_us <= 1.10 * floor_us, out["step"]
+    assert step8 <= 1.25 * floor8, out["step_rank_eighth"]
+    assert cold_us <= 120.0 and cold_us <= 1.6 * copy_us, out["error_sums2_rows_L1_and_L2"]
+    assert stats_us <= 29.0, out["stats"]

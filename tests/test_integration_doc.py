@@ -43,7 +43,7 @@ def rust_type(text):
 
 
 def header_prototypes():
-    text = open(os.path.join(ROOT, "include", "city2ba_hip.h")).read()
+    text = "\n".join(open(os.path.join(ROOT, "include", h)).read() for h in ("city2ba_hip.h", "city2ba_hip_host.h", "city2ba_hip_experimental.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
     for m in re.finditer(r"(?m)^\s*((?:const\s+)?\w+\s*\**)\s*(c2b_\w+)\s*\(([^;{]*)\)\s*;", text):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The index of include/city2ba_hip.h's entry points by level, as the header's top comment carries it.
+"""The index of the boundary's entry points by header and level (include/city2ba_hip.h + city2ba_hip_host.h +
+city2ba_hip_experimental.h), as the main header's top comment carries it.
     python tools/abi_index.py            # print the index block
     python tools/abi_index.py --write    # replace the block between the two marker lines in the header
 tests/test_abi.py checks that the block in the header is what this prints (every exported symbol listed exactly once)."""
@@ -10,6 +11,12 @@ import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "city2ba_hip.h")
+HEADERS = [HEADER, os.path.join(ROOT, "include", "city2ba_hip_host.h"), os.path.join(ROOT, "include", "city2ba_hip_experimental.h")]
+
+
+def all_headers_text():
+    """the three headers, one after the other (what `declared in the header` means to the tests)"""
+    return "\n".join(open(h).read() for h in HEADERS)
 BEGIN, END = " * ---- index of entry points by level (tools/abi_index.py) ----", " * ---- end of index ----"
 
 # (title, first line of the header that belongs to the group) in header order; a group runs to the next one's start
@@ -22,8 +29,7 @@ GROUPS = [
     ("Level 0: statistics", r"^int c2b_stats\("),
     ("collectives (RCCL) and sharded Level-0 forms", r"^typedef struct c2b_comm"),
     ("Level 0: noise", r"^int c2b_add_drift\("),
-    ("f32 extension", r"^int c2b_convert|^int c2b_f64_to_f32|^int c2b_stats_f32"),
-    ("host-side rows (CPU; never touch the GPU)", r"^int c2b_partition_cameras|^int c2b_synthetic_grid_layout"),
+    ("the shard map", r"^int c2b_partition_cameras"),
     ("Level 1: a resident BAProblem", r"^typedef struct c2b_problem c2b_problem"),
     ("Level 1: one shard of a larger problem", r"^int c2b_problem_set_shard"),
 ]
@@ -54,17 +60,24 @@ def index_block():
                 owner = t
         groups[owner or starts[0][1]].append(name)
     out = [BEGIN]
+
+    def emit(title, names):
+        short = [n[4:] for n in names]                      # without the c2b_ prefix
+        out.append(" *   %s (%d):" % (title, len(names)))
+        out.extend(" *     " + b for b in textwrap.wrap(", ".join(short), width=112))
+
     total = 0
     for _, t in starts:
-        names = groups[t]
-        if not names:
-            continue
+        if groups[t]:
+            total += len(groups[t])
+            emit(t, groups[t])
+    out.append(" *   -- city2ba_hip.h: %d entry points --" % total)
+    for h, title in ((HEADERS[1], "city2ba_hip_host.h: host-side rows (CPU; never touch the GPU)"),
+                     (HEADERS[2], "city2ba_hip_experimental.h: diagnostics, calibration, f32 extension")):
+        names = [n for _, n in protos(open(h).read())]
         total += len(names)
-        short = [n[4:] for n in names]                      # without the c2b_ prefix
-        body = textwrap.wrap(", ".join(short), width=112)
-        out.append(" *   %s (%d):" % (t, len(names)))
-        out += [" *     " + b for b in body]
-    out.append(" *   (%d entry points; names above without their c2b_ prefix)" % total)
+        emit(title, names)
+    out.append(" *   (%d entry points in all; names above without their c2b_ prefix)" % total)
     out.append(END)
     return "\n".join(out)
 

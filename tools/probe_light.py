@@ -2,7 +2,7 @@
 """Every light pass of the hot path on the bench grid (--blocks 128), the row-structure forms, 12 launches each back to
 back: project, one-norm error, L1 + L2 in one pass, observation noise + both errors, observation noise alone, the
 visibility predicate (byte mask and ballot words), the statistics (compact centre table), the step kernel twice.
-A target for rocprofv3 --kernel-trace --stats / --pmc ... -- python3 tools/probe_r05.py (tools/profile_r05.sh)."""
+A target for rocprofv3 --kernel-trace --stats / --pmc ... -- python3 tools/probe_light.py (tools/profile_light.sh)."""
 import argparse
 import os
 import sys
