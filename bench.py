@@ -286,6 +286,16 @@ def generator_and_files(dev_index):
                 back.close()
             res[ext + "_read_back_same_size"] = bool(same)
             os.remove(path)
+        # run_noise's device flow end to end (src/bin/city2ba.rs:283-354) on that resident problem, ONE number: the two errors before,
+        # add_drift_normalized (statistics + drift), add_noise with both errors after (camera table + statistics + entity noise +
+        # camera table + the fused observation pass) -- three Level-1 calls, each synchronous; wall clock, second of two rounds
+        from city2ba_amd import noise as N
+        for k in range(2):
+            t = time.perf_counter()
+            g.total_reprojection_errors_l1_l2()
+            N.add_drift_normalized(g, 1e-4, 1e-5, 1e-3, seed=11 + k)
+            N.add_noise_with_errors(g, 1e-3, 1e-4, 1e-3, 1e-3, seed=21 + k)
+            res["run_noise_device_flow_us"] = round((time.perf_counter() - t) * 1e6, 1)
         g.close()
     except Exception as exc:                                      # informational: never fails the bench line
         res["failed"] = "%s: %s" % (type(exc).__name__, exc)
@@ -405,7 +415,7 @@ def light_kernels(sh, dev, ws):
     return out
 
 
-# pass of light_kernels -> its kernel in profiles/r05at_light_sq.json (tools/profile_light.sh: rocprofv3 kernel trace, SQ issue /
+# pass of light_kernels -> its kernel in profiles/r06_light_sq.json (tools/profile_light.sh: rocprofv3 kernel trace, SQ issue /
 # wait counters, FETCH_SIZE and WRITE_SIZE, each in its own pass)
 _LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, true, true, 0>",
                  "error_sum_rows_L2": "k_observations<1, 2, 3, 8, 1, true, true, 2>",
@@ -418,12 +428,12 @@ _LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, true, true, 0>",
 
 def recorded_bound(name):
     """Which bound binds this pass, from COUNTERS -- a recorded figure of a separate rocprofv3 run of
-    these very launches (profiles/r05at_light_sq.json; under the profiler every launch starts from swept caches):
+    these very launches (profiles/r06_light_sq.json; under the profiler every launch starts from swept caches):
     valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x 2.4 GHz x duration), valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 /
     the same, hbm_frac = (2 x FETCH_SIZE + WRITE_SIZE) / duration / 8 TB/s, bound = the larger of the last two if it
     reaches one half, else "latency"."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r05at_light_sq.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r06_light_sq.json")) as fh:
             d = json.load(fh).get(_LIGHT_KERNEL.get(name, ""), None)
         if not d or "bound" not in d:
             return {}
@@ -1024,6 +1034,8 @@ def main():
                 # the device this line was measured on, from the store rates of the output sets the placement search tried
                 "device_store_class": store_class(placement_log),
                 "kept_set_store_GBs": (placement_log[placement_chosen] if placement_log and 0 <= placement_chosen < len(placement_log) else None),
+                #  --assume-store-GBs replaces the rate the launch shape is chosen by: said so, next to the measured one
+                **({"store_GBs_assumed_for_the_launch_shape": args.assume_store_GBs} if args.assume_store_GBs > 0.0 else {}),
                 # the same launch writing into the FIRST allocation the library hands out (no search): what a caller
                 # that passes max_attempts = 1 gets on this device
                 "kernel_us_first_allocation": round(first_us, 2) if first_us else None,
@@ -1071,7 +1083,11 @@ def main():
             out["roofline"]["kernel_over_same_run_store_floor"] = round(kern_avg_s * 1e6 / cal["same_run_store_floor_us"], 4)
             # the same-run copy moves exactly the launch's algorithmic byte count (read + write)
             out["roofline"]["kernel_over_same_run_copy"] = round(kern_avg_s * 1e6 / cal["same_run_copy_us"], 4)
-        if world == 1 and args.blocks == 128 and not args.no_extras and not args.no_live_traffic:
+        #  under a profiler the child rocprofv3 runs would nest: skipped, the recorded figure stays
+        under_profiler = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if under_profiler:
+            out["roofline"]["traffic_live_unavailable"] = "this run is itself under a profiler"
+        if world == 1 and args.blocks == 128 and not args.no_extras and not args.no_live_traffic and not under_profiler:
             # the counters cannot be collected inside the timed run, but they can be collected on THIS box right after it
             t_live, how = live_traffic(kernel_name, args.blocks, outs.store_GBs)
             out["roofline"]["traffic_recorded"] = traffic

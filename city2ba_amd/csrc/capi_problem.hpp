@@ -605,8 +605,17 @@ void c2b_host_free(void *ptr) {
 }
 
 static int compute_stats(c2b_problem *p) {
-    int rc = ensure_camblk(p);
-    if (rc) return rc;
+    // The statistics read the centre table only.  When the camera table is stale because the in-memory cameras MOVED (drift, noise:
+    // bal_valid is off then), the centres alone are derived from the state -- k_cameras_centers, the bits k_cameras_prepare would write
+    // -- instead of the whole table: run_noise's add_noise asks for std() right after add_drift (src/noise.rs:133) and its entity
+    // pass invalidates a camera table again before any pass reads it (38.6 -> ~20 us of that flow, r06).  camblk stays stale.
+    if (!p->blk_valid && !p->bal_valid && p->n_cam > 0) {
+        hipLaunchKernelGGL(k_cameras_centers, dim3(blocks_for(p->n_cam)), dim3(kBlock), 0, p->stream, p->cam15, p->n_cam, p->cen4);
+        LAUNCH_CHECK();
+    } else {
+        int rc = ensure_camblk(p);
+        if (rc) return rc;
+    }
     return c2b_stats(p->camblk, p->cen4, p->n_cam, p->pts4, p->n_pts, p->ws, p->stats, p->stream);
 }
 

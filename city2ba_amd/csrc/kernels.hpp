@@ -317,6 +317,22 @@ __global__ __launch_bounds__(kBlock) void k_cameras_prepare(const double *__rest
     }
 }
 
+// The centre table alone, from the in-memory state (r06): what the statistics need of a camera after something moved it.  The same
+// cm_center on the same operands as fill_camblk -- the same bits as the table k_cameras_prepare<false> would write -- for 152 bytes of
+// traffic per camera instead of 408: Level 1's statistics between add_drift and add_noise_entities (src/noise.rs:133 calls std() on
+// the drifted problem) no longer derive a whole camera table that the entity noise invalidates before any pass reads it.
+__global__ __launch_bounds__(kBlock) void k_cameras_centers(const double *__restrict__ cam15, int64_t n, double *__restrict__ cen4) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double c[12], ctr[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) c[k] = cam15[15 * i + k];
+    cm_center(c, c[9], c[10], c[11], ctr);
+    double2 *o = reinterpret_cast<double2 *>(cen4 + 4 * i);
+    o[0] = make_double2(ctr[0], ctr[1]);
+    o[1] = make_double2(ctr[2], 0.0);
+}
+
 // Camera::from_position_direction, src/baproblem.rs:153-159: loc = -1.0 * dir.rotate_point(position)
 __global__ void k_cameras_from_position_direction(const double *__restrict__ pos, const double *__restrict__ dir,
                                                   int64_t n, double *__restrict__ cam15) {

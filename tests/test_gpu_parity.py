@@ -322,6 +322,22 @@ def test_stats_against_oracle(c2b):
     assert idx == idx0 and np.array_equal(o, o0)                      # index work: exact
 
 
+def test_statistics_of_moved_cameras_come_from_the_centre_refresh_and_carry_the_camera_tables_bits(c2b):
+    """r06: after something moved the cameras (add_drift, add_noise) the Level-1 statistics derive the centre table ALONE from
+    the state (k_cameras_centers) instead of a whole camera table the next entity pass would invalidate unread.  Same cm_center,
+    same operands: the 20 statistics are bit-equal to those of a problem freshly uploaded with the moved cameras (whose statistics
+    read the table k_cameras_prepare wrote) -- (count, mean, M2) triples, min / max, origin and all."""
+    from city2ba_amd import noise as N
+    P = random_problem(701, 3000, 4, seed=29)
+    ba = _upload(c2b, P)
+    N.add_drift_normalized(ba, 1e-3, 1e-4, 1e-2, seed=3)                # leaves the camera table stale
+    moved = ba._stats()                                                 # centres refreshed from the state, table left stale
+    fresh = c2b.BAProblem.from_visibility(ba.cameras(), ba.points(), P["row_ptr"], P["pt_idx"], P["uv"])
+    assert np.array_equal(moved.view(np.uint64), fresh._stats().view(np.uint64))
+    assert np.array_equal(ba.project(), fresh.project())                # ... and the next pass re-derives the whole table as before
+    assert not np.array_equal(moved, _upload(c2b, P)._stats())          # (the drift did move them)
+
+
 def test_drift_origin_tie_goes_to_later(c2b):
     pts = np.array([[1.0, 0, 0], [0.0, 0, 0], [0, 0, 2.0], [0.0, 0.0, 0.0], [3.0, 0, 0]])
     ba = c2b.BAProblem.from_bal([IDENT_CAM], pts, [0, 0], [], np.zeros((0, 2)))

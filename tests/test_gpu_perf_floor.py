@@ -6,11 +6,13 @@ regress the hot path silently, and whatever MI355X the suite runs on reports wha
     shape follows the set's store rate) <= 1.10 x the launch's algorithmic bytes at the streaming-store rate THIS device
     sustains into THAT set, measured in the same process (the device-independent figure of merit: 1.05-1.08 measured on
     slow-store, mixed and fast-store devices over rounds 5-6);
-  * a rank's EIGHTH of the list (2.41 M observations, what a rank of the 8-GPU run launches) <= 1.25 x its own floor of the
-    same kind (1.08-1.19 measured: ramp, tail and fold weigh a tenth of a 95-us launch);
-  * both error norms in one pass, caches swept before every launch: <= 120 us (110-116 measured on every device of rounds
-    5-6, whatever its store class) AND <= 1.6 x a same-process streaming copy of the pass's algorithmic bytes (the
-    device-relative form ADVICE r05 asked for: 1.25-1.4 measured);
+  * a rank's EIGHTH of the list (2.41 M observations, what a rank of the 8-GPU run launches) <= 112 us (92-110 measured over
+    rounds 5-6 by the class of its 0.5-GB output set; 97.4 us into a 5.5 TB/s set in r06).  Absolute on purpose: at this size
+    ramp, tail and fold are a tenth of the launch and neither the store pattern of the same size (0.89 x ... 1.19 x) nor a
+    copy is a stable yardstick;
+  * both error norms in one pass, caches swept before every launch: <= 120 us (110-117 measured on every device of rounds
+    5-6, whatever its store class) AND <= 0.85 x a same-process streaming copy of the pass's algorithmic byte count (the
+    device-relative form ADVICE r05 asked for; the copy reads and writes those bytes: 0.72 measured);
   * the statistics pass, back to back <= 29 us (25-26 us measured since the compact centre table).
 
 Tripwires with 4-10 % of air over what five rounds of devices measured -- a 5 % regression of the step kernel trips --,
@@ -125,6 +127,6 @@ def test_hot_path_stays_within_its_floors_at_the_headline_size(capsys):
             json.dump(out, fh, indent=1)
 
     assert step_us <= 1.10 * floor_us, out["step"]
-    assert step8 <= 1.25 * floor8, out["step_rank_eighth"]
-    assert cold_us <= 120.0 and cold_us <= 1.6 * copy_us, out["error_sums2_rows_L1_and_L2"]
+    assert step8 <= 112.0, out["step_rank_eighth"]
+    assert cold_us <= 120.0 and cold_us <= 0.85 * copy_us, out["error_sums2_rows_L1_and_L2"]
     assert stats_us <= 29.0, out["stats"]
