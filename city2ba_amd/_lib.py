@@ -17,6 +17,7 @@ ERR_OOM = -4
 ERR_NO_DEVICE = -5
 ERR_RCCL = -6
 COMM_ID_BYTES = 128
+ABI_VERSION = 6            # include/city2ba_hip.h: C2B_ABI_VERSION
 CAMBLK_DOUBLES = 32
 STATS_DOUBLES = 20
 
@@ -29,6 +30,7 @@ _int = C.c_int
 # name -> (restype, argtypes).  Kept in one table so tests can check every symbol the header declares.
 SIGNATURES = {
     "c2b_version": (C.c_char_p, []),
+    "c2b_abi_version": (_int, []),
     "c2b_last_error": (C.c_char_p, []),
     "c2b_device_count": (_int, [C.POINTER(_int)]),
     "c2b_workspace_bytes": (_i64, [_i64]),
@@ -254,6 +256,8 @@ def lib():
             f = getattr(L, name)          # AttributeError here = header/library mismatch
             f.restype = res
             f.argtypes = args
+        if L.c2b_abi_version() != ABI_VERSION:       # the number this table of signatures was written against (C2B_ABI_VERSION)
+            raise ImportError("city2ba_amd: %s speaks ABI %d, this binding %d -- rebuild the library" % (LIB_PATH, L.c2b_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

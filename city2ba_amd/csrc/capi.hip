@@ -366,6 +366,7 @@ int sin_impl(const char *who, T *cam15, int64_t n_cam, T *pts4, int64_t n_pts, c
 extern "C" {
 
 const char *c2b_version(void) { return "city2ba_hip 0.6.0 (gfx950)"; }
+int c2b_abi_version(void) { return C2B_ABI_VERSION; }
 const char *c2b_last_error(void) { return g_err; }
 
 int c2b_device_count(int *count) {

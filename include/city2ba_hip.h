@@ -43,8 +43,8 @@
  * which may change between rounds.
  *
  * ---- index of entry points by level (tools/abi_index.py) ----
- *   library (3):
- *     version, last_error, device_count
+ *   library (4):
+ *     version, abi_version, last_error, device_count
  *   Level 0: workspace, camera records, points, rows (14):
  *     workspace_bytes, workspace_init, cameras_from_bal, cameras_to_bal, camblk_doubles, camblk_from_state,
  *     camblk_from_bal, cameras_from_position_direction, project_world, to_world, cameras_transform, points_pad,
@@ -86,7 +86,7 @@
  *   Level 1: one shard of a larger problem (6):
  *     problem_set_shard, problem_stats_sharded, problem_add_drift_sharded, problem_add_noise_sharded,
  *     problem_add_sin_noise_sharded, problem_add_noise_errors_l1_l2_sharded
- *   -- city2ba_hip.h: 118 entry points --
+ *   -- city2ba_hip.h: 119 entry points --
  *   city2ba_hip_host.h: host-side rows (CPU; never touch the GPU) (42):
  *     synthetic_grid_sizes, synthetic_grid_layout, synthetic_line_layout, candidate_pairs, pairs_count, pairs_cam_idx,
  *     pairs_pt_idx, pairs_free, obj_load, obj_model_count, obj_model_name, obj_model_sizes, obj_model_copy,
@@ -99,7 +99,7 @@
  *     workspace_selfcheck, comm_backend, jacobian_tiles_per_wave, jacobian_launch_shape, jacobian_outputs_log,
  *     jacobian_outputs_set_store_rate, calib_store_pattern, calib_copy, convert_f64_to_f32, convert_f32_to_f64,
  *     stats_f32, add_drift_f32, add_drift_normalized_f32, add_noise_entities_f32, add_sin_noise_f32
- *   (175 entry points in all; names above without their c2b_ prefix)
+ *   (176 entry points in all; names above without their c2b_ prefix)
  * ---- end of index ----
  *
  * Every function returns C2B_OK or a negative status; c2b_last_error() gives the text.
@@ -127,6 +127,11 @@ extern "C" {
 #define C2B_STATS_DOUBLES  20  /* mean[3] std[3] min[3] max[3] dim[3] origin[3] origin_idx |std| */
 
 const char *c2b_version(void);
+/* The ABI's number: bumped whenever an existing entry's argument list or a buffer's layout changes (r05 did both without a number:
+ * camblk became a blocked table, c2b_stats* and the camera-table writers gained a pointer in the middle of their lists).  A host
+ * compares c2b_abi_version() with the C2B_ABI_VERSION it was compiled against, once, before its first call. */
+#define C2B_ABI_VERSION 6
+int c2b_abi_version(void);
 const char *c2b_last_error(void);
 int c2b_device_count(int *count);
 
