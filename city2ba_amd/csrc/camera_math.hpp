@@ -256,9 +256,6 @@ __device__ const PowLogRow g_pow_log_tab[C2B_POW_LOG_ROWS] __attribute__((aligne
 __device__ const PowExpRow g_pow_exp_tab[C2B_POW_EXP_ROWS] __attribute__((aligned(16))) = {C2B_EXP_TAB};
 C2B_DEV double pow4_libm(double x) { return pow4_glibc(x, g_pow_log_tab, g_pow_exp_tab); }
 
-// cam points at a camblk-shaped record (LDS or global).  The reference writes |p|^4 as p.magnitude().powf(4.0)
-// (src/baproblem.rs:147-149) = libm pow(sqrt(n), 4.0): pow4_libm above.  With k2 = 0 the term is k2 * n^4 = 0 whatever
-// the rounding of n^4, so that (wave-uniform on the generators' cameras) case skips the square root and the tables.
 // q1 = a1 / b and q2 = a2 / b, both IEEE-correct and bit-identical to the compiler's own expansion of `/` (the
 // v_div_scale / v_rcp / 4 FMA / v_div_fmas / v_div_fixup sequence, restated with the same builtins in the same order),
 // with the refined reciprocal of the shared denominator computed once: 16 instructions and one v_rcp_f64 instead of 22
@@ -290,7 +287,9 @@ C2B_DEV void div2_shared(double a1, double a2, double b, double &q1, double &q2)
 typedef const __attribute__((address_space(3))) double *lds_cptr;
 typedef const __attribute__((address_space(1))) double *glb_cptr;
 
-// The projection in the pieces the kernels assemble it from.
+// The projection in the pieces the kernels assemble it from.  `cam` points at a camblk-shaped record (LDS, global, or anything
+// indexable by record double).  The reference writes |p|^4 as p.magnitude().powf(4.0) (src/baproblem.rs:147-149) = libm's
+// pow(sqrt(n), 4.0): pow4_libm above.
 //   project_head: project_world + the perspective divide + |p|^2;
 //   project_tail: the radial factor and the pixel, |p|^4 handed in;
 //   project_obs_k0: head + tail with |p|^4 = n * n -- FINAL when k2 == 0 (k2 * n^4 = 0 whatever the rounding of n^4), and what
