@@ -421,8 +421,8 @@ _LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, true, true, 0>",
                  "error_sum_rows_L2": "k_observations<1, 2, 3, 8, 1, true, true, 2>",
                  "error_sums2_rows_L1_and_L2": "k_observations<3, 2, 3, 8, 1, true, true, 2>",
                  "add_noise_observations+error_sums2_rows": "k_observations<4, 2, 3, 8, 8, true, true, 2>",
-                 "visibility_rows": "k_observations<2, 2, 3, 8, 1, true, true, 1>",
-                 "visibility_rows_bits": "k_observations<5, 2, 3, 8, 1, true, true, 1>",
+                 "visibility_rows": "k_observations<2, 2, 3, 8, 8, true, true, 1>",
+                 "visibility_rows_bits": "k_observations<5, 2, 3, 8, 8, true, true, 1>",
                  "add_noise_observations": "k_add_noise_observations", "stats": "k_stats_pass1<"}
 
 

@@ -161,7 +161,7 @@ int launch_obs(const double *camblk, const double *pts4, const uint32_t *cam_idx
     constexpr int kNTL = (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) ? 2 : ((MODE == MODE_VISIBILITY || MODE == MODE_VISIBILITY_BITS) ? 1 : 0);
     // the fused noise pass holds the draw's table entries and the camera chunks in flight at once: left alone the allocator takes
     // 68 registers (7 waves per SIMD, one workgroup per CU less); told to leave room for 8 waves it fits 64 without scratch
-    constexpr int kMinW = MODE == MODE_NOISE_ERROR12 ? 8 : 1;
+    constexpr int kMinW = (MODE == MODE_NOISE_ERROR12 || MODE == MODE_VISIBILITY || MODE == MODE_VISIBILITY_BITS) ? 8 : 1;
     if (row_ptr) {          // the *_rows entry points: cam_idx = the tile records of c2b_rows_pack
 #define C2B_ROWS_ARGS camblk, pts4, cam_idx, pt_idx, uv_obs, n, norm, max_dist, uv_out, keep, block_part, ticket, out_sum, st, row_ptr, n_cam, obs_base, seed
         launch_obs_v<MODE, 3, 8, kMinW, true, true, kNTL>(C2B_ROWS_ARGS);

@@ -647,9 +647,12 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
             bool in = local < n_staged;
             lds_cptr cam = (lds_cptr)sCam + (in ? local : 0u) * HOT;
             // every lane: the projection with |p|^4 = n * n (final for k2 == 0); which lanes' cameras have k2 != 0 is kept as a lane
-            // mask in scalar registers -- the pow() route for those runs behind one wave-uniform branch below the loop
+            // mask in scalar registers -- the pow() route for those runs behind one wave-uniform branch below the loop.  What that
+            // route needs of the head is |p| = (px, py): a lane with k2 != 0 carries THEM in the pixel's two registers (its n * n
+            // pixel is not the answer anyway), so nothing is projected twice and nothing more is live across the loop than before.
             Proj p = project_obs_k0(cam, X[t].x, X[t].y, X[t].z);
             uint64_t k2nz = __builtin_amdgcn_ballot_w64(cam[14] != 0.0);
+            if (k2nz != 0 && ((k2nz >> lane) & 1ull)) { p.u = p.px; p.v = p.py; }       // behind a wave-uniform test: free when k2 = 0
             double gx = 0.0, gy = 0.0, gz = 0.0;
             if (VIS) { gx = cam[16]; gy = cam[17]; gz = cam[18]; }
             uint64_t todo = __builtin_amdgcn_ballot_w64(valid && !in);
@@ -670,39 +673,33 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_observations(
                 const bool mine = my >= 0;
                 lds_cptr cam2 = (lds_cptr)sSlow + (mine ? my : 0) * HOT;
                 const Proj q = project_obs_k0(cam2, X[t].x, X[t].y, X[t].z);
+                const bool k2mine = mine && cam2[14] != 0.0;
                 const uint64_t served = __builtin_amdgcn_ballot_w64(mine);
-                k2nz = (k2nz & ~served) | __builtin_amdgcn_ballot_w64(mine && cam2[14] != 0.0);
+                k2nz = (k2nz & ~served) | __builtin_amdgcn_ballot_w64(k2mine);
                 if (mine) {
                     p = q;
+                    if (k2mine) { p.u = q.px; p.v = q.py; }
                     if (VIS) { gx = cam2[16]; gy = cam2[17]; gz = cam2[18]; }
                 }
                 todo &= ~served;
             }
             if (k2nz != 0) {                                             // wave-uniform; cameras with k2 != 0 only (src/baproblem.rs:147-149)
-                // |p|^4 = p.magnitude().powf(4.0) as the reference computes it -- libm's pow -- for the lanes that need it: the whole
-                // projection again (the head's results were not kept: no registers), from the lane's staged camera or, for a lane the
-                // loop above served (its slot was restaged every round), from the table itself
-                struct RowCam {
-                    glb_cptr tab; int64_t c;
-                    __device__ __forceinline__ double operator[](int j) const { return tab[cam_row(c, j >> 1) + (j & 1)]; }
-                };
-                const bool need = (k2nz >> lane) & 1ull;
-                if (need && valid && !in) {
-                    const RowCam rc{(glb_cptr)camblk, (int64_t)ci[t]};
-                    const Proj q = project_obs(rc, X[t].x, X[t].y, X[t].z);
+                // |p|^4 = p.magnitude().powf(4.0) as the reference computes it -- libm's pow -- for the lanes that need it: |p|^2 again
+                // from the (px, py) they carried (the same expression, the same bits), the intrinsics from the lane's staged camera
+                // or, for a lane the loop above served (its slot was restaged every round), from the table itself, then the tail
+                if ((k2nz >> lane) & 1ull) {
+                    Proj q;
+                    q.px = p.u; q.py = p.v;
+                    q.n = q.px * q.px + q.py * q.py;
+                    double f, k1, k2;
+                    if (valid && !in) {
+                        glb_cptr g = (glb_cptr)camblk + cam_row((int64_t)ci[t], 6);      // record doubles 12 ..
+                        f = g[0]; k1 = g[1]; k2 = g[2];
+                    } else {
+                        f = cam[12]; k1 = cam[13]; k2 = cam[14];
+                    }
+                    project_tail(q, f, k1, k2, pow4_libm(sqrt(q.n)));
                     p.u = q.u; p.v = q.v;
-                } else if (need) {
-                    const Proj q = project_obs(cam, X[t].x, X[t].y, X[t].z);
-                    p.u = q.u; p.v = q.v;
-                }
-                // (the observed uv is fetched again behind this branch rather than held across it: the fused noise pass is at its 64
-                // registers without the branch, and the allocator would park a long-lived value of the COMMON path in scratch instead)
-                if (MODE == MODE_ERROR || MODE == MODE_ERROR12 || MODE == MODE_NOISE_ERROR12) {
-                    typedef const __attribute__((address_space(1))) d2_t *glb_d2;          // typed global: the load must not become FLAT
-                    glb_d2 src = (glb_d2)((MODE == MODE_NOISE_ERROR12 ? uv_out : uv_obs) + (valid ? o : n - 1));
-                    asm volatile("" : "+v"(src));
-                    const d2_t t2 = *src;
-                    ob = make_double2(t2.x, t2.y);
                 }
             }
             // keep = |center - p| < max_dist && q.z <= 0 && -1 <= u,v <= 1   (src/synthetic.rs:285-291, src/generate.rs:448-454)
