@@ -415,7 +415,7 @@ def light_kernels(sh, dev, ws):
     return out
 
 
-# pass of light_kernels -> its kernel in profiles/r06_light_sq.json (tools/profile_light.sh: rocprofv3 kernel trace, SQ issue /
+# pass of light_kernels -> its kernel in profiles/r06b_light_sq.json (tools/profile_light.sh: rocprofv3 kernel trace, SQ issue /
 # wait counters, FETCH_SIZE and WRITE_SIZE, each in its own pass)
 _LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, true, true, 0>",
                  "error_sum_rows_L2": "k_observations<1, 2, 3, 8, 1, true, true, 2>",
@@ -428,12 +428,12 @@ _LIGHT_KERNEL = {"project_rows": "k_observations<0, 2, 3, 8, 1, true, true, 0>",
 
 def recorded_bound(name):
     """Which bound binds this pass, from COUNTERS -- a recorded figure of a separate rocprofv3 run of
-    these very launches (profiles/r06_light_sq.json; under the profiler every launch starts from swept caches):
+    these very launches (profiles/r06b_light_sq.json; under the profiler every launch starts from swept caches):
     valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x 2.4 GHz x duration), valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 /
     the same, hbm_frac = (2 x FETCH_SIZE + WRITE_SIZE) / duration / 8 TB/s, bound = the larger of the last two if it
     reaches one half, else "latency"."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r06_light_sq.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r06b_light_sq.json")) as fh:
             d = json.load(fh).get(_LIGHT_KERNEL.get(name, ""), None)
         if not d or "bound" not in d:
             return {}
