@@ -133,7 +133,7 @@ def test_alloc_jacobian_outputs_returns_usable_buffers():
     sh = bench.build_shard(argparse.Namespace(blocks=32), 0, 1, dev)
     n = sh["n_obs"]
     (r, Jc, Jp), log = D.alloc_jacobian_outputs(n, dev, max_attempts=3)
-    assert 1 <= len(log) <= 3 and all(x > 100.0 for x in log)
+    assert 1 <= len(log) <= 3 and all(x > 0.0 for x in log)
     assert len({r.data_ptr(), Jc.data_ptr(), Jp.data_ptr()}) == 3
     r0, Jc0, Jp0 = torch.empty_like(r), torch.empty_like(Jc), torch.empty_like(Jp)
     ws = D.workspace(n, dev)
