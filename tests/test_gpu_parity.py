@@ -165,6 +165,35 @@ def test_device_pow4_is_libm_pow_bit_for_bit_over_two_million_draws(c2b):
     assert np.sum(lm != cr) > 500                                  # ... and these draws do include libm's one-ulp cases
 
 
+def test_device_pow4_takes_glibcs_large_argument_and_overflow_paths(c2b):
+    """The rest of the routine that a projection can read out exactly: |p| from 2^100 to beyond 2^256, i.e. the logarithm's large k,
+    exp_inline's `specialcase` for k > 0 (512 <= 4 ln x < 1024: the scale's exponent is lowered by 1009 and the result multiplied
+    back) and the overflow exit (+inf).  Same read-out as above (k2 = 2^s down to 2^-954, a normal number); where x^4 overflows the
+    pixel is +inf on both sides.  (Results in the subnormal range and subnormal arguments cannot be read out through 1 + k2 x^4;
+    they are held bit for bit on the host, where the same header compiles: tests/test_pow4.py.)"""
+    rng = np.random.default_rng(62)
+    py = np.exp2(np.concatenate([rng.uniform(100.0, 257.5, 60000), rng.uniform(184.0, 256.0, 60000), rng.uniform(255.9, 256.1, 20000)]))
+    px = 0.125
+    nn = px * px + py * py                                         # = py * py here (2^-6 is far below its last place)
+    x = np.sqrt(nn)
+    want, _ = O.pow4_both(x)
+    over = np.isinf(want)
+    assert over.sum() > 5000 and (~over).sum() > 100000 and np.sum(want[~over] > 2.0 ** 1000) > 1000
+    s = np.where(over, 0, 70 - np.floor(np.log2(np.where(over, 1.0, want))).astype(np.int64))
+    got = np.empty_like(want)
+    pts = np.column_stack([np.full(len(py), px), py, -np.ones(len(py))])
+    for sv in np.unique(s):
+        m = np.nonzero(s == sv)[0]
+        cam = O.camera_from_bal([0, 0, 0, 0, 0, 0, 1.0, 0.0, float(np.ldexp(1.0, int(sv)))]).reshape(1, 15)
+        ba = c2b.BAProblem.from_visibility(cam, pts[m], np.array([0, len(m)], dtype=np.uint64), np.arange(len(m), dtype=np.uint64), np.zeros((len(m), 2)))
+        uv = ba.project()
+        ba.close()
+        got[m] = np.ldexp(uv[:, 0], 3 - int(sv))
+        if sv == 0:                                                # the overflow group: both pixel coordinates against the oracle's
+            assert np.array_equal(uv[:300].view(np.uint64), np.array([O.project(cam[0], q) for q in pts[m][:300]]).view(np.uint64))
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), "%d of %d differ" % (np.sum(got != want), len(want))
+
+
 @pytest.mark.parametrize("norm", [1.0, 2.0, 1.5, 3.0])
 def test_total_reprojection_error(c2b, norm):
     P = random_problem(150, 3000, 13, seed=11, noise=1e-2, empty_every=9)
